@@ -1,0 +1,208 @@
+/*
+ * physicl_hip.h -- C ABI of libphysicl_hip.so: the MI355X (gfx950) implementation of PhysiCL's
+ * per-particle time-step hot path.
+ *
+ * This is the drop-in boundary.  The reference crosses it in ONE place: ``CLProgram.run``
+ * (physicl/__init__.py:602-664) and the hand-rolled launch in
+ * ``ScatterDeleteStepReference.__run_cl`` (physicl/light.py:164-205) gather per-object Python
+ * attributes into numpy arrays, copy them to an OpenCL device, launch one kernel and copy the
+ * result back.  A PhysiCL maintainer binds the functions below with ctypes instead of PyOpenCL
+ * (see INTEGRATION.md).  Two levels are offered:
+ *
+ *   Level 1  "reference-ABI kernels"  (pcl_k_*): same argument lists as the three OpenCL kernels
+ *            the reference builds at run time, on raw device pointers.  One call == one
+ *            ``prog.<kernel>(queue, (N,), None, *args)``.
+ *   Level 2  "particle store" (pcl_store_*, pcl_step_*): particles stay resident in HBM as
+ *            structure-of-arrays for the whole simulation and a Step is one fused kernel launch;
+ *            replaces gather + H2D + launch + D2H + Python write-back.
+ *
+ * Conventions: plain C types only; every function returns 0 (PCL_OK) or a negative PCL_ERR_* code
+ * and never throws; pcl_last_error() gives the calling thread's last message.  Unless a parameter
+ * says "host", pointers are DEVICE pointers.  Every entry point binds its context's device to the
+ * calling thread first (the reference creates its context on one thread and launches from the
+ * Simulation thread, physicl/__init__.py:427-429, 501), so calls may come from any thread; at most
+ * one call per context may be in flight at a time.  All work is enqueued on the context's stream;
+ * functions that return values to the host synchronise that stream, the others do not.
+ */
+#ifndef PHYSICL_HIP_H
+#define PHYSICL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCL_ABI_VERSION 1
+
+#define PCL_OK          0
+#define PCL_ERR_HIP    (-1) /* a HIP runtime call or kernel launch failed */
+#define PCL_ERR_ARG    (-2) /* bad argument (null pointer, negative size, unknown enum) */
+#define PCL_ERR_STATE  (-3) /* call not valid in the context's current state */
+#define PCL_ERR_RTC    (-4) /* hipRTC compile/load failure; log is in pcl_last_error() */
+#define PCL_ERR_EXPR   (-5) /* variable_n_fn expression rejected by the validator */
+#define PCL_ERR_NOMEM  (-6) /* device or host allocation failed */
+
+/* Per-particle state = the fields of physicl.Object / PhotonObject that a Step reads or writes
+ * (physicl/__init__.py:390-394, physicl/light.py:26-35), one contiguous fp64 array per component. */
+enum pcl_field {
+    PCL_R0 = 0, PCL_R1, PCL_R2,      /* Object.r   position                    */
+    PCL_V0, PCL_V1, PCL_V2,          /* Object.v   velocity                    */
+    PCL_DR0, PCL_DR1, PCL_DR2,       /* Object.dr  last displacement           */
+    PCL_DV0, PCL_DV1, PCL_DV2,       /* Object.dv  last velocity change        */
+    PCL_E,                           /* PhotonObject.E                         */
+    PCL_NFIELDS
+};
+
+/* pcl_step_scatter_isotropic / pcl_k_light_scatter_step_sphere ``flags`` */
+#define PCL_SCATTER_WAVELENGTH 1 /* wavelength_dep_scattering=True  (light.py:275, 300-301) */
+#define PCL_SCATTER_VARIABLE_N 2 /* variable_n=True                  (light.py:276, 299)     */
+
+/* where a step's three random numbers per photon come from */
+#define PCL_RNG_INPUT  0 /* arrays uploaded with pcl_store_upload_rand: the reference's contract
+                            ("randoms are kernel inputs", light.py:285, __init__.py:606-619)       */
+#define PCL_RNG_PHILOX 1 /* generated in-kernel: Philox4x32-10 keyed by (seed, step, particle id)  */
+
+/* kind[] values (pcl_store_upload_kind) */
+#define PCL_KIND_OBJECT 0 /* plain physicl.Object: moved by Newton, skipped by the light steps
+                             (``if type(obj) != PhotonObject: continue``, light.py:233, 283)      */
+#define PCL_KIND_PHOTON 1
+
+/* index layout of pcl_step_counters() output */
+#define PCL_CNT_N      0 /* particles in the store                                  */
+#define PCL_CNT_XP     1 /* v_x > 0   (ScatterSignMeasureStep, light.py:424)         */
+#define PCL_CNT_YP     2
+#define PCL_CNT_ZP     3
+#define PCL_CNT_PLANE0 4 /* first plane-crossing count (ScatterMeasureStep, light.py:385-399) */
+#define PCL_MAX_PLANES 12
+
+typedef struct pcl_ctx pcl_ctx; /* opaque */
+
+/* ---------------------------------------------------------------- library / context ---------- */
+int         pcl_abi_version(void);
+const char *pcl_last_error(void);                 /* thread-local, never NULL */
+int         pcl_device_count(int *n_out);         /* host pointer */
+
+/* ``stream``: a hipStream_t to adopt (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let
+ * the context create its own non-blocking stream.  Replaces cl.create_some_context() +
+ * cl.CommandQueue() (physicl/__init__.py:428-429). */
+int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out);
+int pcl_ctx_destroy(pcl_ctx *ctx);
+int pcl_ctx_sync(pcl_ctx *ctx);
+int pcl_ctx_stream(pcl_ctx *ctx, void **stream_out);
+/* name: host buffer of name_len bytes.  Replaces Simulation.get_device_info (__init__.py:470-499). */
+int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_bytes, int *n_cu,
+                        int *wavefront);
+
+/* raw device memory for Level 1 callers: replaces cl_array.to_device / cl_array.empty / .get()
+ * (physicl/__init__.py:614, 653, 662).  Copies are asynchronous on the context stream except
+ * pcl_d2h, which returns after the data is in ``host``. */
+int pcl_dev_alloc(pcl_ctx *ctx, int64_t bytes, void **dev_out);
+int pcl_dev_free(pcl_ctx *ctx, void *dev);
+int pcl_h2d(pcl_ctx *ctx, void *dev, const void *host, int64_t bytes);
+int pcl_d2h(pcl_ctx *ctx, void *host, const void *dev, int64_t bytes);
+int pcl_dev_memset(pcl_ctx *ctx, void *dev, int value, int64_t bytes);
+
+/* stream timing with HIP events (bench.py): *ms_out = device time between the two records. */
+int pcl_timer_start(pcl_ctx *ctx);
+int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
+
+/* ---------------------------------------------------------------- Level 1: reference-ABI kernels
+ * Argument ORDER and meaning follow the OpenCL kernels exactly; N is the global work size.        */
+
+/* kernel light_scatter_step_del(dx, dy, dz, rand, n, A, result)          physicl/light.py:146-158 */
+int pcl_k_light_scatter_step_del(pcl_ctx *ctx, const double *dx, const double *dy, const double *dz,
+                                 const double *rand, double n, double A, int32_t *result, int64_t N);
+
+/* kernel test(d0, d1, d2, rand, A, n, res) -- ScatterDeleteStep's CLProgram
+ * body physicl/light.py:239-249, signature generated by physicl/__init__.py:583-597             */
+int pcl_k_scatter_delete_test(pcl_ctx *ctx, const double *d0, const double *d1, const double *d2,
+                              const double *rand, double A, double n, int32_t *res, int64_t N);
+
+/* kernel light_scatter_step_sphere(d0,d1,d2, rtheta,rphi,rand, A,n, [E], [r0,r1,r2], res0,res1,res2)
+ * physicl/light.py:299-315.  ``E`` is read iff flags & PCL_SCATTER_WAVELENGTH; ``r0..r2`` iff
+ * flags & PCL_SCATTER_VARIABLE_N, in which case ``n_expr`` is the OpenCL-C expression the reference
+ * splices into the source (light.py:299) and kernel argument ``n`` is unused, as in the reference.
+ * ``c`` and ``h`` are the values of the literals str(c), str(h).upper() pasted into the source
+ * (light.py:301, 309-311).  Miss: res0[i] = NaN, res1[i]/res2[i] NOT written (light.py:313).      */
+int pcl_k_light_scatter_step_sphere(pcl_ctx *ctx, const double *d0, const double *d1, const double *d2,
+                                    const double *rtheta, const double *rphi, const double *rand,
+                                    double A, double n, const double *E, const double *r0,
+                                    const double *r1, const double *r2, double *res0, double *res1,
+                                    double *res2, int64_t N, int flags, double c, double h,
+                                    const char *n_expr /* host string, may be NULL */);
+
+/* Stable compaction indices of a flag array: idx_out[0..*n_keep) = ascending i with flags[i] == 0
+ * -- the survivors of ``for idx, x in enumerate(out["res"]): if x == 1: sim.remove_obj(...)``
+ * (physicl/light.py:258-260).  idx_out needs room for N entries; n_keep_out is a host pointer.    */
+int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t *idx_out,
+                          int64_t *n_keep_out);
+
+/* Validate a variable_n_fn expression without compiling it (host strings).  Accepted grammar:
+ * numbers, + - * / ( ) , the functions exp sqrt pow log log2 log10 exp2 sin cos tanh fabs fmin fmax,
+ * and the array reads r0[gid] r1[gid] r2[gid] d0[gid] d1[gid] d2[gid] E[gid].                     */
+int pcl_expr_validate(const char *n_expr);
+
+/* ---------------------------------------------------------------- Level 2: resident particle store */
+
+/* Allocate SoA storage for up to ``capacity`` particles (13 fp64 arrays; ids, kinds, the compaction
+ * double buffer and the random-input arrays are allocated on first use).  count is set to 0. */
+int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity);
+int pcl_store_free(pcl_ctx *ctx);
+int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out);
+int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, no sync */
+/* Set the particle count (<= capacity) and declare ids = id_base + index (no id array is read). */
+int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base);
+
+int pcl_store_upload(pcl_ctx *ctx, int field, const double *host, int64_t offset, int64_t n);
+int pcl_store_download(pcl_ctx *ctx, int field, double *host, int64_t offset, int64_t n);
+int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int64_t n);
+int pcl_store_download_ids(pcl_ctx *ctx, int64_t *host, int64_t offset, int64_t n);
+int pcl_store_upload_kind(pcl_ctx *ctx, const uint8_t *host, int64_t offset, int64_t n);
+int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t n);
+/* device pointer of a field's CURRENT buffer (changes after a compaction) */
+int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out);
+
+/* Random inputs for PCL_RNG_INPUT: which = 0 rtheta, 1 rphi, 2 rand; n values for particles
+ * [0, n) in store order (entries of non-photon particles are ignored). */
+int pcl_store_upload_rand(pcl_ctx *ctx, int which, const double *host, int64_t n);
+
+/* Bulk creation on the device of ``n`` photons at r = 0 with v = (c, 0, 0), dr = dv = 0 and
+ * E = e_min + (e_max - e_min) * U^(1/3) -- the SoA equivalent of light.generate_photons with its
+ * default sampler np.random.power(3) (physicl/light.py:112-128).  U is Philox-keyed by
+ * (seed, id_base + index).  Sets count = n, ids = id_base + index, every kind = photon. */
+int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min,
+                           double e_max, uint64_t seed);
+
+/* NewtonianKinematicsStep.run (physicl/newton.py:10-16): dr = v*dt (rounded, stored); r = r + dr.
+ * Applies to every particle of every kind. */
+int pcl_step_newton(pcl_ctx *ctx, double dt);
+
+/* ScatterIsotropicStep.__run_cl (physicl/light.py:281-331) fused: hit test, new direction AND the
+ * host write-back (hit: v = v', dv = v' - v_old; miss: dv = 0).  ``A``/``n`` are the KERNEL
+ * constants, i.e. after the reference's swap (light.py:287); the Python layer applies the swap.
+ * hits_out (host, may be NULL): number of photons scattered in this call; when non-NULL the call
+ * synchronises. */
+int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h,
+                               const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
+                               int64_t *hits_out);
+
+/* ScatterDeleteStep.run (physicl/light.py:231-260) fused: flag kernel + stable compaction of every
+ * state array.  Non-photon particles are never removed.  Outputs are host pointers (may be NULL);
+ * the call synchronises (the new count is needed by exit conditions such as
+ * ``len(sim.objects) == 0``, physicl/__init__.py:414). */
+int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed,
+                            uint32_t step, int64_t *n_alive_out, int64_t *n_removed_out);
+/* The int32 flag array of the most recent pcl_step_scatter_delete, in PRE-compaction order
+ * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */
+int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n);
+
+/* ScatterSignMeasureStep.run + the counting part of ScatterMeasureStep.run
+ * (physicl/light.py:414-431, 374-400).  planes_host: n_planes x 3 doubles, NaN = coordinate not
+ * defining the plane.  out_host: int64[PCL_CNT_PLANE0 + n_planes].  Synchronises. */
+int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int64_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHYSICL_HIP_H */

@@ -1,0 +1,353 @@
+"""ctypes binding of libphysicl_hip.so (include/physicl_hip.h) -- the only way Python reaches the GPU.
+
+There is no CPU fallback: if the library is missing, or a call fails, this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_int, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libphysicl_hip.so")
+
+# enums of include/physicl_hip.h
+R0, R1, R2, V0, V1, V2, DR0, DR1, DR2, DV0, DV1, DV2, E, NFIELDS = range(14)
+FIELD_GROUPS = {"r": (R0, R1, R2), "v": (V0, V1, V2), "dr": (DR0, DR1, DR2), "dv": (DV0, DV1, DV2)}
+SCATTER_WAVELENGTH, SCATTER_VARIABLE_N = 1, 2
+RNG_INPUT, RNG_PHILOX = 0, 1
+KIND_OBJECT, KIND_PHOTON = 0, 1
+CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
+MAX_PLANES = 12
+ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
+             -6: "PCL_ERR_NOMEM"}
+
+
+class HipError(RuntimeError):
+    """A libphysicl_hip call returned a negative code; message is pcl_last_error()."""
+
+    def __init__(self, code, msg):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "PCL_ERR"), code, msg))
+        self.code = code
+
+
+class ExpressionError(HipError, ValueError):
+    """variable_n_fn was rejected (validator or hipRTC compile)."""
+
+
+_dp = POINTER(c_double)
+_vp = c_void_p
+
+# name -> argtypes ; restype is always int except pcl_last_error
+_PROTOTYPES = {
+    "pcl_abi_version": [],
+    "pcl_device_count": [POINTER(c_int)],
+    "pcl_ctx_create": [c_int, _vp, POINTER(_vp)],
+    "pcl_ctx_destroy": [_vp],
+    "pcl_ctx_sync": [_vp],
+    "pcl_ctx_stream": [_vp, POINTER(_vp)],
+    "pcl_ctx_device_info": [_vp, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int)],
+    "pcl_dev_alloc": [_vp, c_int64, POINTER(_vp)],
+    "pcl_dev_free": [_vp, _vp],
+    "pcl_h2d": [_vp, _vp, _vp, c_int64],
+    "pcl_d2h": [_vp, _vp, _vp, c_int64],
+    "pcl_dev_memset": [_vp, _vp, c_int, c_int64],
+    "pcl_timer_start": [_vp],
+    "pcl_timer_stop": [_vp, POINTER(c_double)],
+    "pcl_k_light_scatter_step_del": [_vp, _vp, _vp, _vp, _vp, c_double, c_double, _vp, c_int64],
+    "pcl_k_scatter_delete_test": [_vp, _vp, _vp, _vp, _vp, c_double, c_double, _vp, c_int64],
+    "pcl_k_light_scatter_step_sphere": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, c_double, c_double, _vp, _vp, _vp, _vp,
+                                        _vp, _vp, _vp, c_int64, c_int, c_double, c_double, c_char_p],
+    "pcl_k_compact_indices": [_vp, _vp, c_int64, _vp, POINTER(c_int64)],
+    "pcl_expr_validate": [c_char_p],
+    "pcl_store_alloc": [_vp, c_int64],
+    "pcl_store_free": [_vp],
+    "pcl_store_capacity": [_vp, POINTER(c_int64)],
+    "pcl_store_count": [_vp, POINTER(c_int64)],
+    "pcl_store_set_count": [_vp, c_int64, c_int64],
+    "pcl_store_upload": [_vp, c_int, _vp, c_int64, c_int64],
+    "pcl_store_download": [_vp, c_int, _vp, c_int64, c_int64],
+    "pcl_store_upload_ids": [_vp, _vp, c_int64, c_int64],
+    "pcl_store_download_ids": [_vp, _vp, c_int64, c_int64],
+    "pcl_store_upload_kind": [_vp, _vp, c_int64, c_int64],
+    "pcl_store_download_kind": [_vp, _vp, c_int64, c_int64],
+    "pcl_store_field_ptr": [_vp, c_int, POINTER(_vp)],
+    "pcl_store_upload_rand": [_vp, c_int, _vp, c_int64],
+    "pcl_store_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
+    "pcl_step_newton": [_vp, c_double],
+    "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
+                                   c_uint32, POINTER(c_int64)],
+    "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
+                                POINTER(c_int64)],
+    "pcl_store_last_delete_flags": [_vp, _vp, c_int64],
+    "pcl_step_counters": [_vp, _vp, c_int, _vp],
+}
+EXPORTS = sorted(list(_PROTOTYPES) + ["pcl_last_error"])
+
+_lib = None
+
+
+def load():
+    """dlopen libphysicl_hip.so (built by ``python -m physicl_amd.build``).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "physicl_amd: %s is missing -- build it with `python -m physicl_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOTYPES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    lib.pcl_last_error.argtypes = []
+    lib.pcl_last_error.restype = c_char_p
+    if lib.pcl_abi_version() != 1:
+        raise ImportError("libphysicl_hip ABI version %d, expected 1" % lib.pcl_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = (_lib.pcl_last_error() or b"").decode("utf-8", "replace")
+        raise (ExpressionError if rc in (-4, -5) else HipError)(rc, msg)
+
+
+def device_count():
+    n = c_int(0)
+    rc = load().pcl_device_count(byref(n))
+    return n.value if rc == 0 else 0
+
+
+def validate_expr(expr):
+    lib = load()
+    rc = lib.pcl_expr_validate(expr.encode())
+    if rc != 0:
+        raise ExpressionError(rc, lib.pcl_last_error().decode())
+
+
+def _host(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a, a.ctypes.data_as(c_void_p)
+
+
+class DeviceArray:
+    """Raw device allocation for Level-1 callers (what cl_array.to_device / cl_array.empty gave)."""
+
+    def __init__(self, dev, n, dtype):
+        self.dev, self.n, self.dtype = dev, int(n), np.dtype(dtype)
+        p = c_void_p()
+        check(dev.lib.pcl_dev_alloc(dev.ctx, self.n * self.dtype.itemsize, byref(p)))
+        self.ptr = p
+
+    @classmethod
+    def from_host(cls, dev, arr, dtype=np.float64):
+        arr, hp = _host(arr, dtype)
+        self = cls(dev, arr.size, dtype)
+        check(dev.lib.pcl_h2d(dev.ctx, self.ptr, hp, arr.nbytes))
+        return self
+
+    def fill_bytes(self, value):
+        check(self.dev.lib.pcl_dev_memset(self.dev.ctx, self.ptr, value, self.n * self.dtype.itemsize))
+
+    def get(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        check(self.dev.lib.pcl_d2h(self.dev.ctx, out.ctypes.data_as(c_void_p), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr is not None and self.dev.ctx:
+            check(self.dev.lib.pcl_dev_free(self.dev.ctx, self.ptr))
+        self.ptr = None
+
+
+class Device:
+    """One HIP context (device + stream) and, optionally, one resident particle store."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load()
+        ctx = c_void_p()
+        check(self.lib.pcl_ctx_create(int(device), c_void_p(stream) if stream else None, byref(ctx)))
+        self.ctx = ctx
+        self.device = int(device)
+
+    # ---------------------------------------------------------------- lifecycle
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.pcl_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        check(self.lib.pcl_ctx_sync(self.ctx))
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        hbm, cu, wf = c_int64(), c_int(), c_int()
+        check(self.lib.pcl_ctx_device_info(self.ctx, name, 256, byref(hbm), byref(cu), byref(wf)))
+        return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cu.value,
+                "wavefront": wf.value, "device": self.device}
+
+    def timer_start(self):
+        check(self.lib.pcl_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = c_double()
+        check(self.lib.pcl_timer_stop(self.ctx, byref(ms)))
+        return ms.value
+
+    # ---------------------------------------------------------------- Level 1 (reference-ABI kernels)
+    def array(self, host, dtype=np.float64):
+        return DeviceArray.from_host(self, host, dtype)
+
+    def empty(self, n, dtype=np.float64):
+        return DeviceArray(self, n, dtype)
+
+    def k_light_scatter_step_del(self, dx, dy, dz, rand, n, A, result, N):
+        check(self.lib.pcl_k_light_scatter_step_del(self.ctx, dx.ptr, dy.ptr, dz.ptr, rand.ptr, n, A, result.ptr, N))
+
+    def k_scatter_delete_test(self, d0, d1, d2, rand, A, n, res, N):
+        check(self.lib.pcl_k_scatter_delete_test(self.ctx, d0.ptr, d1.ptr, d2.ptr, rand.ptr, A, n, res.ptr, N))
+
+    def k_light_scatter_step_sphere(self, d0, d1, d2, rtheta, rphi, rand, A, n, E, r, res0, res1, res2, N, flags, c, h,
+                                    n_expr=None):
+        nul = c_void_p()
+        r = r or (None, None, None)
+        check(self.lib.pcl_k_light_scatter_step_sphere(
+            self.ctx, d0.ptr, d1.ptr, d2.ptr, rtheta.ptr, rphi.ptr, rand.ptr, A, n, E.ptr if E is not None else nul,
+            *[x.ptr if x is not None else nul for x in r], res0.ptr, res1.ptr, res2.ptr, N, flags, c, h,
+            n_expr.encode() if n_expr is not None else None))
+
+    def k_compact_indices(self, flags, N, idx_out):
+        keep = c_int64()
+        check(self.lib.pcl_k_compact_indices(self.ctx, flags.ptr, N, idx_out.ptr, byref(keep)))
+        return keep.value
+
+    # ---------------------------------------------------------------- Level 2 (resident store)
+    def store_alloc(self, capacity):
+        check(self.lib.pcl_store_alloc(self.ctx, int(capacity)))
+
+    def store_free(self):
+        check(self.lib.pcl_store_free(self.ctx))
+
+    @property
+    def capacity(self):
+        v = c_int64()
+        check(self.lib.pcl_store_capacity(self.ctx, byref(v)))
+        return v.value
+
+    @property
+    def count(self):
+        v = c_int64()
+        check(self.lib.pcl_store_count(self.ctx, byref(v)))
+        return v.value
+
+    def set_count(self, count, id_base=0):
+        check(self.lib.pcl_store_set_count(self.ctx, int(count), int(id_base)))
+
+    def upload(self, field, host, offset=0):
+        a, hp = _host(host, np.float64)
+        check(self.lib.pcl_store_upload(self.ctx, field, hp, offset, a.size))
+
+    def download(self, field, n=None, offset=0):
+        n = self.count - offset if n is None else n
+        out = np.empty(n, dtype=np.float64)
+        check(self.lib.pcl_store_download(self.ctx, field, out.ctypes.data_as(c_void_p), offset, n))
+        return out
+
+    def upload_ids(self, host, offset=0):
+        a, hp = _host(host, np.int64)
+        check(self.lib.pcl_store_upload_ids(self.ctx, hp, offset, a.size))
+
+    def download_ids(self, n=None, offset=0):
+        n = self.count - offset if n is None else n
+        out = np.empty(n, dtype=np.int64)
+        check(self.lib.pcl_store_download_ids(self.ctx, out.ctypes.data_as(c_void_p), offset, n))
+        return out
+
+    def upload_kind(self, host, offset=0):
+        a, hp = _host(host, np.uint8)
+        check(self.lib.pcl_store_upload_kind(self.ctx, hp, offset, a.size))
+
+    def download_kind(self, n=None, offset=0):
+        n = self.count - offset if n is None else n
+        out = np.empty(n, dtype=np.uint8)
+        check(self.lib.pcl_store_download_kind(self.ctx, out.ctypes.data_as(c_void_p), offset, n))
+        return out
+
+    def field_ptr(self, field):
+        p = c_void_p()
+        check(self.lib.pcl_store_field_ptr(self.ctx, field, byref(p)))
+        return p.value
+
+    def upload_rand(self, which, host):
+        a, hp = _host(host, np.float64)
+        check(self.lib.pcl_store_upload_rand(self.ctx, which, hp, a.size))
+
+    def fill_photons(self, n, id_base, c, e_min, e_max, seed):
+        check(self.lib.pcl_store_fill_photons(self.ctx, int(n), int(id_base), c, e_min, e_max, int(seed)))
+
+    def upload_state(self, state):
+        """state: dict with 'r','v','dr','dv' -> (n,3) or 3 arrays, 'E' -> (n,).  Sets count = n."""
+        n = len(np.asarray(state["E"]))
+        self.set_count(n, int(state.get("id_base", 0)))
+        for g, fids in FIELD_GROUPS.items():
+            a = state.get(g)
+            for k, fid in enumerate(fids):
+                col = np.zeros(n) if a is None else (np.asarray(a)[:, k] if np.ndim(a) == 2 else a[k])
+                self.upload(fid, col)
+        self.upload(E, state["E"])
+        if state.get("id") is not None:
+            self.upload_ids(state["id"])
+        if state.get("kind") is not None:
+            self.upload_kind(state["kind"])
+
+    def download_state(self):
+        n = self.count
+        out = {g: [self.download(fid, n) for fid in fids] for g, fids in FIELD_GROUPS.items()}
+        out["E"] = self.download(E, n)
+        out["id"] = self.download_ids(n)
+        return out
+
+    def step_newton(self, dt):
+        check(self.lib.pcl_step_newton(self.ctx, float(dt)))
+
+    def step_scatter_isotropic(self, A, n, flags, c, h, n_expr=None, rng_mode=RNG_PHILOX, seed=0, step=0,
+                               want_hits=True):
+        hits = c_int64()
+        check(self.lib.pcl_step_scatter_isotropic(
+            self.ctx, float(A), float(n), int(flags), float(c), float(h),
+            n_expr.encode() if n_expr is not None else None, int(rng_mode), int(seed), int(step) & 0xFFFFFFFF,
+            byref(hits) if want_hits else None))
+        return hits.value if want_hits else None
+
+    def step_scatter_delete(self, A, n, rng_mode=RNG_PHILOX, seed=0, step=0):
+        alive, removed = c_int64(), c_int64()
+        check(self.lib.pcl_step_scatter_delete(self.ctx, float(A), float(n), int(rng_mode), int(seed),
+                                               int(step) & 0xFFFFFFFF, byref(alive), byref(removed)))
+        return alive.value, removed.value
+
+    def last_delete_flags(self, n):
+        out = np.empty(n, dtype=np.int32)
+        check(self.lib.pcl_store_last_delete_flags(self.ctx, out.ctypes.data_as(c_void_p), n))
+        return out
+
+    def step_counters(self, planes=()):
+        planes = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros(CNT_PLANE0 + len(planes), dtype=np.int64)
+        check(self.lib.pcl_step_counters(self.ctx, planes.ctypes.data_as(c_void_p) if len(planes) else None,
+                                         len(planes), out.ctypes.data_as(c_void_p)))
+        return out

@@ -1,0 +1,1185 @@
+// physicl_hip.hip -- libphysicl_hip.so: hand-written gfx950 (CDNA4, wave64) kernels + the C ABI of
+// include/physicl_hip.h.  Build: see __graft_entry__.build() (hipcc --offload-arch=gfx950 -O3
+// -ffp-contract=off).  No PyOpenCL, no CUDA compatibility layer, no Triton.
+//
+// Kernel inventory (all HBM-bandwidth-bound streaming kernels; roofline and bytes in DESIGN.md):
+//   k_newton              NewtonianKinematicsStep.run                 physicl/newton.py:10-16
+//   k_delete_flags        light_scatter_step_del / "test"             physicl/light.py:146-158, 239-249
+//   k_sphere<E>           light_scatter_step_sphere                   physicl/light.py:303-315
+//   k_scatter<E>          fused ScatterIsotropicStep.__run_cl         physicl/light.py:281-331
+//   k_delete_mask         delete-flag kernel -> wave64 ballot masks   physicl/light.py:239-249
+//   k_tile_scan           exclusive scan of per-tile survivor counts
+//   k_compact<NF>         stable compaction of the SoA state          physicl/light.py:258-260,
+//                                                                      physicl/__init__.py:455-459
+//   k_counters            ScatterSignMeasureStep / ScatterMeasureStep physicl/light.py:374-431
+//   k_fill_photons        generate_photons (bulk, on device)          physicl/light.py:112-128
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/physicl_hip.h"
+#include "pcl_device.h"
+#include "pcl_rtc_source.inc" // generated: static const char pcl_rtc_source[] = <text of pcl_device.h>
+
+namespace {
+
+// =================================================================================================
+// errors
+// =================================================================================================
+thread_local std::string g_err = "";
+
+int fail(int code, const char *fmt, ...) {
+    char buf[4096];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define PCL_HIP(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e__ = (expr);                                                                           \
+        if (e__ != hipSuccess)                                                                             \
+            return fail(e__ == hipErrorOutOfMemory ? PCL_ERR_NOMEM : PCL_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e__), __FILE__, __LINE__);                                \
+    } while (0)
+
+#define PCL_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != PCL_OK) return rc__; \
+    } while (0)
+
+// =================================================================================================
+// geometry
+// =================================================================================================
+constexpr int kBlock = 256;               // 4 wave64 per workgroup
+constexpr int kTileRows = 32;             // compaction tile = 32 rows of 64 particles
+constexpr int kTile = kTileRows * 64;     // 2048 particles: one workgroup, 8 rows per wave
+constexpr int kCounterSlots = 32;
+
+__host__ __device__ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// =================================================================================================
+// kernels
+// =================================================================================================
+
+// ---- NewtonianKinematicsStep.run: dr = v*dt (rounded, STORED), r = r + dr   newton.py:15-16 -----
+// 96 B per particle-step (6 loads + 6 stores of 8 B).  Each lane moves 16 B per access (two
+// consecutive particles) when the particle count allows; unfused mul/add so results are bit-exact.
+struct newton_args {
+    const double *v[3];
+    double *r[3];
+    double *dr[3];
+    double dt;
+    int64_t N;
+};
+
+__global__ void __launch_bounds__(kBlock) k_newton(newton_args a) {
+    const int64_t npair = a.N >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
+        double2 v[3], r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = reinterpret_cast<const double2 *>(a.v[k])[p];
+            r[k] = reinterpret_cast<const double2 *>(a.r[k])[p];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double2 d;
+            d.x = __dmul_rn(v[k].x, a.dt);
+            d.y = __dmul_rn(v[k].y, a.dt);
+            r[k].x = __dadd_rn(r[k].x, d.x);
+            r[k].y = __dadd_rn(r[k].y, d.y);
+            reinterpret_cast<double2 *>(a.dr[k])[p] = d;
+            reinterpret_cast<double2 *>(a.r[k])[p] = r[k];
+        }
+    }
+    if ((a.N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = a.N - 1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double d = __dmul_rn(a.v[k][i], a.dt);
+            a.dr[k][i] = d;
+            a.r[k][i] = __dadd_rn(a.r[k][i], d);
+        }
+    }
+}
+
+// ---- delete-flag kernel (Level 1): result = (A*n*norm >= rand) ? 1 : 0   light.py:146-158 -------
+__global__ void __launch_bounds__(kBlock) k_delete_flags(const double *__restrict__ d0, const double *__restrict__ d1,
+                                                         const double *__restrict__ d2,
+                                                         const double *__restrict__ rand, double A, double n,
+                                                         int32_t *__restrict__ res, int64_t N) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double An = __dmul_rn(A, n);
+    for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < N; gid += stride) {
+        const double pcoll = __dmul_rn(An, pcl_step_norm(d0[gid], d1[gid], d2[gid]));
+        res[gid] = (pcoll >= rand[gid]) ? 1 : 0;
+    }
+}
+
+// ---- Level 1 sphere kernel + Level 2 fused scatter: ahead-of-time variants (constant n) ----------
+template <bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_sphere(pcl_sphere_args a) {
+    pcl_sphere_body<USE_E, false>(a);
+}
+template <bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args a) {
+    pcl_scatter_body<USE_E, false>(a);
+}
+
+// ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
+// One workgroup per 2048-particle tile; wave w owns rows 8w..8w+7 (64 consecutive particles per
+// row, lane == particle so the ballot bit order IS the particle order -> stable compaction).
+struct delmask_args {
+    const double *d0, *d1, *d2;
+    const double *rand;          // PCL_RNG_INPUT
+    const int64_t *ids;          // PCL_RNG_PHILOX with materialised ids, else NULL
+    const unsigned char *kind;   // NULL = all photons
+    const int32_t *flags_in;     // when non-NULL: take flags from memory instead (pcl_k_compact_indices)
+    uint64_t *masks;             // [n_tiles * 32] bit l of row mask = particle survives
+    int32_t *tile_keep;          // [n_tiles]
+    int64_t id_base, N;
+    double An;                   // A * n, rounded once like the kernel's left-to-right product
+    uint64_t seed;
+    uint32_t step;
+    int rng_mode;
+};
+
+__global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args a) {
+    __shared__ int s_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    int kept = 0;
+#pragma unroll 4
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        bool keep = false;
+        if (i < a.N) {
+            if (a.flags_in) {
+                keep = (a.flags_in[i] == 0);
+            } else {
+                const bool photon = a.kind ? (a.kind[i] != 0) : true;
+                const double pcoll = __dmul_rn(a.An, pcl_step_norm(a.d0[i], a.d1[i], a.d2[i]));
+                double rand;
+                if (a.rng_mode == PCL_RNG_PHX) {
+                    const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u,
+                                                          (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                    rand = pcl_u53(w.x, w.y);
+                } else {
+                    rand = a.rand[i];
+                }
+                keep = !(photon && (pcoll >= rand));
+            }
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) a.masks[tile * kTileRows + row] = m;
+        kept += __popcll(m);
+    }
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ---- delete step, pass 2: exclusive scan of the per-tile counts (one workgroup) ------------------
+__global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ tile_keep, int64_t n_tiles,
+                                                    int64_t *__restrict__ tile_off, int64_t *__restrict__ total) {
+    __shared__ int64_t s_wave[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t per = div_up(n_tiles, 1024);
+    const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+    int64_t sum = 0;
+    for (int64_t k = lo; k < hi; ++k) sum += tile_keep[k];
+    // inclusive scan of the 1024 partial sums: wave shuffle scan, then scan of the 16 wave totals
+    int64_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int64_t up = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += up;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        int64_t w = lane < 16 ? s_wave[lane] : 0;
+        for (int off = 1; off < 16; off <<= 1) {
+            const int64_t up = __shfl_up(w, off, 64);
+            if (lane >= off) w += up;
+        }
+        if (lane < 16) s_wave[lane] = w; // inclusive wave totals
+    }
+    __syncthreads();
+    int64_t run = (wave ? s_wave[wave - 1] : 0) + inc - sum; // exclusive prefix of this thread's chunk
+    for (int64_t k = lo; k < hi; ++k) {
+        tile_off[k] = run;
+        run += tile_keep[k];
+    }
+    if (t == 1023) *total = s_wave[15];
+}
+
+// ---- delete step, pass 3: stable compaction of NF 8-byte arrays (+ optional kind bytes) ----------
+// Reads: 1 bit of mask per particle + the survivors' state; writes the survivors densely, in order.
+constexpr int kMaxCompactFields = 16;
+struct compact_args {
+    const uint64_t *src[kMaxCompactFields];
+    uint64_t *dst[kMaxCompactFields];
+    const unsigned char *ksrc;
+    unsigned char *kdst;
+    int64_t *ids_dst;      // non-NULL with ids_src == NULL: write id_base + i (ids were implicit)
+    const int64_t *ids_src;
+    int64_t *idx_dst;      // non-NULL: write the source index i (pcl_k_compact_indices)
+    const uint64_t *masks;
+    const int64_t *tile_off;
+    int64_t id_base, N;
+};
+
+template <int NF>
+__global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const uint64_t *tm = a.masks + tile * kTileRows;
+    int64_t dest = a.tile_off[tile];
+    for (int r = 0; r < wave * (kTileRows / 4); ++r) dest += __popcll(tm[r]); // rows owned by earlier waves
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll 2
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const uint64_t m = tm[row];
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        if ((m >> lane) & 1ull) {
+            const int64_t o = dest + __popcll(m & below);
+            uint64_t val[NF > 0 ? NF : 1];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) val[f] = a.src[f][i];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) a.dst[f][o] = val[f];
+            if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
+            if (a.kdst) a.kdst[o] = a.ksrc[i];
+            if (a.idx_dst) a.idx_dst[o] = i;
+        }
+        dest += __popcll(m);
+    }
+}
+
+// expand the keep-masks of the last delete back into the reference's int32 ``res`` array
+__global__ void __launch_bounds__(kBlock) k_masks_to_flags(const uint64_t *__restrict__ masks,
+                                                           int32_t *__restrict__ flags, int64_t N) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+        flags[i] = ((masks[i >> 6] >> (i & 63)) & 1ull) ? 0 : 1;
+}
+
+// ---- counters: sign counts + plane crossings, LDS-staged, one atomic per workgroup per counter ---
+struct counter_args {
+    const double *v[3], *r[3], *dr[3];
+    uint64_t *out; // [3 + n_planes]
+    double plane_L[PCL_MAX_PLANES];
+    int plane_ax[PCL_MAX_PLANES];
+    int n_planes;
+    int64_t N;
+};
+
+__global__ void __launch_bounds__(kBlock) k_counters(counter_args a) {
+    __shared__ uint32_t s_part[kBlock / 64][3 + PCL_MAX_PLANES];
+    uint32_t cnt[3 + PCL_MAX_PLANES];
+#pragma unroll
+    for (int k = 0; k < 3 + PCL_MAX_PLANES; ++k) cnt[k] = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
+        cnt[0] += a.v[0][i] > 0.0; // strictly positive: "Do we count 0 as positive? No" light.py:415
+        cnt[1] += a.v[1][i] > 0.0;
+        cnt[2] += a.v[2][i] > 0.0;
+#pragma unroll
+        for (int p = 0; p < PCL_MAX_PLANES; ++p) {
+            if (p < a.n_planes) {
+                const int ax = a.plane_ax[p];
+                const double L = a.plane_L[p], x = a.r[ax][i], prev = __dsub_rn(x, a.dr[ax][i]);
+                cnt[3 + p] += ((prev <= L && L <= x) || (prev >= L && L >= x)); // light.py:386
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3 + PCL_MAX_PLANES; ++k) {
+        uint32_t x = cnt[k];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) s_part[wave][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 + a.n_planes) {
+        const int k = threadIdx.x;
+        const uint64_t tot = (uint64_t)s_part[0][k] + s_part[1][k] + s_part[2][k] + s_part[3][k];
+        if (tot) atomicAdd(&a.out[k], (unsigned long long)tot);
+    }
+}
+
+// ---- bulk photon creation --------------------------------------------------------------------------
+struct fill_args {
+    double *f[PCL_NFIELDS];
+    int64_t n, id_base;
+    double c, e_min, e_max;
+    uint64_t seed;
+};
+
+__global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const uint64_t id = (uint64_t)(a.id_base + i);
+        const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), 0xFFFFFFFFu, 2u, (pcl_u32)a.seed,
+                                              (pcl_u32)(a.seed >> 32));
+        const double u = pcl_u53(w.x, w.y);
+        const double E = __dadd_rn(a.e_min, __dmul_rn(__dsub_rn(a.e_max, a.e_min), pow(u, 1.0 / 3.0)));
+#pragma unroll
+        for (int f = 0; f < PCL_NFIELDS; ++f) {
+            double val = 0.0;
+            if (f == PCL_V0) val = a.c;
+            if (f == PCL_E) val = E;
+            a.f[f][i] = val;
+        }
+    }
+}
+
+// =================================================================================================
+// expression validator (variable_n_fn): keeps arbitrary text out of the hipRTC compile and keeps
+// every array read at index [gid] so a user expression cannot fault the GPU.
+// =================================================================================================
+const char *const kFuncs[] = {"exp", "sqrt", "pow", "log", "log2", "log10", "exp2", "sin",
+                              "cos", "tanh", "fabs", "fmin", "fmax", nullptr};
+const char *const kArrays[] = {"r0", "r1", "r2", "d0", "d1", "d2", "E", nullptr};
+
+bool in_list(const std::string &s, const char *const *list) {
+    for (; *list; ++list)
+        if (s == *list) return true;
+    return false;
+}
+
+int validate_expr(const char *e) {
+    if (!e) return fail(PCL_ERR_EXPR, "variable_n_fn is NULL");
+    const size_t len = strlen(e);
+    if (len == 0 || len > 2000) return fail(PCL_ERR_EXPR, "variable_n_fn is empty or longer than 2000 characters");
+    size_t i = 0;
+    int depth = 0;
+    auto skip_ws = [&]() {
+        while (i < len && (e[i] == ' ' || e[i] == '\t' || e[i] == '\n')) ++i;
+    };
+    while (true) {
+        skip_ws();
+        if (i >= len) break;
+        const char ch = e[i];
+        if ((ch >= '0' && ch <= '9') || ch == '.') {
+            // number: digits [. digits] [e|E [+-] digits] [f|F not allowed: reference is fp64-only]
+            size_t j = i;
+            while (j < len && ((e[j] >= '0' && e[j] <= '9') || e[j] == '.')) ++j;
+            if (j < len && (e[j] == 'e' || e[j] == 'E')) {
+                size_t k = j + 1;
+                if (k < len && (e[k] == '+' || e[k] == '-')) ++k;
+                if (k >= len || e[k] < '0' || e[k] > '9')
+                    return fail(PCL_ERR_EXPR, "variable_n_fn: malformed exponent at offset %zu", j);
+                while (k < len && e[k] >= '0' && e[k] <= '9') ++k;
+                j = k;
+            }
+            if (j < len && ((e[j] >= 'a' && e[j] <= 'z') || (e[j] >= 'A' && e[j] <= 'Z') || e[j] == '_'))
+                return fail(PCL_ERR_EXPR, "variable_n_fn: number followed by '%c' at offset %zu", e[j], j);
+            i = j;
+        } else if ((ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch == '_') {
+            size_t j = i;
+            while (j < len && ((e[j] >= 'a' && e[j] <= 'z') || (e[j] >= 'A' && e[j] <= 'Z') ||
+                               (e[j] >= '0' && e[j] <= '9') || e[j] == '_'))
+                ++j;
+            const std::string id(e + i, j - i);
+            i = j;
+            if (in_list(id, kFuncs)) {
+                skip_ws();
+                if (i >= len || e[i] != '(')
+                    return fail(PCL_ERR_EXPR, "variable_n_fn: function '%s' must be called", id.c_str());
+            } else if (in_list(id, kArrays)) {
+                // must be exactly  name [ gid ]
+                skip_ws();
+                if (i >= len || e[i] != '[') return fail(PCL_ERR_EXPR, "variable_n_fn: '%s' must be indexed as %s[gid]", id.c_str(), id.c_str());
+                ++i;
+                skip_ws();
+                if (len - i < 3 || strncmp(e + i, "gid", 3) != 0)
+                    return fail(PCL_ERR_EXPR, "variable_n_fn: only the index [gid] is allowed on '%s'", id.c_str());
+                i += 3;
+                skip_ws();
+                if (i >= len || e[i] != ']') return fail(PCL_ERR_EXPR, "variable_n_fn: only the index [gid] is allowed on '%s'", id.c_str());
+                ++i;
+            } else {
+                return fail(PCL_ERR_EXPR, "variable_n_fn: identifier '%s' is not allowed", id.c_str());
+            }
+        } else if (ch == '(') {
+            ++depth;
+            ++i;
+        } else if (ch == ')') {
+            if (--depth < 0) return fail(PCL_ERR_EXPR, "variable_n_fn: unbalanced ')' at offset %zu", i);
+            ++i;
+        } else if (ch == '+' || ch == '-' || ch == '*' || ch == '/' || ch == ',') {
+            ++i;
+        } else {
+            return fail(PCL_ERR_EXPR, "variable_n_fn: character '%c' at offset %zu is not allowed", ch, i);
+        }
+    }
+    if (depth != 0) return fail(PCL_ERR_EXPR, "variable_n_fn: unbalanced '('");
+    return PCL_OK;
+}
+
+// =================================================================================================
+// context
+// =================================================================================================
+struct rtc_entry {
+    hipModule_t module = nullptr;
+    hipFunction_t sphere[2] = {nullptr, nullptr};  // [USE_E]
+    hipFunction_t scatter[2] = {nullptr, nullptr}; // [USE_E]
+};
+
+} // namespace
+
+struct pcl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipDeviceProp_t prop;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int grid_cap = 2048; // workgroups for grid-stride kernels: 8 per CU
+
+    // particle store
+    int64_t capacity = 0, count = 0, id_base = 0;
+    bool ids_iota = true;
+    double *field[PCL_NFIELDS] = {};
+    double *field_alt[PCL_NFIELDS] = {}; // compaction double buffer (lazy)
+    int64_t *ids = nullptr, *ids_alt = nullptr;
+    unsigned char *kind = nullptr, *kind_alt = nullptr;
+    double *rnd[3] = {nullptr, nullptr, nullptr};
+    int64_t rnd_n[3] = {0, 0, 0};
+
+    // compaction scratch (sized for scratch_cap particles)
+    int64_t scratch_cap = 0;
+    uint64_t *masks = nullptr;
+    int32_t *tile_keep = nullptr;
+    int64_t *tile_off = nullptr;
+    int64_t last_delete_n = -1;
+
+    // counters: device slots + pinned host mirror
+    uint64_t *d_cnt = nullptr;
+    uint64_t *h_cnt = nullptr;
+
+    std::map<std::string, rtc_entry> rtc;
+};
+
+namespace {
+
+int bind(pcl_ctx *ctx) {
+    if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
+    PCL_HIP(hipSetDevice(ctx->device));
+    return PCL_OK;
+}
+
+int launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(PCL_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return PCL_OK;
+}
+
+int grid_for(const pcl_ctx *ctx, int64_t items, int per_block) {
+    int64_t g = div_up(items, per_block);
+    if (g > ctx->grid_cap) g = ctx->grid_cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <typename T>
+int dev_alloc(T **p, int64_t n) {
+    void *q = nullptr;
+    PCL_HIP(hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+    *p = static_cast<T *>(q);
+    return PCL_OK;
+}
+
+template <typename T>
+void dev_free(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int ensure_scratch(pcl_ctx *ctx, int64_t n) {
+    if (n <= ctx->scratch_cap) return PCL_OK;
+    dev_free(ctx->masks);
+    dev_free(ctx->tile_keep);
+    dev_free(ctx->tile_off);
+    ctx->scratch_cap = 0;
+    const int64_t tiles = div_up(n, kTile);
+    PCL_TRY(dev_alloc(&ctx->masks, tiles * kTileRows));
+    PCL_TRY(dev_alloc(&ctx->tile_keep, tiles));
+    PCL_TRY(dev_alloc(&ctx->tile_off, tiles));
+    ctx->scratch_cap = tiles * kTile;
+    return PCL_OK;
+}
+
+int ensure_alt(pcl_ctx *ctx) {
+    for (int f = 0; f < PCL_NFIELDS; ++f)
+        if (!ctx->field_alt[f]) PCL_TRY(dev_alloc(&ctx->field_alt[f], ctx->capacity));
+    if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
+    if (!ctx->ids_alt) PCL_TRY(dev_alloc(&ctx->ids_alt, ctx->capacity));
+    if (ctx->kind && !ctx->kind_alt) PCL_TRY(dev_alloc(&ctx->kind_alt, ctx->capacity));
+    return PCL_OK;
+}
+
+int need_store(pcl_ctx *ctx) {
+    PCL_TRY(bind(ctx));
+    if (ctx->capacity <= 0) return fail(PCL_ERR_STATE, "no particle store: call pcl_store_alloc first");
+    return PCL_OK;
+}
+
+int check_range(pcl_ctx *ctx, int64_t offset, int64_t n, const void *host) {
+    if (n < 0 || offset < 0 || offset + n > ctx->capacity)
+        return fail(PCL_ERR_ARG, "range [%lld, %lld) outside store capacity %lld", (long long)offset,
+                    (long long)(offset + n), (long long)ctx->capacity);
+    if (n > 0 && !host) return fail(PCL_ERR_ARG, "host pointer is NULL");
+    return PCL_OK;
+}
+
+// ---- hipRTC specialisation cache ---------------------------------------------------------------------
+int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
+    PCL_TRY(validate_expr(expr));
+    auto it = ctx->rtc.find(expr);
+    if (it != ctx->rtc.end()) {
+        *out = &it->second;
+        return PCL_OK;
+    }
+    std::string src = "#define PCL_RTC 1\n#define PCL_N_EXPR (";
+    src += expr;
+    src += ")\n";
+    src += pcl_rtc_source;
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(PCL_ERR_RTC, "hipRTC could not compile variable_n_fn \"%s\": %s\n%s", expr,
+                    hiprtcGetErrorString(r), log.c_str());
+    }
+    size_t code_n = 0;
+    hiprtcGetCodeSize(prog, &code_n);
+    std::vector<char> code(code_n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    rtc_entry ent;
+    PCL_HIP(hipModuleLoadData(&ent.module, code.data()));
+    PCL_HIP(hipModuleGetFunction(&ent.sphere[0], ent.module, "pcl_rtc_sphere_e0"));
+    PCL_HIP(hipModuleGetFunction(&ent.sphere[1], ent.module, "pcl_rtc_sphere_e1"));
+    PCL_HIP(hipModuleGetFunction(&ent.scatter[0], ent.module, "pcl_rtc_scatter_e0"));
+    PCL_HIP(hipModuleGetFunction(&ent.scatter[1], ent.module, "pcl_rtc_scatter_e1"));
+    auto ins = ctx->rtc.emplace(std::string(expr), ent);
+    *out = &ins.first->second;
+    return PCL_OK;
+}
+
+template <typename Args>
+int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const char *what) {
+    size_t sz = sizeof(Args);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    PCL_HIP(hipModuleLaunchKernel(fn, grid, 1, 1, kBlock, 1, 1, 0, ctx->stream, nullptr, config));
+    return launch_check(what);
+}
+
+// run passes 2 and 3 of the compaction pipeline on masks/tile_keep already produced for n particles
+int scan_tiles(pcl_ctx *ctx, int64_t n) {
+    const int64_t tiles = div_up(n, kTile);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
+                       reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1));
+    PCL_TRY(launch_check("k_tile_scan"));
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 1, ctx->d_cnt + kCounterSlots - 1, sizeof(uint64_t),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    return PCL_OK;
+}
+
+} // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int pcl_abi_version(void) { return PCL_ABI_VERSION; }
+const char *pcl_last_error(void) { return g_err.c_str(); }
+
+int pcl_device_count(int *n_out) {
+    if (!n_out) return fail(PCL_ERR_ARG, "n_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *n_out = 0;
+        return fail(PCL_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *n_out = n;
+    return PCL_OK;
+}
+
+int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
+    if (!ctx_out) return fail(PCL_ERR_ARG, "ctx_out is NULL");
+    *ctx_out = nullptr;
+    int n = 0;
+    PCL_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(PCL_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    PCL_HIP(hipSetDevice(device));
+    pcl_ctx *c = new (std::nothrow) pcl_ctx();
+    if (!c) return fail(PCL_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(PCL_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        std::string arch = c->prop.gcnArchName;
+        delete c;
+        return fail(PCL_ERR_HIP, "libphysicl_hip is built for gfx950 (MI355X) only; device %d is %s", device,
+                    arch.c_str());
+    }
+    c->grid_cap = c->prop.multiProcessorCount * 8;
+    if (stream) {
+        c->stream = static_cast<hipStream_t>(stream);
+    } else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            return fail(PCL_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+        }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess) {
+        pcl_ctx_destroy(c);
+        return fail(PCL_ERR_HIP, "context resource allocation failed");
+    }
+    memset(c->h_cnt, 0, kCounterSlots * sizeof(uint64_t));
+    *ctx_out = c;
+    return PCL_OK;
+}
+
+int pcl_ctx_destroy(pcl_ctx *ctx) {
+    if (!ctx) return PCL_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    pcl_store_free(ctx);
+    for (auto &kv : ctx->rtc)
+        if (kv.second.module) (void)hipModuleUnload(kv.second.module);
+    if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
+    if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return PCL_OK;
+}
+
+int pcl_ctx_sync(pcl_ctx *ctx) {
+    PCL_TRY(bind(ctx));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_ctx_stream(pcl_ctx *ctx, void **stream_out) {
+    if (!ctx || !stream_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *stream_out = ctx->stream;
+    return PCL_OK;
+}
+
+int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_bytes, int *n_cu, int *wavefront) {
+    if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (wavefront) *wavefront = ctx->prop.warpSize;
+    return PCL_OK;
+}
+
+int pcl_dev_alloc(pcl_ctx *ctx, int64_t bytes, void **dev_out) {
+    PCL_TRY(bind(ctx));
+    if (!dev_out || bytes < 0) return fail(PCL_ERR_ARG, "bad argument");
+    PCL_HIP(hipMalloc(dev_out, (size_t)(bytes > 0 ? bytes : 1)));
+    return PCL_OK;
+}
+
+int pcl_dev_free(pcl_ctx *ctx, void *dev) {
+    PCL_TRY(bind(ctx));
+    if (dev) {
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        PCL_HIP(hipFree(dev));
+    }
+    return PCL_OK;
+}
+
+int pcl_h2d(pcl_ctx *ctx, void *dev, const void *host, int64_t bytes) {
+    PCL_TRY(bind(ctx));
+    if (bytes < 0 || (bytes > 0 && (!dev || !host))) return fail(PCL_ERR_ARG, "bad argument");
+    if (bytes == 0) return PCL_OK;
+    // pageable host memory: hipMemcpyAsync stages it before returning, so the caller may reuse ``host``
+    PCL_HIP(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_d2h(pcl_ctx *ctx, void *host, const void *dev, int64_t bytes) {
+    PCL_TRY(bind(ctx));
+    if (bytes < 0 || (bytes > 0 && (!dev || !host))) return fail(PCL_ERR_ARG, "bad argument");
+    if (bytes == 0) return PCL_OK;
+    PCL_HIP(hipMemcpyAsync(host, dev, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_dev_memset(pcl_ctx *ctx, void *dev, int value, int64_t bytes) {
+    PCL_TRY(bind(ctx));
+    if (bytes < 0 || (bytes > 0 && !dev)) return fail(PCL_ERR_ARG, "bad argument");
+    if (bytes) PCL_HIP(hipMemsetAsync(dev, value, (size_t)bytes, ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_timer_start(pcl_ctx *ctx) {
+    PCL_TRY(bind(ctx));
+    PCL_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return PCL_OK;
+}
+
+int pcl_timer_stop(pcl_ctx *ctx, double *ms_out) {
+    PCL_TRY(bind(ctx));
+    if (!ms_out) return fail(PCL_ERR_ARG, "ms_out is NULL");
+    PCL_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    PCL_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    PCL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *ms_out = ms;
+    return PCL_OK;
+}
+
+// ------------------------------------------------------------------------------------ Level 1 ----
+int pcl_k_light_scatter_step_del(pcl_ctx *ctx, const double *dx, const double *dy, const double *dz,
+                                 const double *rand, double n, double A, int32_t *result, int64_t N) {
+    PCL_TRY(bind(ctx));
+    if (N < 0) return fail(PCL_ERR_ARG, "N < 0");
+    if (N == 0) return PCL_OK;
+    if (!dx || !dy || !dz || !rand || !result) return fail(PCL_ERR_ARG, "NULL array argument");
+    // the kernel text multiplies ``A * n * norm`` (light.py:150): (A*n) first, whatever the argument order
+    hipLaunchKernelGGL(k_delete_flags, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, dx, dy, dz, rand,
+                       A, n, result, N);
+    return launch_check("light_scatter_step_del");
+}
+
+int pcl_k_scatter_delete_test(pcl_ctx *ctx, const double *d0, const double *d1, const double *d2, const double *rand,
+                              double A, double n, int32_t *res, int64_t N) {
+    return pcl_k_light_scatter_step_del(ctx, d0, d1, d2, rand, n, A, res, N);
+}
+
+int pcl_k_light_scatter_step_sphere(pcl_ctx *ctx, const double *d0, const double *d1, const double *d2,
+                                    const double *rtheta, const double *rphi, const double *rand, double A, double n,
+                                    const double *E, const double *r0, const double *r1, const double *r2,
+                                    double *res0, double *res1, double *res2, int64_t N, int flags, double c, double h,
+                                    const char *n_expr) {
+    PCL_TRY(bind(ctx));
+    if (N < 0) return fail(PCL_ERR_ARG, "N < 0");
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent)); // compile even for N == 0 so a bad expression fails early
+    if (N == 0) return PCL_OK;
+    if (!d0 || !d1 || !d2 || !rtheta || !rphi || !rand || !res0 || !res1 || !res2)
+        return fail(PCL_ERR_ARG, "NULL array argument");
+    if (use_e && !E) return fail(PCL_ERR_ARG, "E is NULL but PCL_SCATTER_WAVELENGTH is set");
+    if (var_n && (!r0 || !r1 || !r2)) return fail(PCL_ERR_ARG, "r0..r2 NULL but PCL_SCATTER_VARIABLE_N is set");
+    pcl_sphere_args a{d0, d1, d2, rtheta, rphi, rand, A, n, E, r0, r1, r2, res0, res1, res2, N, c, h};
+    const int grid = grid_for(ctx, N, kBlock);
+    if (var_n) return launch_module(ctx, ent->sphere[use_e ? 1 : 0], grid, a, "light_scatter_step_sphere (hipRTC)");
+    if (use_e)
+        hipLaunchKernelGGL(k_sphere<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_sphere<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    return launch_check("light_scatter_step_sphere");
+}
+
+int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t *idx_out, int64_t *n_keep_out) {
+    PCL_TRY(bind(ctx));
+    if (N < 0 || !n_keep_out) return fail(PCL_ERR_ARG, "bad argument");
+    *n_keep_out = 0;
+    if (N == 0) return PCL_OK;
+    if (!flags || !idx_out) return fail(PCL_ERR_ARG, "NULL array argument");
+    PCL_TRY(ensure_scratch(ctx, N));
+    ctx->last_delete_n = -1; // scratch masks no longer describe the store
+    const int tiles = (int)div_up(N, kTile);
+    delmask_args m{};
+    m.flags_in = flags;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.N = N;
+    hipLaunchKernelGGL(k_delete_mask, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    PCL_TRY(launch_check("k_delete_mask"));
+    PCL_TRY(scan_tiles(ctx, N));
+    compact_args ca{};
+    ca.idx_dst = idx_out;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.N = N;
+    hipLaunchKernelGGL(k_compact<0>, dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    PCL_TRY(launch_check("k_compact"));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    *n_keep_out = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    return PCL_OK;
+}
+
+int pcl_expr_validate(const char *n_expr) { return validate_expr(n_expr); }
+
+// ------------------------------------------------------------------------------------ Level 2 ----
+int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity) {
+    PCL_TRY(bind(ctx));
+    if (capacity <= 0) return fail(PCL_ERR_ARG, "capacity must be positive");
+    pcl_store_free(ctx);
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        int rc = dev_alloc(&ctx->field[f], capacity);
+        if (rc != PCL_OK) {
+            std::string keep = g_err;
+            pcl_store_free(ctx);
+            g_err = keep;
+            return rc;
+        }
+    }
+    ctx->capacity = capacity;
+    ctx->count = 0;
+    ctx->id_base = 0;
+    ctx->ids_iota = true;
+    return PCL_OK;
+}
+
+int pcl_store_free(pcl_ctx *ctx) {
+    if (!ctx) return PCL_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        dev_free(ctx->field[f]);
+        dev_free(ctx->field_alt[f]);
+    }
+    dev_free(ctx->ids);
+    dev_free(ctx->ids_alt);
+    dev_free(ctx->kind);
+    dev_free(ctx->kind_alt);
+    for (int k = 0; k < 3; ++k) {
+        dev_free(ctx->rnd[k]);
+        ctx->rnd_n[k] = 0;
+    }
+    dev_free(ctx->masks);
+    dev_free(ctx->tile_keep);
+    dev_free(ctx->tile_off);
+    ctx->scratch_cap = 0;
+    ctx->capacity = ctx->count = 0;
+    ctx->last_delete_n = -1;
+    ctx->ids_iota = true;
+    return PCL_OK;
+}
+
+int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out) {
+    if (!ctx || !capacity_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *capacity_out = ctx->capacity;
+    return PCL_OK;
+}
+
+int pcl_store_count(pcl_ctx *ctx, int64_t *count_out) {
+    if (!ctx || !count_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *count_out = ctx->count;
+    return PCL_OK;
+}
+
+int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
+    PCL_TRY(need_store(ctx));
+    if (count < 0 || count > ctx->capacity) return fail(PCL_ERR_ARG, "count %lld outside [0, capacity]", (long long)count);
+    ctx->count = count;
+    ctx->id_base = id_base;
+    ctx->ids_iota = true;
+    ctx->last_delete_n = -1;
+    return PCL_OK;
+}
+
+int pcl_store_upload(pcl_ctx *ctx, int field, const double *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
+    PCL_TRY(check_range(ctx, offset, n, host));
+    return pcl_h2d(ctx, ctx->field[field] + offset, host, n * (int64_t)sizeof(double));
+}
+
+int pcl_store_download(pcl_ctx *ctx, int field, double *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
+    PCL_TRY(check_range(ctx, offset, n, host));
+    return pcl_d2h(ctx, host, ctx->field[field] + offset, n * (int64_t)sizeof(double));
+}
+
+int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    PCL_TRY(check_range(ctx, offset, n, host));
+    if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
+    ctx->ids_iota = false;
+    return pcl_h2d(ctx, ctx->ids + offset, host, n * (int64_t)sizeof(int64_t));
+}
+
+int pcl_store_download_ids(pcl_ctx *ctx, int64_t *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    PCL_TRY(check_range(ctx, offset, n, host));
+    if (ctx->ids_iota) {
+        for (int64_t i = 0; i < n; ++i) host[i] = ctx->id_base + offset + i;
+        return PCL_OK;
+    }
+    return pcl_d2h(ctx, host, ctx->ids + offset, n * (int64_t)sizeof(int64_t));
+}
+
+int pcl_store_upload_kind(pcl_ctx *ctx, const uint8_t *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    PCL_TRY(check_range(ctx, offset, n, host));
+    if (!ctx->kind) {
+        PCL_TRY(dev_alloc(&ctx->kind, ctx->capacity));
+        PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)ctx->capacity, ctx->stream));
+    }
+    return pcl_h2d(ctx, ctx->kind + offset, host, n);
+}
+
+int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    PCL_TRY(check_range(ctx, offset, n, host));
+    if (!ctx->kind) {
+        memset(host, PCL_KIND_PHOTON, (size_t)n);
+        return PCL_OK;
+    }
+    return pcl_d2h(ctx, host, ctx->kind + offset, n);
+}
+
+int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out) {
+    PCL_TRY(need_store(ctx));
+    if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
+    *dev_out = ctx->field[field];
+    return PCL_OK;
+}
+
+int pcl_store_upload_rand(pcl_ctx *ctx, int which, const double *host, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    if (which < 0 || which > 2) return fail(PCL_ERR_ARG, "which must be 0 (rtheta), 1 (rphi) or 2 (rand)");
+    PCL_TRY(check_range(ctx, 0, n, host));
+    if (!ctx->rnd[which]) PCL_TRY(dev_alloc(&ctx->rnd[which], ctx->capacity));
+    ctx->rnd_n[which] = n;
+    return pcl_h2d(ctx, ctx->rnd[which], host, n * (int64_t)sizeof(double));
+}
+
+int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max,
+                           uint64_t seed) {
+    PCL_TRY(need_store(ctx));
+    if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
+    if (n > 0) {
+        fill_args a{};
+        for (int f = 0; f < PCL_NFIELDS; ++f) a.f[f] = ctx->field[f];
+        a.n = n;
+        a.id_base = id_base;
+        a.c = c;
+        a.e_min = e_min;
+        a.e_max = e_max;
+        a.seed = seed;
+        hipLaunchKernelGGL(k_fill_photons, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_fill_photons"));
+        if (ctx->kind) PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)n, ctx->stream));
+    }
+    ctx->count = n;
+    ctx->id_base = id_base;
+    ctx->ids_iota = true;
+    ctx->last_delete_n = -1;
+    return PCL_OK;
+}
+
+int pcl_step_newton(pcl_ctx *ctx, double dt) {
+    PCL_TRY(need_store(ctx));
+    const int64_t N = ctx->count;
+    if (N == 0) return PCL_OK;
+    newton_args a{};
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = ctx->field[PCL_V0 + k];
+        a.r[k] = ctx->field[PCL_R0 + k];
+        a.dr[k] = ctx->field[PCL_DR0 + k];
+    }
+    a.dt = dt;
+    a.N = N;
+    hipLaunchKernelGGL(k_newton, dim3(grid_for(ctx, (N + 1) / 2, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    return launch_check("k_newton");
+}
+
+int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h, const char *n_expr,
+                               int rng_mode, uint64_t seed, uint32_t step, int64_t *hits_out) {
+    PCL_TRY(need_store(ctx));
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
+    const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    const int64_t N = ctx->count;
+    if (hits_out) *hits_out = 0;
+    if (N == 0) return PCL_OK;
+    if (rng_mode == PCL_RNG_INPUT)
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
+                return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
+                            (long long)N);
+    pcl_scatter_args a{};
+    a.d0 = ctx->field[PCL_DR0]; a.d1 = ctx->field[PCL_DR1]; a.d2 = ctx->field[PCL_DR2];
+    a.E = ctx->field[PCL_E];
+    a.r0 = ctx->field[PCL_R0]; a.r1 = ctx->field[PCL_R1]; a.r2 = ctx->field[PCL_R2];
+    a.v0 = ctx->field[PCL_V0]; a.v1 = ctx->field[PCL_V1]; a.v2 = ctx->field[PCL_V2];
+    a.dv0 = ctx->field[PCL_DV0]; a.dv1 = ctx->field[PCL_DV1]; a.dv2 = ctx->field[PCL_DV2];
+    a.rtheta = ctx->rnd[0]; a.rphi = ctx->rnd[1]; a.rand = ctx->rnd[2];
+    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    a.kind = ctx->kind;
+    a.hits = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    a.id_base = ctx->id_base;
+    a.N = N;
+    a.A = A; a.n = n; a.c = c; a.h = h;
+    a.seed = seed;
+    a.step = step;
+    a.rng_mode = rng_mode;
+    PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
+    const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->scatter[use_e ? 1 : 0], grid, a, "scatter_isotropic (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_scatter"));
+    }
+    if (hits_out) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        *hits_out = (int64_t)ctx->h_cnt[0];
+    }
+    return PCL_OK;
+}
+
+int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed, uint32_t step,
+                            int64_t *n_alive_out, int64_t *n_removed_out) {
+    PCL_TRY(need_store(ctx));
+    if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
+    const int64_t N = ctx->count;
+    if (n_alive_out) *n_alive_out = N;
+    if (n_removed_out) *n_removed_out = 0;
+    if (N == 0) return PCL_OK;
+    if (rng_mode == PCL_RNG_INPUT && (!ctx->rnd[2] || ctx->rnd_n[2] < N))
+        return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=2) for all %lld particles", (long long)N);
+    PCL_TRY(ensure_scratch(ctx, N));
+    PCL_TRY(ensure_alt(ctx));
+    const int tiles = (int)div_up(N, kTile);
+    delmask_args m{};
+    m.d0 = ctx->field[PCL_DR0]; m.d1 = ctx->field[PCL_DR1]; m.d2 = ctx->field[PCL_DR2];
+    m.rand = ctx->rnd[2];
+    m.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    m.kind = ctx->kind;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.id_base = ctx->id_base;
+    m.N = N;
+    m.An = A * n; // host fp64 multiply == __dmul_rn (IEEE, no contraction possible on a single product)
+    m.seed = seed;
+    m.step = step;
+    m.rng_mode = rng_mode;
+    hipLaunchKernelGGL(k_delete_mask, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    PCL_TRY(launch_check("k_delete_mask"));
+    PCL_TRY(scan_tiles(ctx, N));
+    compact_args ca{};
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        ca.src[f] = reinterpret_cast<const uint64_t *>(ctx->field[f]);
+        ca.dst[f] = reinterpret_cast<uint64_t *>(ctx->field_alt[f]);
+    }
+    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
+    ca.ids_dst = ctx->ids_alt;
+    ca.ksrc = ctx->kind;
+    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.id_base = ctx->id_base;
+    ca.N = N;
+    hipLaunchKernelGGL(k_compact<PCL_NFIELDS>, dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    PCL_TRY(launch_check("k_compact"));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (alive < 0 || alive > N) return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
+    for (int f = 0; f < PCL_NFIELDS; ++f) std::swap(ctx->field[f], ctx->field_alt[f]);
+    std::swap(ctx->ids, ctx->ids_alt);
+    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
+    ctx->ids_iota = false;
+    ctx->count = alive;
+    ctx->last_delete_n = N;
+    if (n_alive_out) *n_alive_out = alive;
+    if (n_removed_out) *n_removed_out = N - alive;
+    return PCL_OK;
+}
+
+int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    if (ctx->last_delete_n < 0) return fail(PCL_ERR_STATE, "no delete step has run since the store last changed");
+    if (n != ctx->last_delete_n || !flags_host)
+        return fail(PCL_ERR_ARG, "flags_host must hold exactly the pre-delete count %lld", (long long)ctx->last_delete_n);
+    int32_t *d = nullptr;
+    PCL_TRY(dev_alloc(&d, n));
+    hipLaunchKernelGGL(k_masks_to_flags, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->masks, d, n);
+    int rc = launch_check("k_masks_to_flags");
+    if (rc == PCL_OK) rc = pcl_d2h(ctx, flags_host, d, n * (int64_t)sizeof(int32_t));
+    (void)hipFree(d);
+    return rc;
+}
+
+int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store(ctx));
+    if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
+    if (!out_host || (n_planes > 0 && !planes_host)) return fail(PCL_ERR_ARG, "NULL argument");
+    const int64_t N = ctx->count;
+    const int nc = 3 + n_planes;
+    out_host[PCL_CNT_N] = N;
+    for (int k = 0; k < nc; ++k) out_host[1 + k] = 0;
+    if (N == 0) return PCL_OK;
+    counter_args a{};
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = ctx->field[PCL_V0 + k];
+        a.r[k] = ctx->field[PCL_R0 + k];
+        a.dr[k] = ctx->field[PCL_DR0 + k];
+    }
+    for (int p = 0; p < n_planes; ++p) {
+        // first non-NaN of x, y decides the axis, else z                            light.py:385-396
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2);
+        a.plane_ax[p] = ax;
+        a.plane_L[p] = loc[ax];
+    }
+    a.n_planes = n_planes;
+    a.N = N;
+    a.out = ctx->d_cnt + 1;
+    PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)nc * sizeof(uint64_t), ctx->stream));
+    hipLaunchKernelGGL(k_counters, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    PCL_TRY(launch_check("k_counters"));
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)nc * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < nc; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+    return PCL_OK;
+}
+
+} // extern "C"
