@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s and achieved HBM GB/s of the photon time-step hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on; weak-scaled = configs[3]):
+1e8 photons per GPU, r = 0, v = (c,0,0), E power-law between E(700 nm) and E(200 nm)
+(generate_photons default sampler, physicl/light.py:112-128), dt = 5e-3 and
+ScatterIsotropicStep(n=1e-15, A=1e-19, wavelength_dep_scattering=True, variable_n=True,
+variable_n_fn="0.000000001 * exp(r0[gid] - 5)") exactly as examples/variable_n_scattering.ipynb:30,52-56.
+One "step" = one pass of the Simulation loop body (physicl/__init__.py:512-516):
+UpdateTimeStep -> NewtonianKinematicsStep -> ScatterIsotropicStep -> ScatterSignMeasureStep counters,
+then (N > 1) an RCCL all-reduce of the counter vector [N, hits, xp, yp, zp].
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fused scatter step),
+timed with HIP event pairs recorded around every launch inside the timed region (pcl_prof_*).
+`cpu_baseline` = the oracle's C/OpenMP port of the same step timed on this box's host cores on a
+bounded sample of the same photons (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C_LIT = 299792458.0            # str(light.c)          physicl/light.py:14
+H_LIT = 6.62607015e-34         # str(light.h).upper()  physicl/light.py:15
+HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+PROFILES = {
+    # examples/variable_n_scattering.ipynb:30,52-56.  User n=1e-15, A=1e-19; the reference swaps them
+    # into the kernel (light.py:287) and in variable_n mode only the kernel's A (= user n) is live.
+    "example": dict(expr="0.000000001 * exp(r0[gid] - 5)", A_kernel=1e-15, n_kernel=1e-19, dt=5e-3,
+                    arrays_read=("d0", "d1", "d2", "E", "r0"), c_profile=(1, 0.000000001, 5.0)),
+    # atmosphere-like regime of examples/presentation_example_2.ipynb:41 (cl_n2), kernel constant chosen so
+    # that pcoll spans 0.03..1.8: the branchy partial-hit regime (SURVEY.md 8(d) "tame" profile).
+    "tame": dict(expr="2.5E+25 * exp(r2[gid] / 8600.0)", A_kernel=4.08e-56, n_kernel=1.0, dt=1e-5,
+                 arrays_read=("d0", "d1", "d2", "E", "r2"), c_profile=None),
+}
+
+
+def algorithmic_bytes_per_particle(profile, h):
+    """fp64 bytes the fused scatter kernel must move per particle-step (DESIGN.md 'Kernels'):
+    reads  dr (24) + E (8) + the position components the expression names (8 each)
+    writes dv (24, always)
+    on a hit additionally reads v_old (24) and writes v' (24)."""
+    return 8 * len(PROFILES[profile]["arrays_read"]) + 24 + 48.0 * h
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--photons", type=float, default=1e8, help="photons PER GPU (weak scaling)")
+    ap.add_argument("--profile", choices=sorted(PROFILES), default="example")
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-photons", type=float, default=1e7)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline duration")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
+                         % (args.gpus, world))
+
+    from physicl_amd import _hip
+    from physicl_amd.dist import CounterComm
+
+    comm = CounterComm.from_env(backend="nccl")          # no-op communicator when world == 1
+    N = int(args.photons)
+    prof = PROFILES[args.profile]
+    flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
+    e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9   # E_from_wavelength, light.py:39-43
+
+    dev = _hip.Device(local_rank)
+    dev.store_alloc(N)
+    dev.fill_photons(N, rank * N, C_LIT, e_lo, e_hi, args.seed)      # ids are global: shard-independent RNG
+
+    sim_t = 0.0
+    totals = None
+
+    def one_step(k):
+        nonlocal sim_t, totals
+        sim_t += prof["dt"]                                          # UpdateTimeStep   __init__.py:337-343
+        dev.step_newton(prof["dt"])                                  # newton.py:10-16
+        dev.step_scatter_isotropic(prof["A_kernel"], prof["n_kernel"], flags, C_LIT, H_LIT, prof["expr"],
+                                   _hip.RNG_PHILOX, args.seed, k, want_hits=False)   # light.py:281-331
+        cnt = dev.step_counters()                                    # light.py:414-431 (one sync)
+        local = np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
+                          cnt[_hip.CNT_ZP]], dtype=np.int64)
+        totals = comm.allreduce_sum(local)                           # RCCL over xGMI when world > 1
+        return local
+
+    for k in range(args.warmup):
+        one_step(k)
+
+    dev.prof_enable(True)
+    comm.barrier()
+    dev.sync()
+    comm.device_synchronize()
+    t0 = time.perf_counter()
+    hits_local = 0
+    for k in range(args.warmup, args.warmup + args.steps):
+        hits_local += int(one_step(k)[1])
+    dev.sync()
+    comm.device_synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = comm.allreduce_max(elapsed)
+
+    kern = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}
+    dev.prof_enable(False)
+    h_mean = hits_local / float(N * args.steps)
+    bpp = algorithmic_bytes_per_particle(args.profile, h_mean)
+    sc = kern["k_scatter"]
+    achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
+
+    out = None
+    if rank == 0:
+        total_particles = N * world
+        value = total_particles * args.steps / elapsed
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            t = json.load(open(tfile)).get("%s:%d" % (args.profile, N))
+            traffic = t.get("k_scatter_bytes_per_launch") if t else None
+        out = {
+            "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]%s: %.0e photons/GPU, variable-n + wavelength isotropic "
+                                   "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
+                                   "ScatterIsotropic (fused, Philox) + sign counters%s"
+                                   % ("/[3] weak-scaled" if world > 1 else "", N,
+                                      " + RCCL all-reduce of 5 int64 counters" if world > 1 else ""),
+                       "photons_per_gpu": N, "profile": args.profile, "variable_n_fn": prof["expr"], "dt": prof["dt"],
+                       "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "k_scatter (fused ScatterIsotropicStep, hipRTC variable-n)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
+                         "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"]},
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if v["launches"]},
+            "kernels_GBps": {
+                "k_newton": N * 96 / (kern["k_newton"]["avg_ms"] * 1e-3) / 1e9 if kern["k_newton"]["launches"] else None,
+                "k_counters": N * 24 / (kern["k_counters"]["avg_ms"] * 1e-3) / 1e9 if kern["k_counters"]["launches"] else None,
+            },
+            "counters_last_step": {"N": int(totals[0]), "hits": int(totals[1]), "xp": int(totals[2]),
+                                   "yp": int(totals[3]), "zp": int(totals[4])},
+            "device": dev.info()["name"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dev, args, prof)
+
+    dev.store_free()
+    dev.close()
+    comm.close()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def cpu_baseline(dev, args, prof):
+    """The oracle's C/OpenMP port of the same step (newton + fused scatter + sign counters) on the first
+    `cpu_photons` photons of the SAME initial workload, all host cores.  Checker code timed as a
+    baseline: never part of the GPU path."""
+    from oracle import c_oracle as co
+    if prof["c_profile"] is None:
+        return {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
+                "sample": "C port implements the example profile only"}
+    n = int(min(args.cpu_photons, args.photons))
+    # same photons as the GPU run: regenerate the initial state of ids [0, n) on the device and download it
+    dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
+    st = {g: [dev.download(f, n) for f in fids] for g, fids in
+          (("r", (0, 1, 2)), ("v", (3, 4, 5)), ("dr", (6, 7, 8)), ("dv", (9, 10, 11)))}
+    st["E"] = dev.download(12, n)
+    co.set_threads(co.usable_cores())          # the box's CPU share, not every core of the host
+    cores = co.threads()
+    profile, pk, poff = prof["c_profile"]
+
+    def step(k):
+        co.newton(st, prof["dt"])
+        co.scatter_isotropic(st, prof["A_kernel"], prof["n_kernel"], C_LIT, H_LIT, 1, profile, pk, poff, args.seed, k,
+                             ids=None, id_base=0)
+        co.counters(st)
+
+    step(0)                                   # warm-up + calibration
+    t0 = time.perf_counter()
+    step(1)
+    one = time.perf_counter() - t0
+    steps = int(max(2, min(2000, args.cpu_seconds / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for k in range(2, 2 + steps):
+        step(k)
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads, "
+                      "%.1f s)" % (n, steps, cores, el)}
+
+
+if __name__ == "__main__":
+    main()

@@ -95,8 +95,8 @@ int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_byt
                         int *wavefront);
 
 /* raw device memory for Level 1 callers: replaces cl_array.to_device / cl_array.empty / .get()
- * (physicl/__init__.py:614, 653, 662).  Copies are asynchronous on the context stream except
- * pcl_d2h, which returns after the data is in ``host``. */
+ * (physicl/__init__.py:614, 653, 662).  Copies are ordered on the context stream and return when
+ * the host buffer may be reused (pcl_h2d) or holds the data (pcl_d2h). */
 int pcl_dev_alloc(pcl_ctx *ctx, int64_t bytes, void **dev_out);
 int pcl_dev_free(pcl_ctx *ctx, void *dev);
 int pcl_h2d(pcl_ctx *ctx, void *dev, const void *host, int64_t bytes);
@@ -106,6 +106,19 @@ int pcl_dev_memset(pcl_ctx *ctx, void *dev, int value, int64_t bytes);
 /* stream timing with HIP events (bench.py): *ms_out = device time between the two records. */
 int pcl_timer_start(pcl_ctx *ctx);
 int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
+
+/* Per-kernel device timing for bench.py: while enabled, every Level-2 step records a HIP event pair
+ * on the context stream immediately around its kernel launch (no host synchronisation).
+ * pcl_prof_enable(ctx, 1) clears earlier samples; pcl_prof_read synchronises and sums the samples of
+ * one kernel.  Host pointers, any may be NULL. */
+#define PCL_PROF_NEWTON      0 /* k_newton                         */
+#define PCL_PROF_SCATTER     1 /* k_scatter / hipRTC specialisation */
+#define PCL_PROF_DELETE_MASK 2 /* k_delete_mask                    */
+#define PCL_PROF_COMPACT     3 /* k_compact                        */
+#define PCL_PROF_COUNTERS    4 /* k_counters                       */
+int pcl_prof_enable(pcl_ctx *ctx, int on);
+int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out,
+                  double *min_ms_out, double *max_ms_out);
 
 /* ---------------------------------------------------------------- Level 1: reference-ABI kernels
  * Argument ORDER and meaning follow the OpenCL kernels exactly; N is the global work size.        */
@@ -186,6 +199,10 @@ int pcl_step_newton(pcl_ctx *ctx, double dt);
 int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h,
                                const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                                int64_t *hits_out);
+
+/* Hit count of the most recent pcl_step_scatter_isotropic (host pointer).  Free of extra
+ * synchronisation when a pcl_step_counters call has completed since that step. */
+int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out);
 
 /* ScatterDeleteStep.run (physicl/light.py:231-260) fused: flag kernel + stable compaction of every
  * state array.  Non-photon particles are never removed.  Outputs are host pointers (may be NULL);

@@ -19,6 +19,9 @@ RNG_INPUT, RNG_PHILOX = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
+PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS = range(5)
+PROF_NAMES = {PROF_NEWTON: "k_newton", PROF_SCATTER: "k_scatter", PROF_DELETE_MASK: "k_delete_mask",
+              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters"}
 ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
              -6: "PCL_ERR_NOMEM"}
 
@@ -52,6 +55,8 @@ _PROTOTYPES = {
     "pcl_h2d": [_vp, _vp, _vp, c_int64],
     "pcl_d2h": [_vp, _vp, _vp, c_int64],
     "pcl_dev_memset": [_vp, _vp, c_int, c_int64],
+    "pcl_prof_enable": [_vp, c_int],
+    "pcl_prof_read": [_vp, c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double), POINTER(c_double)],
     "pcl_timer_start": [_vp],
     "pcl_timer_stop": [_vp, POINTER(c_double)],
     "pcl_k_light_scatter_step_del": [_vp, _vp, _vp, _vp, _vp, c_double, c_double, _vp, c_int64],
@@ -77,6 +82,7 @@ _PROTOTYPES = {
     "pcl_step_newton": [_vp, c_double],
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
+    "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
                                 POINTER(c_int64)],
     "pcl_store_last_delete_flags": [_vp, _vp, c_int64],
@@ -209,6 +215,15 @@ class Device:
         check(self.lib.pcl_timer_stop(self.ctx, byref(ms)))
         return ms.value
 
+    def prof_enable(self, on=True):
+        check(self.lib.pcl_prof_enable(self.ctx, 1 if on else 0))
+
+    def prof_read(self, kernel_id):
+        n, tot, mn, mx = c_int64(), c_double(), c_double(), c_double()
+        check(self.lib.pcl_prof_read(self.ctx, kernel_id, byref(n), byref(tot), byref(mn), byref(mx)))
+        return {"launches": n.value, "total_ms": tot.value, "min_ms": mn.value, "max_ms": mx.value,
+                "avg_ms": tot.value / n.value if n.value else 0.0}
+
     # ---------------------------------------------------------------- Level 1 (reference-ABI kernels)
     def array(self, host, dtype=np.float64):
         return DeviceArray.from_host(self, host, dtype)
@@ -333,6 +348,11 @@ class Device:
             n_expr.encode() if n_expr is not None else None, int(rng_mode), int(seed), int(step) & 0xFFFFFFFF,
             byref(hits) if want_hits else None))
         return hits.value if want_hits else None
+
+    def last_scatter_hits(self):
+        h = c_int64()
+        check(self.lib.pcl_store_last_scatter_hits(self.ctx, byref(h)))
+        return h.value
 
     def step_scatter_delete(self, A, n, rng_mode=RNG_PHILOX, seed=0, step=0):
         alive, removed = c_int64(), c_int64()

@@ -474,8 +474,18 @@ struct pcl_ctx {
     // counters: device slots + pinned host mirror
     uint64_t *d_cnt = nullptr;
     uint64_t *h_cnt = nullptr;
+    bool hits_on_host = true; // h_cnt[0] holds the hit count of the most recent scatter step
 
     std::map<std::string, rtc_entry> rtc;
+
+    // per-kernel HIP-event timing (pcl_prof_*): pairs recorded immediately around each launch
+    struct prof_slot {
+        hipEvent_t a, b;
+        int kid;
+    };
+    std::vector<prof_slot> prof;
+    size_t prof_used = 0;
+    bool prof_on = false;
 };
 
 namespace {
@@ -593,6 +603,26 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     return PCL_OK;
 }
 
+constexpr size_t kProfMax = 16384;
+
+// record the start event of a timed launch; returns the slot or -1 when profiling is off / full
+int prof_begin(pcl_ctx *ctx, int kid) {
+    if (!ctx->prof_on || ctx->prof_used >= kProfMax) return -1;
+    if (ctx->prof_used == ctx->prof.size()) {
+        pcl_ctx::prof_slot s{nullptr, nullptr, kid};
+        if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return -1;
+        ctx->prof.push_back(s);
+    }
+    const int i = (int)ctx->prof_used++;
+    ctx->prof[i].kid = kid;
+    (void)hipEventRecord(ctx->prof[i].a, ctx->stream);
+    return i;
+}
+
+void prof_end(pcl_ctx *ctx, int slot) {
+    if (slot >= 0) (void)hipEventRecord(ctx->prof[slot].b, ctx->stream);
+}
+
 template <typename Args>
 int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const char *what) {
     size_t sz = sizeof(Args);
@@ -673,6 +703,7 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
         return fail(PCL_ERR_HIP, "context resource allocation failed");
     }
     memset(c->h_cnt, 0, kCounterSlots * sizeof(uint64_t));
+    (void)hipMemset(c->d_cnt, 0, kCounterSlots * sizeof(uint64_t));
     *ctx_out = c;
     return PCL_OK;
 }
@@ -686,6 +717,10 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
         if (kv.second.module) (void)hipModuleUnload(kv.second.module);
     if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    for (auto &p : ctx->prof) {
+        if (p.a) (void)hipEventDestroy(p.a);
+        if (p.b) (void)hipEventDestroy(p.b);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -770,6 +805,36 @@ int pcl_timer_stop(pcl_ctx *ctx, double *ms_out) {
     float ms = 0.f;
     PCL_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *ms_out = ms;
+    return PCL_OK;
+}
+
+int pcl_prof_enable(pcl_ctx *ctx, int on) {
+    PCL_TRY(bind(ctx));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->prof_on = on != 0;
+    ctx->prof_used = 0;
+    return PCL_OK;
+}
+
+int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out, double *min_ms_out,
+                  double *max_ms_out) {
+    PCL_TRY(bind(ctx));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t n = 0;
+    double tot = 0.0, mn = 0.0, mx = 0.0;
+    for (size_t i = 0; i < ctx->prof_used; ++i) {
+        if (ctx->prof[i].kid != kernel_id) continue;
+        float ms = 0.f;
+        PCL_HIP(hipEventElapsedTime(&ms, ctx->prof[i].a, ctx->prof[i].b));
+        tot += ms;
+        mn = (n == 0 || ms < mn) ? ms : mn;
+        mx = (n == 0 || ms > mx) ? ms : mx;
+        ++n;
+    }
+    if (launches_out) *launches_out = n;
+    if (total_ms_out) *total_ms_out = tot;
+    if (min_ms_out) *min_ms_out = mn;
+    if (max_ms_out) *max_ms_out = mx;
     return PCL_OK;
 }
 
@@ -1021,7 +1086,11 @@ int pcl_step_newton(pcl_ctx *ctx, double dt) {
     }
     a.dt = dt;
     a.N = N;
-    hipLaunchKernelGGL(k_newton, dim3(grid_for(ctx, (N + 1) / 2, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    {
+        const int ps__ = prof_begin(ctx, PCL_PROF_NEWTON);
+        hipLaunchKernelGGL(k_newton, dim3(grid_for(ctx, (N + 1) / 2, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+        prof_end(ctx, ps__);
+    }
     return launch_check("k_newton");
 }
 
@@ -1058,7 +1127,9 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     a.step = step;
     a.rng_mode = rng_mode;
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
+    ctx->hits_on_host = false;
     const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
+    const int ps = prof_begin(ctx, PCL_PROF_SCATTER);
     if (var_n) {
         PCL_TRY(launch_module(ctx, ent->scatter[use_e ? 1 : 0], grid, a, "scatter_isotropic (hipRTC)"));
     } else {
@@ -1068,11 +1139,25 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
             hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
         PCL_TRY(launch_check("k_scatter"));
     }
+    prof_end(ctx, ps);
     if (hits_out) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->hits_on_host = true;
         *hits_out = (int64_t)ctx->h_cnt[0];
     }
+    return PCL_OK;
+}
+
+int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
+    PCL_TRY(need_store(ctx));
+    if (!hits_out) return fail(PCL_ERR_ARG, "hits_out is NULL");
+    if (!ctx->hits_on_host) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->hits_on_host = true;
+    }
+    *hits_out = (int64_t)ctx->h_cnt[0];
     return PCL_OK;
 }
 
@@ -1102,7 +1187,9 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     m.seed = seed;
     m.step = step;
     m.rng_mode = rng_mode;
+    const int ps_mask = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     hipLaunchKernelGGL(k_delete_mask, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    prof_end(ctx, ps_mask);
     PCL_TRY(launch_check("k_delete_mask"));
     PCL_TRY(scan_tiles(ctx, N));
     compact_args ca{};
@@ -1118,7 +1205,9 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     ca.tile_off = ctx->tile_off;
     ca.id_base = ctx->id_base;
     ca.N = N;
+    const int ps_cmp = prof_begin(ctx, PCL_PROF_COMPACT);
     hipLaunchKernelGGL(k_compact<PCL_NFIELDS>, dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    prof_end(ctx, ps_cmp);
     PCL_TRY(launch_check("k_compact"));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
@@ -1174,10 +1263,14 @@ int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int
     a.N = N;
     a.out = ctx->d_cnt + 1;
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)nc * sizeof(uint64_t), ctx->stream));
+    const int ps = prof_begin(ctx, PCL_PROF_COUNTERS);
     hipLaunchKernelGGL(k_counters, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
     PCL_TRY(launch_check("k_counters"));
-    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)nc * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    // slot 0 (hits of the last scatter step) rides along, so reading it later costs no extra sync
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(1 + nc) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->hits_on_host = true;
     for (int k = 0; k < nc; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
     return PCL_OK;
 }
