@@ -46,11 +46,14 @@ PROFILES = {
 }
 
 
-def algorithmic_bytes_per_particle(profile, h):
-    """fp64 bytes the fused scatter kernel must move per particle-step (DESIGN.md 'Kernels'):
-    reads  dr (24) + E (8) + the position components the expression names (8 each)
-    writes dv (24, always)
-    on a hit additionally reads v_old (24) and writes v' (24)."""
+def algorithmic_bytes_per_particle(profile, h, mode="separate"):
+    """fp64 bytes the dominant kernel must move per particle-step (DESIGN.md 'Kernels').
+    separate (k_scatter): reads dr (24) + E (8) + the position components the expression names (8 each),
+        writes dv (24, always); a hit additionally reads v_old (24) and writes v' (24): 64 + 48h here.
+    fused (k_fused = Newton + scatter + counters): reads r (24) + v (24) + E (8); writes r (24) + dr (24) +
+        dv (24); a hit additionally writes v' (24): 152 - 24(1-h) = 128 + 24h."""
+    if mode == "fused":
+        return 128 + 24.0 * h
     return 8 * len(PROFILES[profile]["arrays_read"]) + 24 + 48.0 * h
 
 
@@ -61,6 +64,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--photons", type=float, default=1e8, help="photons PER GPU (weak scaling)")
     ap.add_argument("--profile", choices=sorted(PROFILES), default="example")
+    ap.add_argument("--mode", choices=("fused", "separate"), default="fused",
+                    help="fused: the loop body as ONE kernel (pcl_step_fused); separate: one kernel per Step")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-photons", type=float, default=1e7)
@@ -93,12 +98,19 @@ def main():
     def one_step(k):
         nonlocal sim_t, totals
         sim_t += prof["dt"]                                          # UpdateTimeStep   __init__.py:337-343
-        dev.step_newton(prof["dt"])                                  # newton.py:10-16
-        dev.step_scatter_isotropic(prof["A_kernel"], prof["n_kernel"], flags, C_LIT, H_LIT, prof["expr"],
-                                   _hip.RNG_PHILOX, args.seed, k, want_hits=False)   # light.py:281-331
-        cnt = dev.step_counters()                                    # light.py:414-431 (one sync)
-        local = np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
-                          cnt[_hip.CNT_ZP]], dtype=np.int64)
+        if args.mode == "fused":
+            # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles (one sync)
+            o = dev.step_fused(prof["dt"], dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
+                                                n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k),
+                               planes=())
+            local = np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
+        else:
+            dev.step_newton(prof["dt"])                                  # newton.py:10-16
+            dev.step_scatter_isotropic(prof["A_kernel"], prof["n_kernel"], flags, C_LIT, H_LIT, prof["expr"],
+                                       _hip.RNG_PHILOX, args.seed, k, want_hits=False)   # light.py:281-331
+            cnt = dev.step_counters()                                    # light.py:414-431 (one sync)
+            local = np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
+                              cnt[_hip.CNT_ZP]], dtype=np.int64)
         totals = comm.allreduce_sum(local)                           # RCCL over xGMI when world > 1
         return local
 
@@ -122,8 +134,9 @@ def main():
     kern = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}
     dev.prof_enable(False)
     h_mean = hits_local / float(N * args.steps)
-    bpp = algorithmic_bytes_per_particle(args.profile, h_mean)
-    sc = kern["k_scatter"]
+    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode)
+    dominant = "k_fused" if args.mode == "fused" else "k_scatter"
+    sc = kern[dominant]
     achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
 
     out = None
@@ -133,20 +146,23 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
-            t = json.load(open(tfile)).get("%s:%d" % (args.profile, N))
-            traffic = t.get("k_scatter_bytes_per_launch") if t else None
+            t = json.load(open(tfile)).get("%s:%s:%d" % (args.profile, args.mode, N))
+            traffic = t.get(dominant + "_bytes_per_launch") if t else None
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]%s: %.0e photons/GPU, variable-n + wavelength isotropic "
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
-                                   "ScatterIsotropic (fused, Philox) + sign counters%s"
+                                   "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N,
                                       " + RCCL all-reduce of 5 int64 counters" if world > 1 else ""),
-                       "photons_per_gpu": N, "profile": args.profile, "variable_n_fn": prof["expr"], "dt": prof["dt"],
+                       "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_scatter (fused ScatterIsotropicStep, hipRTC variable-n)",
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)"
+                                    if args.mode == "fused" else
+                                    "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
                          "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"]},

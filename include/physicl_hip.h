@@ -116,6 +116,7 @@ int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
 #define PCL_PROF_DELETE_MASK 2 /* k_delete_mask                    */
 #define PCL_PROF_COMPACT     3 /* k_compact                        */
 #define PCL_PROF_COUNTERS    4 /* k_counters                       */
+#define PCL_PROF_FUSED       5 /* k_fused / hipRTC specialisation  */
 int pcl_prof_enable(pcl_ctx *ctx, int on);
 int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out,
                   double *min_ms_out, double *max_ms_out);
@@ -200,7 +201,20 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
                                const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                                int64_t *hits_out);
 
-/* Hit count of the most recent pcl_step_scatter_isotropic (host pointer).  Free of extra
+/* The whole Simulation loop body in ONE kernel: NewtonianKinematicsStep, then (do_scatter != 0)
+ * ScatterIsotropicStep, then (n_planes >= 0) the counters of ScatterSignMeasureStep /
+ * ScatterMeasureStep on the post-step state -- the step order every example and test uses
+ * (test/test_light.py:32-36, physicl/__init__.py:512-516).  Per-particle arithmetic and order are
+ * those of pcl_step_newton + pcl_step_scatter_isotropic + pcl_step_counters, so results are
+ * bit-identical to calling the three; r, v, E are read once and dr is consumed from registers.
+ * Scatter parameters as pcl_step_scatter_isotropic.  n_planes = -1 switches the counters off.
+ * out_host (may be NULL = no synchronisation): int64[5 + n_planes] =
+ *   { N, xp, yp, zp, plane counts..., hits }. */
+int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, int flags, double c,
+                   double h, const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
+                   const double *planes_host, int n_planes, int64_t *out_host);
+
+/* Hit count of the most recent pcl_step_scatter_isotropic / pcl_step_fused (host pointer).  Free of extra
  * synchronisation when a pcl_step_counters call has completed since that step. */
 int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out);
 

@@ -19,9 +19,9 @@ RNG_INPUT, RNG_PHILOX = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
-PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS = range(5)
+PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED = range(6)
 PROF_NAMES = {PROF_NEWTON: "k_newton", PROF_SCATTER: "k_scatter", PROF_DELETE_MASK: "k_delete_mask",
-              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters"}
+              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused"}
 ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
              -6: "PCL_ERR_NOMEM"}
 
@@ -82,6 +82,8 @@ _PROTOTYPES = {
     "pcl_step_newton": [_vp, c_double],
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
+    "pcl_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
+                       c_uint32, _vp, c_int, _vp],
     "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
                                 POINTER(c_int64)],
@@ -348,6 +350,29 @@ class Device:
             n_expr.encode() if n_expr is not None else None, int(rng_mode), int(seed), int(step) & 0xFFFFFFFF,
             byref(hits) if want_hits else None))
         return hits.value if want_hits else None
+
+    def step_fused(self, dt, scatter=None, planes=None, sync=True):
+        """One pass: Newton, then ScatterIsotropic if ``scatter`` (dict: A, n, flags, c, h, n_expr, rng_mode,
+        seed, step), then counters if ``planes`` is not None (sequence of [x,y,z] rows, may be empty).
+        Returns {'N','sign','planes','hits'} when counters are on and sync, else None."""
+        sc = scatter or {}
+        if planes is None:
+            npl, pp, out, op = -1, None, None, None
+        else:
+            pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+            npl = len(pl)
+            pp = pl.ctypes.data_as(c_void_p) if npl else None
+            out = np.zeros(5 + npl, dtype=np.int64) if sync else None
+            op = out.ctypes.data_as(c_void_p) if sync else None
+        expr = sc.get("n_expr")
+        check(self.lib.pcl_step_fused(
+            self.ctx, float(dt), 1 if scatter else 0, float(sc.get("A", 0.0)), float(sc.get("n", 0.0)),
+            int(sc.get("flags", 0)), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
+            expr.encode() if expr is not None else None, int(sc.get("rng_mode", RNG_PHILOX)), int(sc.get("seed", 0)),
+            int(sc.get("step", 0)) & 0xFFFFFFFF, pp, npl, op))
+        if out is None:
+            return None
+        return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + npl].copy(), "hits": int(out[4 + npl])}
 
     def last_scatter_hits(self):
         h = c_int64()

@@ -237,11 +237,224 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args &a) {
     if ((threadIdx.x & 63) == 0 && my_hits) atomicAdd(a.hits, (pcl_u64)my_hits);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Level 2: ONE pass for the whole loop body  Newton -> ScatterIsotropic -> measure counters
+//   physicl/newton.py:15-16, physicl/light.py:303-315 + 325-331, physicl/light.py:385-399 + 424-426
+// Same per-particle arithmetic, in the same order, as the three separate kernels -- so results are
+// bit-identical to running them one after the other -- but r, v, E are read once and dr never
+// travels back from HBM: 128 + 24h B per particle-step instead of 96 + (64 + 48h) + 24.
+// Each lane owns two consecutive particles (16-byte loads/stores); counters are wave-ballot
+// popcounts kept in scalar registers, LDS-staged per workgroup, one atomic per workgroup per counter.
+// ------------------------------------------------------------------------------------------------
+#define PCL_MAXPL 12
+struct pcl_fused_args {
+    double *r0, *r1, *r2;       // Object.r   (read, written)
+    double *v0, *v1, *v2;       // Object.v   (read, written on hit)
+    double *dr0, *dr1, *dr2;    // Object.dr  (written)
+    double *dv0, *dv1, *dv2;    // Object.dv  (written for photons)
+    const double *E;
+    const double *rtheta, *rphi, *rand; // PCL_RNG_IN
+    const pcl_i64 *ids;
+    const unsigned char *kind;
+    pcl_u64 *cnt;               // [0] hits, [1..3] sign counts, [4..] plane crossings
+    pcl_i64 id_base;
+    pcl_i64 N;
+    double dt, A, n, c, h;
+    pcl_u64 seed;
+    pcl_u32 step;
+    int rng_mode;
+    int do_scatter;             // 0: Newton (+ counters) only
+    int n_planes;               // -1: no counters at all
+    double plane_L[PCL_MAXPL];
+    int plane_ax[PCL_MAXPL];
+};
+
+#ifdef PCL_N_EXPR
+// the expression with its array names bound to this particle's in-register values
+__device__ __forceinline__ double pcl_n_expr_val(double r0v, double r1v, double r2v, double d0v, double d1v,
+                                                 double d2v, double Ev) {
+    const double r0[1] = {r0v}, r1[1] = {r1v}, r2[1] = {r2v}, d0[1] = {d0v}, d1[1] = {d1v}, d2[1] = {d2v},
+                 E[1] = {Ev};
+    const int gid = 0;
+    (void)r0; (void)r1; (void)r2; (void)d0; (void)d1; (void)d2; (void)E; (void)gid;
+    return (double)(PCL_N_EXPR);
+}
+#endif
+
+__device__ __forceinline__ double pcl_pick(int ax, double a0, double a1, double a2) {
+    return ax == 0 ? a0 : (ax == 1 ? a1 : a2);
+}
+__device__ __forceinline__ double pcl_sel(const double2 &q, int e) { return e ? q.y : q.x; }
+__device__ __forceinline__ void pcl_put(double2 &q, int e, double x) {
+    if (e) q.y = x; else q.x = x;
+}
+
+template <bool USE_E, bool VAR_N>
+__device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
+    __shared__ pcl_u32 s_cnt[4 + PCL_MAXPL];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 4 + PCL_MAXPL) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // wave-uniform tallies (live in SGPRs): hits, sign x/y/z, plane crossings
+    pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
+    pcl_u32 w_pl[PCL_MAXPL];
+#pragma unroll
+    for (int q = 0; q < PCL_MAXPL; ++q) w_pl[q] = 0;
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const bool counters = a.n_planes >= 0;
+    const pcl_i64 npair = (a.N + 1) >> 1;
+    const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
+    // every lane of a workgroup makes the same number of trips, so ballots always see whole waves
+    for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < npair; base += stride) {
+        const pcl_i64 p = base + threadIdx.x;
+        const bool live_pair = p < npair;
+        const pcl_i64 pp = live_pair ? p : 0; // idle lanes re-read pair 0 and store nothing
+        const bool live[2] = {live_pair && 2 * p < a.N, live_pair && 2 * p + 1 < a.N};
+        double2 R[3], V[3], D[3], DV[3];
+        R[0] = reinterpret_cast<const double2 *>(a.r0)[pp];
+        R[1] = reinterpret_cast<const double2 *>(a.r1)[pp];
+        R[2] = reinterpret_cast<const double2 *>(a.r2)[pp];
+        V[0] = reinterpret_cast<const double2 *>(a.v0)[pp];
+        V[1] = reinterpret_cast<const double2 *>(a.v1)[pp];
+        V[2] = reinterpret_cast<const double2 *>(a.v2)[pp];
+        double2 Ev = make_double2(1.0, 1.0);
+        if (a.do_scatter) Ev = reinterpret_cast<const double2 *>(a.E)[pp];
+        // ---- NewtonianKinematicsStep: dr = v*dt (rounded), r = r + dr              newton.py:15-16
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            D[k].x = __dmul_rn(V[k].x, a.dt);
+            D[k].y = __dmul_rn(V[k].y, a.dt);
+            R[k].x = __dadd_rn(R[k].x, D[k].x);
+            R[k].y = __dadd_rn(R[k].y, D[k].y);
+        }
+        if (live_pair) {
+            reinterpret_cast<double2 *>(a.dr0)[p] = D[0];
+            reinterpret_cast<double2 *>(a.dr1)[p] = D[1];
+            reinterpret_cast<double2 *>(a.dr2)[p] = D[2];
+            reinterpret_cast<double2 *>(a.r0)[p] = R[0];
+            reinterpret_cast<double2 *>(a.r1)[p] = R[1];
+            reinterpret_cast<double2 *>(a.r2)[p] = R[2];
+        }
+        // ---- ScatterIsotropicStep on each of the lane's two particles              light.py:303-331
+        if (a.do_scatter) {
+            bool hit[2], photon[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const pcl_i64 i = 2 * p + e;
+                const double d0 = pcl_sel(D[0], e), d1 = pcl_sel(D[1], e), d2 = pcl_sel(D[2], e);
+                photon[e] = live[e] && (a.kind ? (a.kind[i] != 0) : true);
+                const double norm = pcl_step_norm(d0, d1, d2);
+                double pc;
+                if constexpr (VAR_N) {
+#ifdef PCL_N_EXPR
+                    pc = __dmul_rn(__dmul_rn(a.A, pcl_n_expr_val(pcl_sel(R[0], e), pcl_sel(R[1], e), pcl_sel(R[2], e),
+                                                                  d0, d1, d2, pcl_sel(Ev, e))), norm);
+#else
+                    pc = 0.0;
+#endif
+                } else {
+                    pc = __dmul_rn(__dmul_rn(a.A, a.n), norm);
+                }
+                if constexpr (USE_E) pc = __dmul_rn(pc, pcl_wavelength_term(a.h, a.c, pcl_sel(Ev, e)));
+                double rand = 0.0, rtheta = 0.0, rphi = 0.0;
+                pcl_u32 c0 = 0, c1 = 0;
+                if (photon[e]) {
+                    if (a.rng_mode == PCL_RNG_PHX) {
+                        const pcl_u64 id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
+                        c0 = (pcl_u32)id;
+                        c1 = (pcl_u32)(id >> 32);
+                        const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 0u, k0, k1);
+                        rand = pcl_u53(w.x, w.y);
+                        rtheta = __dmul_rn(__dmul_rn(pcl_u53(w.z, w.w), 2.0), PCL_PI);
+                    } else {
+                        rand = a.rand[i];
+                    }
+                }
+                hit[e] = photon[e] && (pc >= rand);
+                double n0 = 0.0, n1 = 0.0, n2 = 0.0;
+                if (hit[e]) {
+                    if (a.rng_mode == PCL_RNG_PHX) {
+                        const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 1u, k0, k1);
+                        rphi = __dmul_rn(pcl_u53(w.x, w.y), PCL_PI);
+                    } else {
+                        rtheta = a.rtheta[i];
+                        rphi = a.rphi[i];
+                    }
+                    pcl_new_velocity(a.c, rtheta, rphi, n0, n1, n2);
+                }
+                // hit: dv = v' - v_old, v = v' ; miss: dv = 0                       light.py:327-331
+                pcl_put(DV[0], e, hit[e] ? __dsub_rn(n0, pcl_sel(V[0], e)) : 0.0);
+                pcl_put(DV[1], e, hit[e] ? __dsub_rn(n1, pcl_sel(V[1], e)) : 0.0);
+                pcl_put(DV[2], e, hit[e] ? __dsub_rn(n2, pcl_sel(V[2], e)) : 0.0);
+                if (hit[e]) {
+                    pcl_put(V[0], e, n0);
+                    pcl_put(V[1], e, n1);
+                    pcl_put(V[2], e, n2);
+                }
+            }
+            // photons always get dv written; plain Objects keep theirs (light.py:283 skips them)
+            if (photon[0] && photon[1]) {
+                reinterpret_cast<double2 *>(a.dv0)[p] = DV[0];
+                reinterpret_cast<double2 *>(a.dv1)[p] = DV[1];
+                reinterpret_cast<double2 *>(a.dv2)[p] = DV[2];
+            } else {
+                if (photon[0]) { a.dv0[2 * p] = DV[0].x; a.dv1[2 * p] = DV[1].x; a.dv2[2 * p] = DV[2].x; }
+                if (photon[1]) { a.dv0[2 * p + 1] = DV[0].y; a.dv1[2 * p + 1] = DV[1].y; a.dv2[2 * p + 1] = DV[2].y; }
+            }
+            if (hit[0] && hit[1]) {
+                reinterpret_cast<double2 *>(a.v0)[p] = V[0];
+                reinterpret_cast<double2 *>(a.v1)[p] = V[1];
+                reinterpret_cast<double2 *>(a.v2)[p] = V[2];
+            } else {
+                if (hit[0]) { a.v0[2 * p] = V[0].x; a.v1[2 * p] = V[1].x; a.v2[2 * p] = V[2].x; }
+                if (hit[1]) { a.v0[2 * p + 1] = V[0].y; a.v1[2 * p + 1] = V[1].y; a.v2[2 * p + 1] = V[2].y; }
+            }
+            w_hits += (pcl_u32)__popcll(__ballot(hit[0])) + (pcl_u32)__popcll(__ballot(hit[1]));
+        }
+        // ---- measure counters on the post-step state                    light.py:424-426, 385-399
+        if (counters) {
+            w_sx += (pcl_u32)__popcll(__ballot(live[0] && V[0].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[0].y > 0.0));
+            w_sy += (pcl_u32)__popcll(__ballot(live[0] && V[1].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[1].y > 0.0));
+            w_sz += (pcl_u32)__popcll(__ballot(live[0] && V[2].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[2].y > 0.0));
+#pragma unroll
+            for (int q = 0; q < PCL_MAXPL; ++q) {
+                if (q < a.n_planes) {
+                    const int ax = a.plane_ax[q];
+                    const double L = a.plane_L[q];
+                    // by-value picks: selecting between the double2 lvalues would pin R/D in scratch
+                    const double Xx = pcl_pick(ax, R[0].x, R[1].x, R[2].x), Xy = pcl_pick(ax, R[0].y, R[1].y, R[2].y);
+                    const double px = __dsub_rn(Xx, pcl_pick(ax, D[0].x, D[1].x, D[2].x));
+                    const double py = __dsub_rn(Xy, pcl_pick(ax, D[0].y, D[1].y, D[2].y));
+                    const bool cx = live[0] && ((px <= L && L <= Xx) || (px >= L && L >= Xx));
+                    const bool cy = live[1] && ((py <= L && L <= Xy) || (py >= L && L >= Xy));
+                    w_pl[q] += (pcl_u32)__popcll(__ballot(cx)) + (pcl_u32)__popcll(__ballot(cy));
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        if (w_hits) atomicAdd(&s_cnt[0], w_hits);
+        if (counters) {
+            atomicAdd(&s_cnt[1], w_sx);
+            atomicAdd(&s_cnt[2], w_sy);
+            atomicAdd(&s_cnt[3], w_sz);
+#pragma unroll
+            for (int q = 0; q < PCL_MAXPL; ++q)
+                if (q < a.n_planes) atomicAdd(&s_cnt[4 + q], w_pl[q]);
+        }
+    }
+    __syncthreads();
+    const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
+    if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x]) atomicAdd(&a.cnt[threadIdx.x], (pcl_u64)s_cnt[threadIdx.x]);
+}
+
 #ifdef PCL_RTC
 // hipRTC translation unit: one expression, both wavelength variants of both kernels.
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_sphere_e0(pcl_sphere_args a) { pcl_sphere_body<false, true>(a); }
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_sphere_e1(pcl_sphere_args a) { pcl_sphere_body<true, true>(a); }
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_scatter_e0(pcl_scatter_args a) { pcl_scatter_body<false, true>(a); }
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_scatter_e1(pcl_scatter_args a) { pcl_scatter_body<true, true>(a); }
+extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fused_e0(pcl_fused_args a) { pcl_fused_body<false, true>(a); }
+extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fused_e1(pcl_fused_args a) { pcl_fused_body<true, true>(a); }
 #endif
 #endif // PCL_DEVICE_H

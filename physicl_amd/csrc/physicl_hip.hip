@@ -139,6 +139,11 @@ template <bool USE_E>
 __global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args a) {
     pcl_scatter_body<USE_E, false>(a);
 }
+// whole loop body in one pass: Newton -> ScatterIsotropic -> counters (pcl_device.h)
+template <bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args a) {
+    pcl_fused_body<USE_E, false>(a);
+}
 
 // ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
 // One workgroup per 2048-particle tile; wave w owns rows 8w..8w+7 (64 consecutive particles per
@@ -442,6 +447,7 @@ struct rtc_entry {
     hipModule_t module = nullptr;
     hipFunction_t sphere[2] = {nullptr, nullptr};  // [USE_E]
     hipFunction_t scatter[2] = {nullptr, nullptr}; // [USE_E]
+    hipFunction_t fused[2] = {nullptr, nullptr};   // [USE_E]
 };
 
 } // namespace
@@ -509,10 +515,13 @@ int grid_for(const pcl_ctx *ctx, int64_t items, int per_block) {
     return (int)g;
 }
 
+// Every particle array is padded to a multiple of 64 elements: the 16-byte-per-lane kernels load and
+// store whole pairs, so element N of an odd-sized store must exist (its contents are never used).
 template <typename T>
 int dev_alloc(T **p, int64_t n) {
     void *q = nullptr;
-    PCL_HIP(hipMalloc(&q, (size_t)(n > 0 ? n : 1) * sizeof(T)));
+    n = ((n > 0 ? n : 1) + 63) & ~int64_t(63);
+    PCL_HIP(hipMalloc(&q, (size_t)n * sizeof(T)));
     *p = static_cast<T *>(q);
     return PCL_OK;
 }
@@ -598,6 +607,8 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     PCL_HIP(hipModuleGetFunction(&ent.sphere[1], ent.module, "pcl_rtc_sphere_e1"));
     PCL_HIP(hipModuleGetFunction(&ent.scatter[0], ent.module, "pcl_rtc_scatter_e0"));
     PCL_HIP(hipModuleGetFunction(&ent.scatter[1], ent.module, "pcl_rtc_scatter_e1"));
+    PCL_HIP(hipModuleGetFunction(&ent.fused[0], ent.module, "pcl_rtc_fused_e0"));
+    PCL_HIP(hipModuleGetFunction(&ent.fused[1], ent.module, "pcl_rtc_fused_e1"));
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
     return PCL_OK;
@@ -1158,6 +1169,78 @@ int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
         ctx->hits_on_host = true;
     }
     *hits_out = (int64_t)ctx->h_cnt[0];
+    return PCL_OK;
+}
+
+int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, int flags, double c, double h,
+                   const char *n_expr, int rng_mode, uint64_t seed, uint32_t step, const double *planes_host,
+                   int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store(ctx));
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
+    if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
+    if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
+    if (out_host && n_planes < 0) return fail(PCL_ERR_ARG, "out_host given but counters are off (n_planes = -1)");
+    const bool use_e = do_scatter && (flags & PCL_SCATTER_WAVELENGTH), var_n = do_scatter && (flags & PCL_SCATTER_VARIABLE_N);
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    const int64_t N = ctx->count;
+    const int np = n_planes > 0 ? n_planes : 0;
+    if (out_host) {
+        out_host[0] = N;
+        for (int k = 1; k < 5 + np; ++k) out_host[k] = 0;
+    }
+    if (N == 0) return PCL_OK;
+    if (do_scatter && rng_mode == PCL_RNG_INPUT)
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
+                return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
+                            (long long)N);
+    pcl_fused_args a{};
+    a.r0 = ctx->field[PCL_R0]; a.r1 = ctx->field[PCL_R1]; a.r2 = ctx->field[PCL_R2];
+    a.v0 = ctx->field[PCL_V0]; a.v1 = ctx->field[PCL_V1]; a.v2 = ctx->field[PCL_V2];
+    a.dr0 = ctx->field[PCL_DR0]; a.dr1 = ctx->field[PCL_DR1]; a.dr2 = ctx->field[PCL_DR2];
+    a.dv0 = ctx->field[PCL_DV0]; a.dv1 = ctx->field[PCL_DV1]; a.dv2 = ctx->field[PCL_DV2];
+    a.E = ctx->field[PCL_E];
+    a.rtheta = ctx->rnd[0]; a.rphi = ctx->rnd[1]; a.rand = ctx->rnd[2];
+    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    a.kind = ctx->kind;
+    a.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    a.id_base = ctx->id_base;
+    a.N = N;
+    a.dt = dt; a.A = A; a.n = n; a.c = c; a.h = h;
+    a.seed = seed;
+    a.step = step;
+    a.rng_mode = rng_mode;
+    a.do_scatter = do_scatter ? 1 : 0;
+    a.n_planes = n_planes;
+    for (int p = 0; p < np; ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        a.plane_ax[p] = ax;
+        a.plane_L[p] = loc[ax];
+    }
+    PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, (size_t)(4 + np) * sizeof(uint64_t), ctx->stream));
+    ctx->hits_on_host = false;
+    const int grid = grid_for(ctx, (N + 1) / 2, kBlock);
+    const int ps = prof_begin(ctx, PCL_PROF_FUSED);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->fused[use_e ? 1 : 0], grid, a, "step_fused (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL(k_fused<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_fused<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_fused"));
+    }
+    prof_end(ctx, ps);
+    if (out_host) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->hits_on_host = true;
+        for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+        out_host[4 + np] = (int64_t)ctx->h_cnt[0];
+    }
     return PCL_OK;
 }
 

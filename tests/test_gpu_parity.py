@@ -496,3 +496,98 @@ def test_full_size_properties(dev, hip, N):
         assert (alive2, removed2) == (0, alive)
     finally:
         dev.store_free()
+
+
+# ============================================================================ fused loop body
+def _run_separate(d, hip, dt, sc, planes):
+    d.step_newton(dt)
+    hits = d.step_scatter_isotropic(sc["A"], sc["n"], sc["flags"], sc["c"], sc["h"], sc.get("n_expr"),
+                                    rng_mode=sc["rng_mode"], seed=sc.get("seed", 0), step=sc.get("step", 0))
+    cnt = d.step_counters(planes)
+    return hits, cnt
+
+
+@pytest.mark.parametrize("tag", ["base", "lambda", "varn", "varn_radial"])
+@pytest.mark.parametrize("N", [1, 2, 777, 200_001])
+def test_fused_step_is_bit_identical_to_separate_steps(store, hip, tag, N):
+    """pcl_step_fused == pcl_step_newton + pcl_step_scatter_isotropic + pcl_step_counters, bit for bit
+    (same device arithmetic), for every variant, odd sizes, mixed kinds and both RNG modes."""
+    cfg = ISO[tag]
+    rs = np.random.RandomState(N + 31 * len(tag))
+    init = {"r": rs.uniform(-8, 8, (N, 3)), "v": np.tile([C_LIT, 0.0, 0.0], (N, 1)),
+            "dv": rs.normal(size=(N, 3)), "E": rs.uniform(2.8e-19, 9.9e-19, N), "id_base": 1 << 34,
+            "kind": (rs.random_sample(N) < 0.9).astype(np.uint8)}
+    if tag == "base":
+        A_k, n_k, dt = 1e-3, 1e-3, 1e-3
+    elif tag == "lambda":
+        A_k, n_k, dt = 1e-15, 1e-19, 5e-3
+    elif tag == "varn":
+        A_k, n_k, dt = 1e-15, 1e-19, 1e-9
+    else:
+        A_k, n_k, dt = 0.5, 123.0, 1e-9
+    planes = [[0.5, np.nan, np.nan], [np.nan, -1.0, np.nan], [np.nan, np.nan, 2.0]]
+    results = {}
+    for mode in ("separate", "fused"):
+        for rng_mode in (hip.RNG_PHILOX, hip.RNG_INPUT):
+            d = store(N)
+            d.upload_state(init)
+            rs2 = np.random.RandomState(99)
+            log = []
+            for step in range(3):
+                sc = dict(A=A_k, n=n_k, flags=flags_of(hip, cfg), c=C_LIT, h=H_LIT, n_expr=cfg["expr"],
+                          rng_mode=rng_mode, seed=4242, step=step)
+                if rng_mode == hip.RNG_INPUT:
+                    rt, rp, ra = orc.reference_draws(N, rs2)
+                    d.upload_rand(0, rt), d.upload_rand(1, rp), d.upload_rand(2, ra)
+                if mode == "separate":
+                    hits, cnt = _run_separate(d, hip, dt, sc, planes)
+                    log.append((hits, list(cnt)))
+                else:
+                    out = d.step_fused(dt, sc, planes)
+                    log.append((out["hits"], [out["N"]] + list(out["sign"]) + list(out["planes"])))
+                    assert d.last_scatter_hits() == out["hits"]
+            results[(mode, rng_mode)] = (d.download_state(), log)
+    for rng_mode in (hip.RNG_PHILOX, hip.RNG_INPUT):
+        (sa, la), (sb, lb) = results[("separate", rng_mode)], results[("fused", rng_mode)]
+        assert la == lb
+        assert la[0][0] > 0 or N < 10
+        for f in ("r", "v", "dr", "dv"):
+            for k in range(3):
+                assert np.array_equal(sa[f][k], sb[f][k]), (f, k)
+
+
+def test_fused_newton_only_and_counters_only(store, hip):
+    N = 4099
+    rs = np.random.RandomState(8)
+    r, v = rs.normal(size=(N, 3)), rs.normal(size=(N, 3))
+    d = store(N)
+    d.upload_state({"r": r, "v": v, "dv": np.full((N, 3), 5.0), "E": np.ones(N)})
+    assert d.step_fused(0.25) is None                         # Newton only, no counters, no sync
+    out = d.step_fused(0.25, None, [[np.nan, 0.1, np.nan]])    # Newton + counters
+    rr, vv = cols(r), cols(v)
+    for _ in range(2):
+        rr, dr = orc.newton_euler(rr, vv, 0.25)
+    s = d.download_state()
+    assert np.array_equal(np.stack(s["r"], 1), np.stack(rr, 1)) and np.array_equal(np.stack(s["dr"], 1), np.stack(dr, 1))
+    assert np.all(np.stack(s["dv"], 1) == 5.0)                # untouched without a scatter step
+    assert tuple(out["sign"]) == orc.sign_counts(vv) and out["hits"] == 0 and out["N"] == N
+    assert out["planes"][0] == orc.plane_crossings(rr, dr, [np.nan, 0.1, np.nan])
+
+
+def test_fused_chain_vs_reference(golden, store, hip):
+    """Fused loop body against the reference's golden chain (same check as the unfused chain test)."""
+    z = golden("g2_iso_base")
+    N = len(z["k0_rand"])
+    d = store(N)
+    d.upload_state({"r": z["init_r"], "v": np.tile([C_LIT, 0.0, 0.0], (N, 1)), "E": z["init_E"]})
+    for k in range(int(z["K"])):
+        g = lambda nm: z["k%d_%s" % (k, nm)]
+        for w, nm in enumerate(("rtheta", "rphi", "rand")):
+            d.upload_rand(w, g(nm))
+        out = d.step_fused(float(z["dt"]), dict(A=float(g("A")), n=float(g("n")), flags=0, c=C_LIT, h=H_LIT,
+                                                 rng_mode=hip.RNG_INPUT), z["planes"])
+        s = d.download_state()
+        assert np.max(np.abs(np.stack(s["v"], 1) - g("post_v"))) <= V_ABS_TOL
+        assert out["hits"] == (~np.isnan(g("res0"))).sum()
+        assert [int(x) for x in out["planes"]] == [int(x) for x in z["measure_rows"][k][2:]]
+        assert [int(x) for x in out["sign"]] == [int(x) for x in z["sign_rows"][k][2:5]]
