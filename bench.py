@@ -50,9 +50,12 @@ def algorithmic_bytes_per_particle(profile, h, mode="separate"):
     """fp64 bytes the dominant kernel must move per particle-step (DESIGN.md 'Kernels').
     separate (k_scatter): reads dr (24) + E (8) + the position components the expression names (8 each),
         writes dv (24, always); a hit additionally reads v_old (24) and writes v' (24): 64 + 48h here.
-    fused (k_fused = Newton + scatter + counters): reads r (24) + v (24) + E (8); writes r (24) + dr (24) +
-        dv (24); a hit additionally writes v' (24): 152 - 24(1-h) = 128 + 24h."""
-    if mode == "fused":
+    fused-eager (k_fused = Newton + scatter + counters): reads r (24) + v (24) + E (8); writes r (24) +
+        dr (24) + dv (24); a hit additionally writes v' (24): 128 + 24h.
+    fused (PCL_FUSED_LAZY): dr and dv stay implicit (derivable from the v double buffer): 104, hit or miss."""
+    if mode == "fused":      # lazy: reads r (24) + v (24) + E (8); writes r (24) + v (24, double buffer)
+        return 104.0
+    if mode == "fused-eager":
         return 128 + 24.0 * h
     return 8 * len(PROFILES[profile]["arrays_read"]) + 24 + 48.0 * h
 
@@ -64,12 +67,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--photons", type=float, default=1e8, help="photons PER GPU (weak scaling)")
     ap.add_argument("--profile", choices=sorted(PROFILES), default="example")
-    ap.add_argument("--mode", choices=("fused", "separate"), default="fused",
-                    help="fused: the loop body as ONE kernel (pcl_step_fused); separate: one kernel per Step")
+    ap.add_argument("--mode", choices=("fused", "fused-eager", "separate"), default="fused",
+                    help="fused: the loop body as ONE kernel with dr/dv left implicit (pcl_step_fused, "
+                         "PCL_FUSED_LAZY); fused-eager: one kernel, dr/dv written every step; "
+                         "separate: one kernel per Step")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-photons", type=float, default=1e7)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU baseline duration")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,11 +103,11 @@ def main():
     def one_step(k):
         nonlocal sim_t, totals
         sim_t += prof["dt"]                                          # UpdateTimeStep   __init__.py:337-343
-        if args.mode == "fused":
+        if args.mode.startswith("fused"):
             # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles (one sync)
             o = dev.step_fused(prof["dt"], dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
                                                 n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k),
-                               planes=())
+                               planes=(), lazy=(args.mode == "fused"))
             local = np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
         else:
             dev.step_newton(prof["dt"])                                  # newton.py:10-16
@@ -135,7 +140,7 @@ def main():
     dev.prof_enable(False)
     h_mean = hits_local / float(N * args.steps)
     bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode)
-    dominant = "k_fused" if args.mode == "fused" else "k_scatter"
+    dominant = "k_fused" if args.mode.startswith("fused") else "k_scatter"
     sc = kern[dominant]
     achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
 
@@ -160,8 +165,9 @@ def main():
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)"
-                                    if args.mode == "fused" else
+                         "kernel": ("k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
+                                    % (", dr/dv implicit" if args.mode == "fused" else "")
+                                    if args.mode.startswith("fused") else
                                     "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,

@@ -57,6 +57,7 @@ enum pcl_field {
 /* pcl_step_scatter_isotropic / pcl_k_light_scatter_step_sphere ``flags`` */
 #define PCL_SCATTER_WAVELENGTH 1 /* wavelength_dep_scattering=True  (light.py:275, 300-301) */
 #define PCL_SCATTER_VARIABLE_N 2 /* variable_n=True                  (light.py:276, 299)     */
+#define PCL_FUSED_LAZY         4 /* pcl_step_fused only: leave dr and dv implicit (see there)  */
 
 /* where a step's three random numbers per photon come from */
 #define PCL_RNG_INPUT  0 /* arrays uploaded with pcl_store_upload_rand: the reference's contract
@@ -208,6 +209,13 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
  * those of pcl_step_newton + pcl_step_scatter_isotropic + pcl_step_counters, so results are
  * bit-identical to calling the three; r, v, E are read once and dr is consumed from registers.
  * Scatter parameters as pcl_step_scatter_isotropic.  n_planes = -1 switches the counters off.
+ * flags | PCL_FUSED_LAZY: dr and dv are NOT written by the step.  Both are pure functions of data the
+ * store keeps anyway -- dr = v_before * dt (newton.py:15) and dv = v_after - v_before, which is the
+ * reference's v' - v_old on a hit and exactly +0 on a miss (light.py:329-331) -- so the step writes
+ * the new velocities into the other half of a v double buffer (whole lines, no read-modify-write)
+ * and every later call that touches the store (download, field_ptr, any other step) first runs one
+ * materialise pass that produces bit-identical dr/dv arrays.  A chain of lazy steps never pays for
+ * the intermediate dr/dv that nothing reads: 104 B per particle-step instead of 128 + 24h.
  * out_host (may be NULL = no synchronisation): int64[5 + n_planes] =
  *   { N, xp, yp, zp, plane counts..., hits }. */
 int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, int flags, double c,

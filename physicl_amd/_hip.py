@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libphysicl_hip.so")
 # enums of include/physicl_hip.h
 R0, R1, R2, V0, V1, V2, DR0, DR1, DR2, DV0, DV1, DV2, E, NFIELDS = range(14)
 FIELD_GROUPS = {"r": (R0, R1, R2), "v": (V0, V1, V2), "dr": (DR0, DR1, DR2), "dv": (DV0, DV1, DV2)}
-SCATTER_WAVELENGTH, SCATTER_VARIABLE_N = 1, 2
+SCATTER_WAVELENGTH, SCATTER_VARIABLE_N, FUSED_LAZY = 1, 2, 4
 RNG_INPUT, RNG_PHILOX = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
@@ -351,7 +351,7 @@ class Device:
             byref(hits) if want_hits else None))
         return hits.value if want_hits else None
 
-    def step_fused(self, dt, scatter=None, planes=None, sync=True):
+    def step_fused(self, dt, scatter=None, planes=None, sync=True, lazy=False):
         """One pass: Newton, then ScatterIsotropic if ``scatter`` (dict: A, n, flags, c, h, n_expr, rng_mode,
         seed, step), then counters if ``planes`` is not None (sequence of [x,y,z] rows, may be empty).
         Returns {'N','sign','planes','hits'} when counters are on and sync, else None."""
@@ -367,7 +367,7 @@ class Device:
         expr = sc.get("n_expr")
         check(self.lib.pcl_step_fused(
             self.ctx, float(dt), 1 if scatter else 0, float(sc.get("A", 0.0)), float(sc.get("n", 0.0)),
-            int(sc.get("flags", 0)), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
+            int(sc.get("flags", 0)) | (FUSED_LAZY if lazy else 0), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
             expr.encode() if expr is not None else None, int(sc.get("rng_mode", RNG_PHILOX)), int(sc.get("seed", 0)),
             int(sc.get("step", 0)) & 0xFFFFFFFF, pp, npl, op))
         if out is None:

@@ -29,8 +29,13 @@ struct pcl_u32x4 {
 
 __device__ __forceinline__ pcl_u32x4 pcl_philox4x32_10(pcl_u32 c0, pcl_u32 c1, pcl_u32 c2, pcl_u32 c3,
                                                         pcl_u32 k0, pcl_u32 k1) {
+#ifdef PCL_ABLATE_PHILOX /* timing experiment only */
+    const int kRounds = 1;
+#else
+    const int kRounds = 10;
+#endif
 #pragma unroll
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < kRounds; ++round) {
         const pcl_u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         const pcl_u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         const pcl_u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -66,7 +71,12 @@ __device__ __forceinline__ double pcl_step_norm(double d0, double d1, double d2)
 
 // pow((h * c) / E[gid], -4)                           physicl/light.py:301
 __device__ __forceinline__ double pcl_wavelength_term(double h, double c, double E) {
+#ifdef PCL_ABLATE_POW /* timing experiment only */
+    const double x = __ddiv_rn(__dmul_rn(h, c), E), x2 = x * x;
+    return 1.0 / (x2 * x2);
+#else
     return pow(__ddiv_rn(__dmul_rn(h, c), E), -4.0);
+#endif
 }
 
 // res0 = c * sin(rtheta) * cos(rphi); res1 = c * sin(rtheta) * sin(rphi); res2 = c * cos(rtheta)
@@ -74,8 +84,12 @@ __device__ __forceinline__ double pcl_wavelength_term(double h, double c, double
 __device__ __forceinline__ void pcl_new_velocity(double c, double rtheta, double rphi, double &o0, double &o1,
                                                  double &o2) {
     double st, ct, sp, cp;
+#ifdef PCL_ABLATE_TRIG /* timing experiment only */
+    st = rtheta * 0.1; ct = 1.0 - st; sp = rphi * 0.2; cp = 1.0 - sp;
+#else
     sincos(rtheta, &st, &ct);
     sincos(rphi, &sp, &cp);
+#endif
     const double cs = __dmul_rn(c, st);
     o0 = __dmul_rn(cs, cp);
     o1 = __dmul_rn(cs, sp);
@@ -247,11 +261,35 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args &a) {
 // popcounts kept in scalar registers, LDS-staged per workgroup, one atomic per workgroup per counter.
 // ------------------------------------------------------------------------------------------------
 #define PCL_MAXPL 12
+
+// Streaming accesses of the fused pass: every byte is touched once per step, so nothing is worth
+// keeping in L2.  PCL_NT_LOADS / PCL_NT_STORES switch the nontemporal forms on.
+typedef double pcl_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 pcl_ld2(const double *base, pcl_i64 p) {
+#ifdef PCL_NT_LOADS
+    const pcl_d2 t = __builtin_nontemporal_load(reinterpret_cast<const pcl_d2 *>(base) + p);
+    return make_double2(t.x, t.y);
+#else
+    return reinterpret_cast<const double2 *>(base)[p];
+#endif
+}
+__device__ __forceinline__ void pcl_st2(double *base, pcl_i64 p, const double2 &v) {
+#ifdef PCL_NT_STORES
+    pcl_d2 t;
+    t.x = v.x;
+    t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<pcl_d2 *>(base) + p);
+#else
+    reinterpret_cast<double2 *>(base)[p] = v;
+#endif
+}
 struct pcl_fused_args {
     double *r0, *r1, *r2;       // Object.r   (read, written)
-    double *v0, *v1, *v2;       // Object.v   (read, written on hit)
-    double *dr0, *dr1, *dr2;    // Object.dr  (written)
-    double *dv0, *dv1, *dv2;    // Object.dv  (written for photons)
+    const double *vi0, *vi1, *vi2; // Object.v as the step finds it
+    double *vo0, *vo1, *vo2;    // Object.v as the step leaves it: eager = same arrays, written on a hit;
+                                // lazy = the other half of the v double buffer, always written
+    double *dr0, *dr1, *dr2;    // Object.dr  (written; not in lazy mode)
+    double *dv0, *dv1, *dv2;    // Object.dv  (written for photons; not in lazy mode)
     const double *E;
     const double *rtheta, *rphi, *rand; // PCL_RNG_IN
     const pcl_i64 *ids;
@@ -263,6 +301,7 @@ struct pcl_fused_args {
     pcl_u64 seed;
     pcl_u32 step;
     int rng_mode;
+    int lazy;                   // 1: dr/dv stay implicit (dr = v_in*dt, dv = v_out - v_in), see pcl_step_fused
     int do_scatter;             // 0: Newton (+ counters) only
     int n_planes;               // -1: no counters at all
     double plane_L[PCL_MAXPL];
@@ -297,9 +336,6 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
     __syncthreads();
     // wave-uniform tallies (live in SGPRs): hits, sign x/y/z, plane crossings
     pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
-    pcl_u32 w_pl[PCL_MAXPL];
-#pragma unroll
-    for (int q = 0; q < PCL_MAXPL; ++q) w_pl[q] = 0;
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool counters = a.n_planes >= 0;
     const pcl_i64 npair = (a.N + 1) >> 1;
@@ -311,14 +347,14 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
         const pcl_i64 pp = live_pair ? p : 0; // idle lanes re-read pair 0 and store nothing
         const bool live[2] = {live_pair && 2 * p < a.N, live_pair && 2 * p + 1 < a.N};
         double2 R[3], V[3], D[3], DV[3];
-        R[0] = reinterpret_cast<const double2 *>(a.r0)[pp];
-        R[1] = reinterpret_cast<const double2 *>(a.r1)[pp];
-        R[2] = reinterpret_cast<const double2 *>(a.r2)[pp];
-        V[0] = reinterpret_cast<const double2 *>(a.v0)[pp];
-        V[1] = reinterpret_cast<const double2 *>(a.v1)[pp];
-        V[2] = reinterpret_cast<const double2 *>(a.v2)[pp];
+        R[0] = pcl_ld2(a.r0, pp);
+        R[1] = pcl_ld2(a.r1, pp);
+        R[2] = pcl_ld2(a.r2, pp);
+        V[0] = pcl_ld2(a.vi0, pp);
+        V[1] = pcl_ld2(a.vi1, pp);
+        V[2] = pcl_ld2(a.vi2, pp);
         double2 Ev = make_double2(1.0, 1.0);
-        if (a.do_scatter) Ev = reinterpret_cast<const double2 *>(a.E)[pp];
+        if (a.do_scatter) Ev = pcl_ld2(a.E, pp);
         // ---- NewtonianKinematicsStep: dr = v*dt (rounded), r = r + dr              newton.py:15-16
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -328,12 +364,14 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
             R[k].y = __dadd_rn(R[k].y, D[k].y);
         }
         if (live_pair) {
-            reinterpret_cast<double2 *>(a.dr0)[p] = D[0];
-            reinterpret_cast<double2 *>(a.dr1)[p] = D[1];
-            reinterpret_cast<double2 *>(a.dr2)[p] = D[2];
-            reinterpret_cast<double2 *>(a.r0)[p] = R[0];
-            reinterpret_cast<double2 *>(a.r1)[p] = R[1];
-            reinterpret_cast<double2 *>(a.r2)[p] = R[2];
+            if (!a.lazy) {
+                pcl_st2(a.dr0, p, D[0]);
+                pcl_st2(a.dr1, p, D[1]);
+                pcl_st2(a.dr2, p, D[2]);
+            }
+            pcl_st2(a.r0, p, R[0]);
+            pcl_st2(a.r1, p, R[1]);
+            pcl_st2(a.r2, p, R[2]);
         }
         // ---- ScatterIsotropicStep on each of the lane's two particles              light.py:303-331
         if (a.do_scatter) {
@@ -392,22 +430,32 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
                     pcl_put(V[2], e, n2);
                 }
             }
-            // photons always get dv written; plain Objects keep theirs (light.py:283 skips them)
-            if (photon[0] && photon[1]) {
-                reinterpret_cast<double2 *>(a.dv0)[p] = DV[0];
-                reinterpret_cast<double2 *>(a.dv1)[p] = DV[1];
-                reinterpret_cast<double2 *>(a.dv2)[p] = DV[2];
+            if (a.lazy) {
+                // v double buffer: every particle's (possibly new) velocity goes to the other buffer, whole
+                // 16-byte stores; dr and dv are not written -- they stay derivable from (v_in, v_out, dt)
+                if (live_pair) {
+                    pcl_st2(a.vo0, p, V[0]);
+                    pcl_st2(a.vo1, p, V[1]);
+                    pcl_st2(a.vo2, p, V[2]);
+                }
             } else {
-                if (photon[0]) { a.dv0[2 * p] = DV[0].x; a.dv1[2 * p] = DV[1].x; a.dv2[2 * p] = DV[2].x; }
-                if (photon[1]) { a.dv0[2 * p + 1] = DV[0].y; a.dv1[2 * p + 1] = DV[1].y; a.dv2[2 * p + 1] = DV[2].y; }
-            }
-            if (hit[0] && hit[1]) {
-                reinterpret_cast<double2 *>(a.v0)[p] = V[0];
-                reinterpret_cast<double2 *>(a.v1)[p] = V[1];
-                reinterpret_cast<double2 *>(a.v2)[p] = V[2];
-            } else {
-                if (hit[0]) { a.v0[2 * p] = V[0].x; a.v1[2 * p] = V[1].x; a.v2[2 * p] = V[2].x; }
-                if (hit[1]) { a.v0[2 * p + 1] = V[0].y; a.v1[2 * p + 1] = V[1].y; a.v2[2 * p + 1] = V[2].y; }
+                // photons always get dv written; plain Objects keep theirs (light.py:283 skips them)
+                if (photon[0] && photon[1]) {
+                    pcl_st2(a.dv0, p, DV[0]);
+                    pcl_st2(a.dv1, p, DV[1]);
+                    pcl_st2(a.dv2, p, DV[2]);
+                } else {
+                    if (photon[0]) { a.dv0[2 * p] = DV[0].x; a.dv1[2 * p] = DV[1].x; a.dv2[2 * p] = DV[2].x; }
+                    if (photon[1]) { a.dv0[2 * p + 1] = DV[0].y; a.dv1[2 * p + 1] = DV[1].y; a.dv2[2 * p + 1] = DV[2].y; }
+                }
+                if (hit[0] && hit[1]) {
+                    pcl_st2(a.vo0, p, V[0]);
+                    pcl_st2(a.vo1, p, V[1]);
+                    pcl_st2(a.vo2, p, V[2]);
+                } else {
+                    if (hit[0]) { a.vo0[2 * p] = V[0].x; a.vo1[2 * p] = V[1].x; a.vo2[2 * p] = V[2].x; }
+                    if (hit[1]) { a.vo0[2 * p + 1] = V[0].y; a.vo1[2 * p + 1] = V[1].y; a.vo2[2 * p + 1] = V[2].y; }
+                }
             }
             w_hits += (pcl_u32)__popcll(__ballot(hit[0])) + (pcl_u32)__popcll(__ballot(hit[1]));
         }
@@ -416,19 +464,17 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
             w_sx += (pcl_u32)__popcll(__ballot(live[0] && V[0].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[0].y > 0.0));
             w_sy += (pcl_u32)__popcll(__ballot(live[0] && V[1].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[1].y > 0.0));
             w_sz += (pcl_u32)__popcll(__ballot(live[0] && V[2].x > 0.0)) + (pcl_u32)__popcll(__ballot(live[1] && V[2].y > 0.0));
-#pragma unroll
-            for (int q = 0; q < PCL_MAXPL; ++q) {
-                if (q < a.n_planes) {
-                    const int ax = a.plane_ax[q];
-                    const double L = a.plane_L[q];
-                    // by-value picks: selecting between the double2 lvalues would pin R/D in scratch
-                    const double Xx = pcl_pick(ax, R[0].x, R[1].x, R[2].x), Xy = pcl_pick(ax, R[0].y, R[1].y, R[2].y);
-                    const double px = __dsub_rn(Xx, pcl_pick(ax, D[0].x, D[1].x, D[2].x));
-                    const double py = __dsub_rn(Xy, pcl_pick(ax, D[0].y, D[1].y, D[2].y));
-                    const bool cx = live[0] && ((px <= L && L <= Xx) || (px >= L && L >= Xx));
-                    const bool cy = live[1] && ((py <= L && L <= Xy) || (py >= L && L >= Xy));
-                    w_pl[q] += (pcl_u32)__popcll(__ballot(cx)) + (pcl_u32)__popcll(__ballot(cy));
-                }
+            for (int q = 0; q < a.n_planes; ++q) { // rolled: planes are rare, keep their state out of registers
+                const int ax = a.plane_ax[q];
+                const double L = a.plane_L[q];
+                // by-value picks: selecting between the double2 lvalues would pin R/D in scratch
+                const double Xx = pcl_pick(ax, R[0].x, R[1].x, R[2].x), Xy = pcl_pick(ax, R[0].y, R[1].y, R[2].y);
+                const double px = __dsub_rn(Xx, pcl_pick(ax, D[0].x, D[1].x, D[2].x));
+                const double py = __dsub_rn(Xy, pcl_pick(ax, D[0].y, D[1].y, D[2].y));
+                const bool cx = live[0] && ((px <= L && L <= Xx) || (px >= L && L >= Xx));
+                const bool cy = live[1] && ((py <= L && L <= Xy) || (py >= L && L >= Xy));
+                const pcl_u32 nq = (pcl_u32)__popcll(__ballot(cx)) + (pcl_u32)__popcll(__ballot(cy));
+                if (lane == 0 && nq) atomicAdd(&s_cnt[4 + q], nq);
             }
         }
     }
@@ -438,15 +484,155 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args &a) {
             atomicAdd(&s_cnt[1], w_sx);
             atomicAdd(&s_cnt[2], w_sy);
             atomicAdd(&s_cnt[3], w_sz);
-#pragma unroll
-            for (int q = 0; q < PCL_MAXPL; ++q)
-                if (q < a.n_planes) atomicAdd(&s_cnt[4 + q], w_pl[q]);
         }
     }
     __syncthreads();
     const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
     if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x]) atomicAdd(&a.cnt[threadIdx.x], (pcl_u64)s_cnt[threadIdx.x]);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Level 2, fast path of the fused loop body: all-photon store, implicit ids (no compaction yet),
+// device RNG, dr/dv implicit (PCL_FUSED_LAZY), sign counters only.  Same arithmetic as
+// pcl_fused_body -- results are bit-identical -- with 11 instead of 22 live pointers, no
+// per-plane state, and the wavelength factor pow((h*c)/E, -4) read from the store's cache
+// (lam4[i], computed once per photon by k_lam4 with the very same device pow) instead of being
+// re-evaluated every step.  104 B per particle-step.
+// ------------------------------------------------------------------------------------------------
+struct pcl_fast_args {
+    double *r0, *r1, *r2;          // read + written
+    const double *vi0, *vi1, *vi2; // v before the step
+    double *vo0, *vo1, *vo2;       // v after the step (other half of the double buffer)
+    const double *lam4;            // pow((h*c)/E, -4) per photon            (USE_E)
+    const double *E;               // only dereferenced if the expression names E[gid]
+    pcl_u64 *cnt;                  // [0] hits, [1..3] sign counts
+    pcl_i64 id_base, N;
+    double dt, A, n, c;
+    pcl_u64 seed;
+    pcl_u32 step;
+};
+
+template <int VEC> struct pcl_vec;
+template <> struct pcl_vec<1> {
+    __device__ static __forceinline__ void ld(const double *b, pcl_i64 q, double (&o)[1]) { o[0] = b[q]; }
+    __device__ static __forceinline__ void st(double *b, pcl_i64 q, const double (&o)[1]) { b[q] = o[0]; }
+};
+template <> struct pcl_vec<2> {
+    __device__ static __forceinline__ void ld(const double *b, pcl_i64 q, double (&o)[2]) {
+        const double2 t = reinterpret_cast<const double2 *>(b)[q];
+        o[0] = t.x;
+        o[1] = t.y;
+    }
+    __device__ static __forceinline__ void st(double *b, pcl_i64 q, const double (&o)[2]) {
+        reinterpret_cast<double2 *>(b)[q] = make_double2(o[0], o[1]);
+    }
+};
+
+template <int VEC>
+struct pcl_fast_tile {
+    double R[3][VEC], V[3][VEC], L4[VEC];
+};
+
+template <bool USE_E, int VEC>
+__device__ __forceinline__ void pcl_fast_load(const pcl_fast_args &a, pcl_i64 q, pcl_fast_tile<VEC> &t) {
+    pcl_vec<VEC>::ld(a.r0, q, t.R[0]);
+    pcl_vec<VEC>::ld(a.r1, q, t.R[1]);
+    pcl_vec<VEC>::ld(a.r2, q, t.R[2]);
+    pcl_vec<VEC>::ld(a.vi0, q, t.V[0]);
+    pcl_vec<VEC>::ld(a.vi1, q, t.V[1]);
+    pcl_vec<VEC>::ld(a.vi2, q, t.V[2]);
+    if constexpr (USE_E) pcl_vec<VEC>::ld(a.lam4, q, t.L4);
+}
+
+template <bool USE_E, bool VAR_N, int VEC>
+__device__ __forceinline__ void pcl_fast_body(const pcl_fast_args &a) {
+    __shared__ pcl_u32 s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0; // wave-uniform tallies (SGPRs)
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const pcl_i64 nq = (a.N + VEC - 1) / VEC; // VEC-wide groups
+    const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
+    pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x;
+    // register double buffer: the next trip's loads are in flight while this trip computes
+    pcl_fast_tile<VEC> cur;
+    if (base < nq) pcl_fast_load<USE_E, VEC>(a, base + threadIdx.x < nq ? base + threadIdx.x : 0, cur);
+    for (; base < nq; base += stride) {
+        const pcl_i64 q = base + threadIdx.x;
+        const bool live_q = q < nq;
+#ifndef PCL_FAST_NOPIPE
+        pcl_fast_tile<VEC> nxt;
+        const pcl_i64 nb = base + stride;
+        if (nb < nq) pcl_fast_load<USE_E, VEC>(a, nb + threadIdx.x < nq ? nb + threadIdx.x : 0, nxt);
+#endif
+        bool hit[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const pcl_i64 i = q * VEC + e;
+            const bool live = live_q && i < a.N;
+            // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
+            const double d0 = __dmul_rn(cur.V[0][e], a.dt), d1 = __dmul_rn(cur.V[1][e], a.dt),
+                         d2 = __dmul_rn(cur.V[2][e], a.dt);
+            cur.R[0][e] = __dadd_rn(cur.R[0][e], d0);
+            cur.R[1][e] = __dadd_rn(cur.R[1][e], d1);
+            cur.R[2][e] = __dadd_rn(cur.R[2][e], d2);
+            // scatter                                                                light.py:303-315
+            const double norm = pcl_step_norm(d0, d1, d2);
+            double pc;
+            if constexpr (VAR_N) {
+#ifdef PCL_N_EXPR
+                pc = __dmul_rn(__dmul_rn(a.A, pcl_n_expr_val(cur.R[0][e], cur.R[1][e], cur.R[2][e], d0, d1, d2,
+                                                              a.E[live ? i : 0])), norm);
+#else
+                pc = 0.0;
+#endif
+            } else {
+                pc = __dmul_rn(__dmul_rn(a.A, a.n), norm);
+            }
+            if constexpr (USE_E) pc = __dmul_rn(pc, cur.L4[e]);
+            const pcl_u64 id = (pcl_u64)(a.id_base + i);
+            const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u, k0, k1);
+            const double rand = pcl_u53(w.x, w.y);
+            hit[e] = live && (pc >= rand);
+            if (hit[e]) {
+                const double rtheta = __dmul_rn(__dmul_rn(pcl_u53(w.z, w.w), 2.0), PCL_PI);
+                const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 1u, k0, k1);
+                const double rphi = __dmul_rn(pcl_u53(w2.x, w2.y), PCL_PI);
+                pcl_new_velocity(a.c, rtheta, rphi, cur.V[0][e], cur.V[1][e], cur.V[2][e]);
+            }
+            w_hits += (pcl_u32)__popcll(__ballot(hit[e]));
+            w_sx += (pcl_u32)__popcll(__ballot(live && cur.V[0][e] > 0.0));
+            w_sy += (pcl_u32)__popcll(__ballot(live && cur.V[1][e] > 0.0));
+            w_sz += (pcl_u32)__popcll(__ballot(live && cur.V[2][e] > 0.0));
+        }
+        if (live_q) {
+            pcl_vec<VEC>::st(a.r0, q, cur.R[0]);
+            pcl_vec<VEC>::st(a.r1, q, cur.R[1]);
+            pcl_vec<VEC>::st(a.r2, q, cur.R[2]);
+            pcl_vec<VEC>::st(a.vo0, q, cur.V[0]);
+            pcl_vec<VEC>::st(a.vo1, q, cur.V[1]);
+            pcl_vec<VEC>::st(a.vo2, q, cur.V[2]);
+        }
+#ifndef PCL_FAST_NOPIPE
+        cur = nxt;
+#else
+        if (base + stride < nq)
+            pcl_fast_load<USE_E, VEC>(a, base + stride + threadIdx.x < nq ? base + stride + threadIdx.x : 0, cur);
+#endif
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (w_hits) atomicAdd(&s_cnt[0], w_hits);
+        atomicAdd(&s_cnt[1], w_sx);
+        atomicAdd(&s_cnt[2], w_sy);
+        atomicAdd(&s_cnt[3], w_sz);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&a.cnt[threadIdx.x], (pcl_u64)s_cnt[threadIdx.x]);
+}
+
+#ifndef PCL_FAST_VEC
+#define PCL_FAST_VEC 2
+#endif
 
 #ifdef PCL_RTC
 // hipRTC translation unit: one expression, both wavelength variants of both kernels.
@@ -456,5 +642,7 @@ extern "C" __global__ void __launch_bounds__(256) pcl_rtc_scatter_e0(pcl_scatter
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_scatter_e1(pcl_scatter_args a) { pcl_scatter_body<true, true>(a); }
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fused_e0(pcl_fused_args a) { pcl_fused_body<false, true>(a); }
 extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fused_e1(pcl_fused_args a) { pcl_fused_body<true, true>(a); }
+extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fast_e0(pcl_fast_args a) { pcl_fast_body<false, true, PCL_FAST_VEC>(a); }
+extern "C" __global__ void __launch_bounds__(256) pcl_rtc_fast_e1(pcl_fast_args a) { pcl_fast_body<true, true, PCL_FAST_VEC>(a); }
 #endif
 #endif // PCL_DEVICE_H

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -117,6 +118,30 @@ __global__ void __launch_bounds__(kBlock) k_newton(newton_args a) {
     }
 }
 
+// ---- materialise what a lazy fused step left implicit: dr = v_in*dt, dv = v_out - v_in -----------
+// (v_out - v_in is +0 for a particle that was not scattered: exactly the reference's dv = 0)
+struct materialize_args {
+    const double *vin[3], *vout[3];
+    double *dr[3], *dv[3];
+    const unsigned char *kind;
+    double dt;
+    int do_dv;
+    int64_t N;
+};
+
+__global__ void __launch_bounds__(kBlock) k_materialize(materialize_args a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
+        const bool photon = a.kind ? (a.kind[i] != 0) : true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const double vi = a.vin[k][i];
+            a.dr[k][i] = __dmul_rn(vi, a.dt);
+            if (a.do_dv && photon) a.dv[k][i] = __dsub_rn(a.vout[k][i], vi);
+        }
+    }
+}
+
 // ---- delete-flag kernel (Level 1): result = (A*n*norm >= rand) ? 1 : 0   light.py:146-158 -------
 __global__ void __launch_bounds__(kBlock) k_delete_flags(const double *__restrict__ d0, const double *__restrict__ d1,
                                                          const double *__restrict__ d2,
@@ -143,6 +168,19 @@ __global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args a) {
 template <bool USE_E>
 __global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args a) {
     pcl_fused_body<USE_E, false>(a);
+}
+template <bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args a) {
+    pcl_fast_body<USE_E, false, PCL_FAST_VEC>(a);
+}
+
+// per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
+// store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
+__global__ void __launch_bounds__(kBlock) k_lam4(const double *__restrict__ E, double *__restrict__ lam4, double h,
+                                                 double c, int64_t N) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+        lam4[i] = pcl_wavelength_term(h, c, E[i]);
 }
 
 // ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
@@ -448,6 +486,7 @@ struct rtc_entry {
     hipFunction_t sphere[2] = {nullptr, nullptr};  // [USE_E]
     hipFunction_t scatter[2] = {nullptr, nullptr}; // [USE_E]
     hipFunction_t fused[2] = {nullptr, nullptr};   // [USE_E]
+    hipFunction_t fast[2] = {nullptr, nullptr};    // [USE_E]
 };
 
 } // namespace
@@ -467,6 +506,16 @@ struct pcl_ctx {
     double *field_alt[PCL_NFIELDS] = {}; // compaction double buffer (lazy)
     int64_t *ids = nullptr, *ids_alt = nullptr;
     unsigned char *kind = nullptr, *kind_alt = nullptr;
+    // lazy fused steps: second half of the v double buffer + what is still implicit
+    double *vprev[3] = {nullptr, nullptr, nullptr};
+    bool lazy_dr = false;      // dr not materialised: dr = (lazy_dv ? vprev : v) * lazy_dt
+    bool lazy_dv = false;      // dv not materialised: dv = v - vprev (photons)
+    double lazy_dt = 0.0;
+    // cache of pow((h*c)/E, -4) per photon for the fast fused path
+    double *lam4 = nullptr;
+    bool lam4_valid = false;
+    double lam4_h = 0.0, lam4_c = 0.0;
+    int vec = 2; // lanes own 2 particles (16-byte accesses) in the fast path; PCL_FAST_VEC1 experiment = 1
     double *rnd[3] = {nullptr, nullptr, nullptr};
     int64_t rnd_n[3] = {0, 0, 0};
 
@@ -555,10 +604,39 @@ int ensure_alt(pcl_ctx *ctx) {
     return PCL_OK;
 }
 
-int need_store(pcl_ctx *ctx) {
+// Make dr / dv real arrays again after lazy fused steps (no-op otherwise).
+int materialize(pcl_ctx *ctx) {
+    if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
+    const int64_t N = ctx->count;
+    if (N > 0) {
+        materialize_args a{};
+        for (int k = 0; k < 3; ++k) {
+            a.vin[k] = ctx->lazy_dv ? ctx->vprev[k] : ctx->field[PCL_V0 + k];
+            a.vout[k] = ctx->field[PCL_V0 + k];
+            a.dr[k] = ctx->field[PCL_DR0 + k];
+            a.dv[k] = ctx->field[PCL_DV0 + k];
+        }
+        a.kind = ctx->kind;
+        a.dt = ctx->lazy_dt;
+        a.do_dv = ctx->lazy_dv ? 1 : 0;
+        a.N = N;
+        hipLaunchKernelGGL(k_materialize, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_materialize"));
+    }
+    ctx->lazy_dr = ctx->lazy_dv = false;
+    return PCL_OK;
+}
+
+int need_store_raw(pcl_ctx *ctx) {
     PCL_TRY(bind(ctx));
     if (ctx->capacity <= 0) return fail(PCL_ERR_STATE, "no particle store: call pcl_store_alloc first");
     return PCL_OK;
+}
+
+// every entry point that reads or writes store arrays goes through here: implicit dr/dv become real first
+int need_store(pcl_ctx *ctx) {
+    PCL_TRY(need_store_raw(ctx));
+    return materialize(ctx);
 }
 
 int check_range(pcl_ctx *ctx, int64_t offset, int64_t n, const void *host) {
@@ -577,7 +655,21 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
         *out = &it->second;
         return PCL_OK;
     }
-    std::string src = "#define PCL_RTC 1\n#define PCL_N_EXPR (";
+    std::string src = "#define PCL_RTC 1\n";
+    // perf-experiment hook (never set in production): PCL_RTC_EXTRA="NAME1,NAME2" -> "#define NAME 1" lines
+    if (const char *extra = getenv("PCL_RTC_EXTRA")) {
+        std::string tok;
+        for (const char *q = extra;; ++q) {
+            if (*q == ',' || *q == '\0') {
+                if (!tok.empty()) src += "#define " + tok + " 1\n";
+                tok.clear();
+                if (!*q) break;
+            } else if ((*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_') {
+                tok += *q;
+            }
+        }
+    }
+    src += "#define PCL_N_EXPR (";
     src += expr;
     src += ")\n";
     src += pcl_rtc_source;
@@ -609,6 +701,8 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     PCL_HIP(hipModuleGetFunction(&ent.scatter[1], ent.module, "pcl_rtc_scatter_e1"));
     PCL_HIP(hipModuleGetFunction(&ent.fused[0], ent.module, "pcl_rtc_fused_e0"));
     PCL_HIP(hipModuleGetFunction(&ent.fused[1], ent.module, "pcl_rtc_fused_e1"));
+    PCL_HIP(hipModuleGetFunction(&ent.fast[0], ent.module, "pcl_rtc_fast_e0"));
+    PCL_HIP(hipModuleGetFunction(&ent.fast[1], ent.module, "pcl_rtc_fast_e1"));
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
     return PCL_OK;
@@ -697,6 +791,8 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
                     arch.c_str());
     }
     c->grid_cap = c->prop.multiProcessorCount * 8;
+    if (const char *g = getenv("PCL_GRID_PER_CU")) // perf-experiment hook
+        if (atoi(g) > 0) c->grid_cap = c->prop.multiProcessorCount * atoi(g);
     if (stream) {
         c->stream = static_cast<hipStream_t>(stream);
     } else {
@@ -953,6 +1049,10 @@ int pcl_store_free(pcl_ctx *ctx) {
         dev_free(ctx->field[f]);
         dev_free(ctx->field_alt[f]);
     }
+    for (int k = 0; k < 3; ++k) dev_free(ctx->vprev[k]);
+    ctx->lazy_dr = ctx->lazy_dv = false;
+    dev_free(ctx->lam4);
+    ctx->lam4_valid = false;
     dev_free(ctx->ids);
     dev_free(ctx->ids_alt);
     dev_free(ctx->kind);
@@ -990,6 +1090,7 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     ctx->id_base = id_base;
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
+    ctx->lam4_valid = false;
     return PCL_OK;
 }
 
@@ -997,6 +1098,7 @@ int pcl_store_upload(pcl_ctx *ctx, int field, const double *host, int64_t offset
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
+    if (field == PCL_E) ctx->lam4_valid = false;
     return pcl_h2d(ctx, ctx->field[field] + offset, host, n * (int64_t)sizeof(double));
 }
 
@@ -1048,6 +1150,7 @@ int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t
 int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
+    if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
     *dev_out = ctx->field[field];
     return PCL_OK;
 }
@@ -1063,7 +1166,9 @@ int pcl_store_upload_rand(pcl_ctx *ctx, int which, const double *host, int64_t n
 
 int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max,
                            uint64_t seed) {
-    PCL_TRY(need_store(ctx));
+    PCL_TRY(need_store_raw(ctx));
+    ctx->lazy_dr = ctx->lazy_dv = false; // every array is overwritten
+    ctx->lam4_valid = false;
     if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
     if (n > 0) {
         fill_args a{};
@@ -1175,8 +1280,16 @@ int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
 int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, int flags, double c, double h,
                    const char *n_expr, int rng_mode, uint64_t seed, uint32_t step, const double *planes_host,
                    int n_planes, int64_t *out_host) {
-    PCL_TRY(need_store(ctx));
-    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N | PCL_FUSED_LAZY))
+        return fail(PCL_ERR_ARG, "unknown flag bits");
+    const bool lazy = flags & PCL_FUSED_LAZY;
+    if (lazy) {
+        PCL_TRY(need_store_raw(ctx));
+        // a Newton-only pass must not lose the dv of a still-implicit scatter step
+        if (!do_scatter && ctx->lazy_dv) PCL_TRY(materialize(ctx));
+    } else {
+        PCL_TRY(need_store(ctx));
+    }
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
@@ -1196,9 +1309,68 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
                 return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
                             (long long)N);
+    static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
+    if (lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && !ctx->kind && ctx->ids_iota && n_planes <= 0 && !no_fast) {
+        // ---- fast path: all photons, implicit ids, device RNG, implicit dr/dv, sign counters only
+        if (use_e && (!ctx->lam4_valid || ctx->lam4_h != h || ctx->lam4_c != c)) {
+            if (!ctx->lam4) PCL_TRY(dev_alloc(&ctx->lam4, ctx->capacity));
+            hipLaunchKernelGGL(k_lam4, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->field[PCL_E],
+                               ctx->lam4, h, c, N);
+            PCL_TRY(launch_check("k_lam4"));
+            ctx->lam4_valid = true;
+            ctx->lam4_h = h;
+            ctx->lam4_c = c;
+        }
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->vprev[k]) PCL_TRY(dev_alloc(&ctx->vprev[k], ctx->capacity));
+        pcl_fast_args f{};
+        f.r0 = ctx->field[PCL_R0]; f.r1 = ctx->field[PCL_R1]; f.r2 = ctx->field[PCL_R2];
+        f.vi0 = ctx->field[PCL_V0]; f.vi1 = ctx->field[PCL_V1]; f.vi2 = ctx->field[PCL_V2];
+        f.vo0 = ctx->vprev[0]; f.vo1 = ctx->vprev[1]; f.vo2 = ctx->vprev[2];
+        f.lam4 = ctx->lam4;
+        f.E = ctx->field[PCL_E];
+        f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+        f.id_base = ctx->id_base;
+        f.N = N;
+        f.dt = dt; f.A = A; f.n = n; f.c = c;
+        f.seed = seed;
+        f.step = step;
+        PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, 4 * sizeof(uint64_t), ctx->stream));
+        ctx->hits_on_host = false;
+        const int fgrid = grid_for(ctx, div_up(N, PCL_FAST_VEC), kBlock);
+        const int fps = prof_begin(ctx, PCL_PROF_FUSED);
+        if (var_n) {
+            PCL_TRY(launch_module(ctx, ent->fast[use_e ? 1 : 0], fgrid, f, "step_fused fast path (hipRTC)"));
+        } else {
+            if (use_e)
+                hipLaunchKernelGGL(k_fast<true>, dim3(fgrid), dim3(kBlock), 0, ctx->stream, f);
+            else
+                hipLaunchKernelGGL(k_fast<false>, dim3(fgrid), dim3(kBlock), 0, ctx->stream, f);
+            PCL_TRY(launch_check("k_fast"));
+        }
+        prof_end(ctx, fps);
+        for (int k = 0; k < 3; ++k) std::swap(ctx->field[PCL_V0 + k], ctx->vprev[k]); // field[V] = new v
+        ctx->lazy_dv = ctx->lazy_dr = true;
+        ctx->lazy_dt = dt;
+        if (out_host) {
+            PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            PCL_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->hits_on_host = true;
+            for (int k = 0; k < 3; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+            out_host[4] = (int64_t)ctx->h_cnt[0];
+        }
+        return PCL_OK;
+    }
     pcl_fused_args a{};
     a.r0 = ctx->field[PCL_R0]; a.r1 = ctx->field[PCL_R1]; a.r2 = ctx->field[PCL_R2];
-    a.v0 = ctx->field[PCL_V0]; a.v1 = ctx->field[PCL_V1]; a.v2 = ctx->field[PCL_V2];
+    a.vi0 = ctx->field[PCL_V0]; a.vi1 = ctx->field[PCL_V1]; a.vi2 = ctx->field[PCL_V2];
+    a.vo0 = ctx->field[PCL_V0]; a.vo1 = ctx->field[PCL_V1]; a.vo2 = ctx->field[PCL_V2];
+    if (lazy && do_scatter) {
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->vprev[k]) PCL_TRY(dev_alloc(&ctx->vprev[k], ctx->capacity));
+        a.vo0 = ctx->vprev[0]; a.vo1 = ctx->vprev[1]; a.vo2 = ctx->vprev[2];
+    }
+    a.lazy = lazy ? 1 : 0;
     a.dr0 = ctx->field[PCL_DR0]; a.dr1 = ctx->field[PCL_DR1]; a.dr2 = ctx->field[PCL_DR2];
     a.dv0 = ctx->field[PCL_DV0]; a.dv1 = ctx->field[PCL_DV1]; a.dv2 = ctx->field[PCL_DV2];
     a.E = ctx->field[PCL_E];
@@ -1234,6 +1406,14 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
         PCL_TRY(launch_check("k_fused"));
     }
     prof_end(ctx, ps);
+    if (lazy) {
+        if (do_scatter) {
+            for (int k = 0; k < 3; ++k) std::swap(ctx->field[PCL_V0 + k], ctx->vprev[k]); // field[V] = new v
+            ctx->lazy_dv = true;
+        }
+        ctx->lazy_dr = true;
+        ctx->lazy_dt = dt;
+    }
     if (out_host) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -1301,6 +1481,7 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     ctx->ids_iota = false;
     ctx->count = alive;
     ctx->last_delete_n = N;
+    ctx->lam4_valid = false;
     if (n_alive_out) *n_alive_out = alive;
     if (n_removed_out) *n_removed_out = N - alive;
     return PCL_OK;

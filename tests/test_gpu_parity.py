@@ -591,3 +591,77 @@ def test_fused_chain_vs_reference(golden, store, hip):
         assert out["hits"] == (~np.isnan(g("res0"))).sum()
         assert [int(x) for x in out["planes"]] == [int(x) for x in z["measure_rows"][k][2:]]
         assert [int(x) for x in out["sign"]] == [int(x) for x in z["sign_rows"][k][2:5]]
+
+
+# ============================================================================ lazy dr/dv (PCL_FUSED_LAZY)
+@pytest.mark.parametrize("tag", ["base", "varn"])
+@pytest.mark.parametrize("N", [1, 333, 150_001])
+def test_lazy_fused_chain_is_bit_identical_to_eager(store, hip, tag, N):
+    """A chain of lazy fused steps, materialised by whatever touches the store next, leaves exactly the
+    state of the eager chain -- r, v, dr, dv, counters -- including mixed kinds, a Newton-only pass in
+    the middle, and a delete step (which needs the real dr) at the end."""
+    cfg = ISO[tag]
+    rs = np.random.RandomState(N + 7)
+    init = {"r": rs.uniform(-8, 8, (N, 3)), "v": np.tile([C_LIT, 0.0, 0.0], (N, 1)), "dv": rs.normal(size=(N, 3)),
+            "dr": rs.normal(size=(N, 3)), "E": rs.uniform(2.8e-19, 9.9e-19, N), "id_base": 10,
+            "kind": (rs.random_sample(N) < 0.85).astype(np.uint8)}
+    A_k, n_k, dt = (1e-3, 1e-3, 1e-3) if tag == "base" else (1e-15, 1e-19, 1e-9)
+    planes = [[0.5, np.nan, np.nan], [np.nan, np.nan, -2.0]]
+    out = {}
+    for lazy in (False, True):
+        d = store(N)
+        d.upload_state(init)
+        log = []
+        for step in range(5):
+            sc = dict(A=A_k, n=n_k, flags=flags_of(hip, cfg), c=C_LIT, h=H_LIT, n_expr=cfg["expr"],
+                      rng_mode=hip.RNG_PHILOX, seed=31337, step=step)
+            if step == 2:
+                o = d.step_fused(dt * 0.5, None, planes, lazy=lazy)          # Newton-only pass
+            else:
+                o = d.step_fused(dt, sc, planes, lazy=lazy)
+            log.append((o["N"], o["hits"], list(o["sign"]), list(o["planes"])))
+            if step == 3:
+                mid = d.download_state()                                      # forces a materialise mid-chain
+        end = d.download_state()
+        alive, removed = d.step_scatter_delete(A_k if tag == "base" else 1e-3, n_k if tag == "base" else 1e-3,
+                                               hip.RNG_PHILOX, 31337, 99)
+        out[lazy] = (log, mid, end, alive, removed, d.download_state())
+    la, lb = out[False], out[True]
+    assert la[0] == lb[0] and la[3:5] == lb[3:5]
+    for sa, sb in ((la[1], lb[1]), (la[2], lb[2]), (la[5], lb[5])):
+        assert np.array_equal(sa["id"], sb["id"]) and np.array_equal(sa["E"], sb["E"])
+        for f in ("r", "v", "dr", "dv"):
+            for k in range(3):
+                assert np.array_equal(sa[f][k], sb[f][k]), (f, k)
+    # plain Objects never get a dv from the light step, lazily or not
+    obj = init["kind"] == 0
+    assert np.array_equal(np.stack(lb[2]["dv"], 1)[obj], init["dv"][obj])
+
+
+def test_lazy_state_is_materialised_for_every_consumer(store, hip):
+    """Each consumer of dr/dv after a lazy step sees real arrays: separate scatter step, counters with
+    planes, field pointers, a second store_alloc."""
+    N = 10_000
+    d = store(N)
+    v = np.tile([C_LIT, 0.0, 0.0], (N, 1))
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=5, step=0)
+
+    def fresh():
+        d.upload_state({"v": v, "E": np.ones(N)})
+        d.step_fused(1e-3, sc, None, lazy=True)
+
+    fresh()
+    cnt = d.step_counters([[C_LIT * 1e-3, np.nan, np.nan]])             # plane test reads r and dr
+    assert cnt[hip.CNT_PLANE0] == N
+    fresh()
+    hits = d.step_scatter_isotropic(1.0, 1.0, 0, C_LIT, H_LIT, rng_mode=hip.RNG_PHILOX, seed=5, step=1)  # reads dr
+    assert hits == N
+    fresh()
+    assert np.all(d.download(hip.DR0) == C_LIT * 1e-3)
+    dv = np.stack([d.download(hip.DV0 + k) for k in range(3)], 1)
+    vv = np.stack([d.download(hip.V0 + k) for k in range(3)], 1)
+    assert np.array_equal(dv, vv - v)
+    fresh()
+    d.step_newton(1e-3)                                                  # overwrites dr; dv must survive
+    assert np.array_equal(np.stack([d.download(hip.DV0 + k) for k in range(3)], 1),
+                          np.stack([d.download(hip.V0 + k) for k in range(3)], 1) - v)
