@@ -410,11 +410,91 @@ def g6_units():
     _save("g6_units", **out)
 
 
+# Expressions evaluated with the reference's Measurement (M), light module (light) and numpy (np);
+# tests/test_units_parity.py evaluates the same strings with physicl_amd and compares.
+UNIT_OPS = [
+    "M(5, 'kg**1 m**1 s**-2')", "M(5, 'N**1')", "M(1, 'au**1')", "M(3, 'eV**1')", "M(10, 'min**2')",
+    "M([1.5, -2.0, 3.25], 'm**1 s**-1')", "M(8.6e3, 'm')", "M(2, 'km**1')" if False else "M(2, 'L**1')",
+    "M(1, 'au**1') + M(149597870700, 'm**1')", "M(149597870700, 'm**1') + M(1, 'au**1')",
+    "M(0, 'J**1') + M(13.6, 'eV**1')", "(M(0, 'J**1') + M(13.6, 'eV**1')) / light.h",
+    "light.c / ((M(0, 'J**1') + M(13.6, 'eV**1')) / light.h)",
+    "light.E_from_wavelength(M(633e-9, 'm**1'))", "light.wavelength_from_E(light.E_from_wavelength(M(633e-9, 'm**1')))",
+    "light.E_from_wavelength(200e-9)", "(light.h * light.c) / M(1e-19, 'J**1')",
+    "((light.h * light.c) / M(1e-19, 'J**1')) ** -4",
+    "M(5, 'N**1') * M(10, 'min**2')", "M(5, 'N**1') * M(5, 'au**1')", "M(5, 'N**1') / M(5, 'au**1')",
+    "M(5, 'N**1') ** 2", "M(5, 'au**1') ** 2", "M(5, 'au**1') * M(5, 'au**1')", "np.sqrt(M(5, 'au**1'))",
+    "np.sqrt(M(4, 'm**2'))", "M(5, 'au**1') / M(5, 'au**1')", "1 / M(5, 'au**1')", "M(5, 'au**1') + 1", "1 + M(5, 'au**1')",
+    "M(5, 'au**1') - M(1, 'm**1')", "M([1, 2, 3], 'au**1').sum()", "np.sum(M([1, 2, 3], 'au**1'))",
+    "M([light.c, 0, 0], 'm**1 s**-1') * 2", "2 * M([light.c, 0, 0], 'm**1 s**-1')",
+    "M([light.c, 0, 0], 'm**1 s**-1') * np.double(1e-3)", "light.c * [1, 0, 0]", "-M([1.0, -2.0], 'm**1')",
+    "abs(M(-5, 'm**1'))", "np.exp(M(1, 'm**1'))", "M(5, 'au**1') < 3", "M(5, 'au**1') == 5",
+    "M(5, 'N**1') == M(5, 'kg**1 m**1 s**-2')", "M([1., 2., 3.], 'm**1')[1]", "M([1., 2., 3.], 'm**1')[0:2]",
+    "M([1., 2., 3.], 'au**1').copy()", "M([M(1, 'au**1'), 2], 'm**1')", "M(M([1., 2.], 'm**1'), 'm**1')",
+    "float(M(5, 'au**1'))", "M(5, 'au**1').value()", "M(5, 'au**1').valstr()", "M(5, 'au**1').fstr()",
+    "M(5, 'au**1').unitstr()", "str(M(2.5e-7, 'm**1'))", "str(M([1e-9, 2.0], 'm**1'))", "repr(M(5, 'au**1') * M(5, 'au**1'))",
+    "'{}'.format(M(2.5e25, 'm**-3'))", "'{:.3e}'.format(M(2.5e25, 'm**-3'))", "'{:.3f}'.format(M(2.5, 'm**1'))",
+    "__import__('copy').deepcopy(M([1., 2.], 'au**1'))", "np.linalg.norm(M([light.c, 0, 0], 'm**1 s**-1'))",
+    "np.linalg.norm(light.c)", "np.isnan(M([1., np.nan], 'm**1'))", "np.array_equal(M([0., 0.], 'm**1'), np.array([0, 0]))",
+    "M(3.0, 'm**1 s**-1 s**-1')", "M(1, 'Pa**1')", "M(1, 'W**1')", "M(1, 'V**1')", "M(1, 'F**1')", "M(1, 'Ohm**1')",
+    "M(1, 'T**1')", "M(1, 'H**1')", "M(1, 'd**1')", "M(1, 'ha**1')", "M(1, 't**1')", "M(1, 'Da**1')", "M(2, 'h**1')",
+    "M(7, 'kat**1')", "M(7, 'Sv**1')", "M(1, 'lm**1')", "M(4, 'm ^ 2')", "M(4, 'm**2 kg**1')",
+    "np.multiply(M(2, 'm**1'), M(3, 's**1'))", "np.add.reduce(M([1., 2.], 'min**1'))",
+    "M(2, 'm**1') * M([1., 2.], 's**-1') + M([1., 1.], 'm**1 s**-1')",
+]
+
+
+def _describe(x):
+    M = physicl.Measurement
+    d = {"type": type(x).__name__}
+    if isinstance(x, M):
+        d["code"] = np.asarray(x.view(np.ndarray)).astype(np.float64).tolist()
+        d["has_units"] = hasattr(x, "units")
+        if hasattr(x, "units"):
+            d["scale"] = float(np.asarray(x.scale))
+            d["units"] = {k: float(np.asarray(v)) for k, v in x.units.items()}
+            d["original_units"] = {k: float(np.asarray(v)) for k, v in x.original_units.items()}
+            d["unitstr"] = x.unitstr()
+    elif isinstance(x, np.ndarray):
+        d["code"] = x.astype(np.float64).tolist()
+    elif isinstance(x, (float, int, np.floating, np.integer, bool, np.bool_)):
+        d["code"] = float(x)
+    else:
+        d["text"] = str(x)
+    return d
+
+
+def g6_unit_ops():
+    import json
+    M = physicl.Measurement
+    out = {"default": [], "m_scale_1e-3": []}
+    for key in out:
+        if key != "default":
+            M.set_code_scale("m", 0.001)
+        try:
+            for expr in UNIT_OPS:
+                try:
+                    res = _describe(eval(expr, {"M": M, "light": light, "np": np, "__import__": __import__}))
+                except Exception as e:  # the reference raises here; the build must raise too
+                    res = {"raises": type(e).__name__}
+                out[key].append({"expr": expr, "result": res})
+        finally:
+            M.reset_code_scale("m")
+    path = os.path.join(OUT, "g6_unit_ops.json")
+    json.dump(out, open(path, "w"), indent=0)
+    print("wrote g6_unit_ops.json  %d expressions x 2 code scales" % len(UNIT_OPS))
+
+
 def main():
+    only = sys.argv[1:]
+    if only:                      # e.g. `make_golden.py g6_unit_ops` regenerates one fixture
+        for name in only:
+            globals()[name]()
+        return
     g1_newton()
     g2_iso()
     g4_delete()
     g6_units()
+    g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)
     with open(os.path.join(OUT, "kernel_sources.sha256"), "w") as f:
         for k in sorted(_Program.sources):
