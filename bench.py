@@ -72,6 +72,10 @@ def main():
                          "PCL_FUSED_LAZY); fused-eager: one kernel, dr/dv written every step; "
                          "separate: one kernel per Step")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = rehearsal on CPU tensors")
+    ap.add_argument("--device", type=int, default=None,
+                    help="HIP device index for this rank (default LOCAL_RANK); rehearsals put every rank on device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-photons", type=float, default=1e7)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
@@ -87,49 +91,67 @@ def main():
     from physicl_amd import _hip
     from physicl_amd.dist import CounterComm
 
-    comm = CounterComm.from_env(backend="nccl")          # no-op communicator when world == 1
+    comm = CounterComm.from_env(backend=args.backend)    # no-op communicator when world == 1
     N = int(args.photons)
     prof = PROFILES[args.profile]
     flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
     e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9   # E_from_wavelength, light.py:39-43
 
-    dev = _hip.Device(local_rank)
+    dev = _hip.Device(local_rank if args.device is None else args.device)
     dev.store_alloc(N)
     dev.fill_photons(N, rank * N, C_LIT, e_lo, e_hi, args.seed)      # ids are global: shard-independent RNG
 
     sim_t = 0.0
     totals = None
 
-    def one_step(k):
-        nonlocal sim_t, totals
+    fused_sc = lambda k: dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
+                              n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k)
+
+    def launch(k):
+        """Enqueue step k (no host synchronisation)."""
+        nonlocal sim_t
         sim_t += prof["dt"]                                          # UpdateTimeStep   __init__.py:337-343
         if args.mode.startswith("fused"):
-            # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles (one sync)
-            o = dev.step_fused(prof["dt"], dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
-                                                n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k),
-                               planes=(), lazy=(args.mode == "fused"))
-            local = np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
+            # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles
+            dev.step_fused(prof["dt"], fused_sc(k), planes=(), sync=False, lazy=(args.mode == "fused"))
         else:
             dev.step_newton(prof["dt"])                                  # newton.py:10-16
             dev.step_scatter_isotropic(prof["A_kernel"], prof["n_kernel"], flags, C_LIT, H_LIT, prof["expr"],
                                        _hip.RNG_PHILOX, args.seed, k, want_hits=False)   # light.py:281-331
-            cnt = dev.step_counters()                                    # light.py:414-431 (one sync)
-            local = np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
-                              cnt[_hip.CNT_ZP]], dtype=np.int64)
-        totals = comm.allreduce_sum(local)                           # RCCL over xGMI when world > 1
-        return local
 
-    for k in range(args.warmup):
-        one_step(k)
+    def collect():
+        """Wait for the enqueued step and fetch its local counters [N, hits, xp, yp, zp] (one sync)."""
+        if args.mode.startswith("fused"):
+            o = dev.step_fused_read(0)
+            return np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
+        cnt = dev.step_counters()                                        # light.py:414-431
+        return np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
+                         cnt[_hip.CNT_ZP]], dtype=np.int64)
+
+    def run_steps(k0, k1):
+        """Steps k0..k1-1.  The all-reduce of step k's counters (RCCL over xGMI when world > 1) is issued
+        while the GPU already runs step k+1 -- the counters are consumed one step behind (SURVEY.md 8(e));
+        the last one is reduced before the function returns, inside the timed region."""
+        nonlocal totals
+        hits, pending = 0, None
+        for k in range(k0, k1):
+            launch(k)
+            if pending is not None:
+                totals = comm.allreduce_sum(pending)
+            pending = collect()
+            hits += int(pending[1])
+        if pending is not None:
+            totals = comm.allreduce_sum(pending)
+        return hits
+
+    run_steps(0, args.warmup)
 
     dev.prof_enable(True)
     comm.barrier()
     dev.sync()
     comm.device_synchronize()
     t0 = time.perf_counter()
-    hits_local = 0
-    for k in range(args.warmup, args.warmup + args.steps):
-        hits_local += int(one_step(k)[1])
+    hits_local = run_steps(args.warmup, args.warmup + args.steps)
     dev.sync()
     comm.device_synchronize()
     comm.barrier()
@@ -161,7 +183,7 @@ def main():
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N,
-                                      " + RCCL all-reduce of 5 int64 counters" if world > 1 else ""),
+                                      " + %s all-reduce of 5 int64 counters" % ("RCCL" if args.backend == "nccl" else "gloo") if world > 1 else ""),
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
             "roofline": {"bound": "hbm",

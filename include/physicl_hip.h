@@ -222,6 +222,11 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
                    double h, const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                    const double *planes_host, int n_planes, int64_t *out_host);
 
+/* Counters of the most recent pcl_step_fused that was called with out_host == NULL (same layout,
+ * same n_planes).  Synchronises.  Lets a caller overlap host work (e.g. the all-reduce of the previous
+ * step's counters) with the kernel. */
+int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host);
+
 /* Hit count of the most recent pcl_step_scatter_isotropic / pcl_step_fused (host pointer).  Free of extra
  * synchronisation when a pcl_step_counters call has completed since that step. */
 int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out);

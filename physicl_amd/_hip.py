@@ -84,6 +84,7 @@ _PROTOTYPES = {
                                    c_uint32, POINTER(c_int64)],
     "pcl_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                        c_uint32, _vp, c_int, _vp],
+    "pcl_step_fused_read": [_vp, c_int, _vp],
     "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
                                 POINTER(c_int64)],
@@ -373,6 +374,13 @@ class Device:
         if out is None:
             return None
         return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + npl].copy(), "hits": int(out[4 + npl])}
+
+    def step_fused_read(self, n_planes=0):
+        """Counters of the last ``step_fused(..., sync=False)``: same dict as the synchronous call."""
+        out = np.zeros(5 + n_planes, dtype=np.int64)
+        check(self.lib.pcl_step_fused_read(self.ctx, n_planes, out.ctypes.data_as(c_void_p)))
+        return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + n_planes].copy(),
+                "hits": int(out[4 + n_planes])}
 
     def last_scatter_hits(self):
         h = c_int64()

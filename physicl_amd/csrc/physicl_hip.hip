@@ -1265,6 +1265,19 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     return PCL_OK;
 }
 
+int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store_raw(ctx));
+    if (n_planes < 0 || n_planes > PCL_MAX_PLANES || !out_host) return fail(PCL_ERR_ARG, "bad argument");
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + n_planes) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->hits_on_host = true;
+    out_host[0] = ctx->count;
+    for (int k = 0; k < 3 + n_planes; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+    out_host[4 + n_planes] = (int64_t)ctx->h_cnt[0];
+    return PCL_OK;
+}
+
 int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
     PCL_TRY(need_store(ctx));
     if (!hits_out) return fail(PCL_ERR_ARG, "hits_out is NULL");
