@@ -44,7 +44,8 @@ extern "C" {
 #define PCL_ERR_NOMEM  (-6) /* device or host allocation failed */
 
 /* Per-particle state = the fields of physicl.Object / PhotonObject that a Step reads or writes
- * (physicl/__init__.py:390-394, physicl/light.py:26-35), one contiguous fp64 array per component. */
+ * (physicl/__init__.py:390-394, physicl/light.py:26-35), one contiguous array per component, of the
+ * store's dtype. */
 enum pcl_field {
     PCL_R0 = 0, PCL_R1, PCL_R2,      /* Object.r   position                    */
     PCL_V0, PCL_V1, PCL_V2,          /* Object.v   velocity                    */
@@ -53,6 +54,12 @@ enum pcl_field {
     PCL_E,                           /* PhotonObject.E                         */
     PCL_NFIELDS
 };
+
+/* element type of a particle store.  The reference is fp64-only (every input is marshalled as
+ * np.double, physicl/__init__.py:613): PCL_DTYPE_F64 is the parity path; PCL_DTYPE_F32 exists for the
+ * precision sweep of BASELINE.json configs[4]. */
+#define PCL_DTYPE_F64 0
+#define PCL_DTYPE_F32 1
 
 /* pcl_step_scatter_isotropic / pcl_k_light_scatter_step_sphere ``flags`` */
 #define PCL_SCATTER_WAVELENGTH 1 /* wavelength_dep_scattering=True  (light.py:275, 300-301) */
@@ -160,27 +167,31 @@ int pcl_expr_validate(const char *n_expr);
 
 /* ---------------------------------------------------------------- Level 2: resident particle store */
 
-/* Allocate SoA storage for up to ``capacity`` particles (13 fp64 arrays; ids, kinds, the compaction
- * double buffer and the random-input arrays are allocated on first use).  count is set to 0. */
+/* Allocate SoA storage for up to ``capacity`` particles (13 arrays; ids, kinds, the compaction
+ * double buffer and the random-input arrays are allocated on first use).  count is set to 0.
+ * pcl_store_alloc = fp64.  Host buffers passed to upload/download/upload_rand hold elements of the
+ * store's dtype (double or float). */
 int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity);
+int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype);
+int pcl_store_dtype(pcl_ctx *ctx, int *dtype_out);
 int pcl_store_free(pcl_ctx *ctx);
 int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out);
 int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, no sync */
 /* Set the particle count (<= capacity) and declare ids = id_base + index (no id array is read). */
 int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base);
 
-int pcl_store_upload(pcl_ctx *ctx, int field, const double *host, int64_t offset, int64_t n);
-int pcl_store_download(pcl_ctx *ctx, int field, double *host, int64_t offset, int64_t n);
+int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, int64_t n);
+int pcl_store_download(pcl_ctx *ctx, int field, void *host, int64_t offset, int64_t n);
 int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int64_t n);
 int pcl_store_download_ids(pcl_ctx *ctx, int64_t *host, int64_t offset, int64_t n);
 int pcl_store_upload_kind(pcl_ctx *ctx, const uint8_t *host, int64_t offset, int64_t n);
 int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t n);
 /* device pointer of a field's CURRENT buffer (changes after a compaction) */
-int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out);
+int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out);
 
 /* Random inputs for PCL_RNG_INPUT: which = 0 rtheta, 1 rphi, 2 rand; n values for particles
  * [0, n) in store order (entries of non-photon particles are ignored). */
-int pcl_store_upload_rand(pcl_ctx *ctx, int which, const double *host, int64_t n);
+int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n);
 
 /* Bulk creation on the device of ``n`` photons at r = 0 with v = (c, 0, 0), dr = dv = 0 and
  * E = e_min + (e_max - e_min) * U^(1/3) -- the SoA equivalent of light.generate_photons with its

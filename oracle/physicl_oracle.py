@@ -30,36 +30,38 @@ TWO_PI_FACTOR = 2  # rtheta = random() * 2 * np.pi   (light.py:285)
 # ----------------------------------------------------------------------------------------------
 # a1  NewtonianKinematicsStep.run                                   newton.py:10-16
 # ----------------------------------------------------------------------------------------------
-def newton_euler(r, v, dt):
+def newton_euler(r, v, dt, dtype=np.float64):
     """Explicit Euler.  ``dr = v*dt`` is rounded and stored, then ``r = r + dr`` (newton.py:15-16).
 
-    r, v: sequences of three float64 arrays.  Returns (r_new[3], dr[3]).
+    r, v: sequences of three arrays.  Returns (r_new[3], dr[3]).  ``dtype=np.float32`` restates the
+    same arithmetic in single precision (the reference itself is fp64-only); every function below that
+    takes ``dtype`` does the same -- it is what the fp32 device kernels are compared with bit for bit.
     """
-    dt = np.float64(dt)
-    dr = [np.multiply(np.asarray(vc, dtype=np.float64), dt) for vc in v]
-    rn = [np.add(np.asarray(rc, dtype=np.float64), drc) for rc, drc in zip(r, dr)]
+    dt = dtype(dt)
+    dr = [np.multiply(np.asarray(vc, dtype=dtype), dt) for vc in v]
+    rn = [np.add(np.asarray(rc, dtype=dtype), drc) for rc, drc in zip(r, dr)]
     return rn, dr
 
 
 # ----------------------------------------------------------------------------------------------
 # kernel maths shared by a2 / a4 / a5
 # ----------------------------------------------------------------------------------------------
-def step_norm(d0, d1, d2):
+def step_norm(d0, d1, d2, dtype=np.float64):
     """``sqrt(pow(d0,2) + pow(d1,2) + pow(d2,2))`` (light.py:149, 241, 305), left to right."""
-    d0, d1, d2 = (np.asarray(x, dtype=np.float64) for x in (d0, d1, d2))
+    d0, d1, d2 = (np.asarray(x, dtype=dtype) for x in (d0, d1, d2))
     return np.sqrt((d0 * d0 + d1 * d1) + d2 * d2)
 
 
 # ----------------------------------------------------------------------------------------------
 # a4 / a5  delete-flag kernels                          light.py:146-158 and light.py:239-249
 # ----------------------------------------------------------------------------------------------
-def delete_flags(d0, d1, d2, rand, A, n):
+def delete_flags(d0, d1, d2, rand, A, n, dtype=np.float64):
     """``pcoll = A * n * norm; flag = pcoll >= rand ? 1 : 0`` -> int32 (OpenCL ``int``).
 
     ``A`` and ``n`` are the KERNEL arguments, i.e. after the reference's swap (light.py:236).
     """
-    pcoll = (np.float64(A) * np.float64(n)) * step_norm(d0, d1, d2)
-    return (pcoll >= np.asarray(rand, dtype=np.float64)).astype(np.int32)
+    pcoll = (dtype(A) * dtype(n)) * step_norm(d0, d1, d2, dtype)
+    return (pcoll >= np.asarray(rand, dtype=dtype)).astype(np.int32)
 
 
 def survivors(flags):
@@ -89,7 +91,7 @@ _ALLOWED_ARRAYS = ("r0", "r1", "r2", "d0", "d1", "d2", "E")
 _TOKEN = re.compile(r"\s*(?:(\d+\.?\d*(?:[eE][+-]?\d+)?|\.\d+(?:[eE][+-]?\d+)?)|([A-Za-z_]\w*)|(.))")
 
 
-def eval_n_expr(expr, arrays):
+def eval_n_expr(expr, arrays, dtype=np.float64):
     """Evaluate an OpenCL-C ``variable_n_fn`` expression (light.py:299) with numpy.
 
     ``arrays`` maps the kernel's array names (r0, r1, r2, d0.., E) to float64 arrays; ``x[gid]``
@@ -105,14 +107,16 @@ def eval_n_expr(expr, arrays):
     env["gid"] = slice(None)
     for k in _ALLOWED_ARRAYS:
         if k in arrays and arrays[k] is not None:
-            env[k] = np.asarray(arrays[k], dtype=np.float64)
+            env[k] = np.asarray(arrays[k], dtype=dtype)
     with np.errstate(all="ignore"):
+        # numpy >= 2 (NEP 50): Python literals are "weak", so with float32 arrays the whole expression stays
+        # float32 -- the device's fp32 spelling puts an f suffix on every floating literal for the same effect
         val = eval(expr, {"__builtins__": {}}, env)  # noqa: S307  (token-checked above)
     n = len(next(v for v in env.values() if isinstance(v, np.ndarray)))
-    return np.broadcast_to(np.asarray(val, dtype=np.float64), (n,)).copy()
+    return np.broadcast_to(np.asarray(val, dtype=dtype), (n,)).copy()
 
 
-def scatter_pcoll(d0, d1, d2, A, n, *, h=None, c=None, E=None, n_expr=None, r=None):
+def scatter_pcoll(d0, d1, d2, A, n, *, h=None, c=None, E=None, n_expr=None, r=None, dtype=np.float64):
     """Collision probability exactly as the generated kernel text multiplies it (light.py:299-306).
 
     ``pcoll = A * n * norm``                                  (base)
@@ -121,31 +125,32 @@ def scatter_pcoll(d0, d1, d2, A, n, *, h=None, c=None, E=None, n_expr=None, r=No
     Multiplication is left to right.  ``h``/``c`` are the literals pasted into the source
     (``str(h).upper()``, ``str(c)``; light.py:301), i.e. their code-unit values.
     """
-    norm = step_norm(d0, d1, d2)
+    norm = step_norm(d0, d1, d2, dtype)
     with np.errstate(all="ignore"):
         if n_expr is None:
-            p = (np.float64(A) * np.float64(n)) * norm
+            p = (dtype(A) * dtype(n)) * norm
         else:
             arrs = {"d0": d0, "d1": d1, "d2": d2, "E": E}
             if r is not None:
                 arrs.update(r0=r[0], r1=r[1], r2=r[2])
-            p = (np.float64(A) * eval_n_expr(n_expr, arrs)) * norm
+            p = (dtype(A) * eval_n_expr(n_expr, arrs, dtype)) * norm
         if E is not None and h is not None:
-            hc = np.float64(h) * np.float64(c)
-            p = p * np.power(hc / np.asarray(E, dtype=np.float64), np.float64(-4.0))
+            hc = dtype(h) * dtype(c)
+            p = p * np.power(hc / np.asarray(E, dtype=dtype), dtype(-4.0))
     return p
 
 
 def scatter_sphere_kernel(d0, d1, d2, rtheta, rphi, rand, A, n, c, *, h=None, E=None, n_expr=None,
-                          r=None, fill=np.nan):
+                          r=None, fill=np.nan, dtype=np.float64):
     """Kernel ``light_scatter_step_sphere`` (light.py:303-315).
 
     Returns (hit mask, res0, res1, res2).  On a miss ``res0`` is NaN and ``res1``/``res2`` are left
     untouched by the reference (uninitialised device memory); they are returned as ``fill``.
     """
-    pcoll = scatter_pcoll(d0, d1, d2, A, n, h=h, c=c, E=E, n_expr=n_expr, r=r)
-    hit = pcoll >= np.asarray(rand, dtype=np.float64)
-    c = np.float64(c)
+    pcoll = scatter_pcoll(d0, d1, d2, A, n, h=h, c=c, E=E, n_expr=n_expr, r=r, dtype=dtype)
+    hit = pcoll >= np.asarray(rand, dtype=dtype)
+    c = dtype(c)
+    rtheta, rphi = np.asarray(rtheta, dtype=dtype), np.asarray(rphi, dtype=dtype)
     st, ct = np.sin(rtheta), np.cos(rtheta)
     sp, cp = np.sin(rphi), np.cos(rphi)
     res0 = np.where(hit, (c * st) * cp, np.nan)
@@ -154,15 +159,15 @@ def scatter_sphere_kernel(d0, d1, d2, rtheta, rphi, rand, A, n, c, *, h=None, E=
     return hit, res0, res1, res2
 
 
-def scatter_apply(v, hit, res):
+def scatter_apply(v, hit, res, dtype=np.float64):
     """Host write-back of the OpenCL path (light.py:325-331): hit -> ``v = res``, ``dv = v - vold``;
     miss -> ``dv = 0``.  Returns (v_new[3], dv[3])."""
     vn, dv = [], []
     for vc, rc in zip(v, res):
-        vc = np.asarray(vc, dtype=np.float64)
-        new = np.where(hit, rc, vc)
+        vc = np.asarray(vc, dtype=dtype)
+        new = np.where(hit, rc, vc).astype(dtype)
         vn.append(new)
-        dv.append(np.where(hit, new - vc, 0.0))
+        dv.append(np.where(hit, new - vc, dtype(0.0)).astype(dtype))
     return vn, dv
 
 
@@ -228,7 +233,7 @@ def u53(a, b):
     return (a * np.uint64(67108864) + b).astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def philox_draws(seed, step, ids):
+def philox_draws(seed, step, ids, dtype=np.float64):
     """Device-RNG equivalent of ``reference_draws``: keyed by (seed, step, global particle id), so the
     stream of a photon does not depend on how particles are sharded over GPUs or compacted.
 
@@ -242,6 +247,11 @@ def philox_draws(seed, step, ids):
     st = np.uint64(int(step) & 0xFFFFFFFF)
     a = philox4x32_10(lo, hi, st, np.uint64(0), k0, k1)
     b = philox4x32_10(lo, hi, st, np.uint64(1), k0, k1)
+    if dtype == np.float32:
+        # the top 24 bits of the same words: u32 <= u64 < u32 + 2**-24, so both precisions follow one stream
+        u24 = lambda w: (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+        pi32 = np.float32(np.pi)
+        return (u24(a[2]) * np.float32(2)) * pi32, u24(b[0]) * pi32, u24(a[0])
     rand = u53(a[0], a[1])
     rtheta = u53(a[2], a[3]) * 2 * np.pi
     rphi = u53(b[0], b[1]) * np.pi
@@ -263,22 +273,22 @@ def philox_energy(seed, ids, e_min, e_max, power=3.0):
 # ----------------------------------------------------------------------------------------------
 # whole steps on an SoA state dict {r:[3], v:[3], dr:[3], dv:[3], E, id}
 # ----------------------------------------------------------------------------------------------
-def step_newton(state, dt):
-    state["r"], state["dr"] = newton_euler(state["r"], state["v"], dt)
+def step_newton(state, dt, dtype=np.float64):
+    state["r"], state["dr"] = newton_euler(state["r"], state["v"], dt, dtype)
 
 
-def step_scatter_isotropic(state, draws, A_kernel, n_kernel, c, *, h=None, use_E=False, n_expr=None):
+def step_scatter_isotropic(state, draws, A_kernel, n_kernel, c, *, h=None, use_E=False, n_expr=None, dtype=np.float64):
     rtheta, rphi, rand = draws
     hit, r0, r1, r2 = scatter_sphere_kernel(
         state["dr"][0], state["dr"][1], state["dr"][2], rtheta, rphi, rand, A_kernel, n_kernel, c,
         h=h if use_E else None, E=state["E"] if use_E else None, n_expr=n_expr,
-        r=state["r"] if n_expr is not None else None)
-    state["v"], state["dv"] = scatter_apply(state["v"], hit, (r0, r1, r2))
+        r=state["r"] if n_expr is not None else None, dtype=dtype)
+    state["v"], state["dv"] = scatter_apply(state["v"], hit, (r0, r1, r2), dtype)
     return hit
 
 
-def step_scatter_delete(state, rand, A_kernel, n_kernel):
-    flags = delete_flags(state["dr"][0], state["dr"][1], state["dr"][2], rand, A_kernel, n_kernel)
+def step_scatter_delete(state, rand, A_kernel, n_kernel, dtype=np.float64):
+    flags = delete_flags(state["dr"][0], state["dr"][1], state["dr"][2], rand, A_kernel, n_kernel, dtype)
     keep = survivors(flags)
     for f in ("r", "v", "dr", "dv"):
         state[f] = [np.asarray(a)[keep] for a in state[f]]

@@ -17,6 +17,8 @@ FIELD_GROUPS = {"r": (R0, R1, R2), "v": (V0, V1, V2), "dr": (DR0, DR1, DR2), "dv
 SCATTER_WAVELENGTH, SCATTER_VARIABLE_N, FUSED_LAZY = 1, 2, 4
 RNG_INPUT, RNG_PHILOX = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
+DTYPE_F64, DTYPE_F32 = 0, 1
+_NP_DTYPE = {DTYPE_F64: np.float64, DTYPE_F32: np.float32}
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
 PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED = range(6)
@@ -66,6 +68,8 @@ _PROTOTYPES = {
     "pcl_k_compact_indices": [_vp, _vp, c_int64, _vp, POINTER(c_int64)],
     "pcl_expr_validate": [c_char_p],
     "pcl_store_alloc": [_vp, c_int64],
+    "pcl_store_alloc_dtype": [_vp, c_int64, c_int],
+    "pcl_store_dtype": [_vp, POINTER(c_int)],
     "pcl_store_free": [_vp],
     "pcl_store_capacity": [_vp, POINTER(c_int64)],
     "pcl_store_count": [_vp, POINTER(c_int64)],
@@ -255,8 +259,16 @@ class Device:
         return keep.value
 
     # ---------------------------------------------------------------- Level 2 (resident store)
-    def store_alloc(self, capacity):
-        check(self.lib.pcl_store_alloc(self.ctx, int(capacity)))
+    def store_alloc(self, capacity, dtype="f64"):
+        """dtype 'f64' (the reference's precision, default) or 'f32' (precision sweep)."""
+        code = {"f64": DTYPE_F64, "f32": DTYPE_F32, np.float64: DTYPE_F64, np.float32: DTYPE_F32}[dtype]
+        check(self.lib.pcl_store_alloc_dtype(self.ctx, int(capacity), code))
+
+    @property
+    def np_dtype(self):
+        d = c_int()
+        check(self.lib.pcl_store_dtype(self.ctx, byref(d)))
+        return _NP_DTYPE[d.value]
 
     def store_free(self):
         check(self.lib.pcl_store_free(self.ctx))
@@ -277,12 +289,13 @@ class Device:
         check(self.lib.pcl_store_set_count(self.ctx, int(count), int(id_base)))
 
     def upload(self, field, host, offset=0):
-        a, hp = _host(host, np.float64)
+        a, hp = _host(host, self.np_dtype)                 # rounded to the store's precision on the host
         check(self.lib.pcl_store_upload(self.ctx, field, hp, offset, a.size))
 
     def download(self, field, n=None, offset=0):
+        """Field values in the store's own dtype (float64 or float32 array)."""
         n = self.count - offset if n is None else n
-        out = np.empty(n, dtype=np.float64)
+        out = np.empty(n, dtype=self.np_dtype)
         check(self.lib.pcl_store_download(self.ctx, field, out.ctypes.data_as(c_void_p), offset, n))
         return out
 
@@ -312,7 +325,7 @@ class Device:
         return p.value
 
     def upload_rand(self, which, host):
-        a, hp = _host(host, np.float64)
+        a, hp = _host(host, self.np_dtype)
         check(self.lib.pcl_store_upload_rand(self.ctx, which, hp, a.size))
 
     def fill_photons(self, n, id_base, c, e_min, e_max, seed):

@@ -2,17 +2,22 @@
 // include/physicl_hip.h.  Build: see __graft_entry__.build() (hipcc --offload-arch=gfx950 -O3
 // -ffp-contract=off).  No PyOpenCL, no CUDA compatibility layer, no Triton.
 //
-// Kernel inventory (all HBM-bandwidth-bound streaming kernels; roofline and bytes in DESIGN.md):
-//   k_newton              NewtonianKinematicsStep.run                 physicl/newton.py:10-16
+// Kernel inventory (all HBM-bandwidth-bound streaming kernels; roofline and bytes in DESIGN.md).
+// <T> = double (the reference's precision) or float (precision sweep, BASELINE.json configs[4]):
+//   k_newton<T>           NewtonianKinematicsStep.run                 physicl/newton.py:10-16
 //   k_delete_flags        light_scatter_step_del / "test"             physicl/light.py:146-158, 239-249
 //   k_sphere<E>           light_scatter_step_sphere                   physicl/light.py:303-315
-//   k_scatter<E>          fused ScatterIsotropicStep.__run_cl         physicl/light.py:281-331
-//   k_delete_mask         delete-flag kernel -> wave64 ballot masks   physicl/light.py:239-249
+//   k_scatter<T,E>        ScatterIsotropicStep.__run_cl as one step   physicl/light.py:281-331
+//   k_fused<T,E>          Newton + scatter + counters in one pass     (pcl_device.h)
+//   k_fast<T,E>           the same, fast path                         (pcl_device.h)
+//   k_lam4<T>             cache of pow((h*c)/E, -4)                   physicl/light.py:301
+//   k_materialize<T>      dr, dv after lazy fused steps               physicl/newton.py:15, light.py:329-331
+//   k_delete_mask<T>      delete-flag kernel -> wave64 ballot masks   physicl/light.py:239-249
 //   k_tile_scan           exclusive scan of per-tile survivor counts
-//   k_compact<NF>         stable compaction of the SoA state          physicl/light.py:258-260,
+//   k_compact<W,NF>       stable compaction of the SoA state          physicl/light.py:258-260,
 //                                                                      physicl/__init__.py:455-459
-//   k_counters            ScatterSignMeasureStep / ScatterMeasureStep physicl/light.py:374-431
-//   k_fill_photons        generate_photons (bulk, on device)          physicl/light.py:112-128
+//   k_counters<T>         ScatterSignMeasureStep / ScatterMeasureStep physicl/light.py:374-431
+//   k_fill_photons<T>     generate_photons (bulk, on device)          physicl/light.py:112-128
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
@@ -55,18 +60,18 @@ int fail(int code, const char *fmt, ...) {
                         #expr, hipGetErrorString(e__), __FILE__, __LINE__);                                \
     } while (0)
 
-#define PCL_TRY(expr)            \
-    do {                         \
-        int rc__ = (expr);       \
+#define PCL_TRY(expr)                    \
+    do {                                 \
+        int rc__ = (expr);               \
         if (rc__ != PCL_OK) return rc__; \
     } while (0)
 
 // =================================================================================================
 // geometry
 // =================================================================================================
-constexpr int kBlock = 256;               // 4 wave64 per workgroup
-constexpr int kTileRows = 32;             // compaction tile = 32 rows of 64 particles
-constexpr int kTile = kTileRows * 64;     // 2048 particles: one workgroup, 8 rows per wave
+constexpr int kBlock = 256;           // 4 wave64 per workgroup
+constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particles
+constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
 
 __host__ __device__ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -76,68 +81,67 @@ __host__ __device__ inline int64_t div_up(int64_t a, int64_t b) { return (a + b 
 // =================================================================================================
 
 // ---- NewtonianKinematicsStep.run: dr = v*dt (rounded, STORED), r = r + dr   newton.py:15-16 -----
-// 96 B per particle-step (6 loads + 6 stores of 8 B).  Each lane moves 16 B per access (two
-// consecutive particles) when the particle count allows; unfused mul/add so results are bit-exact.
+// 96 B per fp64 particle-step (6 loads + 6 stores).  Each lane moves 16 B per access (VEC consecutive
+// particles); unfused mul/add so results are bit-exact.  Arrays are padded, so the last group is whole.
+template <typename T>
 struct newton_args {
-    const double *v[3];
-    double *r[3];
-    double *dr[3];
-    double dt;
+    const T *v[3];
+    T *r[3];
+    T *dr[3];
+    T dt;
     int64_t N;
 };
 
-__global__ void __launch_bounds__(kBlock) k_newton(newton_args a) {
-    const int64_t npair = a.N >> 1;
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_newton(newton_args<T> a) {
+    typedef pcl_rt<T> R;
+    constexpr int VEC = R::VEC;
+    typedef pcl_vec<T, VEC> VV;
+    const int64_t nq = (a.N + VEC - 1) / VEC;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += stride) {
-        double2 v[3], r[3];
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
+        T v[3][VEC], r[3][VEC], d[3][VEC];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            v[k] = reinterpret_cast<const double2 *>(a.v[k])[p];
-            r[k] = reinterpret_cast<const double2 *>(a.r[k])[p];
+            VV::ld(a.v[k], q, v[k]);
+            VV::ld(a.r[k], q, r[k]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            double2 d;
-            d.x = __dmul_rn(v[k].x, a.dt);
-            d.y = __dmul_rn(v[k].y, a.dt);
-            r[k].x = __dadd_rn(r[k].x, d.x);
-            r[k].y = __dadd_rn(r[k].y, d.y);
-            reinterpret_cast<double2 *>(a.dr[k])[p] = d;
-            reinterpret_cast<double2 *>(a.r[k])[p] = r[k];
-        }
-    }
-    if ((a.N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t i = a.N - 1;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const double d = __dmul_rn(a.v[k][i], a.dt);
-            a.dr[k][i] = d;
-            a.r[k][i] = __dadd_rn(a.r[k][i], d);
+            for (int e = 0; e < VEC; ++e) {
+                d[k][e] = R::mul(v[k][e], a.dt);
+                r[k][e] = R::add(r[k][e], d[k][e]);
+            }
+            VV::st(a.dr[k], q, d[k]);
+            VV::st(a.r[k], q, r[k]);
         }
     }
 }
 
 // ---- materialise what a lazy fused step left implicit: dr = v_in*dt, dv = v_out - v_in -----------
 // (v_out - v_in is +0 for a particle that was not scattered: exactly the reference's dv = 0)
+template <typename T>
 struct materialize_args {
-    const double *vin[3], *vout[3];
-    double *dr[3], *dv[3];
+    const T *vin[3], *vout[3];
+    T *dr[3], *dv[3];
     const unsigned char *kind;
-    double dt;
+    T dt;
     int do_dv;
     int64_t N;
 };
 
-__global__ void __launch_bounds__(kBlock) k_materialize(materialize_args a) {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_materialize(materialize_args<T> a) {
+    typedef pcl_rt<T> R;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
         const bool photon = a.kind ? (a.kind[i] != 0) : true;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const double vi = a.vin[k][i];
-            a.dr[k][i] = __dmul_rn(vi, a.dt);
-            if (a.do_dv && photon) a.dv[k][i] = __dsub_rn(a.vout[k][i], vi);
+            const T vi = a.vin[k][i];
+            a.dr[k][i] = R::mul(vi, a.dt);
+            if (a.do_dv && photon) a.dv[k][i] = R::sub(a.vout[k][i], vi);
         }
     }
 }
@@ -150,58 +154,60 @@ __global__ void __launch_bounds__(kBlock) k_delete_flags(const double *__restric
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const double An = __dmul_rn(A, n);
     for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < N; gid += stride) {
-        const double pcoll = __dmul_rn(An, pcl_step_norm(d0[gid], d1[gid], d2[gid]));
+        const double pcoll = __dmul_rn(An, pcl_step_norm<double>(d0[gid], d1[gid], d2[gid]));
         res[gid] = (pcoll >= rand[gid]) ? 1 : 0;
     }
 }
 
-// ---- Level 1 sphere kernel + Level 2 fused scatter: ahead-of-time variants (constant n) ----------
+// ---- ahead-of-time variants (constant n) of the kernels whose bodies live in pcl_device.h ---------
 template <bool USE_E>
 __global__ void __launch_bounds__(kBlock) k_sphere(pcl_sphere_args a) {
     pcl_sphere_body<USE_E, false>(a);
 }
-template <bool USE_E>
-__global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args a) {
-    pcl_scatter_body<USE_E, false>(a);
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args<T> a) {
+    pcl_scatter_body<T, USE_E, false>(a);
 }
-// whole loop body in one pass: Newton -> ScatterIsotropic -> counters (pcl_device.h)
-template <bool USE_E>
-__global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args a) {
-    pcl_fused_body<USE_E, false>(a);
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args<T> a) {
+    pcl_fused_body<T, USE_E, false>(a);
 }
-template <bool USE_E>
-__global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args a) {
-    pcl_fast_body<USE_E, false, PCL_FAST_VEC>(a);
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
+    pcl_fast_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
 }
 
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
 // store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
-__global__ void __launch_bounds__(kBlock) k_lam4(const double *__restrict__ E, double *__restrict__ lam4, double h,
-                                                 double c, int64_t N) {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_lam4(const T *__restrict__ E, T *__restrict__ lam4, T h, T c, int64_t N) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
-        lam4[i] = pcl_wavelength_term(h, c, E[i]);
+        lam4[i] = pcl_wavelength_term<T>(h, c, E[i]);
 }
 
 // ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
 // One workgroup per 2048-particle tile; wave w owns rows 8w..8w+7 (64 consecutive particles per
 // row, lane == particle so the ballot bit order IS the particle order -> stable compaction).
+template <typename T>
 struct delmask_args {
-    const double *d0, *d1, *d2;
-    const double *rand;          // PCL_RNG_INPUT
-    const int64_t *ids;          // PCL_RNG_PHILOX with materialised ids, else NULL
-    const unsigned char *kind;   // NULL = all photons
-    const int32_t *flags_in;     // when non-NULL: take flags from memory instead (pcl_k_compact_indices)
-    uint64_t *masks;             // [n_tiles * 32] bit l of row mask = particle survives
-    int32_t *tile_keep;          // [n_tiles]
+    const T *d0, *d1, *d2;
+    const T *rand;             // PCL_RNG_INPUT
+    const int64_t *ids;        // PCL_RNG_PHILOX with materialised ids, else NULL
+    const unsigned char *kind; // NULL = all photons
+    const int32_t *flags_in;   // when non-NULL: take flags from memory instead (pcl_k_compact_indices)
+    uint64_t *masks;           // [n_tiles * 32] bit l of row mask = particle survives
+    int32_t *tile_keep;        // [n_tiles]
     int64_t id_base, N;
-    double An;                   // A * n, rounded once like the kernel's left-to-right product
+    T An;                      // A * n, rounded once like the kernel's left-to-right product
     uint64_t seed;
     uint32_t step;
     int rng_mode;
 };
 
-__global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args a) {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
+    typedef pcl_rt<T> R;
     __shared__ int s_cnt[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
@@ -216,13 +222,13 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args a) {
                 keep = (a.flags_in[i] == 0);
             } else {
                 const bool photon = a.kind ? (a.kind[i] != 0) : true;
-                const double pcoll = __dmul_rn(a.An, pcl_step_norm(a.d0[i], a.d1[i], a.d2[i]));
-                double rand;
+                const T pcoll = R::mul(a.An, pcl_step_norm<T>(a.d0[i], a.d1[i], a.d2[i]));
+                T rand;
                 if (a.rng_mode == PCL_RNG_PHX) {
                     const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u,
                                                           (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                    rand = pcl_u53(w.x, w.y);
+                    rand = R::uniform(w.x, w.y);
                 } else {
                     rand = a.rand[i];
                 }
@@ -272,23 +278,23 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     if (t == 1023) *total = s_wave[15];
 }
 
-// ---- delete step, pass 3: stable compaction of NF 8-byte arrays (+ optional kind bytes) ----------
+// ---- delete step, pass 3: stable compaction of NF arrays of W-sized words (+ ids, kind bytes) -----
 // Reads: 1 bit of mask per particle + the survivors' state; writes the survivors densely, in order.
 constexpr int kMaxCompactFields = 16;
 struct compact_args {
-    const uint64_t *src[kMaxCompactFields];
-    uint64_t *dst[kMaxCompactFields];
+    const void *src[kMaxCompactFields];
+    void *dst[kMaxCompactFields];
     const unsigned char *ksrc;
     unsigned char *kdst;
-    int64_t *ids_dst;      // non-NULL with ids_src == NULL: write id_base + i (ids were implicit)
+    int64_t *ids_dst;       // non-NULL with ids_src == NULL: write id_base + i (ids were implicit)
     const int64_t *ids_src;
-    int64_t *idx_dst;      // non-NULL: write the source index i (pcl_k_compact_indices)
+    int64_t *idx_dst;       // non-NULL: write the source index i (pcl_k_compact_indices)
     const uint64_t *masks;
     const int64_t *tile_off;
     int64_t id_base, N;
 };
 
-template <int NF>
+template <typename W, int NF>
 __global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
@@ -303,11 +309,11 @@ __global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
         const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
         if ((m >> lane) & 1ull) {
             const int64_t o = dest + __popcll(m & below);
-            uint64_t val[NF > 0 ? NF : 1];
+            W val[NF > 0 ? NF : 1];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) val[f] = a.src[f][i];
+            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[i];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) a.dst[f][o] = val[f];
+            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[o] = val[f];
             if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
             if (a.kdst) a.kdst[o] = a.ksrc[i];
             if (a.idx_dst) a.idx_dst[o] = i;
@@ -325,30 +331,33 @@ __global__ void __launch_bounds__(kBlock) k_masks_to_flags(const uint64_t *__res
 }
 
 // ---- counters: sign counts + plane crossings, LDS-staged, one atomic per workgroup per counter ---
+template <typename T>
 struct counter_args {
-    const double *v[3], *r[3], *dr[3];
+    const T *v[3], *r[3], *dr[3];
     uint64_t *out; // [3 + n_planes]
-    double plane_L[PCL_MAX_PLANES];
+    T plane_L[PCL_MAX_PLANES];
     int plane_ax[PCL_MAX_PLANES];
     int n_planes;
     int64_t N;
 };
 
-__global__ void __launch_bounds__(kBlock) k_counters(counter_args a) {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_counters(counter_args<T> a) {
+    typedef pcl_rt<T> R;
     __shared__ uint32_t s_part[kBlock / 64][3 + PCL_MAX_PLANES];
     uint32_t cnt[3 + PCL_MAX_PLANES];
 #pragma unroll
     for (int k = 0; k < 3 + PCL_MAX_PLANES; ++k) cnt[k] = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
-        cnt[0] += a.v[0][i] > 0.0; // strictly positive: "Do we count 0 as positive? No" light.py:415
-        cnt[1] += a.v[1][i] > 0.0;
-        cnt[2] += a.v[2][i] > 0.0;
+        cnt[0] += a.v[0][i] > (T)0; // strictly positive: "Do we count 0 as positive? No" light.py:415
+        cnt[1] += a.v[1][i] > (T)0;
+        cnt[2] += a.v[2][i] > (T)0;
 #pragma unroll
         for (int p = 0; p < PCL_MAX_PLANES; ++p) {
             if (p < a.n_planes) {
                 const int ax = a.plane_ax[p];
-                const double L = a.plane_L[p], x = a.r[ax][i], prev = __dsub_rn(x, a.dr[ax][i]);
+                const T L = a.plane_L[p], x = a.r[ax][i], prev = R::sub(x, a.dr[ax][i]);
                 cnt[3 + p] += ((prev <= L && L <= x) || (prev >= L && L >= x)); // light.py:386
             }
         }
@@ -369,19 +378,23 @@ __global__ void __launch_bounds__(kBlock) k_counters(counter_args a) {
 }
 
 // ---- bulk photon creation --------------------------------------------------------------------------
+template <typename T>
 struct fill_args {
-    double *f[PCL_NFIELDS];
+    T *f[PCL_NFIELDS];
     int64_t n, id_base;
     double c, e_min, e_max;
     uint64_t seed;
 };
 
-__global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args a) {
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args<T> a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
         const uint64_t id = (uint64_t)(a.id_base + i);
         const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), 0xFFFFFFFFu, 2u, (pcl_u32)a.seed,
                                               (pcl_u32)(a.seed >> 32));
+        // the energy is always sampled in fp64 and rounded to the store's precision: an fp32 store then
+        // holds exactly float(E_fp64), so both precisions describe the same photons
         const double u = pcl_u53(w.x, w.y);
         const double E = __dadd_rn(a.e_min, __dmul_rn(__dsub_rn(a.e_max, a.e_min), pow(u, 1.0 / 3.0)));
 #pragma unroll
@@ -389,14 +402,15 @@ __global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args a) {
             double val = 0.0;
             if (f == PCL_V0) val = a.c;
             if (f == PCL_E) val = E;
-            a.f[f][i] = val;
+            a.f[f][i] = (T)val;
         }
     }
 }
 
 // =================================================================================================
 // expression validator (variable_n_fn): keeps arbitrary text out of the hipRTC compile and keeps
-// every array read at index [gid] so a user expression cannot fault the GPU.
+// every array read at index [gid] so a user expression cannot fault the GPU.  Optionally produces the
+// fp32 spelling of the expression (an f suffix on every floating literal).
 // =================================================================================================
 const char *const kFuncs[] = {"exp", "sqrt", "pow", "log", "log2", "log10", "exp2", "sin",
                               "cos", "tanh", "fabs", "fmin", "fmax", nullptr};
@@ -408,23 +422,31 @@ bool in_list(const std::string &s, const char *const *list) {
     return false;
 }
 
-int validate_expr(const char *e) {
+int validate_expr(const char *e, std::string *f32_out = nullptr) {
     if (!e) return fail(PCL_ERR_EXPR, "variable_n_fn is NULL");
     const size_t len = strlen(e);
     if (len == 0 || len > 2000) return fail(PCL_ERR_EXPR, "variable_n_fn is empty or longer than 2000 characters");
     size_t i = 0;
     int depth = 0;
+    std::string f32;
     auto skip_ws = [&]() {
-        while (i < len && (e[i] == ' ' || e[i] == '\t' || e[i] == '\n')) ++i;
+        while (i < len && (e[i] == ' ' || e[i] == '\t' || e[i] == '\n')) {
+            f32 += ' ';
+            ++i;
+        }
     };
     while (true) {
         skip_ws();
         if (i >= len) break;
         const char ch = e[i];
         if ((ch >= '0' && ch <= '9') || ch == '.') {
-            // number: digits [. digits] [e|E [+-] digits] [f|F not allowed: reference is fp64-only]
+            // number: digits [. digits] [e|E [+-] digits]; suffixes are not allowed (the reference is fp64-only)
             size_t j = i;
-            while (j < len && ((e[j] >= '0' && e[j] <= '9') || e[j] == '.')) ++j;
+            bool floating = false;
+            while (j < len && ((e[j] >= '0' && e[j] <= '9') || e[j] == '.')) {
+                floating = floating || e[j] == '.';
+                ++j;
+            }
             if (j < len && (e[j] == 'e' || e[j] == 'E')) {
                 size_t k = j + 1;
                 if (k < len && (e[k] == '+' || e[k] == '-')) ++k;
@@ -432,9 +454,12 @@ int validate_expr(const char *e) {
                     return fail(PCL_ERR_EXPR, "variable_n_fn: malformed exponent at offset %zu", j);
                 while (k < len && e[k] >= '0' && e[k] <= '9') ++k;
                 j = k;
+                floating = true;
             }
             if (j < len && ((e[j] >= 'a' && e[j] <= 'z') || (e[j] >= 'A' && e[j] <= 'Z') || e[j] == '_'))
                 return fail(PCL_ERR_EXPR, "variable_n_fn: number followed by '%c' at offset %zu", e[j], j);
+            f32.append(e + i, j - i);
+            if (floating) f32 += 'f';
             i = j;
         } else if ((ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch == '_') {
             size_t j = i;
@@ -443,6 +468,7 @@ int validate_expr(const char *e) {
                 ++j;
             const std::string id(e + i, j - i);
             i = j;
+            f32 += id;
             if (in_list(id, kFuncs)) {
                 skip_ws();
                 if (i >= len || e[i] != '(')
@@ -450,31 +476,38 @@ int validate_expr(const char *e) {
             } else if (in_list(id, kArrays)) {
                 // must be exactly  name [ gid ]
                 skip_ws();
-                if (i >= len || e[i] != '[') return fail(PCL_ERR_EXPR, "variable_n_fn: '%s' must be indexed as %s[gid]", id.c_str(), id.c_str());
+                if (i >= len || e[i] != '[')
+                    return fail(PCL_ERR_EXPR, "variable_n_fn: '%s' must be indexed as %s[gid]", id.c_str(), id.c_str());
                 ++i;
                 skip_ws();
                 if (len - i < 3 || strncmp(e + i, "gid", 3) != 0)
                     return fail(PCL_ERR_EXPR, "variable_n_fn: only the index [gid] is allowed on '%s'", id.c_str());
                 i += 3;
                 skip_ws();
-                if (i >= len || e[i] != ']') return fail(PCL_ERR_EXPR, "variable_n_fn: only the index [gid] is allowed on '%s'", id.c_str());
+                if (i >= len || e[i] != ']')
+                    return fail(PCL_ERR_EXPR, "variable_n_fn: only the index [gid] is allowed on '%s'", id.c_str());
                 ++i;
+                f32 += "[gid]";
             } else {
                 return fail(PCL_ERR_EXPR, "variable_n_fn: identifier '%s' is not allowed", id.c_str());
             }
         } else if (ch == '(') {
             ++depth;
+            f32 += ch;
             ++i;
         } else if (ch == ')') {
             if (--depth < 0) return fail(PCL_ERR_EXPR, "variable_n_fn: unbalanced ')' at offset %zu", i);
+            f32 += ch;
             ++i;
         } else if (ch == '+' || ch == '-' || ch == '*' || ch == '/' || ch == ',') {
+            f32 += ch;
             ++i;
         } else {
             return fail(PCL_ERR_EXPR, "variable_n_fn: character '%c' at offset %zu is not allowed", ch, i);
         }
     }
     if (depth != 0) return fail(PCL_ERR_EXPR, "variable_n_fn: unbalanced '('");
+    if (f32_out) *f32_out = f32;
     return PCL_OK;
 }
 
@@ -483,10 +516,10 @@ int validate_expr(const char *e) {
 // =================================================================================================
 struct rtc_entry {
     hipModule_t module = nullptr;
-    hipFunction_t sphere[2] = {nullptr, nullptr};  // [USE_E]
-    hipFunction_t scatter[2] = {nullptr, nullptr}; // [USE_E]
-    hipFunction_t fused[2] = {nullptr, nullptr};   // [USE_E]
-    hipFunction_t fast[2] = {nullptr, nullptr};    // [USE_E]
+    hipFunction_t sphere[2] = {nullptr, nullptr};     // [USE_E]           (fp64 only: the reference's ABI)
+    hipFunction_t scatter[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [dtype][USE_E]
+    hipFunction_t fused[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t fast[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 
 } // namespace
@@ -499,24 +532,25 @@ struct pcl_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int grid_cap = 2048; // workgroups for grid-stride kernels: 8 per CU
 
-    // particle store
+    // particle store.  Every array holds elements of the store's dtype (8 or 4 bytes).
+    int dtype = PCL_DTYPE_F64;
+    size_t esz = 8;
     int64_t capacity = 0, count = 0, id_base = 0;
     bool ids_iota = true;
-    double *field[PCL_NFIELDS] = {};
-    double *field_alt[PCL_NFIELDS] = {}; // compaction double buffer (lazy)
+    void *field[PCL_NFIELDS] = {};
+    void *field_alt[PCL_NFIELDS] = {}; // compaction double buffer (lazy)
     int64_t *ids = nullptr, *ids_alt = nullptr;
     unsigned char *kind = nullptr, *kind_alt = nullptr;
     // lazy fused steps: second half of the v double buffer + what is still implicit
-    double *vprev[3] = {nullptr, nullptr, nullptr};
-    bool lazy_dr = false;      // dr not materialised: dr = (lazy_dv ? vprev : v) * lazy_dt
-    bool lazy_dv = false;      // dv not materialised: dv = v - vprev (photons)
+    void *vprev[3] = {nullptr, nullptr, nullptr};
+    bool lazy_dr = false; // dr not materialised: dr = (lazy_dv ? vprev : v) * lazy_dt
+    bool lazy_dv = false; // dv not materialised: dv = v - vprev (photons)
     double lazy_dt = 0.0;
     // cache of pow((h*c)/E, -4) per photon for the fast fused path
-    double *lam4 = nullptr;
+    void *lam4 = nullptr;
     bool lam4_valid = false;
     double lam4_h = 0.0, lam4_c = 0.0;
-    int vec = 2; // lanes own 2 particles (16-byte accesses) in the fast path; PCL_FAST_VEC1 experiment = 1
-    double *rnd[3] = {nullptr, nullptr, nullptr};
+    void *rnd[3] = {nullptr, nullptr, nullptr};
     int64_t rnd_n[3] = {0, 0, 0};
 
     // compaction scratch (sized for scratch_cap particles)
@@ -545,6 +579,11 @@ struct pcl_ctx {
 
 namespace {
 
+template <typename T> T *F(pcl_ctx *c, int f) { return static_cast<T *>(c->field[f]); }
+
+// run fn<double> or fn<float> according to the store's dtype
+#define PCL_DISPATCH(ctx, call_f64, call_f32) ((ctx)->dtype == PCL_DTYPE_F64 ? (call_f64) : (call_f32))
+
 int bind(pcl_ctx *ctx) {
     if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
     PCL_HIP(hipSetDevice(ctx->device));
@@ -565,12 +604,18 @@ int grid_for(const pcl_ctx *ctx, int64_t items, int per_block) {
 }
 
 // Every particle array is padded to a multiple of 64 elements: the 16-byte-per-lane kernels load and
-// store whole pairs, so element N of an odd-sized store must exist (its contents are never used).
+// store whole groups, so the elements after N in the last group must exist (their contents are never used).
+int dev_alloc_bytes(void **p, int64_t n_elems, size_t esz) {
+    void *q = nullptr;
+    const int64_t n = ((n_elems > 0 ? n_elems : 1) + 63) & ~int64_t(63);
+    PCL_HIP(hipMalloc(&q, (size_t)n * esz));
+    *p = q;
+    return PCL_OK;
+}
 template <typename T>
 int dev_alloc(T **p, int64_t n) {
     void *q = nullptr;
-    n = ((n > 0 ? n : 1) + 63) & ~int64_t(63);
-    PCL_HIP(hipMalloc(&q, (size_t)n * sizeof(T)));
+    PCL_TRY(dev_alloc_bytes(&q, n, sizeof(T)));
     *p = static_cast<T *>(q);
     return PCL_OK;
 }
@@ -597,7 +642,7 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n) {
 
 int ensure_alt(pcl_ctx *ctx) {
     for (int f = 0; f < PCL_NFIELDS; ++f)
-        if (!ctx->field_alt[f]) PCL_TRY(dev_alloc(&ctx->field_alt[f], ctx->capacity));
+        if (!ctx->field_alt[f]) PCL_TRY(dev_alloc_bytes(&ctx->field_alt[f], ctx->capacity, ctx->esz));
     if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
     if (!ctx->ids_alt) PCL_TRY(dev_alloc(&ctx->ids_alt, ctx->capacity));
     if (ctx->kind && !ctx->kind_alt) PCL_TRY(dev_alloc(&ctx->kind_alt, ctx->capacity));
@@ -605,24 +650,30 @@ int ensure_alt(pcl_ctx *ctx) {
 }
 
 // Make dr / dv real arrays again after lazy fused steps (no-op otherwise).
-int materialize(pcl_ctx *ctx) {
-    if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
+template <typename T>
+int materialize_t(pcl_ctx *ctx) {
     const int64_t N = ctx->count;
     if (N > 0) {
-        materialize_args a{};
+        materialize_args<T> a{};
         for (int k = 0; k < 3; ++k) {
-            a.vin[k] = ctx->lazy_dv ? ctx->vprev[k] : ctx->field[PCL_V0 + k];
-            a.vout[k] = ctx->field[PCL_V0 + k];
-            a.dr[k] = ctx->field[PCL_DR0 + k];
-            a.dv[k] = ctx->field[PCL_DV0 + k];
+            a.vin[k] = static_cast<const T *>(ctx->lazy_dv ? ctx->vprev[k] : ctx->field[PCL_V0 + k]);
+            a.vout[k] = F<T>(ctx, PCL_V0 + k);
+            a.dr[k] = F<T>(ctx, PCL_DR0 + k);
+            a.dv[k] = F<T>(ctx, PCL_DV0 + k);
         }
         a.kind = ctx->kind;
-        a.dt = ctx->lazy_dt;
+        a.dt = (T)ctx->lazy_dt;
         a.do_dv = ctx->lazy_dv ? 1 : 0;
         a.N = N;
-        hipLaunchKernelGGL(k_materialize, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL(k_materialize<T>, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
         PCL_TRY(launch_check("k_materialize"));
     }
+    return PCL_OK;
+}
+
+int materialize(pcl_ctx *ctx) {
+    if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
+    PCL_TRY(PCL_DISPATCH(ctx, materialize_t<double>(ctx), materialize_t<float>(ctx)));
     ctx->lazy_dr = ctx->lazy_dv = false;
     return PCL_OK;
 }
@@ -649,7 +700,8 @@ int check_range(pcl_ctx *ctx, int64_t offset, int64_t n, const void *host) {
 
 // ---- hipRTC specialisation cache ---------------------------------------------------------------------
 int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
-    PCL_TRY(validate_expr(expr));
+    std::string expr_f32;
+    PCL_TRY(validate_expr(expr, &expr_f32));
     auto it = ctx->rtc.find(expr);
     if (it != ctx->rtc.end()) {
         *out = &it->second;
@@ -671,6 +723,8 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     }
     src += "#define PCL_N_EXPR (";
     src += expr;
+    src += ")\n#define PCL_N_EXPR_F (";
+    src += expr_f32;
     src += ")\n";
     src += pcl_rtc_source;
     hiprtcProgram prog;
@@ -697,12 +751,17 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     PCL_HIP(hipModuleLoadData(&ent.module, code.data()));
     PCL_HIP(hipModuleGetFunction(&ent.sphere[0], ent.module, "pcl_rtc_sphere_e0"));
     PCL_HIP(hipModuleGetFunction(&ent.sphere[1], ent.module, "pcl_rtc_sphere_e1"));
-    PCL_HIP(hipModuleGetFunction(&ent.scatter[0], ent.module, "pcl_rtc_scatter_e0"));
-    PCL_HIP(hipModuleGetFunction(&ent.scatter[1], ent.module, "pcl_rtc_scatter_e1"));
-    PCL_HIP(hipModuleGetFunction(&ent.fused[0], ent.module, "pcl_rtc_fused_e0"));
-    PCL_HIP(hipModuleGetFunction(&ent.fused[1], ent.module, "pcl_rtc_fused_e1"));
-    PCL_HIP(hipModuleGetFunction(&ent.fast[0], ent.module, "pcl_rtc_fast_e0"));
-    PCL_HIP(hipModuleGetFunction(&ent.fast[1], ent.module, "pcl_rtc_fast_e1"));
+    const char *dt_tag[2] = {"", "f_"};
+    for (int d = 0; d < 2; ++d)
+        for (int e = 0; e < 2; ++e) {
+            char nm[64];
+            snprintf(nm, sizeof nm, "pcl_rtc_scatter_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.scatter[d][e], ent.module, nm));
+            snprintf(nm, sizeof nm, "pcl_rtc_fused_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.fused[d][e], ent.module, nm));
+            snprintf(nm, sizeof nm, "pcl_rtc_fast_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.fast[d][e], ent.module, nm));
+        }
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
     return PCL_OK;
@@ -736,7 +795,7 @@ int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const ch
     return launch_check(what);
 }
 
-// run passes 2 and 3 of the compaction pipeline on masks/tile_keep already produced for n particles
+// run pass 2 of the compaction pipeline on tile_keep already produced for n particles
 int scan_tiles(pcl_ctx *ctx, int64_t n) {
     const int64_t tiles = div_up(n, kTile);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
@@ -745,6 +804,227 @@ int scan_tiles(pcl_ctx *ctx, int64_t n) {
     PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 1, ctx->d_cnt + kCounterSlots - 1, sizeof(uint64_t),
                            hipMemcpyDeviceToHost, ctx->stream));
     return PCL_OK;
+}
+
+// ---- typed implementations of the Level-2 steps ------------------------------------------------------
+template <typename T>
+int step_newton_t(pcl_ctx *ctx, double dt) {
+    const int64_t N = ctx->count;
+    newton_args<T> a{};
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = F<T>(ctx, PCL_V0 + k);
+        a.r[k] = F<T>(ctx, PCL_R0 + k);
+        a.dr[k] = F<T>(ctx, PCL_DR0 + k);
+    }
+    a.dt = (T)dt;
+    a.N = N;
+    const int ps = prof_begin(ctx, PCL_PROF_NEWTON);
+    hipLaunchKernelGGL(k_newton<T>, dim3(grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
+    return launch_check("k_newton");
+}
+
+template <typename T>
+int fill_photons_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max, uint64_t seed) {
+    fill_args<T> a{};
+    for (int f = 0; f < PCL_NFIELDS; ++f) a.f[f] = F<T>(ctx, f);
+    a.n = n;
+    a.id_base = id_base;
+    a.c = c;
+    a.e_min = e_min;
+    a.e_max = e_max;
+    a.seed = seed;
+    hipLaunchKernelGGL(k_fill_photons<T>, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    return launch_check("k_fill_photons");
+}
+
+template <typename T>
+int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c, double h,
+                   int rng_mode, uint64_t seed, uint32_t step) {
+    const int64_t N = ctx->count;
+    pcl_scatter_args<T> a{};
+    a.d0 = F<T>(ctx, PCL_DR0); a.d1 = F<T>(ctx, PCL_DR1); a.d2 = F<T>(ctx, PCL_DR2);
+    a.E = F<T>(ctx, PCL_E);
+    a.r0 = F<T>(ctx, PCL_R0); a.r1 = F<T>(ctx, PCL_R1); a.r2 = F<T>(ctx, PCL_R2);
+    a.v0 = F<T>(ctx, PCL_V0); a.v1 = F<T>(ctx, PCL_V1); a.v2 = F<T>(ctx, PCL_V2);
+    a.dv0 = F<T>(ctx, PCL_DV0); a.dv1 = F<T>(ctx, PCL_DV1); a.dv2 = F<T>(ctx, PCL_DV2);
+    a.rtheta = static_cast<const T *>(ctx->rnd[0]);
+    a.rphi = static_cast<const T *>(ctx->rnd[1]);
+    a.rand = static_cast<const T *>(ctx->rnd[2]);
+    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    a.kind = ctx->kind;
+    a.hits = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    a.id_base = ctx->id_base;
+    a.N = N;
+    a.A = (T)A; a.n = (T)n; a.c = (T)c; a.h = (T)h;
+    a.seed = seed;
+    a.step = step;
+    a.rng_mode = rng_mode;
+    const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    const int ps = prof_begin(ctx, PCL_PROF_SCATTER);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->scatter[d][use_e ? 1 : 0], grid, a, "scatter_isotropic (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL((k_scatter<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_scatter<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_scatter"));
+    }
+    prof_end(ctx, ps);
+    return PCL_OK;
+}
+
+template <typename T>
+int ensure_lam4_t(pcl_ctx *ctx, double h, double c) {
+    if (ctx->lam4_valid && ctx->lam4_h == h && ctx->lam4_c == c) return PCL_OK;
+    if (!ctx->lam4) PCL_TRY(dev_alloc_bytes(&ctx->lam4, ctx->capacity, ctx->esz));
+    hipLaunchKernelGGL(k_lam4<T>, dim3(grid_for(ctx, ctx->count, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const T *)F<T>(ctx, PCL_E), static_cast<T *>(ctx->lam4), (T)h, (T)c, ctx->count);
+    PCL_TRY(launch_check("k_lam4"));
+    ctx->lam4_valid = true;
+    ctx->lam4_h = h;
+    ctx->lam4_c = c;
+    return PCL_OK;
+}
+
+template <typename T>
+int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c, double h,
+                uint64_t seed, uint32_t step) {
+    const int64_t N = ctx->count;
+    if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
+    for (int k = 0; k < 3; ++k)
+        if (!ctx->vprev[k]) PCL_TRY(dev_alloc_bytes(&ctx->vprev[k], ctx->capacity, ctx->esz));
+    pcl_fast_args<T> f{};
+    f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
+    f.vi0 = F<T>(ctx, PCL_V0); f.vi1 = F<T>(ctx, PCL_V1); f.vi2 = F<T>(ctx, PCL_V2);
+    f.vo0 = static_cast<T *>(ctx->vprev[0]); f.vo1 = static_cast<T *>(ctx->vprev[1]); f.vo2 = static_cast<T *>(ctx->vprev[2]);
+    f.lam4 = static_cast<const T *>(ctx->lam4);
+    f.E = F<T>(ctx, PCL_E);
+    f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    f.id_base = ctx->id_base;
+    f.N = N;
+    f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
+    f.seed = seed;
+    f.step = step;
+    const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    const int ps = prof_begin(ctx, PCL_PROF_FUSED);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->fast[d][use_e ? 1 : 0], grid, f, "step_fused fast path (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL((k_fast<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        else
+            hipLaunchKernelGGL((k_fast<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        PCL_TRY(launch_check("k_fast"));
+    }
+    prof_end(ctx, ps);
+    return PCL_OK;
+}
+
+template <typename T>
+int step_fused_t(pcl_ctx *ctx, double dt, bool do_scatter, double A, double n, bool use_e, bool var_n, rtc_entry *ent,
+                 double c, double h, int rng_mode, uint64_t seed, uint32_t step, const double *planes_host, int n_planes,
+                 bool lazy) {
+    const int64_t N = ctx->count;
+    const int np = n_planes > 0 ? n_planes : 0;
+    pcl_fused_args<T> a{};
+    a.r0 = F<T>(ctx, PCL_R0); a.r1 = F<T>(ctx, PCL_R1); a.r2 = F<T>(ctx, PCL_R2);
+    a.vi0 = F<T>(ctx, PCL_V0); a.vi1 = F<T>(ctx, PCL_V1); a.vi2 = F<T>(ctx, PCL_V2);
+    a.vo0 = F<T>(ctx, PCL_V0); a.vo1 = F<T>(ctx, PCL_V1); a.vo2 = F<T>(ctx, PCL_V2);
+    if (lazy && do_scatter) {
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->vprev[k]) PCL_TRY(dev_alloc_bytes(&ctx->vprev[k], ctx->capacity, ctx->esz));
+        a.vo0 = static_cast<T *>(ctx->vprev[0]); a.vo1 = static_cast<T *>(ctx->vprev[1]); a.vo2 = static_cast<T *>(ctx->vprev[2]);
+    }
+    a.lazy = lazy ? 1 : 0;
+    a.dr0 = F<T>(ctx, PCL_DR0); a.dr1 = F<T>(ctx, PCL_DR1); a.dr2 = F<T>(ctx, PCL_DR2);
+    a.dv0 = F<T>(ctx, PCL_DV0); a.dv1 = F<T>(ctx, PCL_DV1); a.dv2 = F<T>(ctx, PCL_DV2);
+    a.E = F<T>(ctx, PCL_E);
+    a.rtheta = static_cast<const T *>(ctx->rnd[0]);
+    a.rphi = static_cast<const T *>(ctx->rnd[1]);
+    a.rand = static_cast<const T *>(ctx->rnd[2]);
+    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    a.kind = ctx->kind;
+    a.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    a.id_base = ctx->id_base;
+    a.N = N;
+    a.dt = (T)dt; a.A = (T)A; a.n = (T)n; a.c = (T)c; a.h = (T)h;
+    a.seed = seed;
+    a.step = step;
+    a.rng_mode = rng_mode;
+    a.do_scatter = do_scatter ? 1 : 0;
+    a.n_planes = n_planes;
+    for (int p = 0; p < np; ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        a.plane_ax[p] = ax;
+        a.plane_L[p] = (T)loc[ax];
+    }
+    const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    const int ps = prof_begin(ctx, PCL_PROF_FUSED);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->fused[d][use_e ? 1 : 0], grid, a, "step_fused (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL((k_fused<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_fused<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_TRY(launch_check("k_fused"));
+    }
+    prof_end(ctx, ps);
+    return PCL_OK;
+}
+
+template <typename T>
+int delete_mask_t(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed, uint32_t step) {
+    const int64_t N = ctx->count;
+    const int tiles = (int)div_up(N, kTile);
+    delmask_args<T> m{};
+    m.d0 = F<T>(ctx, PCL_DR0); m.d1 = F<T>(ctx, PCL_DR1); m.d2 = F<T>(ctx, PCL_DR2);
+    m.rand = static_cast<const T *>(ctx->rnd[2]);
+    m.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    m.kind = ctx->kind;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.id_base = ctx->id_base;
+    m.N = N;
+    m.An = (T)A * (T)n; // one IEEE multiply in the store's precision == the kernel's (A * n)
+    m.seed = seed;
+    m.step = step;
+    m.rng_mode = rng_mode;
+    const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
+    hipLaunchKernelGGL(k_delete_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    prof_end(ctx, ps);
+    return launch_check("k_delete_mask");
+}
+
+template <typename T>
+int counters_t(pcl_ctx *ctx, const double *planes_host, int n_planes) {
+    const int64_t N = ctx->count;
+    counter_args<T> a{};
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = F<T>(ctx, PCL_V0 + k);
+        a.r[k] = F<T>(ctx, PCL_R0 + k);
+        a.dr[k] = F<T>(ctx, PCL_DR0 + k);
+    }
+    for (int p = 0; p < n_planes; ++p) {
+        // first non-NaN of x, y decides the axis, else z                            light.py:385-396
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2);
+        a.plane_ax[p] = ax;
+        a.plane_L[p] = (T)loc[ax];
+    }
+    a.n_planes = n_planes;
+    a.N = N;
+    a.out = ctx->d_cnt + 1;
+    const int ps = prof_begin(ctx, PCL_PROF_COUNTERS);
+    hipLaunchKernelGGL(k_counters<T>, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
+    return launch_check("k_counters");
 }
 
 } // namespace
@@ -876,7 +1156,6 @@ int pcl_h2d(pcl_ctx *ctx, void *dev, const void *host, int64_t bytes) {
     PCL_TRY(bind(ctx));
     if (bytes < 0 || (bytes > 0 && (!dev || !host))) return fail(PCL_ERR_ARG, "bad argument");
     if (bytes == 0) return PCL_OK;
-    // pageable host memory: hipMemcpyAsync stages it before returning, so the caller may reuse ``host``
     PCL_HIP(hipMemcpyAsync(dev, host, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
     return PCL_OK;
@@ -998,12 +1277,12 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
     PCL_TRY(ensure_scratch(ctx, N));
     ctx->last_delete_n = -1; // scratch masks no longer describe the store
     const int tiles = (int)div_up(N, kTile);
-    delmask_args m{};
+    delmask_args<double> m{};
     m.flags_in = flags;
     m.masks = ctx->masks;
     m.tile_keep = ctx->tile_keep;
     m.N = N;
-    hipLaunchKernelGGL(k_delete_mask, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    hipLaunchKernelGGL(k_delete_mask<double>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     PCL_TRY(launch_check("k_delete_mask"));
     PCL_TRY(scan_tiles(ctx, N));
     compact_args ca{};
@@ -1011,7 +1290,7 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
     ca.masks = ctx->masks;
     ca.tile_off = ctx->tile_off;
     ca.N = N;
-    hipLaunchKernelGGL(k_compact<0>, dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    hipLaunchKernelGGL((k_compact<uint64_t, 0>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
     PCL_TRY(launch_check("k_compact"));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
     *n_keep_out = (int64_t)ctx->h_cnt[kCounterSlots - 1];
@@ -1021,12 +1300,15 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
 int pcl_expr_validate(const char *n_expr) { return validate_expr(n_expr); }
 
 // ------------------------------------------------------------------------------------ Level 2 ----
-int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity) {
+int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     PCL_TRY(bind(ctx));
     if (capacity <= 0) return fail(PCL_ERR_ARG, "capacity must be positive");
+    if (dtype != PCL_DTYPE_F64 && dtype != PCL_DTYPE_F32) return fail(PCL_ERR_ARG, "unknown dtype %d", dtype);
     pcl_store_free(ctx);
+    ctx->dtype = dtype;
+    ctx->esz = dtype == PCL_DTYPE_F64 ? 8 : 4;
     for (int f = 0; f < PCL_NFIELDS; ++f) {
-        int rc = dev_alloc(&ctx->field[f], capacity);
+        int rc = dev_alloc_bytes(&ctx->field[f], capacity, ctx->esz);
         if (rc != PCL_OK) {
             std::string keep = g_err;
             pcl_store_free(ctx);
@@ -1038,6 +1320,14 @@ int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity) {
     ctx->count = 0;
     ctx->id_base = 0;
     ctx->ids_iota = true;
+    return PCL_OK;
+}
+
+int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity) { return pcl_store_alloc_dtype(ctx, capacity, PCL_DTYPE_F64); }
+
+int pcl_store_dtype(pcl_ctx *ctx, int *dtype_out) {
+    if (!ctx || !dtype_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *dtype_out = ctx->dtype;
     return PCL_OK;
 }
 
@@ -1094,19 +1384,19 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     return PCL_OK;
 }
 
-int pcl_store_upload(pcl_ctx *ctx, int field, const double *host, int64_t offset, int64_t n) {
+int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, int64_t n) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
     if (field == PCL_E) ctx->lam4_valid = false;
-    return pcl_h2d(ctx, ctx->field[field] + offset, host, n * (int64_t)sizeof(double));
+    return pcl_h2d(ctx, static_cast<char *>(ctx->field[field]) + offset * ctx->esz, host, n * (int64_t)ctx->esz);
 }
 
-int pcl_store_download(pcl_ctx *ctx, int field, double *host, int64_t offset, int64_t n) {
+int pcl_store_download(pcl_ctx *ctx, int field, void *host, int64_t offset, int64_t n) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
-    return pcl_d2h(ctx, host, ctx->field[field] + offset, n * (int64_t)sizeof(double));
+    return pcl_d2h(ctx, host, static_cast<char *>(ctx->field[field]) + offset * ctx->esz, n * (int64_t)ctx->esz);
 }
 
 int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int64_t n) {
@@ -1147,7 +1437,7 @@ int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t
     return pcl_d2h(ctx, host, ctx->kind + offset, n);
 }
 
-int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out) {
+int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
     if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
@@ -1155,13 +1445,13 @@ int pcl_store_field_ptr(pcl_ctx *ctx, int field, double **dev_out) {
     return PCL_OK;
 }
 
-int pcl_store_upload_rand(pcl_ctx *ctx, int which, const double *host, int64_t n) {
+int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n) {
     PCL_TRY(need_store(ctx));
     if (which < 0 || which > 2) return fail(PCL_ERR_ARG, "which must be 0 (rtheta), 1 (rphi) or 2 (rand)");
     PCL_TRY(check_range(ctx, 0, n, host));
-    if (!ctx->rnd[which]) PCL_TRY(dev_alloc(&ctx->rnd[which], ctx->capacity));
+    if (!ctx->rnd[which]) PCL_TRY(dev_alloc_bytes(&ctx->rnd[which], ctx->capacity, ctx->esz));
     ctx->rnd_n[which] = n;
-    return pcl_h2d(ctx, ctx->rnd[which], host, n * (int64_t)sizeof(double));
+    return pcl_h2d(ctx, ctx->rnd[which], host, n * (int64_t)ctx->esz);
 }
 
 int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max,
@@ -1171,16 +1461,8 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
     ctx->lam4_valid = false;
     if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
     if (n > 0) {
-        fill_args a{};
-        for (int f = 0; f < PCL_NFIELDS; ++f) a.f[f] = ctx->field[f];
-        a.n = n;
-        a.id_base = id_base;
-        a.c = c;
-        a.e_min = e_min;
-        a.e_max = e_max;
-        a.seed = seed;
-        hipLaunchKernelGGL(k_fill_photons, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
-        PCL_TRY(launch_check("k_fill_photons"));
+        PCL_TRY(PCL_DISPATCH(ctx, fill_photons_t<double>(ctx, n, id_base, c, e_min, e_max, seed),
+                             fill_photons_t<float>(ctx, n, id_base, c, e_min, e_max, seed)));
         if (ctx->kind) PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)n, ctx->stream));
     }
     ctx->count = n;
@@ -1192,22 +1474,8 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
 
 int pcl_step_newton(pcl_ctx *ctx, double dt) {
     PCL_TRY(need_store(ctx));
-    const int64_t N = ctx->count;
-    if (N == 0) return PCL_OK;
-    newton_args a{};
-    for (int k = 0; k < 3; ++k) {
-        a.v[k] = ctx->field[PCL_V0 + k];
-        a.r[k] = ctx->field[PCL_R0 + k];
-        a.dr[k] = ctx->field[PCL_DR0 + k];
-    }
-    a.dt = dt;
-    a.N = N;
-    {
-        const int ps__ = prof_begin(ctx, PCL_PROF_NEWTON);
-        hipLaunchKernelGGL(k_newton, dim3(grid_for(ctx, (N + 1) / 2, kBlock)), dim3(kBlock), 0, ctx->stream, a);
-        prof_end(ctx, ps__);
-    }
-    return launch_check("k_newton");
+    if (ctx->count == 0) return PCL_OK;
+    return PCL_DISPATCH(ctx, step_newton_t<double>(ctx, dt), step_newton_t<float>(ctx, dt));
 }
 
 int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h, const char *n_expr,
@@ -1226,67 +1494,16 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
             if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
                 return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
                             (long long)N);
-    pcl_scatter_args a{};
-    a.d0 = ctx->field[PCL_DR0]; a.d1 = ctx->field[PCL_DR1]; a.d2 = ctx->field[PCL_DR2];
-    a.E = ctx->field[PCL_E];
-    a.r0 = ctx->field[PCL_R0]; a.r1 = ctx->field[PCL_R1]; a.r2 = ctx->field[PCL_R2];
-    a.v0 = ctx->field[PCL_V0]; a.v1 = ctx->field[PCL_V1]; a.v2 = ctx->field[PCL_V2];
-    a.dv0 = ctx->field[PCL_DV0]; a.dv1 = ctx->field[PCL_DV1]; a.dv2 = ctx->field[PCL_DV2];
-    a.rtheta = ctx->rnd[0]; a.rphi = ctx->rnd[1]; a.rand = ctx->rnd[2];
-    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
-    a.kind = ctx->kind;
-    a.hits = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
-    a.id_base = ctx->id_base;
-    a.N = N;
-    a.A = A; a.n = n; a.c = c; a.h = h;
-    a.seed = seed;
-    a.step = step;
-    a.rng_mode = rng_mode;
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
-    const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
-    const int ps = prof_begin(ctx, PCL_PROF_SCATTER);
-    if (var_n) {
-        PCL_TRY(launch_module(ctx, ent->scatter[use_e ? 1 : 0], grid, a, "scatter_isotropic (hipRTC)"));
-    } else {
-        if (use_e)
-            hipLaunchKernelGGL(k_scatter<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(k_scatter<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        PCL_TRY(launch_check("k_scatter"));
-    }
-    prof_end(ctx, ps);
+    PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step),
+                         step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step)));
     if (hits_out) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         ctx->hits_on_host = true;
         *hits_out = (int64_t)ctx->h_cnt[0];
     }
-    return PCL_OK;
-}
-
-int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host) {
-    PCL_TRY(need_store_raw(ctx));
-    if (n_planes < 0 || n_planes > PCL_MAX_PLANES || !out_host) return fail(PCL_ERR_ARG, "bad argument");
-    PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + n_planes) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                           ctx->stream));
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->hits_on_host = true;
-    out_host[0] = ctx->count;
-    for (int k = 0; k < 3 + n_planes; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
-    out_host[4 + n_planes] = (int64_t)ctx->h_cnt[0];
-    return PCL_OK;
-}
-
-int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
-    PCL_TRY(need_store(ctx));
-    if (!hits_out) return fail(PCL_ERR_ARG, "hits_out is NULL");
-    if (!ctx->hits_on_host) {
-        PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-        PCL_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->hits_on_host = true;
-    }
-    *hits_out = (int64_t)ctx->h_cnt[0];
     return PCL_OK;
 }
 
@@ -1322,103 +1539,19 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
                 return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
                             (long long)N);
-    static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
-    if (lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && !ctx->kind && ctx->ids_iota && n_planes <= 0 && !no_fast) {
-        // ---- fast path: all photons, implicit ids, device RNG, implicit dr/dv, sign counters only
-        if (use_e && (!ctx->lam4_valid || ctx->lam4_h != h || ctx->lam4_c != c)) {
-            if (!ctx->lam4) PCL_TRY(dev_alloc(&ctx->lam4, ctx->capacity));
-            hipLaunchKernelGGL(k_lam4, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->field[PCL_E],
-                               ctx->lam4, h, c, N);
-            PCL_TRY(launch_check("k_lam4"));
-            ctx->lam4_valid = true;
-            ctx->lam4_h = h;
-            ctx->lam4_c = c;
-        }
-        for (int k = 0; k < 3; ++k)
-            if (!ctx->vprev[k]) PCL_TRY(dev_alloc(&ctx->vprev[k], ctx->capacity));
-        pcl_fast_args f{};
-        f.r0 = ctx->field[PCL_R0]; f.r1 = ctx->field[PCL_R1]; f.r2 = ctx->field[PCL_R2];
-        f.vi0 = ctx->field[PCL_V0]; f.vi1 = ctx->field[PCL_V1]; f.vi2 = ctx->field[PCL_V2];
-        f.vo0 = ctx->vprev[0]; f.vo1 = ctx->vprev[1]; f.vo2 = ctx->vprev[2];
-        f.lam4 = ctx->lam4;
-        f.E = ctx->field[PCL_E];
-        f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
-        f.id_base = ctx->id_base;
-        f.N = N;
-        f.dt = dt; f.A = A; f.n = n; f.c = c;
-        f.seed = seed;
-        f.step = step;
-        PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, 4 * sizeof(uint64_t), ctx->stream));
-        ctx->hits_on_host = false;
-        const int fgrid = grid_for(ctx, div_up(N, PCL_FAST_VEC), kBlock);
-        const int fps = prof_begin(ctx, PCL_PROF_FUSED);
-        if (var_n) {
-            PCL_TRY(launch_module(ctx, ent->fast[use_e ? 1 : 0], fgrid, f, "step_fused fast path (hipRTC)"));
-        } else {
-            if (use_e)
-                hipLaunchKernelGGL(k_fast<true>, dim3(fgrid), dim3(kBlock), 0, ctx->stream, f);
-            else
-                hipLaunchKernelGGL(k_fast<false>, dim3(fgrid), dim3(kBlock), 0, ctx->stream, f);
-            PCL_TRY(launch_check("k_fast"));
-        }
-        prof_end(ctx, fps);
-        for (int k = 0; k < 3; ++k) std::swap(ctx->field[PCL_V0 + k], ctx->vprev[k]); // field[V] = new v
-        ctx->lazy_dv = ctx->lazy_dr = true;
-        ctx->lazy_dt = dt;
-        if (out_host) {
-            PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-            PCL_HIP(hipStreamSynchronize(ctx->stream));
-            ctx->hits_on_host = true;
-            for (int k = 0; k < 3; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
-            out_host[4] = (int64_t)ctx->h_cnt[0];
-        }
-        return PCL_OK;
-    }
-    pcl_fused_args a{};
-    a.r0 = ctx->field[PCL_R0]; a.r1 = ctx->field[PCL_R1]; a.r2 = ctx->field[PCL_R2];
-    a.vi0 = ctx->field[PCL_V0]; a.vi1 = ctx->field[PCL_V1]; a.vi2 = ctx->field[PCL_V2];
-    a.vo0 = ctx->field[PCL_V0]; a.vo1 = ctx->field[PCL_V1]; a.vo2 = ctx->field[PCL_V2];
-    if (lazy && do_scatter) {
-        for (int k = 0; k < 3; ++k)
-            if (!ctx->vprev[k]) PCL_TRY(dev_alloc(&ctx->vprev[k], ctx->capacity));
-        a.vo0 = ctx->vprev[0]; a.vo1 = ctx->vprev[1]; a.vo2 = ctx->vprev[2];
-    }
-    a.lazy = lazy ? 1 : 0;
-    a.dr0 = ctx->field[PCL_DR0]; a.dr1 = ctx->field[PCL_DR1]; a.dr2 = ctx->field[PCL_DR2];
-    a.dv0 = ctx->field[PCL_DV0]; a.dv1 = ctx->field[PCL_DV1]; a.dv2 = ctx->field[PCL_DV2];
-    a.E = ctx->field[PCL_E];
-    a.rtheta = ctx->rnd[0]; a.rphi = ctx->rnd[1]; a.rand = ctx->rnd[2];
-    a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
-    a.kind = ctx->kind;
-    a.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
-    a.id_base = ctx->id_base;
-    a.N = N;
-    a.dt = dt; a.A = A; a.n = n; a.c = c; a.h = h;
-    a.seed = seed;
-    a.step = step;
-    a.rng_mode = rng_mode;
-    a.do_scatter = do_scatter ? 1 : 0;
-    a.n_planes = n_planes;
-    for (int p = 0; p < np; ++p) {
-        const double *loc = planes_host + 3 * p;
-        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
-        a.plane_ax[p] = ax;
-        a.plane_L[p] = loc[ax];
-    }
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, (size_t)(4 + np) * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
-    const int grid = grid_for(ctx, (N + 1) / 2, kBlock);
-    const int ps = prof_begin(ctx, PCL_PROF_FUSED);
-    if (var_n) {
-        PCL_TRY(launch_module(ctx, ent->fused[use_e ? 1 : 0], grid, a, "step_fused (hipRTC)"));
+    static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
+    const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && !ctx->kind && ctx->ids_iota && n_planes <= 0 && !no_fast;
+    if (fast) {
+        // all photons, implicit ids, device RNG, implicit dr/dv, sign counters only
+        PCL_TRY(PCL_DISPATCH(ctx, step_fast_t<double>(ctx, dt, A, n, use_e, var_n, ent, c, h, seed, step),
+                             step_fast_t<float>(ctx, dt, A, n, use_e, var_n, ent, c, h, seed, step)));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL(k_fused<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(k_fused<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        PCL_TRY(launch_check("k_fused"));
+        PCL_TRY(PCL_DISPATCH(
+            ctx, step_fused_t<double>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy),
+            step_fused_t<float>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy)));
     }
-    prof_end(ctx, ps);
     if (lazy) {
         if (do_scatter) {
             for (int k = 0; k < 3; ++k) std::swap(ctx->field[PCL_V0 + k], ctx->vprev[k]); // field[V] = new v
@@ -1437,6 +1570,31 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     return PCL_OK;
 }
 
+int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store_raw(ctx));
+    if (n_planes < 0 || n_planes > PCL_MAX_PLANES || !out_host) return fail(PCL_ERR_ARG, "bad argument");
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + n_planes) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->hits_on_host = true;
+    out_host[0] = ctx->count;
+    for (int k = 0; k < 3 + n_planes; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+    out_host[4 + n_planes] = (int64_t)ctx->h_cnt[0];
+    return PCL_OK;
+}
+
+int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
+    PCL_TRY(need_store_raw(ctx));
+    if (!hits_out) return fail(PCL_ERR_ARG, "hits_out is NULL");
+    if (!ctx->hits_on_host) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->hits_on_host = true;
+    }
+    *hits_out = (int64_t)ctx->h_cnt[0];
+    return PCL_OK;
+}
+
 int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed, uint32_t step,
                             int64_t *n_alive_out, int64_t *n_removed_out) {
     PCL_TRY(need_store(ctx));
@@ -1450,28 +1608,13 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     const int tiles = (int)div_up(N, kTile);
-    delmask_args m{};
-    m.d0 = ctx->field[PCL_DR0]; m.d1 = ctx->field[PCL_DR1]; m.d2 = ctx->field[PCL_DR2];
-    m.rand = ctx->rnd[2];
-    m.ids = ctx->ids_iota ? nullptr : ctx->ids;
-    m.kind = ctx->kind;
-    m.masks = ctx->masks;
-    m.tile_keep = ctx->tile_keep;
-    m.id_base = ctx->id_base;
-    m.N = N;
-    m.An = A * n; // host fp64 multiply == __dmul_rn (IEEE, no contraction possible on a single product)
-    m.seed = seed;
-    m.step = step;
-    m.rng_mode = rng_mode;
-    const int ps_mask = prof_begin(ctx, PCL_PROF_DELETE_MASK);
-    hipLaunchKernelGGL(k_delete_mask, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
-    prof_end(ctx, ps_mask);
-    PCL_TRY(launch_check("k_delete_mask"));
+    PCL_TRY(PCL_DISPATCH(ctx, delete_mask_t<double>(ctx, A, n, rng_mode, seed, step),
+                         delete_mask_t<float>(ctx, A, n, rng_mode, seed, step)));
     PCL_TRY(scan_tiles(ctx, N));
     compact_args ca{};
     for (int f = 0; f < PCL_NFIELDS; ++f) {
-        ca.src[f] = reinterpret_cast<const uint64_t *>(ctx->field[f]);
-        ca.dst[f] = reinterpret_cast<uint64_t *>(ctx->field_alt[f]);
+        ca.src[f] = ctx->field[f];
+        ca.dst[f] = ctx->field_alt[f];
     }
     ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
     ca.ids_dst = ctx->ids_alt;
@@ -1482,12 +1625,16 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     ca.id_base = ctx->id_base;
     ca.N = N;
     const int ps_cmp = prof_begin(ctx, PCL_PROF_COMPACT);
-    hipLaunchKernelGGL(k_compact<PCL_NFIELDS>, dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    if (ctx->dtype == PCL_DTYPE_F64)
+        hipLaunchKernelGGL((k_compact<uint64_t, PCL_NFIELDS>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    else
+        hipLaunchKernelGGL((k_compact<uint32_t, PCL_NFIELDS>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
     prof_end(ctx, ps_cmp);
     PCL_TRY(launch_check("k_compact"));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
-    if (alive < 0 || alive > N) return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
+    if (alive < 0 || alive > N)
+        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
     for (int f = 0; f < PCL_NFIELDS; ++f) std::swap(ctx->field[f], ctx->field_alt[f]);
     std::swap(ctx->ids, ctx->ids_alt);
     if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
@@ -1523,27 +1670,8 @@ int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int
     out_host[PCL_CNT_N] = N;
     for (int k = 0; k < nc; ++k) out_host[1 + k] = 0;
     if (N == 0) return PCL_OK;
-    counter_args a{};
-    for (int k = 0; k < 3; ++k) {
-        a.v[k] = ctx->field[PCL_V0 + k];
-        a.r[k] = ctx->field[PCL_R0 + k];
-        a.dr[k] = ctx->field[PCL_DR0 + k];
-    }
-    for (int p = 0; p < n_planes; ++p) {
-        // first non-NaN of x, y decides the axis, else z                            light.py:385-396
-        const double *loc = planes_host + 3 * p;
-        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2);
-        a.plane_ax[p] = ax;
-        a.plane_L[p] = loc[ax];
-    }
-    a.n_planes = n_planes;
-    a.N = N;
-    a.out = ctx->d_cnt + 1;
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)nc * sizeof(uint64_t), ctx->stream));
-    const int ps = prof_begin(ctx, PCL_PROF_COUNTERS);
-    hipLaunchKernelGGL(k_counters, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
-    prof_end(ctx, ps);
-    PCL_TRY(launch_check("k_counters"));
+    PCL_TRY(PCL_DISPATCH(ctx, counters_t<double>(ctx, planes_host, n_planes), counters_t<float>(ctx, planes_host, n_planes)));
     // slot 0 (hits of the last scatter step) rides along, so reading it later costs no extra sync
     PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(1 + nc) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
