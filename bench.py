@@ -205,6 +205,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dev, args, prof)
+            out["cpu_baseline_python"] = cpu_baseline_python(dev, args, prof)
 
     dev.store_free()
     dev.close()
@@ -249,6 +250,21 @@ def cpu_baseline(dev, args, prof):
     return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads, "
                       "%.1f s)" % (n, steps, cores, el)}
+
+
+def cpu_baseline_python(dev, args, prof):
+    """Second CPU figure, for scale: the reference-SHAPED path (one Python object per photon, a Python loop
+    per step, oracle/pyloop.py) on the first 1e4 photons of the same workload, 1 core -- the cost model of
+    the reference's own CPU path (BASELINE.md section 2 measured 1.5e4..2.4e4 particle-steps/s for it)."""
+    from oracle import pyloop
+    if prof["c_profile"] is None:
+        return None
+    n = 10000
+    dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
+    E = dev.download(12, n)
+    value, steps, el = pyloop.time_steps(E, prof["dt"], prof["A_kernel"], prof["n_kernel"], True, prof["c_profile"], 3.0)
+    return {"value": value, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d photons x %d steps, per-object Python loops (oracle/pyloop.py), %.1f s" % (n, steps, el)}
 
 
 if __name__ == "__main__":

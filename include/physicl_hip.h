@@ -248,7 +248,17 @@ int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out);
  * ``len(sim.objects) == 0``, physicl/__init__.py:414). */
 int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed,
                             uint32_t step, int64_t *n_alive_out, int64_t *n_removed_out);
-/* The int32 flag array of the most recent pcl_step_scatter_delete, in PRE-compaction order
+/* The loop body of a delete simulation as one pipeline: NewtonianKinematicsStep, then ScatterDeleteStep,
+ * then (n_planes >= 0) the measure counters on the survivors -- the step order of test/test_light.py:52-59.
+ * Pass 1 moves the particles and computes the delete flags in one sweep over r and v; pass 3 (the stable
+ * compaction) counts while the survivors go through its registers.  Bit-identical to pcl_step_newton +
+ * pcl_step_scatter_delete + pcl_step_counters.  flags: 0 or PCL_FUSED_LAZY (dr is neither written nor moved:
+ * it stays v*dt until something reads it).  out_host (may be NULL): int64[5 + n_planes] =
+ * { N alive, xp, yp, zp, plane counts..., removed }.  Synchronises (the new count is needed on the host). */
+int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags, int rng_mode, uint64_t seed,
+                          uint32_t step, const double *planes_host, int n_planes, int64_t *out_host);
+
+/* The int32 flag array of the most recent pcl_step_scatter_delete / pcl_step_fused_delete, in PRE-compaction order
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */
 int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n);
 

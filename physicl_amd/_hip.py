@@ -92,6 +92,7 @@ _PROTOTYPES = {
     "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
                                 POINTER(c_int64)],
+    "pcl_step_fused_delete": [_vp, c_double, c_double, c_double, c_int, c_int, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_store_last_delete_flags": [_vp, _vp, c_int64],
     "pcl_step_counters": [_vp, _vp, c_int, _vp],
 }
@@ -405,6 +406,22 @@ class Device:
         check(self.lib.pcl_step_scatter_delete(self.ctx, float(A), float(n), int(rng_mode), int(seed),
                                                int(step) & 0xFFFFFFFF, byref(alive), byref(removed)))
         return alive.value, removed.value
+
+    def step_fused_delete(self, dt, A, n, rng_mode=RNG_PHILOX, seed=0, step=0, planes=None, lazy=False):
+        """Newton + ScatterDelete (+ counters on the survivors if ``planes`` is not None) as one pipeline.
+        Returns {'N' (alive), 'removed', 'sign', 'planes'}."""
+        if planes is None:
+            npl, pp = -1, None
+        else:
+            pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+            npl = len(pl)
+            pp = pl.ctypes.data_as(c_void_p) if npl else None
+        k = max(npl, 0)
+        out = np.zeros(5 + k, dtype=np.int64)
+        check(self.lib.pcl_step_fused_delete(self.ctx, float(dt), float(A), float(n), FUSED_LAZY if lazy else 0,
+                                             int(rng_mode), int(seed), int(step) & 0xFFFFFFFF, pp, npl,
+                                             out.ctypes.data_as(c_void_p)))
+        return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + k].copy(), "removed": int(out[4 + k])}
 
     def last_delete_flags(self, n):
         out = np.empty(n, dtype=np.int32)

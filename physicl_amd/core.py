@@ -453,14 +453,15 @@ class Simulation(threading.Thread):
 
     # ------------------------------------------------------------------ the loop
     def _build_plan(self):
-        """Group consecutive fusable device-native steps: [Newton][ScatterIsotropic]?[counting measures]*."""
+        """Group consecutive fusable device-native steps:
+        [Newton][ScatterIsotropic | ScatterDelete]?[counting measures]*  -> one kernel (pipeline) per pass."""
         steps = list(self.steps.values())
         plan, i = [], 0
         while i < len(steps):
             s = steps[i]
             if self.fuse and self._dev is not None and getattr(s, "_fuse_role", None) == "newton":
                 group, j = [s], i + 1
-                if j < len(steps) and getattr(steps[j], "_fuse_role", None) == "scatter_iso":
+                if j < len(steps) and getattr(steps[j], "_fuse_role", None) in ("scatter_iso", "scatter_delete"):
                     group.append(steps[j])
                     j += 1
                 n_planes = 0
@@ -503,8 +504,24 @@ class Simulation(threading.Thread):
         self._to_device()
         dev, hip = self._dev, self._hip
         scatter = next((s for s in group if s._fuse_role == "scatter_iso"), None)
+        delete = next((s for s in group if s._fuse_role == "scatter_delete"), None)
         measures = [s for s in group if s._fuse_role == "measure"]
         planes = [p for m in measures for p in m._plane_rows()]
+        if delete is not None:
+            mode = self._rng_mode()
+            if mode == hip.RNG_INPUT:
+                self._host_randoms("delete")
+            A_k, n_k = delete._kernel_consts()
+            out = dev.step_fused_delete(self._dt_code(), A_k, n_k, mode, self.seed, self._next_launch(),
+                                        planes if measures else None, lazy=True)
+            g = self._global(np.concatenate([[out["N"], out["removed"]], out["sign"], out["planes"]]))
+            self._alive, delete.removed = int(g[0]), int(g[1])
+            k = 5
+            for m in measures:
+                npl = m._n_planes()
+                m._record(self, int(g[0]), g[2:5], g[k:k + npl])
+                k += npl
+            return
         sc = None
         if scatter is not None:
             sc = scatter._kernel_params(self)

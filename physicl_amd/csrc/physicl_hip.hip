@@ -29,6 +29,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/physicl_hip.h"
@@ -319,6 +320,150 @@ __global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
             if (a.idx_dst) a.idx_dst[o] = i;
         }
         dest += __popcll(m);
+    }
+}
+
+// ---- fused loop body for delete simulations, pass 1: Newton + delete flag -> ballot masks ---------------
+//   physicl/newton.py:15-16 then physicl/light.py:239-249, one pass over r and v (72 B fp64 per particle when
+//   dr stays implicit, 96 B when it is written).  Tile geometry of k_delete_mask (lane == particle).
+template <typename T>
+struct newtonmask_args {
+    const T *v[3];
+    T *r[3];
+    T *dr[3];                  // written unless lazy
+    const T *rand;             // PCL_RNG_INPUT
+    const int64_t *ids;
+    const unsigned char *kind;
+    uint64_t *masks;
+    int32_t *tile_keep;
+    int64_t id_base, N;
+    T dt, An;
+    uint64_t seed;
+    uint32_t step;
+    int rng_mode;
+    int lazy;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
+    typedef pcl_rt<T> R;
+    __shared__ int s_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    int kept = 0;
+#pragma unroll 2
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        bool keep = false;
+        if (i < a.N) {
+            T d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                d[k] = R::mul(a.v[k][i], a.dt);
+                a.r[k][i] = R::add(a.r[k][i], d[k]);
+                if (!a.lazy) a.dr[k][i] = d[k];
+            }
+            const bool photon = a.kind ? (a.kind[i] != 0) : true;
+            const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2]));
+            T rand;
+            if (a.rng_mode == PCL_RNG_PHX) {
+                const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
+                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u, (pcl_u32)a.seed,
+                                                      (pcl_u32)(a.seed >> 32));
+                rand = R::uniform(w.x, w.y);
+            } else {
+                rand = a.rand[i];
+            }
+            keep = !(photon && (pcoll >= rand));
+        }
+        const uint64_t m = __ballot(keep);
+        if (lane == 0) a.masks[tile * kTileRows + row] = m;
+        kept += __popcll(m);
+    }
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ---- pass 3 with the measure counters folded in: the survivors' r, v (and dr) pass through registers anyway ----
+//   field order in compact_args: r0 r1 r2 v0 v1 v2 [dr0 dr1 dr2] dv0 dv1 dv2 E   (dr present iff HAS_DR)
+template <typename T>
+struct compact_counter_args {
+    uint64_t *cnt; // [1..3] sign counts, [4..] plane crossings (slot 0 is the scatter-hit counter)
+    T plane_L[PCL_MAX_PLANES];
+    int plane_ax[PCL_MAX_PLANES];
+    int n_planes;  // -1: no counters
+    T dt;          // dr = v*dt when it is implicit
+};
+
+template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
+template <> __device__ __forceinline__ double word_as<double, uint64_t>(uint64_t w) { return __longlong_as_double((long long)w); }
+template <> __device__ __forceinline__ float word_as<float, uint32_t>(uint32_t w) { return __uint_as_float(w); }
+
+template <typename T, typename W, bool HAS_DR>
+__global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compact_counter_args<T> c) {
+    typedef pcl_rt<T> R;
+    constexpr int NF = HAS_DR ? 13 : 10;
+    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t tile = blockIdx.x;
+    const uint64_t *tm = a.masks + tile * kTileRows;
+    int64_t dest = a.tile_off[tile];
+    for (int r = 0; r < wave * (kTileRows / 4); ++r) dest += __popcll(tm[r]);
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t w_s[3] = {0, 0, 0};
+#pragma unroll 2
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const uint64_t m = tm[row];
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        const bool keep = (m >> lane) & 1ull;
+        W val[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) val[f] = 0;
+        if (keep) {
+            const int64_t o = dest + __popcll(m & below);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[i];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[o] = val[f];
+            if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
+            if (a.kdst) a.kdst[o] = a.ksrc[i];
+        }
+        if (c.n_planes >= 0) { // wave-uniform
+            T rv[3], vv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                rv[k] = word_as<T, W>(val[k]);
+                vv[k] = word_as<T, W>(val[3 + k]);
+                w_s[k] += (uint32_t)__popcll(__ballot(keep && vv[k] > (T)0));
+            }
+            for (int p = 0; p < c.n_planes; ++p) {
+                const int ax = c.plane_ax[p];
+                const T L = c.plane_L[p];
+                const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
+                T dx;
+                if constexpr (HAS_DR)
+                    dx = pcl_pick<T>(ax, word_as<T, W>(val[6]), word_as<T, W>(val[7]), word_as<T, W>(val[8]));
+                else
+                    dx = R::mul(pcl_pick<T>(ax, vv[0], vv[1], vv[2]), c.dt);
+                const T prev = R::sub(x, dx);
+                const uint32_t np = (uint32_t)__popcll(__ballot(keep && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+            }
+        }
+        dest += __popcll(m);
+    }
+    if (c.n_planes >= 0) {
+        if (lane == 0)
+            for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
+        __syncthreads();
+        const int nslots = 4 + (c.n_planes > 0 ? c.n_planes : 0);
+        if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+            atomicAdd(&c.cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
@@ -1027,6 +1172,71 @@ int counters_t(pcl_ctx *ctx, const double *planes_host, int n_planes) {
     return launch_check("k_counters");
 }
 
+template <typename T>
+int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int rng_mode, uint64_t seed, uint32_t step,
+                   const double *planes_host, int n_planes) {
+    const int64_t N = ctx->count;
+    const int tiles = (int)div_up(N, kTile);
+    newtonmask_args<T> m{};
+    for (int k = 0; k < 3; ++k) {
+        m.v[k] = F<T>(ctx, PCL_V0 + k);
+        m.r[k] = F<T>(ctx, PCL_R0 + k);
+        m.dr[k] = F<T>(ctx, PCL_DR0 + k);
+    }
+    m.rand = static_cast<const T *>(ctx->rnd[2]);
+    m.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    m.kind = ctx->kind;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.id_base = ctx->id_base;
+    m.N = N;
+    m.dt = (T)dt;
+    m.An = (T)A * (T)n;
+    m.seed = seed;
+    m.step = step;
+    m.rng_mode = rng_mode;
+    m.lazy = lazy ? 1 : 0;
+    const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
+    hipLaunchKernelGGL(k_newton_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    prof_end(ctx, ps);
+    PCL_TRY(launch_check("k_newton_mask"));
+    PCL_TRY(scan_tiles(ctx, N));
+    compact_args ca{};
+    int nf = 0;
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        if (lazy && f >= PCL_DR0 && f <= PCL_DR2) continue; // implicit: dr = v*dt, nothing to move
+        ca.src[nf] = ctx->field[f];
+        ca.dst[nf] = ctx->field_alt[f];
+        ++nf;
+    }
+    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
+    ca.ids_dst = ctx->ids_alt;
+    ca.ksrc = ctx->kind;
+    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.id_base = ctx->id_base;
+    ca.N = N;
+    compact_counter_args<T> cc{};
+    cc.cnt = ctx->d_cnt;
+    cc.n_planes = n_planes;
+    cc.dt = (T)dt;
+    for (int p = 0; p < (n_planes > 0 ? n_planes : 0); ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        cc.plane_ax[p] = ax;
+        cc.plane_L[p] = (T)loc[ax];
+    }
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+    const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
+    if (lazy)
+        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    else
+        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    prof_end(ctx, pc);
+    return launch_check("k_compact_count");
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1644,6 +1854,57 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     ctx->lam4_valid = false;
     if (n_alive_out) *n_alive_out = alive;
     if (n_removed_out) *n_removed_out = N - alive;
+    return PCL_OK;
+}
+
+int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags, int rng_mode, uint64_t seed,
+                          uint32_t step, const double *planes_host, int n_planes, int64_t *out_host) {
+    if (flags & ~PCL_FUSED_LAZY) return fail(PCL_ERR_ARG, "unknown flag bits");
+    const bool lazy = flags & PCL_FUSED_LAZY;
+    PCL_TRY(need_store_raw(ctx));
+    // a still-implicit dv (lazy scatter step) has to become real before the state is moved; an implicit dr is
+    // simply superseded by this step's Newton move
+    if (ctx->lazy_dv) PCL_TRY(materialize(ctx));
+    ctx->lazy_dr = false;
+    if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
+    if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
+    if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
+    const int64_t N = ctx->count;
+    const int np = n_planes > 0 ? n_planes : 0;
+    if (out_host)
+        for (int k = 0; k < 5 + np; ++k) out_host[k] = 0;
+    if (N == 0) return PCL_OK;
+    if (rng_mode == PCL_RNG_INPUT && (!ctx->rnd[2] || ctx->rnd_n[2] < N))
+        return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=2) for all %lld particles", (long long)N);
+    PCL_TRY(ensure_scratch(ctx, N));
+    PCL_TRY(ensure_alt(ctx));
+    PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
+    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, rng_mode, seed, step, planes_host, n_planes),
+                         fused_delete_t<float>(ctx, dt, A, n, lazy, rng_mode, seed, step, planes_host, n_planes)));
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (alive < 0 || alive > N)
+        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        if (lazy && f >= PCL_DR0 && f <= PCL_DR2) continue; // dr buffers were not part of the move
+        std::swap(ctx->field[f], ctx->field_alt[f]);
+    }
+    std::swap(ctx->ids, ctx->ids_alt);
+    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
+    ctx->ids_iota = false;
+    ctx->count = alive;
+    ctx->last_delete_n = N;
+    ctx->lam4_valid = false;
+    if (lazy) {
+        ctx->lazy_dr = true; // dr = v*dt with the (unchanged) velocities of the survivors
+        ctx->lazy_dt = dt;
+    }
+    if (out_host) {
+        out_host[0] = alive;
+        for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+        out_host[4 + np] = N - alive;
+    }
     return PCL_OK;
 }
 

@@ -103,17 +103,22 @@ class ScatterDeleteStep(DeviceStep):
     + stable compaction of the whole state, fused in pcl_step_scatter_delete.  The reference hands its
     kernel ``A := n`` and ``n := A`` (light.py:236); the product is the same."""
 
+    _fuse_role = "scatter_delete"
+
     def __init__(self, n, A):
         self.n, self.A = n, A
         self.built = False
         self.removed = 0
+
+    def _kernel_consts(self):
+        return _kernel_const(self.n), _kernel_const(self.A)      # kernel A := user n, n := user A (light.py:236)
 
     def _device_run(self, sim):
         hip, dev = sim._hip, sim._dev
         mode = sim._rng_mode()
         if mode == hip.RNG_INPUT:
             sim._host_randoms("delete")
-        A_k, n_k = _kernel_const(self.n), _kernel_const(self.A)
+        A_k, n_k = self._kernel_consts()
         alive, removed = dev.step_scatter_delete(A_k, n_k, mode, sim.seed, sim._next_launch())
         g = sim._global([alive, removed])
         sim._alive, self.removed = int(g[0]), int(g[1])

@@ -665,3 +665,67 @@ def test_lazy_state_is_materialised_for_every_consumer(store, hip):
     d.step_newton(1e-3)                                                  # overwrites dr; dv must survive
     assert np.array_equal(np.stack([d.download(hip.DV0 + k) for k in range(3)], 1),
                           np.stack([d.download(hip.V0 + k) for k in range(3)], 1) - v)
+
+
+# ============================================================================ fused Newton + delete (+ counters)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N", [1, 64, 2049, 500_003])
+def test_fused_delete_is_bit_identical_to_separate_steps(dev, hip, N, dtype):
+    """pcl_step_fused_delete (eager and lazy) == pcl_step_newton + pcl_step_scatter_delete + pcl_step_counters:
+    same survivors, same state bit for bit, same counters; mixed kinds; both RNG modes; delete chains."""
+    rs = np.random.RandomState(N)
+    init = {"r": rs.normal(size=(N, 3)) * 1e5, "v": rs.normal(size=(N, 3)) * 1e8, "dv": rs.normal(size=(N, 3)),
+            "dr": rs.normal(size=(N, 3)), "E": rs.uniform(1, 2, N), "id_base": 1000,
+            "kind": (rs.random_sample(N) < 0.9).astype(np.uint8)}
+    planes = [[1e5, np.nan, np.nan], [np.nan, -2e4, np.nan]]
+    results = {}
+    for mode in ("separate", "eager", "lazy"):
+        for rng_mode in (hip.RNG_PHILOX, hip.RNG_INPUT):
+            dev.store_alloc(N, dtype)
+            dev.upload_state(init)
+            rs2 = np.random.RandomState(7)
+            log = []
+            for step in range(4):
+                n_now = dev.count
+                if rng_mode == hip.RNG_INPUT:
+                    dev.upload_rand(2, rs2.random_sample(max(n_now, 1)))
+                if mode == "separate":
+                    dev.step_newton(1e-3)
+                    alive, removed = dev.step_scatter_delete(3e-6, 1e-3, rng_mode, 5, step)
+                    cnt = dev.step_counters(planes)
+                    log.append((alive, removed, list(cnt[1:])))
+                else:
+                    o = dev.step_fused_delete(1e-3, 3e-6, 1e-3, rng_mode, 5, step, planes, lazy=(mode == "lazy"))
+                    log.append((o["N"], o["removed"], list(o["sign"]) + list(o["planes"])))
+                flags = dev.last_delete_flags(n_now) if n_now else None
+                log.append(None if flags is None else int(flags.sum()))
+            results[(mode, rng_mode)] = (log, dev.download_state(), dev.download_kind())
+    for rng_mode in (hip.RNG_PHILOX, hip.RNG_INPUT):
+        la, sa, ka = results[("separate", rng_mode)]
+        for mode in ("eager", "lazy"):
+            lb, sb, kb = results[(mode, rng_mode)]
+            assert la == lb, (mode, la[:2], lb[:2])
+            assert np.array_equal(sa["id"], sb["id"]) and np.array_equal(sa["E"], sb["E"]) and np.array_equal(ka, kb)
+            for f in ("r", "v", "dr", "dv"):
+                for k in range(3):
+                    assert np.array_equal(sa[f][k], sb[f][k]), (mode, f, k)
+    assert results[("separate", hip.RNG_PHILOX)][0][0][1] > 0 or N < 100
+
+
+def test_fused_delete_after_lazy_scatter_keeps_dv(dev, hip):
+    """A lazy scatter step leaves dv implicit; the fused delete that follows must move the real dv."""
+    N = 50_000
+    outs = []
+    for lazy in (False, True):
+        dev.store_alloc(N)
+        dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, 3)
+        sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=3, step=0)
+        dev.step_fused(1e-3, sc, (), lazy=lazy)
+        o = dev.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 3, 1, [[0.0, np.nan, np.nan]], lazy=lazy)
+        outs.append((o["N"], o["removed"], list(o["sign"]), list(o["planes"]), dev.download_state()))
+    a, b = outs
+    assert a[:4] == b[:4] and a[1] > 0
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(a[4][f][k], b[4][f][k]), (f, k)
+    assert np.any(a[4]["dv"][0] != 0)

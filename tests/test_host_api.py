@@ -130,8 +130,8 @@ def test_fusion_plan_groups_only_adjacent_native_steps():
     for i, s in enumerate((upd, nk, sc, sign, meas, Drift(), nk2 := newton.NewtonianKinematicsStep(), dele)):
         sim.add_step(i, s)
     plan = sim._build_plan()
-    assert [k for k, _ in plan] == ["single", "fused", "single", "single", "single"]
-    assert plan[1][1] == [nk, sc, sign, meas] and plan[3][1] is nk2       # Newton + Delete is not fused
+    assert [k for k, _ in plan] == ["single", "fused", "single", "fused"]
+    assert plan[1][1] == [nk, sc, sign, meas] and plan[3][1] == [nk2, dele]   # Newton + Delete: one pipeline
     sim.fuse = False
     assert all(k == "single" for k, _ in sim._build_plan())
     sim._dev = None

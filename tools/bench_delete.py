@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--photons", type=float, default=1e7)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--mode", choices=("fused", "fused-eager", "separate"), default="fused")
     a = ap.parse_args()
     N = int(a.photons)
     dev = _hip.Device(0)
@@ -38,9 +39,13 @@ def main():
         per_step = []
         for k in range(a.steps):
             n_before = dev.count
-            dev.step_newton(1e-3)
-            alive, removed = dev.step_scatter_delete(1e-3, 1e-3, _hip.RNG_PHILOX, a.seed, k)
-            cnt = dev.step_counters(plane)
+            if a.mode == "separate":
+                dev.step_newton(1e-3)
+                alive, removed = dev.step_scatter_delete(1e-3, 1e-3, _hip.RNG_PHILOX, a.seed, k)
+                cnt = dev.step_counters(plane)
+            else:
+                alive = dev.step_fused_delete(1e-3, 1e-3, 1e-3, _hip.RNG_PHILOX, a.seed, k, plane,
+                                              lazy=(a.mode == "fused"))["N"]
             work += n_before
             per_step.append((n_before, alive))
         dev.sync()
@@ -56,12 +61,17 @@ def main():
     # effective bandwidth of the three delete passes over the whole run (bytes from DESIGN.md section 4)
     tot = sum(nb for nb, _ in per_step)
     surv = sum(al for _, al in per_step)
+    nf = {"separate": 13, "fused-eager": 13, "fused": 10}[a.mode]             # 8-byte fields moved per survivor (+ ids)
+    out["mode"] = a.mode
     out["GBps"] = {
-        "k_newton": tot * 96 / (kern["k_newton"]["total_ms"] * 1e-3) / 1e9,
-        "k_delete_mask": tot * 24.125 / (kern["k_delete_mask"]["total_ms"] * 1e-3) / 1e9,
-        "k_compact(algorithmic: mask bit + survivors read+written)": (tot * 0.125 + surv * 2 * 112) /
-                                                                     (kern["k_compact"]["total_ms"] * 1e-3) / 1e9,
-    }
+        "k_compact(algorithmic: mask bit + survivors read+written)": (tot * 0.125 + surv * 2 * 8 * (nf + 1)) /
+                                                                     (kern["k_compact"]["total_ms"] * 1e-3) / 1e9}
+    if a.mode == "separate":
+        out["GBps"]["k_newton"] = tot * 96 / (kern["k_newton"]["total_ms"] * 1e-3) / 1e9
+        out["GBps"]["k_delete_mask"] = tot * 24.125 / (kern["k_delete_mask"]["total_ms"] * 1e-3) / 1e9
+    else:
+        out["GBps"]["k_newton_mask"] = tot * (72.125 if a.mode == "fused" else 96.125) / \
+            (kern["k_delete_mask"]["total_ms"] * 1e-3) / 1e9
     print(json.dumps(out))
     dev.close()
 
