@@ -72,6 +72,8 @@ def main():
                          "PCL_FUSED_LAZY); fused-eager: one kernel, dr/dv written every step; "
                          "separate: one kernel per Step")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
+                    help="f64 = the reference's precision (the headline number); f32 = precision-sweep build")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = rehearsal on CPU tensors")
     ap.add_argument("--device", type=int, default=None,
@@ -98,7 +100,7 @@ def main():
     e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9   # E_from_wavelength, light.py:39-43
 
     dev = _hip.Device(local_rank if args.device is None else args.device)
-    dev.store_alloc(N)
+    dev.store_alloc(N, args.dtype)
     dev.fill_photons(N, rank * N, C_LIT, e_lo, e_hi, args.seed)      # ids are global: shard-independent RNG
 
     sim_t = 0.0
@@ -161,7 +163,7 @@ def main():
     kern = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}
     dev.prof_enable(False)
     h_mean = hits_local / float(N * args.steps)
-    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode)
+    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode) * (0.5 if args.dtype == "f32" else 1.0)
     dominant = "k_fused" if args.mode.startswith("fused") else "k_scatter"
     sc = kern[dominant]
     achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
@@ -178,7 +180,7 @@ def main():
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]%s: %.0e photons/GPU, variable-n + wavelength isotropic "
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
@@ -203,7 +205,7 @@ def main():
                                    "yp": int(totals[3]), "zp": int(totals[4])},
             "device": dev.info()["name"],
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
             out["cpu_baseline"] = cpu_baseline(dev, args, prof)
             out["cpu_baseline_python"] = cpu_baseline_python(dev, args, prof)
 
