@@ -200,6 +200,12 @@ int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n);
 int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min,
                            double e_max, uint64_t seed);
 
+/* The same for a tabulated energy distribution: cdf_host[nbins] (non-decreasing, last = 1) and grid_host[nbins];
+ * photon energy = grid[x] for the first x with cdf[x] >= U -- the binned Planck sampler
+ * planck_phot_distribution (physicl/light.py:73-104) for all n photons at once (host pointers). */
+int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, const double *cdf_host,
+                                 const double *grid_host, int nbins, uint64_t seed);
+
 /* NewtonianKinematicsStep.run (physicl/newton.py:10-16): dr = v*dt (rounded, stored); r = r + dr.
  * Applies to every particle of every kind. */
 int pcl_step_newton(pcl_ctx *ctx, double dt);

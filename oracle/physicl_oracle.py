@@ -270,6 +270,30 @@ def philox_energy(seed, ids, e_min, e_max, power=3.0):
     return np.float64(e_min) + (np.float64(e_max) - np.float64(e_min)) * np.power(u, 1.0 / power)
 
 
+def planck_table(e_min, e_max, T, bins, kB=1.380649e-23):
+    """Binned Planck CDF of planck_phot_distribution (light.py:73-96): grid = linspace(min, max, bins); bin x
+    carries the integral of planck_distribution (light.py:53-60: 15/(pi^4 kT) * x^3 * exp(-x), x = E/kT) over
+    [grid[x], grid[x+1]], normalised.  The reference integrates with scipy.quad; the integrand has the closed
+    antiderivative -exp(-x)(x^3 + 3x^2 + 6x + 6), used here (agrees with quad to its own tolerance).
+    Returns (cdf[bins-1], grid[bins-1]): the value for bin x is grid[x]."""
+    grid = np.linspace(e_min, e_max, int(bins))
+    x = grid / (kB * T)
+    F = -np.exp(-x) * (x ** 3 + 3 * x ** 2 + 6 * x + 6)
+    mass = np.diff(F)
+    cdf = np.cumsum(mass / mass.sum())
+    cdf[-1] = 1.0
+    return cdf, grid[:-1].copy()
+
+
+def philox_table_energy(seed, ids, cdf, grid):
+    """Device table sampler (Philox block 3 of step 0xFFFFFFFF): first x with cdf[x] >= u -> grid[x]."""
+    ids = np.asarray(ids, dtype=np.uint64)
+    lo, hi = ids & _U32, ids >> np.uint64(32)
+    w = philox4x32_10(lo, hi, np.uint64(0xFFFFFFFF), np.uint64(3), int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    u = u53(w[0], w[1])
+    return np.asarray(grid)[np.minimum(np.searchsorted(cdf, u, side="left"), len(cdf) - 1)]
+
+
 # ----------------------------------------------------------------------------------------------
 # whole steps on an SoA state dict {r:[3], v:[3], dr:[3], dv:[3], E, id}
 # ----------------------------------------------------------------------------------------------

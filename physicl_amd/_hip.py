@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "pcl_store_field_ptr": [_vp, c_int, POINTER(_vp)],
     "pcl_store_upload_rand": [_vp, c_int, _vp, c_int64],
     "pcl_store_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
+    "pcl_store_fill_photons_table": [_vp, c_int64, c_int64, c_double, _vp, _vp, c_int, c_uint64],
     "pcl_step_newton": [_vp, c_double],
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
@@ -331,6 +332,12 @@ class Device:
 
     def fill_photons(self, n, id_base, c, e_min, e_max, seed):
         check(self.lib.pcl_store_fill_photons(self.ctx, int(n), int(id_base), c, e_min, e_max, int(seed)))
+
+    def fill_photons_table(self, n, id_base, c, cdf, grid, seed):
+        cdf, cp = _host(cdf, np.float64)
+        grid, gp = _host(grid, np.float64)
+        assert cdf.shape == grid.shape
+        check(self.lib.pcl_store_fill_photons_table(self.ctx, int(n), int(id_base), c, cp, gp, len(cdf), int(seed)))
 
     def upload_state(self, state):
         """state: dict with 'r','v','dr','dv' -> (n,3) or 3 arrays, 'E' -> (n,).  Sets count = n."""

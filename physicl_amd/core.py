@@ -116,8 +116,9 @@ class PhotonBatch:
     (physicl/light.py:112-128).  ``Simulation.add_objs(batch)`` creates them directly in device
     memory (1e8 photons take milliseconds instead of hours and ~100 GB of Python objects)."""
 
-    def __init__(self, n, e_min, e_max, seed=0):
+    def __init__(self, n, e_min, e_max, seed=0, table=None):
         self.n, self.e_min, self.e_max, self.seed = int(n), float(np.asarray(e_min)), float(np.asarray(e_max)), int(seed)
+        self.table = table        # (cdf, grid): tabulated energy distribution instead of the power law
 
     def __len__(self):
         return self.n
@@ -329,7 +330,10 @@ class Simulation(threading.Thread):
             if dev.capacity < hi - lo or dev.capacity == 0:
                 dev.store_alloc(max(hi - lo, 1))
             from .light import c as _c
-            dev.fill_photons(hi - lo, lo, float(np.asarray(_c)), b.e_min, b.e_max, b.seed)
+            if b.table is not None:
+                dev.fill_photons_table(hi - lo, lo, float(np.asarray(_c)), b.table[0], b.table[1], b.seed)
+            else:
+                dev.fill_photons(hi - lo, lo, float(np.asarray(_c)), b.e_min, b.e_max, b.seed)
             self._alive = b.n
             self._residency = DEVICE
             return

@@ -552,6 +552,43 @@ __global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args<T> a) {
     }
 }
 
+// ---- bulk photon creation from a tabulated energy distribution (Planck sampler) ----------------------
+//   physicl/light.py:73-104: draw u, find the bin x with cdf[x-1] <= u <= cdf[x], return grid[x]
+//   (u below cdf[0] -- where the reference returns None -- yields grid[0], the lower edge of bin 0)
+template <typename T>
+struct fill_table_args {
+    T *f[PCL_NFIELDS];
+    const double *cdf, *grid;
+    int nbins;
+    int64_t n, id_base;
+    double c;
+    uint64_t seed;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_fill_table(fill_table_args<T> a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const uint64_t id = (uint64_t)(a.id_base + i);
+        const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), 0xFFFFFFFFu, 3u, (pcl_u32)a.seed,
+                                              (pcl_u32)(a.seed >> 32));
+        const double u = pcl_u53(w.x, w.y);
+        int lo = 0, hi = a.nbins - 1; // smallest x with cdf[x] >= u
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (a.cdf[mid] >= u) hi = mid; else lo = mid + 1;
+        }
+        const double E = a.grid[lo];
+#pragma unroll
+        for (int f = 0; f < PCL_NFIELDS; ++f) {
+            double val = 0.0;
+            if (f == PCL_V0) val = a.c;
+            if (f == PCL_E) val = E;
+            a.f[f][i] = (T)val;
+        }
+    }
+}
+
 // =================================================================================================
 // expression validator (variable_n_fn): keeps arbitrary text out of the hipRTC compile and keeps
 // every array read at index [gid] so a user expression cannot fault the GPU.  Optionally produces the
@@ -981,6 +1018,22 @@ int fill_photons_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_
     a.seed = seed;
     hipLaunchKernelGGL(k_fill_photons<T>, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
     return launch_check("k_fill_photons");
+}
+
+template <typename T>
+int fill_table_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, const double *cdf_dev, const double *grid_dev,
+                 int nbins, uint64_t seed) {
+    fill_table_args<T> a{};
+    for (int f = 0; f < PCL_NFIELDS; ++f) a.f[f] = F<T>(ctx, f);
+    a.cdf = cdf_dev;
+    a.grid = grid_dev;
+    a.nbins = nbins;
+    a.n = n;
+    a.id_base = id_base;
+    a.c = c;
+    a.seed = seed;
+    hipLaunchKernelGGL(k_fill_table<T>, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    return launch_check("k_fill_table");
 }
 
 template <typename T>
@@ -1673,6 +1726,33 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
     if (n > 0) {
         PCL_TRY(PCL_DISPATCH(ctx, fill_photons_t<double>(ctx, n, id_base, c, e_min, e_max, seed),
                              fill_photons_t<float>(ctx, n, id_base, c, e_min, e_max, seed)));
+        if (ctx->kind) PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)n, ctx->stream));
+    }
+    ctx->count = n;
+    ctx->id_base = id_base;
+    ctx->ids_iota = true;
+    ctx->last_delete_n = -1;
+    return PCL_OK;
+}
+
+int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, const double *cdf_host,
+                                 const double *grid_host, int nbins, uint64_t seed) {
+    PCL_TRY(need_store_raw(ctx));
+    if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
+    if (nbins < 1 || !cdf_host || !grid_host) return fail(PCL_ERR_ARG, "bad table");
+    ctx->lazy_dr = ctx->lazy_dv = false;
+    ctx->lam4_valid = false;
+    if (n > 0) {
+        double *tab = nullptr;
+        PCL_TRY(dev_alloc(&tab, 2 * (int64_t)nbins));
+        int rc = pcl_h2d(ctx, tab, cdf_host, nbins * (int64_t)sizeof(double));
+        if (rc == PCL_OK) rc = pcl_h2d(ctx, tab + nbins, grid_host, nbins * (int64_t)sizeof(double));
+        if (rc == PCL_OK)
+            rc = PCL_DISPATCH(ctx, fill_table_t<double>(ctx, n, id_base, c, tab, tab + nbins, nbins, seed),
+                              fill_table_t<float>(ctx, n, id_base, c, tab, tab + nbins, nbins, seed));
+        if (rc == PCL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PCL_ERR_HIP, "sync failed");
+        (void)hipFree(tab);
+        PCL_TRY(rc);
         if (ctx->kind) PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)n, ctx->stream));
     }
     ctx->count = n;

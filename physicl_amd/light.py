@@ -39,9 +39,11 @@ def planck_distribution(E, T):
     """Normalised Planck photon-energy density, J**-1 (physicl/light.py:53-60).  Set-up time only."""
     E_ = E.__unscaled__() if isinstance(E, Measurement) else E
     T_ = T.__unscaled__() if isinstance(T, Measurement) else T
-    kT = kB.__unscaled__() * T_
-    x = E_ / kT
-    return Measurement(15 / (np.pi ** 4 * kT) * x ** 3 / np.e ** x, "J**-1")
+    k_ = kB.__unscaled__()
+    # operation order of the reference (bit-exact): 15/(pi^4 kB T) * (E/(kB T))^3 * 1/e^(E/(kB T))
+    norm = 15 / (np.pi ** 4 * k_ * T_)
+    x = E_ / (k_ * T_)
+    return Measurement(norm * (x ** 3) * (1 / (np.e ** (E_ / (k_ * T_)))), "J**-1")
 
 
 def planck_probability(E_min, E_max, T, integrator=None):
@@ -79,10 +81,23 @@ def generate_photons(n, fn=lambda: np.random.power(3), min=0, max=0, bins=-1, di
     return [PhotonObject(E=min + (max - min) * fn(), v=Measurement([c, 0, 0], "m**1 s**-1")) for _ in range(int(n))]
 
 
-def generate_photons_bulk(n, min=0, max=0, seed=0):
-    """Same distribution as ``generate_photons`` with its default sampler, created directly in device
-    memory when the simulation first needs it (returns a PhotonBatch for ``sim.add_objs``)."""
-    return PhotonBatch(n, min, max, seed)
+def generate_photons_bulk(n, min=0, max=0, seed=0, T=None, bins=1000):
+    """``n`` photons created directly in device memory when the simulation first needs them (returns a
+    PhotonBatch for ``sim.add_objs``).  Default: the distribution of ``generate_photons`` with its default
+    sampler.  With a temperature ``T``: energies from the binned Planck distribution between ``min`` and
+    ``max`` -- ``generate_photons_from_E([planck_phot_distribution(min, max, T, bins) ...])``
+    (physicl/light.py:73-110) for all photons at once; the bin masses use the closed-form integral of the
+    Planck density instead of ``bins`` calls to scipy.quad."""
+    if T is None:
+        return PhotonBatch(n, min, max, seed)
+    lo, hi, T_ = (float(np.asarray(v.__unscaled__() if isinstance(v, Measurement) else v)) for v in (min, max, T))
+    grid = np.linspace(lo, hi, int(bins))
+    xk = grid / (float(np.asarray(kB.__unscaled__())) * T_)
+    mass = np.diff(-np.exp(-xk) * (xk ** 3 + 3 * xk ** 2 + 6 * xk + 6))
+    cdf = np.cumsum(mass / mass.sum())
+    cdf[-1] = 1.0
+    scale = float(np.asarray(Measurement(1, "J**1").scale))          # table energies in code units
+    return PhotonBatch(n, lo * scale, hi * scale, seed, table=(cdf, grid[:-1] * scale))
 
 
 # ---------------------------------------------------------------------------------------------- helpers

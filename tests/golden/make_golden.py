@@ -440,6 +440,10 @@ UNIT_OPS = [
     "M(7, 'kat**1')", "M(7, 'Sv**1')", "M(1, 'lm**1')", "M(4, 'm ^ 2')", "M(4, 'm**2 kg**1')",
     "np.multiply(M(2, 'm**1'), M(3, 's**1'))", "np.add.reduce(M([1., 2.], 'min**1'))",
     "M(2, 'm**1') * M([1., 2.], 's**-1') + M([1., 1.], 'm**1 s**-1')",
+    # Planck helpers (set-up time): density values and one bin mass, the inputs of the tabulated sampler
+    "light.planck_distribution(M(3e-19, 'J**1'), 5778)", "light.planck_distribution(2.5e-19, M(5778, 'K**1'))",
+    "light.planck_distribution(np.linspace(8e-20, 9e-19, 5), 5778)",
+    "float(light.planck_probability(1e-19, 2e-19, 5778)[0])",
 ]
 
 

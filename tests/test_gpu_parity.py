@@ -729,3 +729,13 @@ def test_fused_delete_after_lazy_scatter_keeps_dv(dev, hip):
         for k in range(3):
             assert np.array_equal(a[4][f][k], b[4][f][k]), (f, k)
     assert np.any(a[4]["dv"][0] != 0)
+
+
+def test_fill_photons_from_planck_table_bit_exact(store, hip):
+    N, base, seed = 300_000, 7, 99
+    cdf, grid = orc.planck_table(7.9e-20, 9.9e-19, 5778.0, 1000)
+    d = store(N)
+    d.fill_photons_table(N, base, C_LIT, cdf, grid, seed)
+    s = d.download_state()
+    assert np.array_equal(s["E"], orc.philox_table_energy(seed, np.arange(N) + base, cdf, grid))   # integer work: exact
+    assert np.all(s["v"][0] == C_LIT) and not np.any(s["r"][0]) and np.array_equal(s["id"], np.arange(N) + base)

@@ -206,3 +206,19 @@ def test_philox_draws_ranges_and_independence():
     # ids above 2**32 use the high counter word
     hi = orc.philox_draws(1, 0, np.array([1 << 32, 0], dtype=np.int64))[2]
     assert hi[0] != hi[1]
+
+
+def test_planck_table_matches_the_reference_density():
+    """Closed-form bin masses == numerical integration of the reference's planck_distribution formula
+    (physicl/light.py:53-60); sampled energies follow that table."""
+    import scipy.integrate
+    kB, T, lo, hi = 1.380649e-23, 5778.0, 7.9e-20, 9.9e-19
+    cdf, grid = orc.planck_table(lo, hi, T, 40)
+    dens = lambda E: 15 / (np.pi ** 4 * kB * T) * (E / (kB * T)) ** 3 / np.e ** (E / (kB * T))
+    edges = np.linspace(lo, hi, 40)
+    mass = np.array([scipy.integrate.quad(dens, edges[k], edges[k + 1])[0] for k in range(39)])
+    assert np.allclose(np.cumsum(mass / mass.sum()), cdf, rtol=1e-10, atol=1e-13)
+    assert np.array_equal(grid, edges[:-1]) and cdf[-1] == 1.0 and np.all(np.diff(cdf) > 0)
+    E = orc.philox_table_energy(3, np.arange(200000), cdf, grid)
+    counts = np.array([(E == g).sum() for g in grid]) / len(E)
+    assert np.max(np.abs(counts - np.diff(np.concatenate([[0.0], cdf])))) < 4e-3
