@@ -80,7 +80,7 @@ def main():
                     help="HIP device index for this rank (default LOCAL_RANK); rehearsals put every rank on device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-photons", type=float, default=1e7)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU baseline duration")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU baseline duration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -208,6 +208,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
             out["cpu_baseline"] = cpu_baseline(dev, args, prof)
             out["cpu_baseline_python"] = cpu_baseline_python(dev, args, prof)
+            out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev, args, prof)
 
     dev.store_free()
     dev.close()
@@ -252,6 +253,27 @@ def cpu_baseline(dev, args, prof):
     return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
             "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads, "
                       "%.1f s)" % (n, steps, cores, el)}
+
+
+def cpu_baseline_numpy(dev, args, prof):
+    """Third CPU figure: the numpy-vectorised oracle (oracle/physicl_oracle.py) on the first 1e6 photons, 1 core
+    (BASELINE.md section 4, item 2)."""
+    from oracle import physicl_oracle as orc
+    n = 1_000_000
+    dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
+    st = {g: [dev.download(f, n) for f in fids] for g, fids in
+          (("r", (0, 1, 2)), ("v", (3, 4, 5)), ("dr", (6, 7, 8)), ("dv", (9, 10, 11)))}
+    st["E"], st["id"] = dev.download(12, n), np.arange(n, dtype=np.int64)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 4.0:
+        orc.step_newton(st, prof["dt"])
+        orc.step_scatter_isotropic(st, orc.philox_draws(args.seed, steps, st["id"]), prof["A_kernel"], prof["n_kernel"],
+                                   C_LIT, h=H_LIT, use_E=True, n_expr=prof["expr"])
+        orc.sign_counts(st["v"])
+        steps += 1
+    el = time.perf_counter() - t0
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d photons x %d steps, numpy-vectorised oracle, %.1f s" % (n, steps, el)}
 
 
 def cpu_baseline_python(dev, args, prof):
