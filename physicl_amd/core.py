@@ -245,6 +245,7 @@ class Simulation(threading.Thread):
         self._readonly_scope = False  # inside a host step that promises not to modify objects
         self._dev_lock = threading.RLock()   # one device call in flight per context (include/physicl_hip.h)
         self._uploaded, self._upload_lo = [], 0
+        self._all_photons = True
         self.hits = 0                 # photons scattered by the most recent ScatterIsotropicStep
         if self.cl_on:
             from . import _hip
@@ -334,6 +335,7 @@ class Simulation(threading.Thread):
                 dev.fill_photons_table(hi - lo, lo, float(np.asarray(_c)), b.table[0], b.table[1], b.seed)
             else:
                 dev.fill_photons(hi - lo, lo, float(np.asarray(_c)), b.e_min, b.e_max, b.seed)
+            self._all_photons = True
             self._alive = b.n
             self._residency = DEVICE
             return
@@ -354,7 +356,8 @@ class Simulation(threading.Thread):
                 kind[k] = 1
                 E[k] = float(np.asarray(o.E))
         state = dict(cols, E=E, id_base=lo)
-        if not kind.all():
+        self._all_photons = bool(kind.all())
+        if not self._all_photons:
             state["kind"] = kind
         dev.upload_state(state)
         self._uploaded = mine                     # shells, index == device id - lo
@@ -433,9 +436,11 @@ class Simulation(threading.Thread):
         rtheta, rphi, rand (physicl/light.py:285, physicl/__init__.py:606-619); delete draws one."""
         dev = self._dev
         n = dev.count
-        kind = dev.download_kind(n) if n else np.zeros(0, np.uint8)
-        ph = kind != 0
-        m = int(ph.sum())
+        if self._all_photons:                      # the common case: no kind array to consult
+            ph, m = slice(None), n
+        else:
+            ph = dev.download_kind(n) != 0 if n else np.zeros(0, bool)
+            m = int(ph.sum())
         if which == "iso":
             u = np.random.random((m, 3))
             full = np.zeros((n, 3))

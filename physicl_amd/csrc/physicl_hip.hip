@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -881,6 +882,13 @@ int check_range(pcl_ctx *ctx, int64_t offset, int64_t n, const void *host) {
 }
 
 // ---- hipRTC specialisation cache ---------------------------------------------------------------------
+// Two levels: compiled code objects are kept per process (keyed by arch + defines + expression), loaded
+// modules per context.  A second Simulation with the same variable_n_fn only pays hipModuleLoadData.
+std::mutex g_code_mutex;
+std::map<std::string, std::vector<char>> g_code_cache;
+
+int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &code, rtc_entry **out);
+
 int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     std::string expr_f32;
     PCL_TRY(validate_expr(expr, &expr_f32));
@@ -888,6 +896,13 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     if (it != ctx->rtc.end()) {
         *out = &it->second;
         return PCL_OK;
+    }
+    const char *extra_env = getenv("PCL_RTC_EXTRA");
+    const std::string code_key = std::string(ctx->prop.gcnArchName) + "|" + (extra_env ? extra_env : "") + "|" + expr;
+    {
+        std::lock_guard<std::mutex> lock(g_code_mutex);
+        auto ci = g_code_cache.find(code_key);
+        if (ci != g_code_cache.end()) return load_rtc_module(ctx, expr, ci->second, out);
     }
     std::string src = "#define PCL_RTC 1\n";
     // perf-experiment hook (never set in production): PCL_RTC_EXTRA="NAME1,NAME2" -> "#define NAME 1" lines
@@ -929,6 +944,14 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     std::vector<char> code(code_n);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    {
+        std::lock_guard<std::mutex> lock(g_code_mutex);
+        g_code_cache[code_key] = code;
+    }
+    return load_rtc_module(ctx, expr, code, out);
+}
+
+int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &code, rtc_entry **out) {
     rtc_entry ent;
     PCL_HIP(hipModuleLoadData(&ent.module, code.data()));
     PCL_HIP(hipModuleGetFunction(&ent.sphere[0], ent.module, "pcl_rtc_sphere_e0"));

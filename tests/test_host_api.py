@@ -172,3 +172,17 @@ def test_planck_helpers_are_usable_at_setup_time():
     np.random.seed(0)
     E = light.planck_phot_distribution(light.E_from_wavelength(2500e-9), light.E_from_wavelength(200e-9), 5778, bins=50)
     assert E is None or 7e-20 < float(E) < 1e-18
+
+
+def test_alias_package_does_not_import_light_eagerly():
+    """Scripts set the code scale BEFORE importing physicl.light (code_unit_scale_test.ipynb:55): the alias
+    package must not create c and h behind their back."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import physicl as phys; "
+            "assert 'physicl_amd.light' not in sys.modules and 'physicl.light' not in sys.modules; "
+            "phys.Measurement.set_code_scale('m', 0.001); import physicl.light as light; "
+            "assert float(light.c) == 299792.458, float(light.c); print('ok')") % __import__("os").path.dirname(
+                __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-500:]
