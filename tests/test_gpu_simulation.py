@@ -244,3 +244,62 @@ def test_variable_n_example_through_the_plugin_api():
 def test_device_info():
     info = phys.Simulation.get_device_info()
     assert len(info) >= 1 and all("gfx950" in k for k in info)
+
+
+def test_foreign_threads_can_poll_and_touch_objects_while_the_simulation_runs():
+    """The reference's usage pattern: the simulation runs on its own thread while the main thread polls
+    get_state() (every example) -- and may even index sim.objects.  len()/get_state never touch the device;
+    object access waits for the pass in flight, syncs the state back and the run continues from it."""
+    import time
+    sim = phys.Simulation(cl_on=True, rng="philox", seed=5, exit=lambda s: s.t >= 0.2995)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(2000)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    sim.add_step(3, sign)
+    sim.start()
+    polls, touched = 0, 0
+    while sim.running or polls == 0:
+        st = sim.get_state()
+        assert st["objects"] == 2000
+        polls += 1
+        if polls % 3 == 0 and sim.running:
+            o = sim.objects[17]                      # forces a device -> host sync between two passes
+            assert o.uid == 17 and np.isfinite(np.asarray(o.r)).all()
+            touched += 1
+        time.sleep(0.002)
+    sim.join()
+    assert sim.error is None and len(sign.data) == 300 and polls > 1
+    # the interleaved syncs did not disturb the physics: same result as an undisturbed run
+    ref = phys.Simulation(cl_on=True, rng="philox", seed=5, exit=lambda s: s.t >= 0.2995)
+    ref.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(2000)])
+    ref.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    ref.add_step(1, phys.newton.NewtonianKinematicsStep())
+    ref.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign2 = phys.light.ScatterSignMeasureStep(None, True)
+    ref.add_step(3, sign2)
+    run(ref)
+    assert np.array_equal(np.array(sign.data), np.array(sign2.data))
+    assert np.array_equal(np.array([np.asarray(o.r) for o in sim.objects]), np.array([np.asarray(o.r) for o in ref.objects]))
+
+
+def test_two_simulations_back_to_back_share_the_device():
+    """runtime1-style: several Simulations (contexts) in one process, one after the other and alive together."""
+    sims = []
+    for seed in (1, 2):
+        s = phys.Simulation(cl_on=True, rng="philox", seed=seed, exit=lambda c: c.t >= 0.0095)
+        s.add_objs(phys.light.generate_photons_bulk(50_000, min=1e-19, max=2e-19, seed=seed))
+        s.add_step(0, phys.UpdateTimeStep(lambda c: np.double(0.001)))
+        s.add_step(1, phys.newton.NewtonianKinematicsStep())
+        s.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001),
+                                                      variable_n=True, variable_n_fn="0.001 * exp(r1[gid] / 1e9)"))
+        sims.append(s)
+    for s in sims:
+        s.start()
+    for s in sims:
+        s.join()
+        assert s.error is None and len(s.ts) == 10 and s.hits > 0
+    assert sims[0].hits != sims[1].hits
