@@ -165,6 +165,17 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
  * and the array reads r0[gid] r1[gid] r2[gid] d0[gid] d1[gid] d2[gid] E[gid].                     */
 int pcl_expr_validate(const char *n_expr);
 
+/* User kernels -- the role of CLProgram.build_kernel()/run() (physicl/__init__.py:583-597, 648-656): the
+ * caller supplies the parameter list it generated from its CLInput/CLOutput metadata (e.g.
+ * "double *d0, double A, int *res") and the kernel BODY in the OpenCL-C dialect the reference's kernels use
+ * (get_global_id(0), __global, NAN, pow/sqrt/sin/cos/exp ...).  The body is compiled with hipRTC (unfused
+ * arithmetic) into a kernel that runs once per work-item 0..n-1.  argbuf = the arguments packed as a C struct
+ * in declaration order (pointers and doubles 8-byte aligned, ints 4).  Unlike variable_n_fn expressions a body
+ * is arbitrary code and is NOT validated: like any OpenCL kernel it can read out of bounds. */
+int pcl_user_kernel_build(pcl_ctx *ctx, const char *name, const char *params, const char *body, void **kernel_out);
+int pcl_user_kernel_launch(pcl_ctx *ctx, void *kernel, int64_t n, const void *argbuf, int64_t argbuf_bytes);
+int pcl_user_kernel_free(pcl_ctx *ctx, void *kernel);
+
 /* ---------------------------------------------------------------- Level 2: resident particle store */
 
 /* Allocate SoA storage for up to ``capacity`` particles (13 arrays; ids, kinds, the compaction

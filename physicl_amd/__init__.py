@@ -12,5 +12,11 @@ from .core import (CLInput, CLOutput, CLProgram, DeviceStep, MeasureStep, Object
                    Simulation, Step, UpdateTimeStep)
 
 __version__ = "0.1.0"
+
+
+def _hip_error():
+    """The exception class raised for device / hipRTC failures (lazy: importing the package stays GPU-free)."""
+    from ._hip import HipError
+    return HipError
 __all__ = ["Measurement", "MeasurementError", "Step", "DeviceStep", "UpdateTimeStep", "MeasureStep", "Object",
            "ObjectList", "PhotonBatch", "Simulation", "CLInput", "CLOutput", "CLProgram"]

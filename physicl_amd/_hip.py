@@ -67,6 +67,9 @@ _PROTOTYPES = {
                                         _vp, _vp, _vp, c_int64, c_int, c_double, c_double, c_char_p],
     "pcl_k_compact_indices": [_vp, _vp, c_int64, _vp, POINTER(c_int64)],
     "pcl_expr_validate": [c_char_p],
+    "pcl_user_kernel_build": [_vp, c_char_p, c_char_p, c_char_p, POINTER(_vp)],
+    "pcl_user_kernel_launch": [_vp, _vp, c_int64, _vp, c_int64],
+    "pcl_user_kernel_free": [_vp, _vp],
     "pcl_store_alloc": [_vp, c_int64],
     "pcl_store_alloc_dtype": [_vp, c_int64, c_int],
     "pcl_store_dtype": [_vp, POINTER(c_int)],
@@ -178,6 +181,36 @@ class DeviceArray:
         self.ptr = None
 
 
+_CTYPES = {"double": c_double, "int": c_int32, "float": ctypes.c_float, "long": c_int64}
+
+
+class UserKernel:
+    """A hipRTC-compiled user kernel (``pcl_user_kernel_*``): the device side of ``CLProgram``."""
+
+    def __init__(self, dev, name, params, body):
+        self.dev, self.name, self.params = dev, name, list(params)
+        decl = ", ".join("%s %s%s" % (ct, "*" if ptr else "", nm) for ct, nm, ptr in self.params)
+        h = c_void_p()
+        rc = dev.lib.pcl_user_kernel_build(dev.ctx, name.encode(), decl.encode(), body.encode(), byref(h))
+        if rc != 0:
+            raise HipError(rc, dev.lib.pcl_last_error().decode("utf-8", "replace"))
+        self.handle = h
+        fields = [("a%d" % i, c_void_p if ptr else _CTYPES[ct]) for i, (ct, nm, ptr) in enumerate(self.params)]
+        self._argtype = type("pcl_args_" + name, (ctypes.Structure,), {"_fields_": fields})
+
+    def __call__(self, n, *args):
+        assert len(args) == len(self.params), "kernel %s takes %d arguments" % (self.name, len(self.params))
+        packed = self._argtype()
+        for i, ((ct, nm, ptr), a) in enumerate(zip(self.params, args)):
+            setattr(packed, "a%d" % i, a.ptr if ptr else _CTYPES[ct](a).value)
+        check(self.dev.lib.pcl_user_kernel_launch(self.dev.ctx, self.handle, int(n), byref(packed), ctypes.sizeof(packed)))
+
+    def free(self):
+        if self.handle is not None and self.dev.ctx:
+            self.dev.lib.pcl_user_kernel_free(self.dev.ctx, self.handle)
+        self.handle = None
+
+
 class Device:
     """One HIP context (device + stream) and, optionally, one resident particle store."""
 
@@ -259,6 +292,10 @@ class Device:
         keep = c_int64()
         check(self.lib.pcl_k_compact_indices(self.ctx, flags.ptr, N, idx_out.ptr, byref(keep)))
         return keep.value
+
+    def user_kernel(self, name, params, body):
+        """Compile a kernel body (OpenCL-C dialect) with hipRTC.  params: [(ctype, name, is_pointer), ...]."""
+        return UserKernel(self, name, params, body)
 
     # ---------------------------------------------------------------- Level 2 (resident store)
     def store_alloc(self, capacity, dtype="f64"):

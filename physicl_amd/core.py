@@ -634,20 +634,96 @@ class CLOutput:
 
 
 class CLProgram:
-    """The reference builds an OpenCL kernel from ``kernel_code`` and runs it over per-object arrays
-    (physicl/__init__.py:567-664).  The steps of this build do not go through it; the three kernels
-    the reference ships are available natively (see ``physicl_amd._hip.Device.k_*`` and
-    INTEGRATION.md).  Arbitrary OpenCL-C bodies are not translated."""
+    """User-defined kernels with the reference's glue API (physicl/__init__.py:567-664): describe the
+    inputs with ``CLInput`` (per-object attributes, per-object expressions, constants, tracked objects),
+    the outputs with ``CLOutput``, give the kernel BODY in the OpenCL-C dialect of the reference's kernels;
+    ``build_kernel()`` compiles it (hipRTC instead of an OpenCL driver) and ``run()`` gathers the inputs
+    from ``sim.objects``, launches one work-item per gathered object and returns ``{output name: ndarray}``.
+
+    This is the reference's slow path by design (a Python gather per call); the steps shipped with this
+    build do not use it.  Same contract as the reference: every array input is marshalled as float64
+    whatever its ``ctype`` (physicl/__init__.py:613); ``int`` outputs are 32-bit; the global size is the
+    length of the first ``"obj"`` input; ``obj_track`` lists (e.g. ``pht``) are left on the program
+    object for the caller.
+    """
 
     def __init__(self, sim, name, kernel_code):
         self.sim, self.prog_name, self.kernel_code = sim, name, kernel_code
         self.prep_metadata, self.output_metadata, self.variables, self.prog = [], [], {}, None
 
+    def _signature(self):
+        params = []
+        for item in self.prep_metadata:
+            if item.type in ("obj", "obj_def"):
+                params.append((item.ctype, item.name, True))
+            elif item.type == "const":
+                params.append((item.ctype, item.name, False))
+        params.extend((o.ctype, o.name, True) for o in self.output_metadata)
+        return params
+
     def build_kernel(self):
-        raise NotImplementedError(
-            "CLProgram: this build ships hand-written HIP kernels for light_scatter_step_del, test and "
-            "light_scatter_step_sphere (physicl_amd._hip.Device.k_*) and does not compile OpenCL C; "
-            "see INTEGRATION.md for binding them from a PhysiCL checkout")
+        dev = self.sim._need_device("CLProgram")
+        self.prog = dev.user_kernel(self.prog_name, self._signature(), self.kernel_code)
+
+    def _gather(self):
+        """One pass over sim.objects.  The per-object statements run in metadata order inside a single
+        ``for obj in ...`` loop (an ``obj_action`` may ``continue`` to skip an object), exactly the execution
+        model scripts written against the reference rely on."""
+        lists = [it.name for it in self.prep_metadata if it.type in ("obj", "obj_def", "obj_track")]
+        body = []
+        for it in self.prep_metadata:
+            if it.type == "obj":
+                body.append("%s.append(obj.%s)" % (it.name, it.obj_attr))
+            elif it.type == "obj_def":
+                body.append("%s.append(%s)" % (it.name, it.obj_def))
+            elif it.type == "obj_track":
+                body.append("%s.append(%s)" % (it.name, it.obj_track))
+            elif it.type == "obj_action":
+                body.append(it.code)
+        src = "for obj in _objects:\n\t" + "\n\t".join(body) if body else ""
+        import types
+        from . import light, newton
+        ns = {"np": np, "self": self, "_objects": list(self.sim.objects),
+              "physicl": types.SimpleNamespace(light=light, newton=newton, **{k: globals()[k] for k in (
+                  "Measurement", "Object", "Step", "Simulation")})}
+        ns["phys"] = ns["physicl"]
+        for nm in lists:
+            ns[nm] = []
+        exec(src, ns)                          # noqa: S102 -- user-supplied gather code, as in the reference
+        return {nm: ns[nm] for nm in lists}
 
     def run(self):
-        self.build_kernel()
+        if self.prog is None:
+            self.build_kernel()
+        dev = self.sim._dev
+        with self.sim._dev_lock:
+            got = self._gather()
+            for it in self.prep_metadata:
+                if it.type == "obj_track":
+                    setattr(self, it.name, got[it.name])
+            n, args, temps = None, [], []
+            for it in self.prep_metadata:
+                if it.type in ("obj", "obj_def"):
+                    arr = np.array(got[it.name], dtype=np.double)
+                    setattr(self, it.name + "_np", arr)
+                    if n is None and it.type == "obj":
+                        n = arr.shape[0]
+                    d = dev.array(arr)
+                    temps.append(d)
+                    args.append(d)
+                elif it.type == "const":
+                    args.append(float(np.double(it.const_value)))
+            if n is None:
+                raise ValueError("CLProgram needs at least one input of type 'obj' to define the global size")
+            outs = []
+            for o in self.output_metadata:
+                d = dev.empty(max(n, 1), {"int": np.int32, "double": np.float64, "float": np.float32}[o.ctype])
+                temps.append(d)
+                outs.append(d)
+                args.append(d)
+            try:
+                self.prog(n, *args)
+                return {o.name: d.get()[:n] for o, d in zip(self.output_metadata, outs)}
+            finally:
+                for d in temps:
+                    d.free()

@@ -1585,6 +1585,94 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
 
 int pcl_expr_validate(const char *n_expr) { return validate_expr(n_expr); }
 
+// ---- user kernels: what CLProgram.build_kernel / run did with OpenCL (physicl/__init__.py:583-597, 656) -------
+struct pcl_user_kernel {
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+};
+
+int pcl_user_kernel_build(pcl_ctx *ctx, const char *name, const char *params, const char *body, void **kernel_out) {
+    PCL_TRY(bind(ctx));
+    if (!name || !params || !body || !kernel_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *kernel_out = nullptr;
+    for (const char *q = name; *q; ++q)
+        if (!((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_'))
+            return fail(PCL_ERR_ARG, "kernel name '%s' is not an identifier", name);
+    // the OpenCL-C dialect the reference's kernels are written in, mapped onto HIP; one work-item per element,
+    // work-items beyond the global size return before the body runs
+    std::string src =
+        "#define __kernel\n#define __global\n#define __constant const\n#define __private\n"
+        "#define get_global_id(d) ((int)(blockIdx.x * blockDim.x + threadIdx.x))\n"
+        "#define get_global_size(d) ((int)pcl_n__)\n"
+        "#ifndef NAN\n#define NAN __builtin_nan(\"\")\n#endif\n"
+        "#ifndef INFINITY\n#define INFINITY __builtin_inf()\n#endif\n"
+        "#ifndef M_PI\n#define M_PI 3.14159265358979323846\n#endif\n"
+        "extern \"C\" __global__ void __launch_bounds__(256) ";
+    src += name;
+    src += "(";
+    src += params;
+    src += (*params ? ", " : "");
+    src += "long long pcl_n__) {\n  if ((long long)blockIdx.x * blockDim.x + threadIdx.x >= pcl_n__) return;\n";
+    src += body;
+    src += "\n}\n";
+    hiprtcProgram prog;
+    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_user_kernel.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+    r = hiprtcCompileProgram(prog, 4, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(PCL_ERR_RTC, "hipRTC could not compile kernel '%s': %s\n%s", name, hiprtcGetErrorString(r), log.c_str());
+    }
+    size_t code_n = 0;
+    hiprtcGetCodeSize(prog, &code_n);
+    std::vector<char> code(code_n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    pcl_user_kernel *k = new (std::nothrow) pcl_user_kernel();
+    if (!k) return fail(PCL_ERR_NOMEM, "out of host memory");
+    if (hipModuleLoadData(&k->module, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->module, name) != hipSuccess) {
+        if (k->module) (void)hipModuleUnload(k->module);
+        delete k;
+        return fail(PCL_ERR_RTC, "could not load kernel '%s'", name);
+    }
+    *kernel_out = k;
+    return PCL_OK;
+}
+
+int pcl_user_kernel_launch(pcl_ctx *ctx, void *kernel, int64_t n, const void *argbuf, int64_t argbuf_bytes) {
+    PCL_TRY(bind(ctx));
+    if (!kernel || n < 0 || argbuf_bytes < 0 || (argbuf_bytes > 0 && !argbuf)) return fail(PCL_ERR_ARG, "bad argument");
+    if (n == 0) return PCL_OK;
+    pcl_user_kernel *k = static_cast<pcl_user_kernel *>(kernel);
+    // kernarg = the caller's packed arguments + the trailing global size (8-byte aligned)
+    std::vector<char> buf(((size_t)argbuf_bytes + 7) / 8 * 8 + 8, 0);
+    if (argbuf_bytes) memcpy(buf.data(), argbuf, (size_t)argbuf_bytes);
+    const long long nn = n;
+    memcpy(buf.data() + buf.size() - 8, &nn, 8);
+    size_t sz = buf.size();
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, buf.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    const int64_t blocks = div_up(n, kBlock);
+    if (blocks > 0x7FFFFFFF) return fail(PCL_ERR_ARG, "global size too large");
+    PCL_HIP(hipModuleLaunchKernel(k->fn, (unsigned)blocks, 1, 1, kBlock, 1, 1, 0, ctx->stream, nullptr, config));
+    return launch_check("user kernel");
+}
+
+int pcl_user_kernel_free(pcl_ctx *ctx, void *kernel) {
+    PCL_TRY(bind(ctx));
+    if (!kernel) return PCL_OK;
+    pcl_user_kernel *k = static_cast<pcl_user_kernel *>(kernel);
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    if (k->module) (void)hipModuleUnload(k->module);
+    delete k;
+    return PCL_OK;
+}
+
 // ------------------------------------------------------------------------------------ Level 2 ----
 int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     PCL_TRY(bind(ctx));

@@ -303,3 +303,64 @@ def test_two_simulations_back_to_back_share_the_device():
         s.join()
         assert s.error is None and len(s.ts) == 10 and s.hits > 0
     assert sims[0].hits != sims[1].hits
+
+
+def test_user_step_built_on_clprogram(golden):
+    """A user-defined Step written against the reference's kernel-glue API (CLInput / CLOutput / CLProgram,
+    physicl/__init__.py:543-664): gather per-object inputs, run an OpenCL-C body, act on the result.
+    Here: an absorber like ScatterDeleteStep, with its own kernel text; checked against the oracle."""
+    from oracle import physicl_oracle as orc
+
+    class MyAbsorber(phys.Step):
+        def __init__(self, sigma):
+            self.sigma, self.prog = sigma, None
+
+        def run(self, sim):
+            if self.prog is None:
+                skip = phys.CLInput(name="only_photons", type="obj_action",
+                                    code="if type(obj) != physicl.light.PhotonObject:\n \t\t continue")
+                d = [phys.CLInput(name="d%d" % k, type="obj", obj_attr="dr[%d]" % k) for k in range(3)]
+                u = phys.CLInput(name="u", type="obj_def", obj_def="np.random.random()")
+                sg = phys.CLInput(name="sigma", type="const", const_value=str(self.sigma))
+                who = phys.CLInput(name="who", type="obj_track", obj_track="obj")
+                self.prog = phys.CLProgram(sim, "absorb", """
+                    int gid = get_global_id(0);
+                    double path = sqrt(d0[gid] * d0[gid] + d1[gid] * d1[gid] + d2[gid] * d2[gid]);
+                    gone[gid] = (sigma * path >= u[gid]) ? 1 : 0;
+                    depth[gid] = sigma * path;
+                """)
+                self.prog.prep_metadata = [skip] + d + [u, who, sg]
+                self.prog.output_metadata = [phys.CLOutput(name="gone", ctype="int"), phys.CLOutput(name="depth")]
+                self.prog.build_kernel()
+            out = self.prog.run()
+            self.last = out
+            for idx, x in enumerate(out["gone"]):
+                if x == 1:
+                    sim.remove_obj(self.prog.who[idx])
+
+    sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= 0.0025)
+    objs = [phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+            for i in range(3000)]
+    objs.insert(10, phys.Object(v=phys.Measurement([5.0, 0, 0], "m**1 s**-1"), uid=-1))     # skipped by the obj_action
+    sim.add_objs(objs)
+    absorber = MyAbsorber(np.double(1e-6))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, absorber)
+    np.random.seed(99)
+    run(sim)
+    # replay with the oracle: same random stream (one draw per photon per step), same kernel maths
+    rs = np.random.RandomState(99)
+    alive = np.arange(3000)
+    for step in range(3):
+        n = len(alive)
+        d0 = np.full(n, 299792458.0 * 0.001)
+        flags = orc.delete_flags(d0, np.zeros(n), np.zeros(n), rs.random_sample(n), 1e-6, 1.0)
+        alive = alive[orc.survivors(flags)]
+    assert [o.uid for o in sim.objects] == [*alive[alive < 10], -1, *alive[alive >= 10]]    # order kept, Object untouched
+    assert absorber.last["gone"].dtype == np.int32 and absorber.last["depth"].dtype == np.float64
+    assert np.all(absorber.last["depth"] == 1e-6 * (299792458.0 * 0.001))
+    with pytest.raises(phys._hip_error()):
+        bad = phys.CLProgram(sim, "broken", "int gid = get_global_id(0); res[gid] = undefined_symbol;")
+        bad.prep_metadata, bad.output_metadata = [phys.CLInput(name="d0", type="obj", obj_attr="dr[0]")], [phys.CLOutput(name="res")]
+        bad.build_kernel()

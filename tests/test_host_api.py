@@ -145,8 +145,12 @@ def test_measure_step_csv_and_kernel_glue_stubs(tmp_path):
     i = phys.CLInput(name="d0", type="obj", obj_attr="dr[0]")
     o = phys.CLOutput(name="res", ctype="int")
     assert (i.name, i.ctype, o.ctype) == ("d0", "double", "int")
-    with pytest.raises(NotImplementedError, match="INTEGRATION.md"):
-        phys.CLProgram(None, "test", "int gid = get_global_id(0);").build_kernel()
+    sim = phys.Simulation(cl_on=False)
+    prog = phys.CLProgram(sim, "k", "int gid = get_global_id(0); res[gid] = 1;")
+    prog.prep_metadata, prog.output_metadata = [i, phys.CLInput(name="A", type="const", const_value="2.5")], [o]
+    assert prog._signature() == [("double", "d0", True), ("double", "A", False), ("int", "res", True)]
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        prog.build_kernel()
     with pytest.raises(NotImplementedError):
         light.ScatterMeasureStep(None, True, [], measure_E=True)
 
