@@ -93,7 +93,7 @@ def main():
     from physicl_amd import _hip
     from physicl_amd.dist import CounterComm
 
-    comm = CounterComm.from_env(backend=args.backend)    # no-op communicator when world == 1
+    comm = CounterComm.from_env(backend=args.backend, device_index=args.device)   # no-op communicator when world == 1
     N = int(args.photons)
     prof = PROFILES[args.profile]
     flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
@@ -185,7 +185,7 @@ def main():
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N,
-                                      " + %s all-reduce of 5 int64 counters" % ("RCCL" if args.backend == "nccl" else "gloo") if world > 1 else ""),
+                                      " + %s all-reduce of 5 int64 counters" % ("RCCL" if comm.backend == "nccl" else "gloo") if world > 1 else ""),
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
             "roofline": {"bound": "hbm",

@@ -24,11 +24,13 @@ def shard_range(n_global, rank, world):
 class CounterComm:
     """Sum/max all-reduce of tiny host vectors across the ranks of one node."""
 
-    def __init__(self, rank=0, world=1, backend="nccl", local_rank=0, _init=True):
+    def __init__(self, rank=0, world=1, backend="nccl", local_rank=0, _init=True, device_index=None):
         self.rank, self.world, self.backend, self.local_rank = int(rank), int(world), backend, int(local_rank)
+        dev_index = self.local_rank if device_index is None else int(device_index)
         self._dist = None
         self._torch = None
         self._dev = None
+        self._group = None
         if self.world > 1 and _init:
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
             import torch
@@ -37,19 +39,50 @@ class CounterComm:
             if backend == "nccl":
                 if not torch.cuda.is_available():
                     raise RuntimeError("backend 'nccl' (RCCL) needs a GPU; use backend='gloo' for CPU runs")
-                torch.cuda.set_device(self.local_rank)
-                self._dev = torch.device("cuda", self.local_rank)
+                torch.cuda.set_device(dev_index)
+                self._dev = torch.device("cuda", dev_index)
             else:
                 self._dev = torch.device("cpu")
             if not dist.is_initialized():
-                kw = {"device_id": self._dev} if backend == "nccl" else {}
-                dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+                self._init_group(backend)
+
+    def _init_group(self, backend):
+        """Control plane = a gloo process group (always comes up).  For backend "nccl" the counter all-reduce
+        runs on an RCCL group created on top of it and proven with one tiny all-reduce; if RCCL cannot be
+        brought up the counters stay on gloo (40 bytes per step: no effect on throughput) and ``self.backend``
+        says so."""
+        import datetime
+        torch, dist = self._torch, self._dist
+        dist.init_process_group(backend="gloo", rank=self.rank, world_size=self.world,
+                                timeout=datetime.timedelta(seconds=300))
+        self._group = None                      # None = the default (gloo) group
+        if backend != "nccl":
+            return
+        ok = 0
+        try:
+            g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            probe = torch.ones(1, dtype=torch.int64, device=self._dev)
+            dist.all_reduce(probe, group=g)
+            ok = int(int(probe.cpu()[0]) == self.world)
+        except Exception as e:                      # noqa: BLE001 -- any RCCL bring-up failure
+            import sys
+            print("physicl_amd.dist: RCCL unavailable (%s: %s); reducing the counters over gloo"
+                  % (type(e).__name__, str(e).splitlines()[0][:200]), file=sys.stderr)
+        # every rank must take the same decision
+        agree = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+        if int(agree[0]) == 1:
+            self._group = g
+        else:
+            if os.environ.get("PCL_NO_GLOO_FALLBACK"):
+                raise RuntimeError("RCCL process group could not be created")
+            self.backend, self._dev = "gloo", torch.device("cpu")
 
     @classmethod
-    def from_env(cls, backend="nccl"):
+    def from_env(cls, backend="nccl", device_index=None):
         """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run."""
         return cls(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), backend,
-                   int(os.environ.get("LOCAL_RANK", "0")))
+                   int(os.environ.get("LOCAL_RANK", "0")), device_index=device_index)
 
     def shard(self, n_global):
         return shard_range(n_global, self.rank, self.world)
@@ -60,15 +93,15 @@ class CounterComm:
         if self.world == 1:
             return a.copy()
         t = self._torch.from_numpy(a.copy()).to(self._dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return t.cpu().numpy()
 
     def allreduce_max(self, x):
         if self.world == 1:
             return float(x)
-        t = self._torch.tensor([float(x)], dtype=self._torch.float64, device=self._dev)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t.cpu()[0])
+        t = self._torch.tensor([float(x)], dtype=self._torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)          # control plane (gloo)
+        return float(t[0])
 
     def barrier(self):
         if self.world > 1:
