@@ -131,19 +131,30 @@ def main():
                          cnt[_hip.CNT_ZP]], dtype=np.int64)
 
     def run_steps(k0, k1):
-        """Steps k0..k1-1.  The all-reduce of step k's counters (RCCL over xGMI when world > 1) is issued
-        while the GPU already runs step k+1 -- the counters are consumed one step behind (SURVEY.md 8(e));
-        the last one is reduced before the function returns, inside the timed region."""
+        """Steps k0..k1-1, software-pipelined: step k+1 is enqueued BEFORE the host waits for step k's counters
+        (two counter banks in the library), so the GPU never idles on Python; the all-reduce of step k's
+        counters (RCCL over xGMI when world > 1) runs while the GPU computes step k+1 -- counters are consumed
+        one step behind; the last one is read and reduced inside the timed region."""
         nonlocal totals
-        hits, pending = 0, None
-        for k in range(k0, k1):
+        hits = 0
+        if not args.mode.startswith("fused") or os.environ.get("PCL_BENCH_NOPIPE"):
+            for k in range(k0, k1):
+                launch(k)
+                c = collect()
+                hits += int(c[1])
+                totals = comm.allreduce_sum(c)
+            return hits
+        if k1 > k0:
+            launch(k0)
+        for k in range(k0 + 1, k1):
             launch(k)
-            if pending is not None:
-                totals = comm.allreduce_sum(pending)
-            pending = collect()
-            hits += int(pending[1])
-        if pending is not None:
-            totals = comm.allreduce_sum(pending)
+            c = collect()                      # counters of step k-1
+            hits += int(c[1])
+            totals = comm.allreduce_sum(c)
+        if k1 > k0:
+            c = collect()
+            hits += int(c[1])
+            totals = comm.allreduce_sum(c)
         return hits
 
     run_steps(0, args.warmup)

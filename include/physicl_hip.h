@@ -250,9 +250,10 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
                    double h, const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                    const double *planes_host, int n_planes, int64_t *out_host);
 
-/* Counters of the most recent pcl_step_fused that was called with out_host == NULL (same layout,
- * same n_planes).  Synchronises.  Lets a caller overlap host work (e.g. the all-reduce of the previous
- * step's counters) with the kernel. */
+/* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
+ * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --
+ * the call waits for step k only (an event, not the stream), so the GPU runs step k+1 while the host handles
+ * step k's counters (exit condition, all-reduce, measure rows). */
 int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host);
 
 /* Hit count of the most recent pcl_step_scatter_isotropic / pcl_step_fused (host pointer).  Free of extra

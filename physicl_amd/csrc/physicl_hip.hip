@@ -747,6 +747,16 @@ struct pcl_ctx {
     uint64_t *d_cnt = nullptr;
     uint64_t *h_cnt = nullptr;
     bool hits_on_host = true; // h_cnt[0] holds the hit count of the most recent scatter step
+    // two counter banks for pcl_step_fused calls that do not synchronise: step k+1 is enqueued before the host
+    // reads step k's counters, so the GPU never waits for Python (pcl_step_fused_read drains them in order)
+    uint64_t *d_bank[2] = {nullptr, nullptr};
+    uint64_t *h_bank[2] = {nullptr, nullptr};
+    hipEvent_t bank_ev[2] = {nullptr, nullptr};
+    int64_t bank_count[2] = {0, 0};
+    int bank_np[2] = {0, 0};
+    int bank_head = 0, bank_pending = 0; // FIFO of un-read async steps: banks head, head^1
+    int last_async_bank = -1;            // bank of the most recent step if it was asynchronous, else -1
+    uint64_t *cnt_target = nullptr;      // where the running step's kernels accumulate
 
     std::map<std::string, rtc_entry> rtc;
 
@@ -1123,7 +1133,7 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     f.vo0 = static_cast<T *>(ctx->vprev[0]); f.vo1 = static_cast<T *>(ctx->vprev[1]); f.vo2 = static_cast<T *>(ctx->vprev[2]);
     f.lam4 = static_cast<const T *>(ctx->lam4);
     f.E = F<T>(ctx, PCL_E);
-    f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    f.cnt = reinterpret_cast<pcl_u64 *>(ctx->cnt_target);
     f.id_base = ctx->id_base;
     f.N = N;
     f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
@@ -1169,7 +1179,7 @@ int step_fused_t(pcl_ctx *ctx, double dt, bool do_scatter, double A, double n, b
     a.rand = static_cast<const T *>(ctx->rnd[2]);
     a.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
     a.kind = ctx->kind;
-    a.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
+    a.cnt = reinterpret_cast<pcl_u64 *>(ctx->cnt_target);
     a.id_base = ctx->id_base;
     a.N = N;
     a.dt = (T)dt; a.A = (T)A; a.n = (T)n; a.c = (T)c; a.h = (T)h;
@@ -1377,6 +1387,15 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
     }
     memset(c->h_cnt, 0, kCounterSlots * sizeof(uint64_t));
     (void)hipMemset(c->d_cnt, 0, kCounterSlots * sizeof(uint64_t));
+    for (int b = 0; b < 2; ++b) {
+        if (hipMalloc(reinterpret_cast<void **>(&c->d_bank[b]), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&c->h_bank[b]), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
+            hipEventCreateWithFlags(&c->bank_ev[b], hipEventDisableTiming) != hipSuccess) {
+            pcl_ctx_destroy(c);
+            return fail(PCL_ERR_HIP, "context resource allocation failed");
+        }
+    }
+    c->cnt_target = c->d_cnt;
     *ctx_out = c;
     return PCL_OK;
 }
@@ -1390,6 +1409,11 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
         if (kv.second.module) (void)hipModuleUnload(kv.second.module);
     if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    for (int b = 0; b < 2; ++b) {
+        if (ctx->d_bank[b]) (void)hipFree(ctx->d_bank[b]);
+        if (ctx->h_bank[b]) (void)hipHostFree(ctx->h_bank[b]);
+        if (ctx->bank_ev[b]) (void)hipEventDestroy(ctx->bank_ev[b]);
+    }
     for (auto &p : ctx->prof) {
         if (p.a) (void)hipEventDestroy(p.a);
         if (p.b) (void)hipEventDestroy(p.b);
@@ -1897,6 +1921,7 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
                             (long long)N);
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
+    ctx->last_async_bank = -1;
     PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step),
                          step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step)));
     if (hits_out) {
@@ -1940,8 +1965,20 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             if (!ctx->rnd[k] || ctx->rnd_n[k] < N)
                 return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=%d) for all %lld particles", k,
                             (long long)N);
-    PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, (size_t)(4 + np) * sizeof(uint64_t), ctx->stream));
+    // synchronous call: the context's counter slots; asynchronous call with counters: the next free bank
+    const bool use_bank = !out_host && n_planes >= 0;
+    int bank = -1;
+    if (use_bank) {
+        if (ctx->bank_pending >= 2)
+            return fail(PCL_ERR_STATE, "two un-read asynchronous fused steps are outstanding: call pcl_step_fused_read");
+        bank = (ctx->bank_head + ctx->bank_pending) & 1;
+        ctx->cnt_target = ctx->d_bank[bank];
+    } else {
+        ctx->cnt_target = ctx->d_cnt;
+    }
+    PCL_HIP(hipMemsetAsync(ctx->cnt_target, 0, (size_t)(4 + np) * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
+    ctx->last_async_bank = bank;
     static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
     const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && !ctx->kind && ctx->ids_iota && n_planes <= 0 && !no_fast;
     if (fast) {
@@ -1961,6 +1998,15 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
         ctx->lazy_dr = true;
         ctx->lazy_dt = dt;
     }
+    ctx->cnt_target = ctx->d_cnt;
+    if (use_bank) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_bank[bank], ctx->d_bank[bank], (size_t)(4 + np) * sizeof(uint64_t),
+                               hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipEventRecord(ctx->bank_ev[bank], ctx->stream));
+        ctx->bank_count[bank] = N;
+        ctx->bank_np[bank] = np;
+        ++ctx->bank_pending;
+    }
     if (out_host) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -1974,19 +2020,26 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
 int pcl_step_fused_read(pcl_ctx *ctx, int n_planes, int64_t *out_host) {
     PCL_TRY(need_store_raw(ctx));
     if (n_planes < 0 || n_planes > PCL_MAX_PLANES || !out_host) return fail(PCL_ERR_ARG, "bad argument");
-    PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, (size_t)(4 + n_planes) * sizeof(uint64_t), hipMemcpyDeviceToHost,
-                           ctx->stream));
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->hits_on_host = true;
-    out_host[0] = ctx->count;
-    for (int k = 0; k < 3 + n_planes; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
-    out_host[4 + n_planes] = (int64_t)ctx->h_cnt[0];
+    if (ctx->bank_pending == 0) return fail(PCL_ERR_STATE, "no asynchronous fused step is waiting to be read");
+    const int b = ctx->bank_head;
+    if (ctx->bank_np[b] != n_planes) return fail(PCL_ERR_ARG, "n_planes differs from the step being read (%d)", ctx->bank_np[b]);
+    PCL_HIP(hipEventSynchronize(ctx->bank_ev[b])); // waits for THAT step only; later steps keep running
+    out_host[0] = ctx->bank_count[b];
+    for (int k = 0; k < 3 + n_planes; ++k) out_host[1 + k] = (int64_t)ctx->h_bank[b][1 + k];
+    out_host[4 + n_planes] = (int64_t)ctx->h_bank[b][0];
+    ctx->bank_head ^= 1;
+    --ctx->bank_pending;
     return PCL_OK;
 }
 
 int pcl_store_last_scatter_hits(pcl_ctx *ctx, int64_t *hits_out) {
     PCL_TRY(need_store_raw(ctx));
     if (!hits_out) return fail(PCL_ERR_ARG, "hits_out is NULL");
+    if (ctx->last_async_bank >= 0) { // the most recent step was an asynchronous fused one: its bank holds the hits
+        PCL_HIP(hipEventSynchronize(ctx->bank_ev[ctx->last_async_bank]));
+        *hits_out = (int64_t)ctx->h_bank[ctx->last_async_bank][0];
+        return PCL_OK;
+    }
     if (!ctx->hits_on_host) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));

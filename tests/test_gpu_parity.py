@@ -739,3 +739,30 @@ def test_fill_photons_from_planck_table_bit_exact(store, hip):
     s = d.download_state()
     assert np.array_equal(s["E"], orc.philox_table_energy(seed, np.arange(N) + base, cdf, grid))   # integer work: exact
     assert np.all(s["v"][0] == C_LIT) and not np.any(s["r"][0]) and np.array_equal(s["id"], np.arange(N) + base)
+
+
+def test_async_fused_steps_are_pipelined_and_read_in_order(store, hip):
+    """Two asynchronous fused steps may be in flight; pcl_step_fused_read returns them oldest first and the
+    values equal those of synchronous calls."""
+    N = 300_001
+    sc = lambda k: dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=8, step=k)
+    d = store(N)
+    d.fill_photons(N, 0, C_LIT, 1.0, 1.0, 8)
+    sync_rows = [d.step_fused(1e-3, sc(k), (), lazy=True) for k in range(5)]
+    d.fill_photons(N, 0, C_LIT, 1.0, 1.0, 8)
+    rows = []
+    assert d.step_fused(1e-3, sc(0), (), sync=False, lazy=True) is None
+    for k in range(1, 5):
+        d.step_fused(1e-3, sc(k), (), sync=False, lazy=True)      # step k enqueued ...
+        rows.append(d.step_fused_read(0))                           # ... while step k-1 is read
+    assert d.last_scatter_hits() == sync_rows[4]["hits"]            # most recent step, not yet read
+    rows.append(d.step_fused_read(0))
+    for a, b in zip(sync_rows, rows):
+        assert a["hits"] == b["hits"] and list(a["sign"]) == list(b["sign"]) and a["N"] == b["N"] == N
+    with pytest.raises(hip.HipError, match="no asynchronous"):
+        d.step_fused_read(0)
+    d.step_fused(1e-3, sc(5), (), sync=False, lazy=True)
+    d.step_fused(1e-3, sc(6), (), sync=False, lazy=True)
+    with pytest.raises(hip.HipError, match="outstanding"):
+        d.step_fused(1e-3, sc(7), (), sync=False, lazy=True)
+    d.step_fused_read(0), d.step_fused_read(0)
