@@ -186,7 +186,7 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
-            t = json.load(open(tfile)).get("%s:%s:%d" % (args.profile, args.mode, N))
+            t = json.load(open(tfile)).get("%s:%s%s:%d" % (args.profile, args.mode, "-f32" if args.dtype == "f32" else "", N))
             traffic = t.get(dominant + "_bytes_per_launch") if t else None
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
