@@ -178,15 +178,10 @@ int pcl_user_kernel_free(pcl_ctx *ctx, void *kernel);
 
 /* ---------------------------------------------------------------- Level 2: resident particle store */
 
-/* Allocate storage for up to ``capacity`` particles; count is set to 0.  pcl_store_alloc = fp64.
- * The 13 fields (plus 4 internal rows: the velocity double buffer and the wavelength-term cache) live in ONE
- * allocation, tiled:  element i of a field is at  row0 + (i / T) * tile_stride + (i % T)  elements, T =
- * tile_len = 2048 particles, tile_stride = 17 * T -- so the ~13 streams a step reads are interleaved at 16 KiB
- * (fp64) granularity inside one slab and every HBM channel sees the same mix, wherever the driver placed the
- * slab.  upload/download translate to and from dense host arrays; pcl_store_layout reports T and the stride
- * for callers that read the rows directly.  ids, kinds, the compaction double buffer and the random-input
- * arrays are dense and allocated on first use.  Host buffers passed to upload/download/upload_rand hold
- * elements of the store's dtype (double or float). */
+/* Allocate SoA storage for up to ``capacity`` particles (13 arrays; ids, kinds, the compaction
+ * double buffer and the random-input arrays are allocated on first use).  count is set to 0.
+ * pcl_store_alloc = fp64.  Host buffers passed to upload/download/upload_rand hold elements of the
+ * store's dtype (double or float). */
 int pcl_store_alloc(pcl_ctx *ctx, int64_t capacity);
 int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype);
 int pcl_store_dtype(pcl_ctx *ctx, int *dtype_out);
@@ -202,10 +197,8 @@ int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int6
 int pcl_store_download_ids(pcl_ctx *ctx, int64_t *host, int64_t offset, int64_t n);
 int pcl_store_upload_kind(pcl_ctx *ctx, const uint8_t *host, int64_t offset, int64_t n);
 int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t n);
-/* device pointer of element 0 of a field's CURRENT row (changes after a compaction and after a lazy fused
- * step); element i is at row0[(i / tile_len) * tile_stride + i % tile_len], see pcl_store_layout */
+/* device pointer of a field's CURRENT buffer (changes after a compaction) */
 int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out);
-int pcl_store_layout(pcl_ctx *ctx, int64_t *tile_len_out, int64_t *tile_stride_out);
 
 /* Random inputs for PCL_RNG_INPUT: which = 0 rtheta, 1 rphi, 2 rand; n values for particles
  * [0, n) in store order (entries of non-photon particles are ignored). */

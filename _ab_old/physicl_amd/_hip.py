@@ -84,7 +84,6 @@ _PROTOTYPES = {
     "pcl_store_upload_kind": [_vp, _vp, c_int64, c_int64],
     "pcl_store_download_kind": [_vp, _vp, c_int64, c_int64],
     "pcl_store_field_ptr": [_vp, c_int, POINTER(_vp)],
-    "pcl_store_layout": [_vp, POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_upload_rand": [_vp, c_int, _vp, c_int64],
     "pcl_store_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
     "pcl_store_fill_photons_table": [_vp, c_int64, c_int64, c_double, _vp, _vp, c_int, c_uint64],
@@ -363,12 +362,6 @@ class Device:
         p = c_void_p()
         check(self.lib.pcl_store_field_ptr(self.ctx, field, byref(p)))
         return p.value
-
-    def layout(self):
-        """(tile_len, tile_stride) in elements: element i of a row is at row0[(i // T) * stride + i % T]."""
-        t, ts = c_int64(), c_int64()
-        check(self.lib.pcl_store_layout(self.ctx, byref(t), byref(ts)))
-        return t.value, ts.value
 
     def upload_rand(self, which, host):
         a, hp = _host(host, self.np_dtype)

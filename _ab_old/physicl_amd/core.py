@@ -1,0 +1,729 @@
+"""Simulation runtime: the reference's plugin API (physicl/__init__.py:293-541) on top of a particle
+store that lives in HBM.
+
+Same public names and call signatures as the reference -- ``Step.run(sim)`` / ``terminate(sim)``,
+``UpdateTimeStep(fn)``, ``MeasureStep(out_fn)``, ``Object(**kw)``, ``Simulation(**kw)`` with
+``add_step / add_obj / add_objs / remove_obj / remove_step / start / join / get_state`` -- so
+scripts written for PhysiCL run unchanged.  What differs is where the particles are:
+
+* The reference keeps a Python list of objects and, every step, gathers attributes into numpy
+  arrays, copies them to the device, launches, copies back and writes attributes again
+  (physicl/__init__.py:602-664, physicl/light.py:325-331).
+* Here the particles are uploaded ONCE into structure-of-arrays device memory and every
+  device-native step (Newton, scatter, delete, the counting measure steps) is a kernel launch on
+  that memory.  ``sim.objects`` is a list-like proxy: ``len()`` is answered from the alive count,
+  anything else (indexing, iteration, a user-written Step that loops over objects) first brings
+  the state back into the Python objects, and the next device step re-uploads it.  User plugins
+  therefore keep working, at the reference's speed; all-native step lists run at HBM speed.
+
+There is no CPU implementation of the device-native steps: with ``cl_on=False`` no device context
+is created (as in the reference) and running such a step raises.
+"""
+import copy
+import threading
+import time
+
+import numpy as np
+
+from .units import Measurement
+
+HOST, DEVICE, BOTH = "host", "device", "both"   # where the authoritative particle state is
+
+
+class Step:
+    """Base class of every plugin (physicl/__init__.py:293-322)."""
+    _device_native = False      # True: implements _device_run(sim) on the resident store
+    _touches_objects = True     # False: only reads/writes scalars of the simulation (t, dt)
+    _reads_only = False         # True: host step that never modifies objects (no re-upload needed)
+
+    def __init__(self):
+        pass
+
+    def __compile_cl__(self, sim):
+        pass
+
+    def run(self, sim):
+        pass
+
+    def terminate(self, sim):
+        pass
+
+
+class DeviceStep(Step):
+    """A step implemented as HIP kernels on the resident particle store (``_device_run``).  Called
+    directly (``step.run(sim)``) it uploads the objects if need be and launches; inside
+    ``Simulation.run`` the loop may fuse it with its neighbours."""
+    _device_native = True
+
+    def _device_run(self, sim):
+        raise NotImplementedError
+
+    def run(self, sim):
+        sim._need_device(type(self).__name__)
+        with sim._dev_lock:
+            sim._to_device()
+            self._device_run(sim)
+
+
+class UpdateTimeStep(Step):
+    """``dt = fn(sim); t += dt; ts.append(t)`` (physicl/__init__.py:324-343)."""
+    _touches_objects = False
+
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def run(self, sim):
+        sim.dt = self.fn(sim)
+        sim.t += sim.dt
+        sim.ts.append(copy.deepcopy(sim.t))
+
+
+class MeasureStep(Step):
+    """Collects one row per step in ``self.data``; optional CSV at terminate
+    (physicl/__init__.py:345-378)."""
+
+    def __init__(self, out_fn=None):
+        self.out_fn = out_fn
+        self.data = []
+
+    def terminate(self, sim):
+        if self.out_fn is None:
+            return
+        rows = self.data.values() if isinstance(self.data, dict) else self.data
+        with open(self.out_fn, "w") as f:
+            for row in rows:
+                f.write(", ".join(str(i) for i in list(row)) + "\n")
+
+
+class Object:
+    """Generic particle: r, dr, dv, v, a (3-vectors) + any keyword attributes
+    (physicl/__init__.py:381-396)."""
+
+    def __init__(self, **kwargs):
+        self.r = Measurement([0] * 3, "m**1")
+        self.dr = Measurement([0] * 3, "m**1")
+        self.dv = Measurement([0] * 3, "m**1 s**-2")
+        self.v = Measurement([0] * 3, "m**1 s**-1")
+        self.a = Measurement([0] * 3, "m**1 s**-2")
+        for attr, val in kwargs.items():
+            setattr(self, attr, val)
+
+
+class PhotonBatch:
+    """``n`` photons described, not instantiated: r = 0, v = (c,0,0), E = min + (max-min) * U**(1/3)
+    -- what ``light.generate_photons(n, min=, max=)`` makes one Python object at a time
+    (physicl/light.py:112-128).  ``Simulation.add_objs(batch)`` creates them directly in device
+    memory (1e8 photons take milliseconds instead of hours and ~100 GB of Python objects)."""
+
+    def __init__(self, n, e_min, e_max, seed=0, table=None):
+        self.n, self.e_min, self.e_max, self.seed = int(n), float(np.asarray(e_min)), float(np.asarray(e_max)), int(seed)
+        self.table = table        # (cdf, grid): tabulated energy distribution instead of the power law
+
+    def __len__(self):
+        return self.n
+
+
+class ObjectList:
+    """``sim.objects``: behaves like the reference's plain list (physicl/__init__.py:421)."""
+
+    def __init__(self, sim, items=()):
+        self._sim = sim
+        self._items = list(items)
+
+    # cheap: never moves data
+    def __len__(self):
+        return self._sim._object_count()
+
+    def __bool__(self):
+        return len(self) > 0
+
+    # everything else needs real Python objects
+    def _host(self, mutate):
+        self._sim._to_host(mutate and not self._sim._readonly_scope)
+        return self._items
+
+    def __iter__(self):
+        return iter(self._host(True))          # callers may modify the objects they iterate over
+
+    def __getitem__(self, i):
+        return self._host(True)[i]
+
+    def __contains__(self, o):
+        return o in self._host(False)
+
+    def index(self, o):
+        return self._host(False).index(o)
+
+    def __setitem__(self, i, o):
+        self._host(True)[i] = o
+
+    def __delitem__(self, i):
+        del self._host(True)[i]
+
+    def append(self, o):
+        self._host(True).append(o)
+
+    def extend(self, it):
+        self._host(True).extend(it)
+
+    def insert(self, i, o):
+        self._host(True).insert(i, o)
+
+    def remove(self, o):
+        self._host(True).remove(o)
+
+    def pop(self, i=-1):
+        return self._host(True).pop(i)
+
+    def clear(self):
+        self._host(True).clear()
+
+    def __eq__(self, other):
+        return list(self._host(False)) == list(other)
+
+    def __repr__(self):
+        if self._sim._residency == DEVICE:
+            return "<ObjectList: %d particles resident on the HIP device>" % len(self)
+        return repr(self._items)
+
+
+class Simulation(threading.Thread):
+    """Runs the steps, in the order they were added, until ``exit(sim)`` is true
+    (physicl/__init__.py:400-541).
+
+    Extra keyword attributes understood by this build (all optional):
+      device   HIP device index (default 0, or LOCAL_RANK when ``comm`` is given)
+      rng      "numpy": the light steps draw their randoms from ``np.random`` on the host, in the
+               reference's order (3 per photon per step: rtheta, rphi, rand; 1 for delete), so a
+               seeded run reproduces the reference's OpenCL path;  "philox": drawn in-kernel,
+               keyed by (seed, launch number, photon id) -- the fast mode.  Default "numpy",
+               "philox" for simulations created from a PhotonBatch.
+      seed     Philox seed
+      fuse     True (default): consecutive Newton / ScatterIsotropic / counting-measure steps run
+               as ONE kernel (bit-identical results)
+      comm     a physicl_amd.dist.CounterComm: this process owns one index shard of the particles;
+               counters (alive, hits, measure rows) are all-reduced
+    """
+
+    def __init__(self, *args, **kwargs):
+        threading.Thread.__init__(self)
+        # older scripts: Simulation({"cl_on": ...}) or Simulation(params={...})  (examples/trace_ex.py:7, runtime1.py:21)
+        if args and isinstance(args[0], dict):
+            kwargs = dict(args[0], **kwargs)
+        if isinstance(kwargs.get("params"), dict):
+            kwargs = dict(kwargs.pop("params"), **kwargs)
+        self.bounds = np.zeros(3)
+        self.cl_on = True
+        self.exit = lambda x: len(x.objects) == 0
+        self.state_fn = lambda x: {"objects": len(x.objects), "t": x.t, "dt": x.dt,
+                                   "run_time": time.time() - x.start_time}
+        self.state_need_lock = False
+        self.device = None
+        self.rng = None
+        self.seed = 0
+        self.fuse = True
+        self.comm = None
+        for attr, val in kwargs.items():
+            setattr(self, attr, val)
+        self.dt = Measurement(np.double(0), "s**1")
+        self.t = Measurement(np.double(0), "s**1")
+        self._objects = ObjectList(self)
+        self.steps = {}
+        self._state_lock = threading.Lock()
+        self.running = False
+        self.start_time = 0
+        self.error = None
+        # device-side state
+        self._dev = None
+        self._residency = HOST
+        self._batch = None            # PhotonBatch not yet / already created on the device
+        self._alive = 0               # host mirror of the (global) alive count while DEVICE-resident
+        self._scattered = False       # a device scatter step has replaced velocities since the upload
+        self._launch = 0              # Philox "step" word: one per light-step launch
+        self._plan_key, self._plan = None, None
+        self._readonly_scope = False  # inside a host step that promises not to modify objects
+        self._dev_lock = threading.RLock()   # one device call in flight per context (include/physicl_hip.h)
+        self._uploaded, self._upload_lo = [], 0
+        self._all_photons = True
+        self.hits = 0                 # photons scattered by the most recent ScatterIsotropicStep
+        if self.cl_on:
+            from . import _hip
+            self._hip = _hip
+            dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
+            self._dev = _hip.Device(dev_index)     # raises if there is no GPU / no library: no fallback
+        self.cl_ctx = self._dev                     # reference attribute names (physicl/__init__.py:428-429)
+        self.cl_q = self._dev
+
+    # ------------------------------------------------------------------ objects
+    @property
+    def objects(self):
+        return self._objects
+
+    @objects.setter
+    def objects(self, value):
+        self._to_host(True)
+        self._objects = ObjectList(self, value)
+
+    def _object_count(self):
+        if self._residency == DEVICE or self._residency == BOTH:
+            return self._alive
+        if self._batch is not None:
+            return self._batch.n
+        return len(self._objects._items)
+
+    def add_obj(self, obj):
+        if isinstance(obj, PhotonBatch):
+            return self.add_objs(obj)
+        if self._batch is not None:
+            raise NotImplementedError("cannot mix explicit objects with a PhotonBatch")
+        self._objects.append(obj)
+
+    def add_objs(self, objs):
+        if isinstance(objs, PhotonBatch):
+            if self._batch is not None or self._objects._items:
+                raise NotImplementedError("a PhotonBatch must be the simulation's only source of particles")
+            self._batch = objs
+            if self.rng is None:
+                self.rng = "philox"
+            return
+        if self._batch is not None:
+            raise NotImplementedError("cannot mix explicit objects with a PhotonBatch")
+        self._objects.extend(objs)
+
+    def remove_obj(self, obj):
+        self._objects.remove(obj)
+
+    # ------------------------------------------------------------------ steps
+    def add_step(self, idx, step):
+        if idx in self.steps:
+            raise IndexError("Cannot add a step to an existing index.")
+        self.steps[idx] = step
+
+    def remove_step(self, idx):
+        if self.running:
+            raise RuntimeError("Cannot remove a Step while the simulation is running.")
+        self.steps.pop(idx)
+
+    # ------------------------------------------------------------------ device residency
+    def _need_device(self, what):
+        if self._dev is None:
+            raise RuntimeError("%s runs on the HIP device only and this Simulation was created with cl_on=False "
+                               "(this build has no CPU implementation of the hot path)" % what)
+        return self._dev
+
+    def _shard(self, n_global):
+        return self.comm.shard(n_global) if self.comm is not None else (0, n_global)
+
+    def _to_device(self):
+        """Make the device store authoritative (upload if the Python objects are)."""
+        with self._dev_lock:
+            self._to_device_locked()
+
+    def _to_device_locked(self):
+        if self._residency in (DEVICE, BOTH):
+            self._residency = DEVICE
+            return
+        dev = self._need_device("this step")
+        if self._batch is not None:
+            b = self._batch
+            lo, hi = self._shard(b.n)
+            if dev.capacity < hi - lo or dev.capacity == 0:
+                dev.store_alloc(max(hi - lo, 1))
+            from .light import c as _c
+            if b.table is not None:
+                dev.fill_photons_table(hi - lo, lo, float(np.asarray(_c)), b.table[0], b.table[1], b.seed)
+            else:
+                dev.fill_photons(hi - lo, lo, float(np.asarray(_c)), b.e_min, b.e_max, b.seed)
+            self._all_photons = True
+            self._alive = b.n
+            self._residency = DEVICE
+            return
+        items = self._objects._items
+        lo, hi = self._shard(len(items))
+        mine = items[lo:hi]
+        n = len(mine)
+        if dev.capacity < max(n, 1):
+            dev.store_alloc(max(n, 1))
+        from .light import PhotonObject
+        cols = {g: np.empty((n, 3)) for g in ("r", "v", "dr", "dv")}
+        E = np.ones(n)
+        kind = np.zeros(n, dtype=np.uint8)
+        for k, o in enumerate(mine):
+            for g in cols:
+                cols[g][k] = np.asarray(getattr(o, g), dtype=np.float64).reshape(3)
+            if type(o) is PhotonObject:          # exact type, as the reference's ``type(obj) != PhotonObject``
+                kind[k] = 1
+                E[k] = float(np.asarray(o.E))
+        state = dict(cols, E=E, id_base=lo)
+        self._all_photons = bool(kind.all())
+        if not self._all_photons:
+            state["kind"] = kind
+        dev.upload_state(state)
+        self._uploaded = mine                     # shells, index == device id - lo
+        self._upload_lo = lo
+        self._alive = len(items)
+        self._scattered = False
+        self._residency = DEVICE
+
+    def _to_host(self, mutate=True):
+        """Bring the state back into Python objects.  mutate=False keeps the device copy valid."""
+        with self._dev_lock:
+            self._to_host_locked(mutate)
+
+    def _to_host_locked(self, mutate):
+        if self._residency == HOST:
+            return
+        if self.comm is not None and self.comm.world > 1:
+            raise NotImplementedError("per-object access to a sharded simulation: use the counters / "
+                                      "Simulation.download() on each rank, or run on a single GPU")
+        if self._residency == BOTH:
+            if mutate:
+                self._residency = HOST
+            return
+        dev = self._dev
+        if self._batch is not None:
+            self._materialise_batch()
+        s = dev.download_state()
+        ids = s["id"] - self._upload_lo
+        shells = self._uploaded
+        keep = [shells[i] for i in ids]
+        r, v, dr, dv = (np.stack(s[g], 1) if len(ids) else np.zeros((0, 3)) for g in ("r", "v", "dr", "dv"))
+        for k, o in enumerate(keep):
+            o.r = Measurement._from_code(r[k], like=o.r, units="m**1")
+            o.dr = Measurement._from_code(dr[k], units="m**1")
+            if self._scattered:
+                o.v = np.array(v[k], dtype=np.double)         # the reference leaves a plain ndarray (light.py:328)
+                o.dv = np.array(dv[k], dtype=np.double)
+            else:
+                o.v = Measurement._from_code(v[k], like=o.v, units="m**1 s**-1") if isinstance(o.v, Measurement) \
+                    else np.array(v[k], dtype=np.double)
+        self._objects._items[:] = keep
+        self._uploaded = keep
+        self._upload_lo = 0
+        if len(keep):
+            dev.upload_ids(np.arange(len(keep), dtype=np.int64))     # ids == positions in the shell list again
+        self._residency = HOST if mutate else BOTH
+
+    def _materialise_batch(self):
+        """Turn a device-created PhotonBatch into real PhotonObjects (only sensible for small n)."""
+        n = self._dev.count
+        if n > 5_000_000:
+            raise MemoryError("refusing to create %d Python PhotonObjects; use the counters / download arrays" % n)
+        from .light import PhotonObject, c as _c
+        cval = np.asarray(_c)
+        ids = self._dev.download_ids()
+        E = self._dev.download(self._hip.E)
+        self._uploaded = {}
+        shells = [PhotonObject.__new__(PhotonObject) for _ in range(n)]
+        for o, e, i in zip(shells, E, ids):
+            Object.__init__(o, E=np.double(e), v=Measurement._from_code([cval, 0, 0], units="m**1 s**-1"), uid=int(i))
+        self._uploaded = shells
+        self._upload_lo = 0
+        self._dev.upload_ids(np.arange(n, dtype=np.int64))
+        self._batch = None
+
+    # ------------------------------------------------------------------ helpers for the device-native steps
+    def _dt_code(self):
+        return float(np.asarray(self.dt))
+
+    def _next_launch(self):
+        self._launch += 1
+        return self._launch
+
+    def _host_randoms(self, which):
+        """Upload this step's host-drawn randoms (rng == 'numpy').  Reference order: per photon
+        rtheta, rphi, rand (physicl/light.py:285, physicl/__init__.py:606-619); delete draws one."""
+        dev = self._dev
+        n = dev.count
+        if self._all_photons:                      # the common case: no kind array to consult
+            ph, m = slice(None), n
+        else:
+            ph = dev.download_kind(n) != 0 if n else np.zeros(0, bool)
+            m = int(ph.sum())
+        if which == "iso":
+            u = np.random.random((m, 3))
+            full = np.zeros((n, 3))
+            full[ph, 0] = u[:, 0] * 2 * np.pi
+            full[ph, 1] = u[:, 1] * np.pi
+            full[ph, 2] = u[:, 2]
+            for w in range(3):
+                dev.upload_rand(w, np.ascontiguousarray(full[:, w]))
+        else:
+            full = np.zeros(n)
+            full[ph] = np.random.random(m)
+            dev.upload_rand(2, full)
+
+    def _rng_mode(self):
+        return self._hip.RNG_PHILOX if (self.rng or "numpy") == "philox" else self._hip.RNG_INPUT
+
+    def _global(self, values):
+        return self.comm.allreduce_sum(values) if self.comm is not None else np.asarray(values, dtype=np.int64)
+
+    # ------------------------------------------------------------------ the loop
+    def _build_plan(self):
+        """Group consecutive fusable device-native steps:
+        [Newton][ScatterIsotropic | ScatterDelete]?[counting measures]*  -> one kernel (pipeline) per pass."""
+        steps = list(self.steps.values())
+        plan, i = [], 0
+        while i < len(steps):
+            s = steps[i]
+            if self.fuse and self._dev is not None and getattr(s, "_fuse_role", None) == "newton":
+                group, j = [s], i + 1
+                if j < len(steps) and getattr(steps[j], "_fuse_role", None) in ("scatter_iso", "scatter_delete"):
+                    group.append(steps[j])
+                    j += 1
+                n_planes = 0
+                while j < len(steps) and getattr(steps[j], "_fuse_role", None) == "measure" and \
+                        n_planes + steps[j]._n_planes() <= 12:
+                    n_planes += steps[j]._n_planes()
+                    group.append(steps[j])
+                    j += 1
+                if len(group) > 1:
+                    plan.append(("fused", group))
+                    i = j
+                    continue
+            plan.append(("single", s))
+            i += 1
+        return plan
+
+    def _run_pass(self):
+        with self._dev_lock:
+            self._run_pass_locked()
+
+    def _run_pass_locked(self):
+        key = tuple(id(s) for s in self.steps.values()) + (self.fuse,)
+        if key != self._plan_key:
+            self._plan_key, self._plan = key, self._build_plan()
+        for kind, item in self._plan:
+            if kind == "fused":
+                self._run_fused(item)
+            elif item._device_native:
+                self._to_device()
+                item._device_run(self)
+            else:
+                # host plugin: sim.objects brings the state back into the Python objects on first touch
+                self._readonly_scope = bool(item._reads_only)
+                try:
+                    item.run(self)
+                finally:
+                    self._readonly_scope = False
+
+    def _run_fused(self, group):
+        self._to_device()
+        dev, hip = self._dev, self._hip
+        scatter = next((s for s in group if s._fuse_role == "scatter_iso"), None)
+        delete = next((s for s in group if s._fuse_role == "scatter_delete"), None)
+        measures = [s for s in group if s._fuse_role == "measure"]
+        planes = [p for m in measures for p in m._plane_rows()]
+        if delete is not None:
+            mode = self._rng_mode()
+            if mode == hip.RNG_INPUT:
+                self._host_randoms("delete")
+            A_k, n_k = delete._kernel_consts()
+            out = dev.step_fused_delete(self._dt_code(), A_k, n_k, mode, self.seed, self._next_launch(),
+                                        planes if measures else None, lazy=True)
+            g = self._global(np.concatenate([[out["N"], out["removed"]], out["sign"], out["planes"]]))
+            self._alive, delete.removed = int(g[0]), int(g[1])
+            k = 5
+            for m in measures:
+                npl = m._n_planes()
+                m._record(self, int(g[0]), g[2:5], g[k:k + npl])
+                k += npl
+            return
+        sc = None
+        if scatter is not None:
+            sc = scatter._kernel_params(self)
+            sc.update(rng_mode=self._rng_mode(), seed=self.seed, step=self._next_launch())
+            if sc["rng_mode"] == hip.RNG_INPUT:
+                self._host_randoms("iso")
+            self._scattered = True
+        # dr/dv stay implicit unless something after this pass looks at them (the store materialises on demand)
+        out = dev.step_fused(self._dt_code(), sc, planes if (measures or scatter) else None, sync=True, lazy=True)
+        if out is not None:
+            if scatter is not None:
+                self.hits = int(self._global([out["hits"]])[0])
+            glob = self._global(np.concatenate([[out["N"]], out["sign"], out["planes"]]))
+            k = 4
+            for m in measures:
+                npl = m._n_planes()
+                m._record(self, int(glob[0]), glob[1:4], glob[k:k + npl])
+                k += npl
+
+    def run(self):
+        self.start_time = time.time()
+        self.t = 0
+        self.dt = 0
+        self.ts = []
+        self.running = True
+        try:
+            while not self.exit(self):
+                with self._state_lock:
+                    self._run_pass()
+            with self._state_lock:
+                for step in self.steps.values():
+                    step.terminate(self)
+                self.run_time = time.time() - self.start_time
+        except BaseException as e:          # a dead simulation thread must not look like a running one
+            self.error = e
+            raise
+        finally:
+            self.running = False
+
+    def get_state(self):
+        if self.state_need_lock:
+            with self._state_lock:
+                return self.state_fn(self)
+        return self.state_fn(self)
+
+    # ------------------------------------------------------------------ device introspection
+    @staticmethod
+    def get_device_info():
+        """{device name: properties} for every visible HIP device (the reference dumps OpenCL
+        platform/device info here, physicl/__init__.py:470-499)."""
+        from . import _hip
+        out = {}
+        for i in range(_hip.device_count()):
+            with _hip.Device(i) as d:
+                info = d.info()
+                out["%d: %s" % (i, info["name"])] = info
+        return out
+
+    @staticmethod
+    def set_dev(id):
+        """The reference's stub (physicl/__init__.py:526-529); pass ``device=`` to Simulation instead."""
+
+    def download(self, field):
+        """(n, 3) or (n,) array of a state field ('r','v','dr','dv','E','id') straight from the device --
+        the way to look at 1e8 photons without creating Python objects."""
+        self._to_device()
+        d = self._dev
+        if field == "E":
+            return d.download(self._hip.E)
+        if field == "id":
+            return d.download_ids()
+        return np.stack([d.download(f) for f in self._hip.FIELD_GROUPS[field]], 1)
+
+    def close(self):
+        """Free the device store and context (also happens at garbage collection)."""
+        if self._dev is not None:
+            if self._residency == DEVICE and self._batch is None:
+                self._to_host(True)
+            self._dev.close()
+            self._dev = None
+
+
+# ----------------------------------------------------------------------------------------------
+# kernel-glue classes of the reference (physicl/__init__.py:543-664), kept for source compatibility
+# ----------------------------------------------------------------------------------------------
+class CLInput:
+    types = ["obj", "obj_def", "obj_action", "const", "other"]
+
+    def __init__(self, **kw):
+        self.name, self.type = kw["name"], kw["type"]
+        self.ctype = kw.get("ctype", "double")
+        self.obj_attr, self.obj_def, self.obj_track = kw.get("obj_attr"), kw.get("obj_def"), kw.get("obj_track")
+        self.code = kw.get("code")
+        self.const_value = kw.get("const_value")
+
+
+class CLOutput:
+    def __init__(self, **kw):
+        self.name = kw["name"]
+        self.ctype = kw.get("ctype", "double")
+
+
+class CLProgram:
+    """User-defined kernels with the reference's glue API (physicl/__init__.py:567-664): describe the
+    inputs with ``CLInput`` (per-object attributes, per-object expressions, constants, tracked objects),
+    the outputs with ``CLOutput``, give the kernel BODY in the OpenCL-C dialect of the reference's kernels;
+    ``build_kernel()`` compiles it (hipRTC instead of an OpenCL driver) and ``run()`` gathers the inputs
+    from ``sim.objects``, launches one work-item per gathered object and returns ``{output name: ndarray}``.
+
+    This is the reference's slow path by design (a Python gather per call); the steps shipped with this
+    build do not use it.  Same contract as the reference: every array input is marshalled as float64
+    whatever its ``ctype`` (physicl/__init__.py:613); ``int`` outputs are 32-bit; the global size is the
+    length of the first ``"obj"`` input; ``obj_track`` lists (e.g. ``pht``) are left on the program
+    object for the caller.
+    """
+
+    def __init__(self, sim, name, kernel_code):
+        self.sim, self.prog_name, self.kernel_code = sim, name, kernel_code
+        self.prep_metadata, self.output_metadata, self.variables, self.prog = [], [], {}, None
+
+    def _signature(self):
+        params = []
+        for item in self.prep_metadata:
+            if item.type in ("obj", "obj_def"):
+                params.append((item.ctype, item.name, True))
+            elif item.type == "const":
+                params.append((item.ctype, item.name, False))
+        params.extend((o.ctype, o.name, True) for o in self.output_metadata)
+        return params
+
+    def build_kernel(self):
+        dev = self.sim._need_device("CLProgram")
+        self.prog = dev.user_kernel(self.prog_name, self._signature(), self.kernel_code)
+
+    def _gather(self):
+        """One pass over sim.objects.  The per-object statements run in metadata order inside a single
+        ``for obj in ...`` loop (an ``obj_action`` may ``continue`` to skip an object), exactly the execution
+        model scripts written against the reference rely on."""
+        lists = [it.name for it in self.prep_metadata if it.type in ("obj", "obj_def", "obj_track")]
+        body = []
+        for it in self.prep_metadata:
+            if it.type == "obj":
+                body.append("%s.append(obj.%s)" % (it.name, it.obj_attr))
+            elif it.type == "obj_def":
+                body.append("%s.append(%s)" % (it.name, it.obj_def))
+            elif it.type == "obj_track":
+                body.append("%s.append(%s)" % (it.name, it.obj_track))
+            elif it.type == "obj_action":
+                body.append(it.code)
+        src = "for obj in _objects:\n\t" + "\n\t".join(body) if body else ""
+        import types
+        from . import light, newton
+        ns = {"np": np, "self": self, "_objects": list(self.sim.objects),
+              "physicl": types.SimpleNamespace(light=light, newton=newton, **{k: globals()[k] for k in (
+                  "Measurement", "Object", "Step", "Simulation")})}
+        ns["phys"] = ns["physicl"]
+        for nm in lists:
+            ns[nm] = []
+        exec(src, ns)                          # noqa: S102 -- user-supplied gather code, as in the reference
+        return {nm: ns[nm] for nm in lists}
+
+    def run(self):
+        if self.prog is None:
+            self.build_kernel()
+        dev = self.sim._dev
+        with self.sim._dev_lock:
+            got = self._gather()
+            for it in self.prep_metadata:
+                if it.type == "obj_track":
+                    setattr(self, it.name, got[it.name])
+            n, args, temps = None, [], []
+            for it in self.prep_metadata:
+                if it.type in ("obj", "obj_def"):
+                    arr = np.array(got[it.name], dtype=np.double)
+                    setattr(self, it.name + "_np", arr)
+                    if n is None and it.type == "obj":
+                        n = arr.shape[0]
+                    d = dev.array(arr)
+                    temps.append(d)
+                    args.append(d)
+                elif it.type == "const":
+                    args.append(float(np.double(it.const_value)))
+            if n is None:
+                raise ValueError("CLProgram needs at least one input of type 'obj' to define the global size")
+            outs = []
+            for o in self.output_metadata:
+                d = dev.empty(max(n, 1), {"int": np.int32, "double": np.float64, "float": np.float32}[o.ctype])
+                temps.append(d)
+                outs.append(d)
+                args.append(d)
+            try:
+                self.prog(n, *args)
+                return {o.name: d.get()[:n] for o, d in zip(self.output_metadata, outs)}
+            finally:
+                for d in temps:
+                    d.free()

@@ -144,23 +144,6 @@ template <> struct pcl_vec<float, 4> {
 };
 
 // ------------------------------------------------------------------------------------------------
-// Tiled store layout ("AoSoA"): a tile holds PCL_T consecutive particles; inside a tile every field is one
-// contiguous row of PCL_T elements and the rows lie back to back: [tile][field][PCL_T].  A Level-2 kernel
-// gets, per field, the address of that field's row in tile 0 plus ``ts`` = elements from one tile to the
-// next.  Lanes still read consecutive elements (full coalescing) but the 13+ streams of a pass now fall into
-// one contiguous ~100-270 KiB region per tile, so how the driver scatters large allocations over HBM
-// channels no longer decides the speed (tools/bw_probe2.hip).
-// ------------------------------------------------------------------------------------------------
-#define PCL_TLOG 11
-#define PCL_T (1 << PCL_TLOG)
-__device__ __forceinline__ pcl_i64 pcl_tix(pcl_i64 i, pcl_i64 ts) { return (i >> PCL_TLOG) * ts + (i & (PCL_T - 1)); }
-template <int VEC>
-__device__ __forceinline__ pcl_i64 pcl_tq(pcl_i64 q, pcl_i64 ts) { // q counts VEC-wide groups of elements
-    constexpr int LG = PCL_TLOG - (VEC == 4 ? 2 : (VEC == 2 ? 1 : 0));
-    return (q >> LG) * (ts / VEC) + (q & ((1 << LG) - 1));
-}
-
-// ------------------------------------------------------------------------------------------------
 // reference kernel maths
 // ------------------------------------------------------------------------------------------------
 // sqrt(pow(d0,2) + pow(d1,2) + pow(d2,2))            physicl/light.py:149, 241, 305
@@ -290,7 +273,6 @@ struct pcl_scatter_args {
     pcl_u64 *hits;             // one counter, += photons scattered
     pcl_i64 id_base;
     pcl_i64 N;
-    pcl_i64 ts;                // tile stride of the store (elements)
     T A, n, c, h;
     pcl_u64 seed;
     pcl_u32 step;
@@ -315,16 +297,14 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
             pcoll[j] = (T)0;
             if (i < a.N) {
                 photon[j] = a.kind ? (a.kind[i] != 0) : true;
-                const pcl_i64 ti = pcl_tix(i, a.ts);
-                pcoll[j] = pcl_pcoll<T, USE_E, VAR_N>(a.A, a.n, a.h, a.c, a.d0[ti], a.d1[ti], a.d2[ti], a.r0[ti],
-                                                      a.r1[ti], a.r2[ti], a.E[ti]);
+                pcoll[j] = pcl_pcoll<T, USE_E, VAR_N>(a.A, a.n, a.h, a.c, a.d0[i], a.d1[i], a.d2[i], a.r0[i], a.r1[i],
+                                                      a.r2[i], a.E[i]);
             }
         }
 #pragma unroll
         for (int j = 0; j < PCL_SCATTER_ROWS; ++j) {
             const pcl_i64 i = base + (pcl_i64)j * blockDim.x + threadIdx.x;
             if (i >= a.N || !photon[j]) continue;
-            const pcl_i64 ti = pcl_tix(i, a.ts);
             T rand, rtheta = (T)0, rphi = (T)0;
             pcl_u32 c0 = 0, c1 = 0;
             if (a.rng_mode == PCL_RNG_PHX) {
@@ -348,18 +328,18 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
                 }
                 T n0, n1, n2;
                 pcl_new_velocity<T>(a.c, rtheta, rphi, n0, n1, n2);
-                const T o0 = a.v0[ti], o1 = a.v1[ti], o2 = a.v2[ti];
-                a.v0[ti] = n0;
-                a.v1[ti] = n1;
-                a.v2[ti] = n2;
-                a.dv0[ti] = R::sub(n0, o0);
-                a.dv1[ti] = R::sub(n1, o1);
-                a.dv2[ti] = R::sub(n2, o2);
+                const T o0 = a.v0[i], o1 = a.v1[i], o2 = a.v2[i];
+                a.v0[i] = n0;
+                a.v1[i] = n1;
+                a.v2[i] = n2;
+                a.dv0[i] = R::sub(n0, o0);
+                a.dv1[i] = R::sub(n1, o1);
+                a.dv2[i] = R::sub(n2, o2);
                 ++my_hits;
             } else {
-                a.dv0[ti] = (T)0;
-                a.dv1[ti] = (T)0;
-                a.dv2[ti] = (T)0;
+                a.dv0[i] = (T)0;
+                a.dv1[i] = (T)0;
+                a.dv2[i] = (T)0;
             }
         }
     }
@@ -393,7 +373,6 @@ struct pcl_fused_args {
     pcl_u64 *cnt;                // [0] hits, [1..3] sign counts, [4..] plane crossings
     pcl_i64 id_base;
     pcl_i64 N;
-    pcl_i64 ts;                  // tile stride of the store (elements)
     T dt, A, n, c, h;
     pcl_u64 seed;
     pcl_u32 step;
@@ -428,8 +407,7 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
-        const pcl_i64 qq = pcl_tq<VEC>(live_q ? q : 0, a.ts); // idle lanes re-read group 0 and store nothing
-        const pcl_i64 qs = pcl_tq<VEC>(q, a.ts);               // where this lane's group lives
+        const pcl_i64 qq = live_q ? q : 0; // idle lanes re-read group 0 and store nothing
         T Rr[3][VEC], V[3][VEC], D[3][VEC], DV[3][VEC], Ev[VEC];
         VV::ld(a.r0, qq, Rr[0]);
         VV::ld(a.r1, qq, Rr[1]);
@@ -450,13 +428,13 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
             }
         if (live_q) {
             if (!a.lazy) {
-                VV::st(a.dr0, qs, D[0]);
-                VV::st(a.dr1, qs, D[1]);
-                VV::st(a.dr2, qs, D[2]);
+                VV::st(a.dr0, q, D[0]);
+                VV::st(a.dr1, q, D[1]);
+                VV::st(a.dr2, q, D[2]);
             }
-            VV::st(a.r0, qs, Rr[0]);
-            VV::st(a.r1, qs, Rr[1]);
-            VV::st(a.r2, qs, Rr[2]);
+            VV::st(a.r0, q, Rr[0]);
+            VV::st(a.r1, q, Rr[1]);
+            VV::st(a.r2, q, Rr[2]);
         }
         bool live[VEC];
 #pragma unroll
@@ -514,36 +492,36 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
                 // v double buffer: every particle's (possibly new) velocity goes to the other buffer, whole
                 // 16-byte stores; dr and dv are not written -- they stay derivable from (v_in, v_out, dt)
                 if (live_q) {
-                    VV::st(a.vo0, qs, V[0]);
-                    VV::st(a.vo1, qs, V[1]);
-                    VV::st(a.vo2, qs, V[2]);
+                    VV::st(a.vo0, q, V[0]);
+                    VV::st(a.vo1, q, V[1]);
+                    VV::st(a.vo2, q, V[2]);
                 }
             } else {
                 // photons always get dv written; plain Objects keep theirs (light.py:283 skips them)
                 if (all_photon) {
-                    VV::st(a.dv0, qs, DV[0]);
-                    VV::st(a.dv1, qs, DV[1]);
-                    VV::st(a.dv2, qs, DV[2]);
+                    VV::st(a.dv0, q, DV[0]);
+                    VV::st(a.dv1, q, DV[1]);
+                    VV::st(a.dv2, q, DV[2]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
                         if (photon[e]) {
-                            a.dv0[qs * VEC + e] = DV[0][e];
-                            a.dv1[qs * VEC + e] = DV[1][e];
-                            a.dv2[qs * VEC + e] = DV[2][e];
+                            a.dv0[q * VEC + e] = DV[0][e];
+                            a.dv1[q * VEC + e] = DV[1][e];
+                            a.dv2[q * VEC + e] = DV[2][e];
                         }
                 }
                 if (all_hit) {
-                    VV::st(a.vo0, qs, V[0]);
-                    VV::st(a.vo1, qs, V[1]);
-                    VV::st(a.vo2, qs, V[2]);
+                    VV::st(a.vo0, q, V[0]);
+                    VV::st(a.vo1, q, V[1]);
+                    VV::st(a.vo2, q, V[2]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
                         if (hit[e]) {
-                            a.vo0[qs * VEC + e] = V[0][e];
-                            a.vo1[qs * VEC + e] = V[1][e];
-                            a.vo2[qs * VEC + e] = V[2][e];
+                            a.vo0[q * VEC + e] = V[0][e];
+                            a.vo1[q * VEC + e] = V[1][e];
+                            a.vo2[q * VEC + e] = V[2][e];
                         }
                 }
             }
@@ -601,7 +579,6 @@ struct pcl_fast_args {
     const T *E;               // only dereferenced if the expression names E[gid]
     pcl_u64 *cnt;             // [0] hits, [1..3] sign counts
     pcl_i64 id_base, N;
-    pcl_i64 ts;               // tile stride of the store (elements)
     T dt, A, n, c;
     pcl_u64 seed;
     pcl_u32 step;
@@ -638,13 +615,13 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
     pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x;
     // register double buffer: the next trip's loads are in flight while this trip computes
     pcl_fast_tile<T, VEC> cur;
-    if (base < nq) pcl_fast_load<T, USE_E, VEC>(a, pcl_tq<VEC>(base + threadIdx.x < nq ? base + threadIdx.x : 0, a.ts), cur);
+    if (base < nq) pcl_fast_load<T, USE_E, VEC>(a, base + threadIdx.x < nq ? base + threadIdx.x : 0, cur);
     for (; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
         pcl_fast_tile<T, VEC> nxt;
         const pcl_i64 nb = base + stride;
-        if (nb < nq) pcl_fast_load<T, USE_E, VEC>(a, pcl_tq<VEC>(nb + threadIdx.x < nq ? nb + threadIdx.x : 0, a.ts), nxt);
+        if (nb < nq) pcl_fast_load<T, USE_E, VEC>(a, nb + threadIdx.x < nq ? nb + threadIdx.x : 0, nxt);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const pcl_i64 i = q * VEC + e;
@@ -656,7 +633,7 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
             cur.R[2][e] = R::add(cur.R[2][e], d2);
             // scatter                                                                light.py:303-315
             T pc = pcl_pcoll<T, false, VAR_N>(a.A, a.n, (T)0, a.c, d0, d1, d2, cur.R[0][e], cur.R[1][e], cur.R[2][e],
-                                              a.E[pcl_tix(live ? i : 0, a.ts)]);
+                                              a.E[live ? i : 0]);
             if constexpr (USE_E) pc = R::mul(pc, cur.L4[e]);
             const pcl_u64 id = (pcl_u64)(a.id_base + i);
             const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u, k0, k1);
@@ -674,13 +651,12 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
             w_sz += (pcl_u32)__popcll(__ballot(live && cur.V[2][e] > (T)0));
         }
         if (live_q) {
-            const pcl_i64 qs = pcl_tq<VEC>(q, a.ts);
-            VV::st(a.r0, qs, cur.R[0]);
-            VV::st(a.r1, qs, cur.R[1]);
-            VV::st(a.r2, qs, cur.R[2]);
-            VV::st(a.vo0, qs, cur.V[0]);
-            VV::st(a.vo1, qs, cur.V[1]);
-            VV::st(a.vo2, qs, cur.V[2]);
+            VV::st(a.r0, q, cur.R[0]);
+            VV::st(a.r1, q, cur.R[1]);
+            VV::st(a.r2, q, cur.R[2]);
+            VV::st(a.vo0, q, cur.V[0]);
+            VV::st(a.vo1, q, cur.V[1]);
+            VV::st(a.vo2, q, cur.V[2]);
         }
         cur = nxt;
     }

@@ -75,9 +75,6 @@ constexpr int kBlock = 256;           // 4 wave64 per workgroup
 constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particles
 constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
-constexpr int kRows = PCL_NFIELDS + 4;       // rows per tile of the store slab: 13 fields + vprev0..2 + lam4
-constexpr int kRowVprev = PCL_NFIELDS, kRowLam4 = PCL_NFIELDS + 3;
-constexpr int64_t kTileT = PCL_T;            // particles per tile (rows of 2048 elements)
 
 __host__ __device__ inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -95,7 +92,6 @@ struct newton_args {
     T *dr[3];
     T dt;
     int64_t N;
-    int64_t ts; // tile stride (elements)
 };
 
 template <typename T>
@@ -107,11 +103,10 @@ __global__ void __launch_bounds__(kBlock) k_newton(newton_args<T> a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += stride) {
         T v[3][VEC], r[3][VEC], d[3][VEC];
-        const int64_t qt = pcl_tq<VEC>(q, a.ts);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            VV::ld(a.v[k], qt, v[k]);
-            VV::ld(a.r[k], qt, r[k]);
+            VV::ld(a.v[k], q, v[k]);
+            VV::ld(a.r[k], q, r[k]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -120,8 +115,8 @@ __global__ void __launch_bounds__(kBlock) k_newton(newton_args<T> a) {
                 d[k][e] = R::mul(v[k][e], a.dt);
                 r[k][e] = R::add(r[k][e], d[k][e]);
             }
-            VV::st(a.dr[k], qt, d[k]);
-            VV::st(a.r[k], qt, r[k]);
+            VV::st(a.dr[k], q, d[k]);
+            VV::st(a.r[k], q, r[k]);
         }
     }
 }
@@ -136,7 +131,6 @@ struct materialize_args {
     T dt;
     int do_dv;
     int64_t N;
-    int64_t ts;
 };
 
 template <typename T>
@@ -145,12 +139,11 @@ __global__ void __launch_bounds__(kBlock) k_materialize(materialize_args<T> a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
         const bool photon = a.kind ? (a.kind[i] != 0) : true;
-        const int64_t ti = pcl_tix(i, a.ts);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const T vi = a.vin[k][ti];
-            a.dr[k][ti] = R::mul(vi, a.dt);
-            if (a.do_dv && photon) a.dv[k][ti] = R::sub(a.vout[k][ti], vi);
+            const T vi = a.vin[k][i];
+            a.dr[k][i] = R::mul(vi, a.dt);
+            if (a.do_dv && photon) a.dv[k][i] = R::sub(a.vout[k][i], vi);
         }
     }
 }
@@ -189,13 +182,10 @@ __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
 // store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
 template <typename T>
-__global__ void __launch_bounds__(kBlock) k_lam4(const T *__restrict__ E, T *__restrict__ lam4, T h, T c, int64_t N,
-                                                 int64_t ts) {
+__global__ void __launch_bounds__(kBlock) k_lam4(const T *__restrict__ E, T *__restrict__ lam4, T h, T c, int64_t N) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
-        const int64_t ti = pcl_tix(i, ts);
-        lam4[ti] = pcl_wavelength_term<T>(h, c, E[ti]);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride)
+        lam4[i] = pcl_wavelength_term<T>(h, c, E[i]);
 }
 
 // ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
@@ -211,7 +201,6 @@ struct delmask_args {
     uint64_t *masks;           // [n_tiles * 32] bit l of row mask = particle survives
     int32_t *tile_keep;        // [n_tiles]
     int64_t id_base, N;
-    int64_t ts;
     T An;                      // A * n, rounded once like the kernel's left-to-right product
     uint64_t seed;
     uint32_t step;
@@ -235,8 +224,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
                 keep = (a.flags_in[i] == 0);
             } else {
                 const bool photon = a.kind ? (a.kind[i] != 0) : true;
-                const int64_t ti = pcl_tix(i, a.ts);
-                const T pcoll = R::mul(a.An, pcl_step_norm<T>(a.d0[ti], a.d1[ti], a.d2[ti]));
+                const T pcoll = R::mul(a.An, pcl_step_norm<T>(a.d0[i], a.d1[i], a.d2[i]));
                 T rand;
                 if (a.rng_mode == PCL_RNG_PHX) {
                     const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
@@ -306,7 +294,6 @@ struct compact_args {
     const uint64_t *masks;
     const int64_t *tile_off;
     int64_t id_base, N;
-    int64_t ts; // tile stride of BOTH slabs (elements)
 };
 
 template <typename W, int NF>
@@ -325,11 +312,10 @@ __global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
         if ((m >> lane) & 1ull) {
             const int64_t o = dest + __popcll(m & below);
             W val[NF > 0 ? NF : 1];
-            const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
+            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[i];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[to] = val[f];
+            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[o] = val[f];
             if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
             if (a.kdst) a.kdst[o] = a.ksrc[i];
             if (a.idx_dst) a.idx_dst[o] = i;
@@ -352,7 +338,6 @@ struct newtonmask_args {
     uint64_t *masks;
     int32_t *tile_keep;
     int64_t id_base, N;
-    int64_t ts;
     T dt, An;
     uint64_t seed;
     uint32_t step;
@@ -374,12 +359,11 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
         bool keep = false;
         if (i < a.N) {
             T d[3];
-            const int64_t ti = pcl_tix(i, a.ts);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                d[k] = R::mul(a.v[k][ti], a.dt);
-                a.r[k][ti] = R::add(a.r[k][ti], d[k]);
-                if (!a.lazy) a.dr[k][ti] = d[k];
+                d[k] = R::mul(a.v[k][i], a.dt);
+                a.r[k][i] = R::add(a.r[k][i], d[k]);
+                if (!a.lazy) a.dr[k][i] = d[k];
             }
             const bool photon = a.kind ? (a.kind[i] != 0) : true;
             const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2]));
@@ -443,11 +427,10 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
         for (int f = 0; f < NF; ++f) val[f] = 0;
         if (keep) {
             const int64_t o = dest + __popcll(m & below);
-            const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
+            for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[i];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[to] = val[f];
+            for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[o] = val[f];
             if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
             if (a.kdst) a.kdst[o] = a.ksrc[i];
         }
@@ -502,7 +485,6 @@ struct counter_args {
     int plane_ax[PCL_MAX_PLANES];
     int n_planes;
     int64_t N;
-    int64_t ts;
 };
 
 template <typename T>
@@ -514,15 +496,14 @@ __global__ void __launch_bounds__(kBlock) k_counters(counter_args<T> a) {
     for (int k = 0; k < 3 + PCL_MAX_PLANES; ++k) cnt[k] = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.N; i += stride) {
-        const int64_t ti = pcl_tix(i, a.ts);
-        cnt[0] += a.v[0][ti] > (T)0; // strictly positive: "Do we count 0 as positive? No" light.py:415
-        cnt[1] += a.v[1][ti] > (T)0;
-        cnt[2] += a.v[2][ti] > (T)0;
+        cnt[0] += a.v[0][i] > (T)0; // strictly positive: "Do we count 0 as positive? No" light.py:415
+        cnt[1] += a.v[1][i] > (T)0;
+        cnt[2] += a.v[2][i] > (T)0;
 #pragma unroll
         for (int p = 0; p < PCL_MAX_PLANES; ++p) {
             if (p < a.n_planes) {
                 const int ax = a.plane_ax[p];
-                const T L = a.plane_L[p], x = a.r[ax][ti], prev = R::sub(x, a.dr[ax][ti]);
+                const T L = a.plane_L[p], x = a.r[ax][i], prev = R::sub(x, a.dr[ax][i]);
                 cnt[3 + p] += ((prev <= L && L <= x) || (prev >= L && L >= x)); // light.py:386
             }
         }
@@ -547,7 +528,6 @@ template <typename T>
 struct fill_args {
     T *f[PCL_NFIELDS];
     int64_t n, id_base;
-    int64_t ts;
     double c, e_min, e_max;
     uint64_t seed;
 };
@@ -568,7 +548,7 @@ __global__ void __launch_bounds__(kBlock) k_fill_photons(fill_args<T> a) {
             double val = 0.0;
             if (f == PCL_V0) val = a.c;
             if (f == PCL_E) val = E;
-            a.f[f][pcl_tix(i, a.ts)] = (T)val;
+            a.f[f][i] = (T)val;
         }
     }
 }
@@ -582,7 +562,6 @@ struct fill_table_args {
     const double *cdf, *grid;
     int nbins;
     int64_t n, id_base;
-    int64_t ts;
     double c;
     uint64_t seed;
 };
@@ -606,7 +585,7 @@ __global__ void __launch_bounds__(kBlock) k_fill_table(fill_table_args<T> a) {
             double val = 0.0;
             if (f == PCL_V0) val = a.c;
             if (f == PCL_E) val = E;
-            a.f[f][pcl_tix(i, a.ts)] = (T)val;
+            a.f[f][i] = (T)val;
         }
     }
 }
@@ -741,14 +720,8 @@ struct pcl_ctx {
     size_t esz = 8;
     int64_t capacity = 0, count = 0, id_base = 0;
     bool ids_iota = true;
-    // Tiled slab [tile][row][kTileT]: rows 0..12 = the 13 fields, 13..15 = the second half of the v double buffer,
-    // 16 = the lam4 cache.  row[] says which physical row currently plays which role (the v buffers swap roles
-    // after every lazy fused step); field[f] / vprev[k] / lam4 are the addresses of those rows in tile 0.
-    void *slab = nullptr, *slab_alt = nullptr; // slab_alt: compaction destination (lazy)
-    int row[kRows];
-    int64_t tiles = 0;
     void *field[PCL_NFIELDS] = {};
-    void *field_alt[PCL_NFIELDS] = {};
+    void *field_alt[PCL_NFIELDS] = {}; // compaction double buffer (lazy)
     int64_t *ids = nullptr, *ids_alt = nullptr;
     unsigned char *kind = nullptr, *kind_alt = nullptr;
     // lazy fused steps: second half of the v double buffer + what is still implicit
@@ -800,52 +773,6 @@ struct pcl_ctx {
 namespace {
 
 template <typename T> T *F(pcl_ctx *c, int f) { return static_cast<T *>(c->field[f]); }
-
-inline int64_t tile_stride(const pcl_ctx *c) { return (int64_t)kRows * kTileT; } // elements from tile to tile
-
-// recompute the tile-0 row addresses after the slab pointers or the row roles changed
-void refresh_rows(pcl_ctx *c) {
-    const size_t rowb = (size_t)kTileT * c->esz;
-    for (int f = 0; f < PCL_NFIELDS; ++f) {
-        c->field[f] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[f] : nullptr;
-        c->field_alt[f] = c->slab_alt ? static_cast<char *>(c->slab_alt) + rowb * c->row[f] : nullptr;
-    }
-    for (int k = 0; k < 3; ++k) c->vprev[k] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[kRowVprev + k] : nullptr;
-    c->lam4 = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[kRowLam4] : nullptr;
-}
-
-// element i of a row lives at (i / T) * tile_stride + i % T
-inline int64_t tix_host(int64_t i) { return (i / kTileT) * ((int64_t)kRows * kTileT) + (i % kTileT); }
-
-// copy n elements [offset, offset+n) of one row between a dense host array and the tiled slab
-int copy_row(pcl_ctx *ctx, void *row0, void *host, int64_t offset, int64_t n, bool to_device) {
-    char *h = static_cast<char *>(host);
-    const size_t esz = ctx->esz;
-    int64_t i = offset;
-    while (n > 0) {
-        const int64_t lo = i % kTileT;
-        char *d = static_cast<char *>(row0) + (size_t)tix_host(i) * esz;
-        if (lo == 0 && n >= kTileT) {
-            const int64_t k = n / kTileT; // whole tiles: one strided copy
-            PCL_HIP(hipMemcpy2DAsync(to_device ? (void *)d : (void *)h, to_device ? (size_t)kRows * kTileT * esz : (size_t)kTileT * esz,
-                                     to_device ? (const void *)h : (const void *)d, to_device ? (size_t)kTileT * esz : (size_t)kRows * kTileT * esz,
-                                     (size_t)kTileT * esz, (size_t)k, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
-                                     ctx->stream));
-            i += k * kTileT;
-            h += (size_t)k * kTileT * esz;
-            n -= k * kTileT;
-        } else {
-            const int64_t len = (kTileT - lo) < n ? (kTileT - lo) : n;
-            PCL_HIP(hipMemcpyAsync(to_device ? (void *)d : (void *)h, to_device ? (const void *)h : (const void *)d, (size_t)len * esz,
-                                   to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, ctx->stream));
-            i += len;
-            h += (size_t)len * esz;
-            n -= len;
-        }
-    }
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
-    return PCL_OK;
-}
 
 // run fn<double> or fn<float> according to the store's dtype
 #define PCL_DISPATCH(ctx, call_f64, call_f32) ((ctx)->dtype == PCL_DTYPE_F64 ? (call_f64) : (call_f32))
@@ -907,10 +834,8 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n) {
 }
 
 int ensure_alt(pcl_ctx *ctx) {
-    if (!ctx->slab_alt) {
-        PCL_HIP(hipMalloc(&ctx->slab_alt, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
-        refresh_rows(ctx);
-    }
+    for (int f = 0; f < PCL_NFIELDS; ++f)
+        if (!ctx->field_alt[f]) PCL_TRY(dev_alloc_bytes(&ctx->field_alt[f], ctx->capacity, ctx->esz));
     if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
     if (!ctx->ids_alt) PCL_TRY(dev_alloc(&ctx->ids_alt, ctx->capacity));
     if (ctx->kind && !ctx->kind_alt) PCL_TRY(dev_alloc(&ctx->kind_alt, ctx->capacity));
@@ -933,7 +858,6 @@ int materialize_t(pcl_ctx *ctx) {
         a.dt = (T)ctx->lazy_dt;
         a.do_dv = ctx->lazy_dv ? 1 : 0;
         a.N = N;
-        a.ts = tile_stride(ctx);
         hipLaunchKernelGGL(k_materialize<T>, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
         PCL_TRY(launch_check("k_materialize"));
     }
@@ -1109,7 +1033,6 @@ int step_newton_t(pcl_ctx *ctx, double dt) {
     }
     a.dt = (T)dt;
     a.N = N;
-    a.ts = tile_stride(ctx);
     const int ps = prof_begin(ctx, PCL_PROF_NEWTON);
     hipLaunchKernelGGL(k_newton<T>, dim3(grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock)), dim3(kBlock), 0, ctx->stream, a);
     prof_end(ctx, ps);
@@ -1122,7 +1045,6 @@ int fill_photons_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_
     for (int f = 0; f < PCL_NFIELDS; ++f) a.f[f] = F<T>(ctx, f);
     a.n = n;
     a.id_base = id_base;
-    a.ts = tile_stride(ctx);
     a.c = c;
     a.e_min = e_min;
     a.e_max = e_max;
@@ -1141,7 +1063,6 @@ int fill_table_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, const doubl
     a.nbins = nbins;
     a.n = n;
     a.id_base = id_base;
-    a.ts = tile_stride(ctx);
     a.c = c;
     a.seed = seed;
     hipLaunchKernelGGL(k_fill_table<T>, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, a);
@@ -1166,7 +1087,6 @@ int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc
     a.hits = reinterpret_cast<pcl_u64 *>(ctx->d_cnt);
     a.id_base = ctx->id_base;
     a.N = N;
-    a.ts = tile_stride(ctx);
     a.A = (T)A; a.n = (T)n; a.c = (T)c; a.h = (T)h;
     a.seed = seed;
     a.step = step;
@@ -1190,8 +1110,9 @@ int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc
 template <typename T>
 int ensure_lam4_t(pcl_ctx *ctx, double h, double c) {
     if (ctx->lam4_valid && ctx->lam4_h == h && ctx->lam4_c == c) return PCL_OK;
+    if (!ctx->lam4) PCL_TRY(dev_alloc_bytes(&ctx->lam4, ctx->capacity, ctx->esz));
     hipLaunchKernelGGL(k_lam4<T>, dim3(grid_for(ctx, ctx->count, kBlock)), dim3(kBlock), 0, ctx->stream,
-                       (const T *)F<T>(ctx, PCL_E), static_cast<T *>(ctx->lam4), (T)h, (T)c, ctx->count, tile_stride(ctx));
+                       (const T *)F<T>(ctx, PCL_E), static_cast<T *>(ctx->lam4), (T)h, (T)c, ctx->count);
     PCL_TRY(launch_check("k_lam4"));
     ctx->lam4_valid = true;
     ctx->lam4_h = h;
@@ -1204,6 +1125,8 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
                 uint64_t seed, uint32_t step) {
     const int64_t N = ctx->count;
     if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
+    for (int k = 0; k < 3; ++k)
+        if (!ctx->vprev[k]) PCL_TRY(dev_alloc_bytes(&ctx->vprev[k], ctx->capacity, ctx->esz));
     pcl_fast_args<T> f{};
     f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
     f.vi0 = F<T>(ctx, PCL_V0); f.vi1 = F<T>(ctx, PCL_V1); f.vi2 = F<T>(ctx, PCL_V2);
@@ -1213,7 +1136,6 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     f.cnt = reinterpret_cast<pcl_u64 *>(ctx->cnt_target);
     f.id_base = ctx->id_base;
     f.N = N;
-    f.ts = tile_stride(ctx);
     f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
     f.seed = seed;
     f.step = step;
@@ -1244,6 +1166,8 @@ int step_fused_t(pcl_ctx *ctx, double dt, bool do_scatter, double A, double n, b
     a.vi0 = F<T>(ctx, PCL_V0); a.vi1 = F<T>(ctx, PCL_V1); a.vi2 = F<T>(ctx, PCL_V2);
     a.vo0 = F<T>(ctx, PCL_V0); a.vo1 = F<T>(ctx, PCL_V1); a.vo2 = F<T>(ctx, PCL_V2);
     if (lazy && do_scatter) {
+        for (int k = 0; k < 3; ++k)
+            if (!ctx->vprev[k]) PCL_TRY(dev_alloc_bytes(&ctx->vprev[k], ctx->capacity, ctx->esz));
         a.vo0 = static_cast<T *>(ctx->vprev[0]); a.vo1 = static_cast<T *>(ctx->vprev[1]); a.vo2 = static_cast<T *>(ctx->vprev[2]);
     }
     a.lazy = lazy ? 1 : 0;
@@ -1258,7 +1182,6 @@ int step_fused_t(pcl_ctx *ctx, double dt, bool do_scatter, double A, double n, b
     a.cnt = reinterpret_cast<pcl_u64 *>(ctx->cnt_target);
     a.id_base = ctx->id_base;
     a.N = N;
-    a.ts = tile_stride(ctx);
     a.dt = (T)dt; a.A = (T)A; a.n = (T)n; a.c = (T)c; a.h = (T)h;
     a.seed = seed;
     a.step = step;
@@ -1300,7 +1223,6 @@ int delete_mask_t(pcl_ctx *ctx, double A, double n, int rng_mode, uint64_t seed,
     m.tile_keep = ctx->tile_keep;
     m.id_base = ctx->id_base;
     m.N = N;
-    m.ts = tile_stride(ctx);
     m.An = (T)A * (T)n; // one IEEE multiply in the store's precision == the kernel's (A * n)
     m.seed = seed;
     m.step = step;
@@ -1329,7 +1251,6 @@ int counters_t(pcl_ctx *ctx, const double *planes_host, int n_planes) {
     }
     a.n_planes = n_planes;
     a.N = N;
-    a.ts = tile_stride(ctx);
     a.out = ctx->d_cnt + 1;
     const int ps = prof_begin(ctx, PCL_PROF_COUNTERS);
     hipLaunchKernelGGL(k_counters<T>, dim3(grid_for(ctx, N, kBlock)), dim3(kBlock), 0, ctx->stream, a);
@@ -1355,7 +1276,6 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int r
     m.tile_keep = ctx->tile_keep;
     m.id_base = ctx->id_base;
     m.N = N;
-    m.ts = tile_stride(ctx);
     m.dt = (T)dt;
     m.An = (T)A * (T)n;
     m.seed = seed;
@@ -1383,7 +1303,6 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int r
     ca.tile_off = ctx->tile_off;
     ca.id_base = ctx->id_base;
     ca.N = N;
-    ca.ts = tile_stride(ctx);
     compact_counter_args<T> cc{};
     cc.cnt = ctx->d_cnt;
     cc.n_planes = n_planes;
@@ -1681,7 +1600,6 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
     ca.masks = ctx->masks;
     ca.tile_off = ctx->tile_off;
     ca.N = N;
-    ca.ts = tile_stride(ctx);
     hipLaunchKernelGGL((k_compact<uint64_t, 0>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
     PCL_TRY(launch_check("k_compact"));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -1787,10 +1705,15 @@ int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     pcl_store_free(ctx);
     ctx->dtype = dtype;
     ctx->esz = dtype == PCL_DTYPE_F64 ? 8 : 4;
-    ctx->tiles = div_up(capacity, kTileT);
-    for (int k = 0; k < kRows; ++k) ctx->row[k] = k;
-    PCL_HIP(hipMalloc(&ctx->slab, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
-    refresh_rows(ctx);
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        int rc = dev_alloc_bytes(&ctx->field[f], capacity, ctx->esz);
+        if (rc != PCL_OK) {
+            std::string keep = g_err;
+            pcl_store_free(ctx);
+            g_err = keep;
+            return rc;
+        }
+    }
     ctx->capacity = capacity;
     ctx->count = 0;
     ctx->id_base = 0;
@@ -1810,11 +1733,13 @@ int pcl_store_free(pcl_ctx *ctx) {
     if (!ctx) return PCL_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    dev_free(ctx->slab);
-    dev_free(ctx->slab_alt);
-    ctx->tiles = 0;
-    refresh_rows(ctx); // all row addresses -> NULL
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        dev_free(ctx->field[f]);
+        dev_free(ctx->field_alt[f]);
+    }
+    for (int k = 0; k < 3; ++k) dev_free(ctx->vprev[k]);
     ctx->lazy_dr = ctx->lazy_dv = false;
+    dev_free(ctx->lam4);
     ctx->lam4_valid = false;
     dev_free(ctx->ids);
     dev_free(ctx->ids_alt);
@@ -1862,14 +1787,14 @@ int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, 
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
     if (field == PCL_E) ctx->lam4_valid = false;
-    return copy_row(ctx, ctx->field[field], const_cast<void *>(host), offset, n, true);
+    return pcl_h2d(ctx, static_cast<char *>(ctx->field[field]) + offset * ctx->esz, host, n * (int64_t)ctx->esz);
 }
 
 int pcl_store_download(pcl_ctx *ctx, int field, void *host, int64_t offset, int64_t n) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
-    return copy_row(ctx, ctx->field[field], host, offset, n, false);
+    return pcl_d2h(ctx, host, static_cast<char *>(ctx->field[field]) + offset * ctx->esz, n * (int64_t)ctx->esz);
 }
 
 int pcl_store_upload_ids(pcl_ctx *ctx, const int64_t *host, int64_t offset, int64_t n) {
@@ -1915,13 +1840,6 @@ int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out) {
     if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
     if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
     *dev_out = ctx->field[field];
-    return PCL_OK;
-}
-
-int pcl_store_layout(pcl_ctx *ctx, int64_t *tile_len_out, int64_t *tile_stride_out) {
-    PCL_TRY(need_store_raw(ctx));
-    if (tile_len_out) *tile_len_out = kTileT;
-    if (tile_stride_out) *tile_stride_out = tile_stride(ctx);
     return PCL_OK;
 }
 
@@ -2074,8 +1992,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     }
     if (lazy) {
         if (do_scatter) {
-            for (int k = 0; k < 3; ++k) std::swap(ctx->row[PCL_V0 + k], ctx->row[kRowVprev + k]); // V rows = new v
-            refresh_rows(ctx);
+            for (int k = 0; k < 3; ++k) std::swap(ctx->field[PCL_V0 + k], ctx->vprev[k]); // field[V] = new v
             ctx->lazy_dv = true;
         }
         ctx->lazy_dr = true;
@@ -2161,7 +2078,6 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     ca.tile_off = ctx->tile_off;
     ca.id_base = ctx->id_base;
     ca.N = N;
-    ca.ts = tile_stride(ctx);
     const int ps_cmp = prof_begin(ctx, PCL_PROF_COMPACT);
     if (ctx->dtype == PCL_DTYPE_F64)
         hipLaunchKernelGGL((k_compact<uint64_t, PCL_NFIELDS>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
@@ -2173,8 +2089,7 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
     if (alive < 0 || alive > N)
         return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
-    std::swap(ctx->slab, ctx->slab_alt); // every field row was written into the other slab
-    refresh_rows(ctx);
+    for (int f = 0; f < PCL_NFIELDS; ++f) std::swap(ctx->field[f], ctx->field_alt[f]);
     std::swap(ctx->ids, ctx->ids_alt);
     if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
     ctx->ids_iota = false;
@@ -2215,8 +2130,10 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
     if (alive < 0 || alive > N)
         return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
-    std::swap(ctx->slab, ctx->slab_alt); // (lazy: the dr rows of the new slab are stale -- dr is implicit anyway)
-    refresh_rows(ctx);
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        if (lazy && f >= PCL_DR0 && f <= PCL_DR2) continue; // dr buffers were not part of the move
+        std::swap(ctx->field[f], ctx->field_alt[f]);
+    }
     std::swap(ctx->ids, ctx->ids_alt);
     if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
     ctx->ids_iota = false;

@@ -1,0 +1,300 @@
+"""physicl.light equivalent: photons, scatter / delete steps and the counting measure steps, all on
+the device store.  Public names follow the reference module (physicl/light.py); the OpenCL kernels
+it builds at run time are replaced by the hand-written HIP kernels of libphysicl_hip.so."""
+import copy
+
+import numpy as np
+import numpy.linalg as np_lin
+
+from .core import DeviceStep, MeasureStep, Object, PhotonBatch, Step
+from .units import Measurement
+
+# SI-defined constants (physicl/light.py:14-16); Measurements, so they follow the code scale in force at import
+c = Measurement(np.double(299792458), "m**1 s**-1")
+h = Measurement(np.double(6.62607015e-34), "J**1 s**1")
+kB = Measurement(np.double(1.380649e-23), "J**1 K**-1")
+
+
+class PhotonObject(Object):
+    """Photon: needs an energy ``E`` and ``|v| == |c|`` (physicl/light.py:18-35)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        if np_lin.norm(self.v) != np_lin.norm(c):
+            raise Exception("Not a valid speed.")
+        if "E" not in kwargs:
+            raise Exception("Needs a valid energy.")
+
+
+def E_from_wavelength(wavelength):
+    return (h * c) / wavelength
+
+
+def wavelength_from_E(E):
+    return (h * c) / E
+
+
+# ---------------------------------------------------------------------------------------------- Planck sampling
+def planck_distribution(E, T):
+    """Normalised Planck photon-energy density, J**-1 (physicl/light.py:53-60).  Set-up time only."""
+    E_ = E.__unscaled__() if isinstance(E, Measurement) else E
+    T_ = T.__unscaled__() if isinstance(T, Measurement) else T
+    k_ = kB.__unscaled__()
+    # operation order of the reference (bit-exact): 15/(pi^4 kB T) * (E/(kB T))^3 * 1/e^(E/(kB T))
+    norm = 15 / (np.pi ** 4 * k_ * T_)
+    x = E_ / (k_ * T_)
+    return Measurement(norm * (x ** 3) * (1 / (np.e ** (E_ / (k_ * T_)))), "J**-1")
+
+
+def planck_probability(E_min, E_max, T, integrator=None):
+    import scipy.integrate
+    integrator = integrator or (lambda fn, a, b: scipy.integrate.quad(fn, a, b))
+    return integrator(lambda x: planck_distribution(x, T), E_min, E_max)
+
+
+_planck_cache = {"key": None, "cdf": None}
+
+
+def planck_phot_distribution(E_min, E_max, T, bins=1000):
+    """One photon energy drawn from the binned Planck CDF (physicl/light.py:73-104)."""
+    key = [float(np.asarray(x.__unscaled__() if isinstance(x, Measurement) else x)) for x in (E_min, E_max, T, bins)]
+    lo, hi, T_, nb = key
+    grid = np.linspace(lo, hi, int(nb))
+    if _planck_cache["key"] != key:
+        area = np.array([planck_probability(grid[k], grid[k + 1], T_)[0] for k in range(len(grid) - 1)])
+        _planck_cache["key"], _planck_cache["cdf"] = key, np.cumsum(area / area.sum())
+    cdf = _planck_cache["cdf"]
+    u = np.random.rand()
+    for k in range(1, len(cdf)):
+        if cdf[k] >= u >= cdf[k - 1]:
+            return Measurement(grid[k], "J**1")
+
+
+def generate_photons_from_E(E):
+    return [PhotonObject(E=x, v=c * [1, 0, 0]) for x in E]
+
+
+def generate_photons(n, fn=lambda: np.random.power(3), min=0, max=0, bins=-1, dist=None):
+    """``n`` PhotonObjects moving along +x with ``E = min + (max - min) * fn()`` (physicl/light.py:112-128).
+    ``bins``/``dist`` are accepted and ignored like in the older scripts (examples/runtime1.py:67).
+    For large n use ``generate_photons_bulk``."""
+    return [PhotonObject(E=min + (max - min) * fn(), v=Measurement([c, 0, 0], "m**1 s**-1")) for _ in range(int(n))]
+
+
+def generate_photons_bulk(n, min=0, max=0, seed=0, T=None, bins=1000):
+    """``n`` photons created directly in device memory when the simulation first needs them (returns a
+    PhotonBatch for ``sim.add_objs``).  Default: the distribution of ``generate_photons`` with its default
+    sampler.  With a temperature ``T``: energies from the binned Planck distribution between ``min`` and
+    ``max`` -- ``generate_photons_from_E([planck_phot_distribution(min, max, T, bins) ...])``
+    (physicl/light.py:73-110) for all photons at once; the bin masses use the closed-form integral of the
+    Planck density instead of ``bins`` calls to scipy.quad."""
+    if T is None:
+        return PhotonBatch(n, min, max, seed)
+    lo, hi, T_ = (float(np.asarray(v.__unscaled__() if isinstance(v, Measurement) else v)) for v in (min, max, T))
+    grid = np.linspace(lo, hi, int(bins))
+    xk = grid / (float(np.asarray(kB.__unscaled__())) * T_)
+    mass = np.diff(-np.exp(-xk) * (xk ** 3 + 3 * xk ** 2 + 6 * xk + 6))
+    cdf = np.cumsum(mass / mass.sum())
+    cdf[-1] = 1.0
+    scale = float(np.asarray(Measurement(1, "J**1").scale))          # table energies in code units
+    return PhotonBatch(n, lo * scale, hi * scale, seed, table=(cdf, grid[:-1] * scale))
+
+
+# ---------------------------------------------------------------------------------------------- helpers
+def _kernel_const(x):
+    """The reference pastes ``str(value)`` into the kernel call and parses it with ``np.double``
+    (physicl/light.py:236, 287; physicl/__init__.py:648): the code-unit number."""
+    return float(np.double(str(x)))
+
+
+def _c_h_literals():
+    """Values of the literals str(c), str(h).upper() inside the kernel text (physicl/light.py:301, 309)."""
+    return float(str(c)), float(str(h).upper())
+
+
+# ---------------------------------------------------------------------------------------------- delete
+class ScatterDeleteStep(DeviceStep):
+    """Removes each photon with probability ``A*n*|dr|`` per step (physicl/light.py:225-260): flag kernel
+    + stable compaction of the whole state, fused in pcl_step_scatter_delete.  The reference hands its
+    kernel ``A := n`` and ``n := A`` (light.py:236); the product is the same."""
+
+    _fuse_role = "scatter_delete"
+
+    def __init__(self, n, A):
+        self.n, self.A = n, A
+        self.built = False
+        self.removed = 0
+
+    def _kernel_consts(self):
+        return _kernel_const(self.n), _kernel_const(self.A)      # kernel A := user n, n := user A (light.py:236)
+
+    def _device_run(self, sim):
+        hip, dev = sim._hip, sim._dev
+        mode = sim._rng_mode()
+        if mode == hip.RNG_INPUT:
+            sim._host_randoms("delete")
+        A_k, n_k = self._kernel_consts()
+        alive, removed = dev.step_scatter_delete(A_k, n_k, mode, sim.seed, sim._next_launch())
+        g = sim._global([alive, removed])
+        sim._alive, self.removed = int(g[0]), int(g[1])
+
+
+class ScatterDeleteStepReference(ScatterDeleteStep):
+    """Second statement of the same step in the reference (physicl/light.py:131-223): same kernel maths with
+    the argument order (dx, dy, dz, rand, n, A, result)."""
+
+
+# ---------------------------------------------------------------------------------------------- isotropic scatter
+class ScatterIsotropicStep(DeviceStep):
+    """Isotropic re-direction with probability ``A * n * |dr|`` (physicl/light.py:262-359).
+
+    Options as in the reference: ``wavelength_dep_scattering`` multiplies by ``pow((h*c)/E, -4)``;
+    ``variable_n`` replaces ``n`` by the OpenCL-C expression ``variable_n_fn`` over ``r0[gid]``,
+    ``r1[gid]``, ``r2[gid]`` (compiled into the kernel with hipRTC).
+
+    Reference quirk kept: the kernel receives ``A := n`` and ``n := A`` (light.py:287), so with
+    ``variable_n=True`` the user's ``A`` is unused and ``n`` (default 1) scales the probability.
+    """
+    _fuse_role = "scatter_iso"
+
+    def __init__(self, **kwargs):
+        self.n = kwargs.get("n", 1)
+        self.A = kwargs.get("A", 1)
+        self.wavelength_dep_scattering = kwargs.get("wavelength_dep_scattering", False)
+        self.variable_n = kwargs.get("variable_n", False)
+        self.variable_n_fn = kwargs.get("variable_n_fn", None)
+        self.prog = None
+        self.built = False
+
+    def _kernel_params(self, sim):
+        hip = sim._hip
+        flags = (hip.SCATTER_WAVELENGTH if self.wavelength_dep_scattering else 0) | \
+                (hip.SCATTER_VARIABLE_N if self.variable_n else 0)
+        c_lit, h_lit = _c_h_literals()
+        expr = str(self.variable_n_fn) if self.variable_n else None
+        return dict(A=_kernel_const(self.n), n=_kernel_const(self.A), flags=flags, c=c_lit, h=h_lit, n_expr=expr)
+
+    def _device_run(self, sim):
+        hip, dev = sim._hip, sim._dev
+        p = self._kernel_params(sim)
+        mode = sim._rng_mode()
+        if mode == hip.RNG_INPUT:
+            sim._host_randoms("iso")
+        hits = dev.step_scatter_isotropic(p["A"], p["n"], p["flags"], p["c"], p["h"], p["n_expr"], mode, sim.seed,
+                                          sim._next_launch())
+        sim._scattered = True
+        sim.hits = int(sim._global([hits])[0])
+
+
+class ScatterSphericalStep(ScatterIsotropicStep):
+    """Spelling used by the shipped examples: ``ScatterSphericalStep(n, A, wavelength_dep_scattering=...)``
+    (examples/runtime1.py:77, examples/variable_n_scattering.ipynb:56)."""
+
+    def __init__(self, n=1, A=1, **kwargs):
+        super().__init__(n=n, A=A, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------- measure steps
+def _plane_axis(loc):
+    loc = np.asarray(loc, dtype=np.float64).reshape(3)
+    return loc
+
+
+class _CountingMeasure(DeviceStep, MeasureStep):
+    """Measure steps whose rows are counters: one fused reduction on the device."""
+    _fuse_role = "measure"
+
+    def _n_planes(self):
+        return 0
+
+    def _plane_rows(self):
+        return []
+
+    def _device_run(self, sim):
+        cnt = sim._dev.step_counters(self._plane_rows())
+        g = sim._global(cnt)
+        self._record(sim, int(g[0]), g[1:4], g[4:])
+
+
+class ScatterMeasureStep(_CountingMeasure):
+    """Row per step: ``[t, N, crossings of plane 0, ...]`` (physicl/light.py:361-404).  A plane is a
+    3-vector with NaN in the coordinates that do not define it.  ``measure_E`` (per-plane lists of the
+    crossing photons' energies) is not provided by this build."""
+
+    def __init__(self, out_fn, measure_n=True, measure_locs=[], measure_E=False):
+        MeasureStep.__init__(self, out_fn)
+        if measure_E:
+            raise NotImplementedError("ScatterMeasureStep(measure_E=True): variable-length energy lists are outside "
+                                      "the device path of this build")
+        self.measure_locs, self.measure_n, self.measure_E = measure_locs, measure_n, measure_E
+
+    def _n_planes(self):
+        return len(self.measure_locs)
+
+    def _plane_rows(self):
+        return [np.asarray(loc, dtype=np.float64).reshape(3) for loc in self.measure_locs]
+
+    def _record(self, sim, n, sign, planes):
+        row = [sim.t]
+        if self.measure_n:
+            row.append(n)
+        row.extend(int(x) for x in planes)
+        self.data.append(np.array(row))
+
+
+class ScatterSignMeasureStep(_CountingMeasure):
+    """Row per step: ``[t, N, #v_x>0, #v_y>0, #v_z>0]`` (physicl/light.py:406-431)."""
+
+    def __init__(self, out_fn, measure_n=True):
+        MeasureStep.__init__(self, out_fn)
+        self.measure_n = measure_n
+
+    def _record(self, sim, n, sign, planes):
+        row = [sim.t]
+        if self.measure_n:
+            row.append(n)
+        row.extend(int(x) for x in sign)
+        self.data.append(np.array(row))
+
+
+class TracePathMeasureStep(MeasureStep):
+    """Records every object's position at every step (physicl/light.py:433-483): O(N*T) host memory, a
+    diagnostic for small N.  Host plugin: the particle state is copied back into the Python objects each
+    step (read-only, so nothing is re-uploaded)."""
+    _reads_only = True
+
+    def __init__(self, out_fn, trace_type=Object, id_info_fn=lambda x: str(type(x)), trace_dv=False):
+        super().__init__(out_fn)
+        self.trace_type, self.id_info_fn, self.trace_dv = trace_type, id_info_fn, trace_dv
+        self.id_counter = 0
+        self.id_dict, self.pos_dict = {}, {}
+
+    def run(self, sim):
+        for obj in sim.objects:
+            tid = obj.__dict__.get("__trace_path_id")
+            if tid is None:
+                tid = obj.__dict__["__trace_path_id"] = self.id_counter
+                self.id_dict[tid] = self.id_info_fn(obj)
+                self.pos_dict[tid] = {"start": copy.deepcopy(sim.t), "pos": []}
+                if self.trace_dv:
+                    self.pos_dict[tid]["freq"] = 0
+                self.id_counter += 1
+            self.pos_dict[tid]["pos"].append(copy.deepcopy(obj.r))
+            if self.trace_dv and np.any(np.asarray(obj.dv) != 0):
+                self.pos_dict[tid]["freq"] += 1
+
+    def terminate(self, sim):
+        """data[0] = ["t", t0, t1, ...]; data[1+i] = [id info, (freq,) NaN-padded positions of object i]."""
+        cols = len(sim.ts)
+        table = [["t"] + copy.deepcopy(sim.ts)]
+        for i in range(len(self.id_dict)):
+            row = [self.id_dict[i]]
+            if self.trace_dv:
+                row.append(self.pos_dict[i]["freq"])
+            before = sim.ts.index(self.pos_dict[i]["start"])
+            after = cols - len(self.pos_dict[i]["pos"])
+            row.extend([np.nan, np.nan, np.nan] * before)
+            row.extend(self.pos_dict[i]["pos"])
+            row.extend([np.nan, np.nan, np.nan] * after)
+            table.append(row)
+        self.data = table

@@ -1,0 +1,83 @@
+"""GPU, 2 processes sharing device 0, gloo for the counter all-reduce: a sharded Simulation (index
+shards, global-id-keyed RNG, all-reduced counters) produces exactly the rows of the single-process run.
+(RCCL itself needs >= 2 GPUs; the driver's multi-GPU bench exercises it.  Everything else of the
+N > 1 path -- sharding, id bases, the reduce of the counter vector, exit on the GLOBAL alive count --
+runs here on real kernels.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import physicl as phys, physicl.light, physicl.newton
+from physicl_amd.dist import CounterComm
+comm = CounterComm.from_env(backend="gloo")
+kind = %(kind)r
+sim = phys.Simulation(cl_on=True, device=0, comm=comm if comm.world > 1 else None, seed=21, rng="philox",
+                      exit=(lambda s: len(s.objects) < 2000) if kind == "delete" else (lambda s: s.t >= 0.0055))
+N = 150001
+if kind == "batch" or kind == "delete":
+    sim.add_objs(phys.light.generate_photons_bulk(N, min=phys.light.E_from_wavelength(700e-9),
+                                                  max=phys.light.E_from_wavelength(200e-9), seed=21))
+else:
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(3e-19), uid=i)
+                  for i in range(3001)])
+sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+if kind == "delete":
+    sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+else:
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001), wavelength_dep_scattering=False))
+m1 = phys.light.ScatterMeasureStep(None, True, [[6e5, np.nan, np.nan], [np.nan, 0.0, np.nan]])
+m2 = phys.light.ScatterSignMeasureStep(None, True)
+sim.add_step(3, m1)
+sim.add_step(4, m2)
+sim.run()
+print(json.dumps({"rank": comm.rank, "m1": [[float(x) for x in r] for r in m1.data], "m2": [[float(x) for x in r] for r in m2.data],
+                  "alive": len(sim.objects), "hits": int(sim.hits), "local": int(sim._dev.count)}))
+comm.close()
+"""
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_world(world, kind):
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "kind": kind}], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=600)
+        assert p.returncode == 0, e[-3000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    return sorted(outs, key=lambda d: d["rank"])
+
+
+@pytest.mark.parametrize("kind", ["batch", "objects", "delete"])
+def test_two_shards_reproduce_the_single_process_rows(kind):
+    one = run_world(1, kind)[0]
+    two = run_world(2, kind)
+    for rank in two:
+        assert rank["m1"] == one["m1"] and rank["m2"] == one["m2"]       # every rank records the GLOBAL rows
+        assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
+    assert two[0]["local"] + two[1]["local"] == one["local"]
+    assert len(one["m1"]) >= 5 and one["m1"][0][1] > 0

@@ -1,0 +1,366 @@
+"""GPU: whole simulations through the reference's plugin API (``import physicl as phys``), compared
+with the golden vectors recorded from the reference and with the reference's own two integration
+tests (test/test_light.py:27-66)."""
+import numpy as np
+import pytest
+
+import physicl as phys
+import physicl.light
+import physicl.newton
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+V_ABS_TOL = 4 * np.spacing(C_LIT)
+
+
+def rand_ray():                                     # test/test_light.py:12-17
+    return {"s": np.array([0] * 3, dtype=np.double), "v": np.array([phys.light.c, 0, 0], dtype=np.double),
+            "E": np.double(1)}
+
+
+def make_sim(n=10000, **kw):                        # test/test_light.py:19-24
+    s = phys.Simulation(bounds=np.array([1000, 1000, 1000]), cl_on=True, exit=lambda cond: cond.t >= 0.100, **kw)
+    for i in range(n):
+        s.add_obj(phys.light.PhotonObject(uid=i, **rand_ray()))
+    return s
+
+
+def run(sim):
+    sim.start()
+    sim.join()
+    assert sim.error is None
+    return sim
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_scatter_spherical(rng):
+    """test/test_light.py:27-43, thresholds unchanged."""
+    np.random.seed(3)
+    x = make_sim(rng=rng, seed=3)
+    x.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    x.add_step(1, phys.newton.NewtonianKinematicsStep())
+    x.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    step = phys.light.ScatterSignMeasureStep(None, True)
+    x.add_step(3, step)
+    run(x)
+    error = (np.double(step.data[0][1] * 0.5) - (sum([y[2] for y in step.data]) / len(step.data))) / \
+        np.double(step.data[0][1] * 0.5)
+    assert np.isclose(error, 0, 0, 0.10)
+    assert len(step.data) == 100 and step.data[0][1] == 10000
+
+
+@pytest.mark.parametrize("rng", ["numpy", "philox"])
+def test_scatter_delete(rng):
+    """test/test_light.py:45-66, thresholds unchanged."""
+    np.random.seed(4)
+    x = make_sim(rng=rng, seed=4)
+    x.exit = lambda x: len(x.objects) == 0
+    N_i = len(x.objects)
+    x.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    x.add_step(1, phys.newton.NewtonianKinematicsStep())
+    n, A = 0.001, 0.001
+    x.add_step(2, phys.light.ScatterDeleteStep(np.double(n), np.double(A)))
+    step = phys.light.ScatterMeasureStep(None, True, [[1 / (n * A), np.nan, np.nan]])
+    x.add_step(3, step)
+    run(x)
+    N_x = sum(step.data[2])
+    error = (np.e ** -1 - (N_x / N_i)) / (np.e ** -1)
+    assert np.isclose(error, 0, 0, 0.10)
+    assert len(x.objects) == 0 and step.data[-1][1] == 0
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_seeded_isotropic_run_reproduces_the_reference(golden, fuse):
+    """np.random.seed + the same step list as the reference's OpenCL path: the measure rows (exact
+    integers) and the final velocities match the golden run, fused into one kernel or not."""
+    z = golden("g2_iso_base")
+    N, K, dt = len(z["k0_rand"]), int(z["K"]), float(z["dt"])
+    sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= (K - 0.5) * dt, fuse=fuse)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(N)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(z["A_user"]), n=np.double(z["n_user"])))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
+    sim.add_step(3, sign)
+    sim.add_step(4, meas)
+    np.random.seed(int(z["seed"]))
+    run(sim)
+    assert np.array_equal(np.array(sign.data, dtype=np.float64), z["sign_rows"])
+    assert np.array_equal(np.array(meas.data, dtype=np.float64), z["measure_rows"])
+    assert sim.hits == (~np.isnan(z["k%d_res0" % (K - 1)])).sum()
+    v = np.array([np.asarray(o.v) for o in sim.objects])
+    dv = np.array([np.asarray(o.dv) for o in sim.objects])
+    r = np.array([np.asarray(o.r) for o in sim.objects])
+    dr = np.array([np.asarray(o.dr) for o in sim.objects])
+    last = "k%d_post_" % (K - 1)
+    assert np.max(np.abs(v - z[last + "v"])) <= V_ABS_TOL and np.max(np.abs(dv - z[last + "dv"])) <= 2 * V_ABS_TOL
+    assert np.max(np.abs(dr - z[last + "dr"])) <= V_ABS_TOL * dt + 1e-12
+    assert np.max(np.abs(r - z[last + "r"])) <= K * V_ABS_TOL * dt + 4 * np.spacing(np.abs(r).max())
+    assert [o.uid for o in sim.objects] == list(range(N))
+
+
+def test_seeded_delete_run_reproduces_the_reference(golden):
+    z = golden("g4_delete")
+    N = int(z["N"])
+    sim = phys.Simulation(cl_on=True)                                   # default exit: no objects left
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(N)])
+    survivors = []
+
+    class Census(phys.Step):                                            # a user plugin that walks sim.objects
+        def run(self, s):
+            survivors.append([o.uid for o in s.objects])
+
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(z["dt"])))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterDeleteStep(np.double(z["n_user"]), np.double(z["A_user"])))
+    meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    sim.add_step(3, meas)
+    sim.add_step(4, sign)
+    sim.add_step(5, Census())
+    np.random.seed(int(z["seed"]))
+    run(sim)
+    K = int(z["K"])
+    assert len(survivors) == K
+    for k in range(K):
+        assert survivors[k] == list(z["k%d_survivor_uid" % k])
+    assert np.array_equal(np.array(meas.data, dtype=np.float64), z["measure_rows"])
+    assert np.array_equal(np.array(sign.data, dtype=np.float64), z["sign_rows"])
+    assert len(sim.objects) == 0 and sim.ts == pytest.approx([float(z["dt"]) * (k + 1) for k in range(K)])
+
+
+def test_host_plugin_between_device_steps_round_trips_the_state():
+    """A user Step that edits objects in Python sits between device steps: the state goes
+    device -> objects -> device every pass and nothing is lost or reordered."""
+    class Kick(phys.Step):
+        def run(self, s):
+            for o in s.objects:
+                if o.uid == 7:
+                    o.r = o.r + np.array([0.0, 1.0, 0.0])
+
+    def build(with_plugin):
+        sim = phys.Simulation(cl_on=True, rng="philox", seed=9, exit=lambda s: s.t >= 0.0045)
+        sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                      for i in range(500)])
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        if with_plugin:
+            sim.add_step(2, Kick())
+        sim.add_step(3, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+        return run(sim)
+
+    a, b = build(False), build(True)
+    ra = np.array([np.asarray(o.r) for o in a.objects])
+    rb = np.array([np.asarray(o.r) for o in b.objects])
+    assert np.array_equal(ra[:, 0], rb[:, 0]) and np.array_equal(ra[:, 2], rb[:, 2])
+    d = rb[:, 1] - ra[:, 1]
+    assert d[7] == pytest.approx(5.0) and np.count_nonzero(np.delete(d, 7)) == 0
+    assert np.array_equal(np.array([np.asarray(o.v) for o in a.objects]), np.array([np.asarray(o.v) for o in b.objects]))
+
+
+def test_mixed_objects_and_trace_path():
+    sim = phys.Simulation(cl_on=True, rng="philox", seed=2, exit=lambda s: s.t >= 0.0035)
+    objs = []
+    for i in range(40):
+        if i % 4 == 0:
+            objs.append(phys.Object(v=phys.Measurement([1.0, 2.0, 3.0], "m**1 s**-1"), uid=i))
+        else:
+            objs.append(phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i))
+    sim.add_objs(objs)
+    tp = phys.light.TracePathMeasureStep(None, trace_dv=True)
+    sim.add_step(3, phys.UpdateTimeStep(lambda s: 0.001))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=1.0, n=1.0))           # pcoll >> 1: every photon scatters
+    sim.add_step(0, tp)
+    run(sim)
+    assert len(tp.data) == 41 and tp.data[0][0] == "t" and len(tp.data[0]) == 5
+    plain = sim.objects[0]
+    assert np.allclose(np.asarray(plain.r), 4 * 0.001 * np.array([1.0, 2.0, 3.0]))
+    assert np.array_equal(np.asarray(plain.v), [1.0, 2.0, 3.0]) and not np.any(np.asarray(plain.dv))
+    photon_row, plain_row = tp.data[2], tp.data[1]
+    assert photon_row[1] == 4 and plain_row[1] == 0                         # freq: dv != 0 on every step / never
+    assert len(photon_row) == 2 + 4 and np.asarray(photon_row[2]).shape == (3,)
+    speeds = [np.linalg.norm(np.asarray(o.v)) for o in sim.objects if type(o) is phys.light.PhotonObject]
+    assert np.allclose(speeds, C_LIT, rtol=1e-15)
+
+
+def test_photon_batch_runs_without_python_objects():
+    n = 2_000_000
+    sim = phys.Simulation(cl_on=True, seed=12, exit=lambda s: s.t >= 0.0095)
+    sim.add_objs(phys.light.generate_photons_bulk(n, min=phys.light.E_from_wavelength(700e-9),
+                                                  max=phys.light.E_from_wavelength(200e-9), seed=12))
+    assert len(sim.objects) == n and sim.rng == "philox"
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    sim.add_step(3, sign)
+    run(sim)
+    assert len(sign.data) == 10 and all(row[1] == n for row in sign.data)
+    p = 1e-6 * C_LIT * 1e-3
+    assert abs(sim.hits - n * p) < 6 * np.sqrt(n * p)
+    frac_xp = sign.data[-1][2] / n                                          # -> 1/2 as photons randomise
+    assert 0.5 < frac_xp < (1 - p) ** 10 + 0.5 and abs(sign.data[-1][3] / n - 0.5 * (1 - (1 - p) ** 10)) < 0.01
+    r = sim.download("r")
+    assert r.shape == (n, 3) and np.isfinite(r).all()
+    E = sim.download("E")
+    assert E.min() >= float(phys.light.E_from_wavelength(700e-9)) and E.max() <= float(phys.light.E_from_wavelength(200e-9))
+    with pytest.raises(NotImplementedError):
+        sim.add_obj(phys.Object())
+
+
+def test_variable_n_example_through_the_plugin_api():
+    """examples/variable_n_scattering.ipynb:52-60 with the legacy spellings, small N."""
+    import phys as old
+    import phys.light
+    import phys.newton
+    cl_n = "0.000000001 * exp(r0[gid] - 5)"
+    sim = old.Simulation(cl_on=True, exit=lambda cond: cond.t >= 0.0245)
+    sim.add_step(2, old.UpdateTimeStep(lambda c: 0.005))
+    sim.add_step(1, old.newton.NewtonianKinematicsStep())
+    sim.add_step(3, old.light.ScatterSphericalStep(0.000000000000001, 0.0000000000000000001,
+                                                   wavelength_dep_scattering=True, variable_n=True, variable_n_fn=cl_n))
+    tp = old.light.TracePathMeasureStep(None)
+    sim.add_step(0, tp)
+    np.random.seed(1)
+    sim.add_objs(old.light.generate_photons(200, bins=10, min=old.light.E_from_wavelength(200e-9),
+                                            max=old.light.E_from_wavelength(700e-9)))
+    run(sim)
+    assert len(tp.data) == 201 and len(tp.data[1]) == 1 + 5
+    # the exp() overflow regime: every photon at x > 0 scatters every step (SURVEY.md 8(d) caveat)
+    assert sim.hits > 0
+    with pytest.raises(ValueError):
+        bad = old.Simulation(cl_on=True, exit=lambda c: c.t >= 0.001)
+        bad.add_objs(old.light.generate_photons(2, min=1e-19, max=2e-19))
+        bad.add_step(0, old.UpdateTimeStep(lambda c: 0.001))
+        bad.add_step(1, old.light.ScatterSphericalStep(1, 1, variable_n=True, variable_n_fn="r0[gid+1]"))
+        bad.run()
+
+
+def test_device_info():
+    info = phys.Simulation.get_device_info()
+    assert len(info) >= 1 and all("gfx950" in k for k in info)
+
+
+def test_foreign_threads_can_poll_and_touch_objects_while_the_simulation_runs():
+    """The reference's usage pattern: the simulation runs on its own thread while the main thread polls
+    get_state() (every example) -- and may even index sim.objects.  len()/get_state never touch the device;
+    object access waits for the pass in flight, syncs the state back and the run continues from it."""
+    import time
+    sim = phys.Simulation(cl_on=True, rng="philox", seed=5, exit=lambda s: s.t >= 0.2995)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(2000)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    sim.add_step(3, sign)
+    sim.start()
+    polls, touched = 0, 0
+    while sim.running or polls == 0:
+        st = sim.get_state()
+        assert st["objects"] == 2000
+        polls += 1
+        if polls % 3 == 0 and sim.running:
+            o = sim.objects[17]                      # forces a device -> host sync between two passes
+            assert o.uid == 17 and np.isfinite(np.asarray(o.r)).all()
+            touched += 1
+        time.sleep(0.002)
+    sim.join()
+    assert sim.error is None and len(sign.data) == 300 and polls > 1
+    # the interleaved syncs did not disturb the physics: same result as an undisturbed run
+    ref = phys.Simulation(cl_on=True, rng="philox", seed=5, exit=lambda s: s.t >= 0.2995)
+    ref.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                  for i in range(2000)])
+    ref.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    ref.add_step(1, phys.newton.NewtonianKinematicsStep())
+    ref.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign2 = phys.light.ScatterSignMeasureStep(None, True)
+    ref.add_step(3, sign2)
+    run(ref)
+    assert np.array_equal(np.array(sign.data), np.array(sign2.data))
+    assert np.array_equal(np.array([np.asarray(o.r) for o in sim.objects]), np.array([np.asarray(o.r) for o in ref.objects]))
+
+
+def test_two_simulations_back_to_back_share_the_device():
+    """runtime1-style: several Simulations (contexts) in one process, one after the other and alive together."""
+    sims = []
+    for seed in (1, 2):
+        s = phys.Simulation(cl_on=True, rng="philox", seed=seed, exit=lambda c: c.t >= 0.0095)
+        s.add_objs(phys.light.generate_photons_bulk(50_000, min=1e-19, max=2e-19, seed=seed))
+        s.add_step(0, phys.UpdateTimeStep(lambda c: np.double(0.001)))
+        s.add_step(1, phys.newton.NewtonianKinematicsStep())
+        s.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001),
+                                                      variable_n=True, variable_n_fn="0.001 * exp(r1[gid] / 1e9)"))
+        sims.append(s)
+    for s in sims:
+        s.start()
+    for s in sims:
+        s.join()
+        assert s.error is None and len(s.ts) == 10 and s.hits > 0
+    assert sims[0].hits != sims[1].hits
+
+
+def test_user_step_built_on_clprogram(golden):
+    """A user-defined Step written against the reference's kernel-glue API (CLInput / CLOutput / CLProgram,
+    physicl/__init__.py:543-664): gather per-object inputs, run an OpenCL-C body, act on the result.
+    Here: an absorber like ScatterDeleteStep, with its own kernel text; checked against the oracle."""
+    from oracle import physicl_oracle as orc
+
+    class MyAbsorber(phys.Step):
+        def __init__(self, sigma):
+            self.sigma, self.prog = sigma, None
+
+        def run(self, sim):
+            if self.prog is None:
+                skip = phys.CLInput(name="only_photons", type="obj_action",
+                                    code="if type(obj) != physicl.light.PhotonObject:\n \t\t continue")
+                d = [phys.CLInput(name="d%d" % k, type="obj", obj_attr="dr[%d]" % k) for k in range(3)]
+                u = phys.CLInput(name="u", type="obj_def", obj_def="np.random.random()")
+                sg = phys.CLInput(name="sigma", type="const", const_value=str(self.sigma))
+                who = phys.CLInput(name="who", type="obj_track", obj_track="obj")
+                self.prog = phys.CLProgram(sim, "absorb", """
+                    int gid = get_global_id(0);
+                    double path = sqrt(d0[gid] * d0[gid] + d1[gid] * d1[gid] + d2[gid] * d2[gid]);
+                    gone[gid] = (sigma * path >= u[gid]) ? 1 : 0;
+                    depth[gid] = sigma * path;
+                """)
+                self.prog.prep_metadata = [skip] + d + [u, who, sg]
+                self.prog.output_metadata = [phys.CLOutput(name="gone", ctype="int"), phys.CLOutput(name="depth")]
+                self.prog.build_kernel()
+            out = self.prog.run()
+            self.last = out
+            for idx, x in enumerate(out["gone"]):
+                if x == 1:
+                    sim.remove_obj(self.prog.who[idx])
+
+    sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= 0.0025)
+    objs = [phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+            for i in range(3000)]
+    objs.insert(10, phys.Object(v=phys.Measurement([5.0, 0, 0], "m**1 s**-1"), uid=-1))     # skipped by the obj_action
+    sim.add_objs(objs)
+    absorber = MyAbsorber(np.double(1e-6))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, absorber)
+    np.random.seed(99)
+    run(sim)
+    # replay with the oracle: same random stream (one draw per photon per step), same kernel maths
+    rs = np.random.RandomState(99)
+    alive = np.arange(3000)
+    for step in range(3):
+        n = len(alive)
+        d0 = np.full(n, 299792458.0 * 0.001)
+        flags = orc.delete_flags(d0, np.zeros(n), np.zeros(n), rs.random_sample(n), 1e-6, 1.0)
+        alive = alive[orc.survivors(flags)]
+    assert [o.uid for o in sim.objects] == [*alive[alive < 10], -1, *alive[alive >= 10]]    # order kept, Object untouched
+    assert absorber.last["gone"].dtype == np.int32 and absorber.last["depth"].dtype == np.float64
+    assert np.all(absorber.last["depth"] == 1e-6 * (299792458.0 * 0.001))
+    with pytest.raises(phys._hip_error()):
+        bad = phys.CLProgram(sim, "broken", "int gid = get_global_id(0); res[gid] = undefined_symbol;")
+        bad.prep_metadata, bad.output_metadata = [phys.CLInput(name="d0", type="obj", obj_attr="dr[0]")], [phys.CLOutput(name="res")]
+        bad.build_kernel()

@@ -1,0 +1,192 @@
+"""CPU: the plugin API of the host layer (no GPU needed: cl_on=False, host plugins only)."""
+import threading
+
+import numpy as np
+import pytest
+
+import physicl_amd as phys
+import physicl_amd.light as light
+import physicl_amd.newton as newton
+
+
+def photons(n):
+    return [light.PhotonObject(v=np.array([light.c, 0, 0], dtype=np.double), E=np.double(1), uid=i) for i in range(n)]
+
+
+class Drift(phys.Step):
+    """A user plugin written against the reference API: a per-object Python loop."""
+
+    def run(self, sim):
+        for o in sim.objects:
+            o.r = o.r + np.asarray(o.v) * sim.dt
+
+
+class Reaper(phys.Step):
+    def run(self, sim):
+        for o in list(sim.objects):
+            if o.uid % 2 == 0 and sim.t >= 0.002:
+                sim.remove_obj(o)
+
+
+def test_alias_packages_expose_the_reference_names():
+    import physicl
+    import physicl.light
+    import physicl.newton
+    import phys
+    import phys.light
+    for mod in (physicl, phys):
+        for name in ("Measurement", "MeasurementError", "Step", "UpdateTimeStep", "MeasureStep", "Object",
+                     "Simulation", "CLInput", "CLOutput", "CLProgram"):
+            assert hasattr(mod, name), name
+    for name in ("c", "h", "kB", "PhotonObject", "E_from_wavelength", "wavelength_from_E", "planck_distribution",
+                 "planck_probability", "planck_phot_distribution", "generate_photons", "generate_photons_from_E",
+                 "ScatterDeleteStepReference", "ScatterDeleteStep", "ScatterIsotropicStep", "ScatterMeasureStep",
+                 "ScatterSignMeasureStep", "TracePathMeasureStep", "ScatterSphericalStep"):
+        assert hasattr(physicl.light, name) and hasattr(phys.light, name), name
+    assert physicl.newton.NewtonianKinematicsStep is newton.NewtonianKinematicsStep
+    assert physicl.Simulation is phys.Simulation is __import__("physicl_amd").Simulation
+
+
+def test_simulation_runs_host_plugins_in_insertion_order_on_its_own_thread():
+    order = []
+
+    class Tag(phys.Step):
+        def __init__(self, tag):
+            self.tag = tag
+
+        def run(self, sim):
+            order.append((self.tag, threading.current_thread() is sim))
+
+        def terminate(self, sim):
+            order.append(("end" + self.tag, True))
+
+    sim = phys.Simulation(cl_on=False, exit=lambda s: s.t >= 0.003)
+    sim.add_step(2, phys.UpdateTimeStep(lambda s: np.double(0.001)))     # keys are labels, not an order
+    sim.add_step(1, Tag("a"))
+    sim.add_step(3, Tag("b"))
+    with pytest.raises(IndexError):
+        sim.add_step(1, Tag("dup"))
+    sim.start()
+    sim.join()
+    assert order == [("a", True), ("b", True)] * 3 + [("enda", True), ("endb", True)]
+    assert sim.ts == pytest.approx([0.001, 0.002, 0.003]) and not sim.running and sim.run_time >= 0
+    sim.remove_step(3)
+    assert list(sim.steps) == [2, 1]
+
+
+def test_default_exit_state_and_get_state():
+    sim = phys.Simulation(cl_on=False)
+    assert sim.exit(sim) is True                     # no objects -> finished (physicl/__init__.py:414)
+    sim.add_objs(photons(3))
+    st = sim.get_state()
+    assert st["objects"] == 3 and set(st) == {"objects", "t", "dt", "run_time"}
+    sim.state_need_lock = True
+    assert sim.get_state()["objects"] == 3
+    assert sim.cl_ctx is None and sim.cl_q is None
+
+
+def test_legacy_constructor_spellings():
+    a = phys.Simulation({"cl_on": False, "exit": lambda c: True})
+    b = phys.Simulation(params={"cl_on": False, "bounds": np.array([1, 2, 3])})
+    assert a.cl_on is False and b.cl_on is False and list(b.bounds) == [1, 2, 3]
+
+
+def test_host_plugins_see_and_modify_real_objects():
+    sim = phys.Simulation(cl_on=False, exit=lambda s: s.t >= 0.004)
+    sim.add_objs(photons(6))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, Drift())
+    sim.add_step(2, Reaper())
+    sim.start()
+    sim.join()
+    assert sim.error is None
+    assert [o.uid for o in sim.objects] == [1, 3, 5] and len(sim.objects) == 3
+    assert float(sim.objects[0].r[0]) == pytest.approx(4 * 0.001 * 299792458.0)
+    assert sim.objects[0] in sim.objects and sim.objects.index(sim.objects[1]) == 1
+
+
+def test_device_steps_refuse_to_run_without_a_device():
+    sim = phys.Simulation(cl_on=False, exit=lambda s: s.t >= 0.001)
+    sim.add_objs(photons(2))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, newton.NewtonianKinematicsStep())
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        sim.run()
+    assert sim.running is False and isinstance(sim.error, RuntimeError)
+    for step in (light.ScatterIsotropicStep(A=1e-3, n=1e-3), light.ScatterDeleteStep(1e-3, 1e-3),
+                 light.ScatterSignMeasureStep(None)):
+        with pytest.raises(RuntimeError, match="no CPU implementation"):
+            step.run(sim)
+
+
+def test_fusion_plan_groups_only_adjacent_native_steps():
+    sim = phys.Simulation(cl_on=False)
+    sim._dev = object()                               # planning only looks at whether a device exists
+    upd, nk = phys.UpdateTimeStep(lambda s: 1e-3), newton.NewtonianKinematicsStep()
+    sc = light.ScatterIsotropicStep(A=1e-3, n=1e-3)
+    sign = light.ScatterSignMeasureStep(None)
+    meas = light.ScatterMeasureStep(None, True, [[1.0, np.nan, np.nan]])
+    dele = light.ScatterDeleteStep(1e-3, 1e-3)
+    for i, s in enumerate((upd, nk, sc, sign, meas, Drift(), nk2 := newton.NewtonianKinematicsStep(), dele)):
+        sim.add_step(i, s)
+    plan = sim._build_plan()
+    assert [k for k, _ in plan] == ["single", "fused", "single", "fused"]
+    assert plan[1][1] == [nk, sc, sign, meas] and plan[3][1] == [nk2, dele]   # Newton + Delete: one pipeline
+    sim.fuse = False
+    assert all(k == "single" for k, _ in sim._build_plan())
+    sim._dev = None
+
+
+def test_measure_step_csv_and_kernel_glue_stubs(tmp_path):
+    m = phys.MeasureStep(str(tmp_path / "out.csv"))
+    m.data = [np.array([0.001, 5, 2]), np.array([0.002, 4, 1])]
+    m.terminate(None)
+    assert (tmp_path / "out.csv").read_text().splitlines() == ["0.001, 5.0, 2.0", "0.002, 4.0, 1.0"]
+    i = phys.CLInput(name="d0", type="obj", obj_attr="dr[0]")
+    o = phys.CLOutput(name="res", ctype="int")
+    assert (i.name, i.ctype, o.ctype) == ("d0", "double", "int")
+    sim = phys.Simulation(cl_on=False)
+    prog = phys.CLProgram(sim, "k", "int gid = get_global_id(0); res[gid] = 1;")
+    prog.prep_metadata, prog.output_metadata = [i, phys.CLInput(name="A", type="const", const_value="2.5")], [o]
+    assert prog._signature() == [("double", "d0", True), ("double", "A", False), ("int", "res", True)]
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        prog.build_kernel()
+    with pytest.raises(NotImplementedError):
+        light.ScatterMeasureStep(None, True, [], measure_E=True)
+
+
+def test_kernel_constants_follow_the_reference_swap_and_code_scale():
+    sim = phys.Simulation(cl_on=False)
+    sim._hip = __import__("physicl_amd._hip", fromlist=["x"])
+    st = light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.002), wavelength_dep_scattering=True,
+                                    variable_n=True, variable_n_fn="1e-9 * exp(r0[gid] - 5)")
+    p = st._kernel_params(sim)
+    assert (p["A"], p["n"]) == (0.002, 0.001)                      # kernel A := user n (light.py:287)
+    assert p["flags"] == 3 and p["n_expr"] == "1e-9 * exp(r0[gid] - 5)"
+    assert (p["c"], p["h"]) == (299792458.0, 6.62607015e-34)
+    n = phys.Measurement(2.0e25, "m**-3")
+    assert light._kernel_const(n) == 2.0e25
+    legacy = light.ScatterSphericalStep(0.5, 0.25, wavelength_dep_scattering=True)
+    assert (legacy.n, legacy.A, legacy.wavelength_dep_scattering) == (0.5, 0.25, True)
+
+
+def test_planck_helpers_are_usable_at_setup_time():
+    d = light.planck_distribution(phys.Measurement(3e-19, "J**1"), 5778)
+    assert d.units == {"M": -1, "L": -2, "T": 2} and 0 < float(d) < 1e19
+    np.random.seed(0)
+    E = light.planck_phot_distribution(light.E_from_wavelength(2500e-9), light.E_from_wavelength(200e-9), 5778, bins=50)
+    assert E is None or 7e-20 < float(E) < 1e-18
+
+
+def test_alias_package_does_not_import_light_eagerly():
+    """Scripts set the code scale BEFORE importing physicl.light (code_unit_scale_test.ipynb:55): the alias
+    package must not create c and h behind their back."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import physicl as phys; "
+            "assert 'physicl_amd.light' not in sys.modules and 'physicl.light' not in sys.modules; "
+            "phys.Measurement.set_code_scale('m', 0.001); import physicl.light as light; "
+            "assert float(light.c) == 299792.458, float(light.c); print('ok')") % __import__("os").path.dirname(
+                __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-500:]

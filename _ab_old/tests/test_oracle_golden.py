@@ -1,0 +1,224 @@
+"""Pin the CPU oracle against the golden vectors produced by running the reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+C_LIT = 299792458.0          # str(c)           light.py:14, 301
+H_LIT = 6.62607015e-34       # str(h).upper()   light.py:15, 301
+
+# Stated tolerance for transcendental results: <= 4 ulp of |v| = c per component.
+V_ABS_TOL = 4 * np.spacing(C_LIT)
+
+
+def cols(a):
+    return [np.ascontiguousarray(a[:, i]) for i in range(3)]
+
+
+# ------------------------------------------------------------------ G1 newton: bit-exact
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_newton_bit_exact(golden, case):
+    z = golden("g1_newton")
+    r, v = cols(z["r_init"]), cols(z["v_init"])
+    dt = float(z["c%d_dt" % case])
+    for k in range(1, 11):
+        r, dr = orc.newton_euler(r, v, dt)
+        if k in (1, 10):
+            assert np.array_equal(np.stack(r, 1), z["c%d_r_after%d" % (case, k)])
+            assert np.array_equal(np.stack(dr, 1), z["c%d_dr_after%d" % (case, k)])
+
+
+def test_newton_config1(golden):
+    z = golden("g1_newton")
+    r = [np.zeros(4)] * 3
+    v = [np.full(4, C_LIT), np.zeros(4), np.zeros(4)]
+    for _ in range(100):
+        r, dr = orc.newton_euler(r, v, 0.001)
+    assert np.array_equal(np.stack(r, 1)[0], z["cfg1_r_after100"])
+    assert np.array_equal(np.stack(dr, 1)[0], z["cfg1_dr_after100"])
+
+
+# ------------------------------------------------------------------ G2 isotropic scatter, CL path
+ISO = {
+    "base": dict(use_E=False, expr=None),
+    "lambda": dict(use_E=True, expr=None),
+    "varn": dict(use_E=True, expr="0.000000001 * exp(r0[gid] - 5)"),
+    "varn_radial": dict(use_E=False,
+                        expr="2.5 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - 6.0)/(3.5))"),
+    "varn_overflow": dict(use_E=True, expr="0.000000001 * exp(r0[gid] - 5)"),
+}
+
+
+def tie_ok(pcoll, rand, mism):
+    """Hit-mask mismatches are tolerated only where pcoll and rand agree to 1e-14 relative."""
+    return np.all(np.abs(pcoll[mism] - rand[mism]) <= 1e-14 * np.abs(pcoll[mism]))
+
+
+@pytest.mark.parametrize("tag", sorted(ISO))
+def test_iso_kernel_and_writeback(golden, tag):
+    z = golden("g2_iso_" + tag)
+    cfg = ISO[tag]
+    K = int(z["K"])
+    # quirk 1: the kernel's A is the user's n and vice versa (light.py:287)
+    assert float(z["k0_A"]) == float(z["n_user"]) and float(z["k0_n"]) == float(z["A_user"])
+    prev_v = None
+    for k in range(K):
+        g = lambda nm: z["k%d_%s" % (k, nm)]
+        E = g("E") if cfg["use_E"] else None
+        r = [g("r0"), g("r1"), g("r2")] if cfg["expr"] else None
+        hit, r0, r1, r2 = orc.scatter_sphere_kernel(
+            g("d0"), g("d1"), g("d2"), g("rtheta"), g("rphi"), g("rand"), float(g("A")), float(g("n")), C_LIT,
+            h=H_LIT if cfg["use_E"] else None, E=E, n_expr=cfg["expr"], r=r, fill=-7.0)
+        ref_hit = ~np.isnan(g("res0"))
+        mism = hit != ref_hit
+        if mism.any():
+            pc = orc.scatter_pcoll(g("d0"), g("d1"), g("d2"), float(g("A")), float(g("n")), h=H_LIT, c=C_LIT,
+                                   E=E, n_expr=cfg["expr"], r=r)
+            assert tie_ok(pc, g("rand"), mism)
+        both = hit & ref_hit
+        for mine, ref in ((r0, g("res0")), (r1, g("res1")), (r2, g("res2"))):
+            assert np.max(np.abs(mine[both] - ref[both]), initial=0.0) <= V_ABS_TOL
+        # res1/res2 untouched on a miss (quirk 3): generator pre-filled them with -7
+        miss = ~ref_hit
+        assert np.all(g("res1")[miss] == -7.0) and np.all(g("res2")[miss] == -7.0)
+        # host write-back (light.py:325-331) from the REFERENCE's kernel outputs: exact
+        if prev_v is None:
+            prev_v = [np.full(len(hit), C_LIT), np.zeros(len(hit)), np.zeros(len(hit))]
+        vn, dv = orc.scatter_apply(prev_v, ref_hit, (g("res0"), g("res1"), g("res2")))
+        assert np.array_equal(np.stack(vn, 1), g("post_v"))
+        assert np.array_equal(np.stack(dv, 1), g("post_dv"))
+        prev_v = vn
+        # the kernel's d inputs are the stored dr of the Newton step (bit-exact chain)
+        assert np.array_equal(np.stack([g("d0"), g("d1"), g("d2")], 1), g("post_dr"))
+
+
+@pytest.mark.parametrize("tag", sorted(ISO))
+def test_iso_rng_order(golden, tag):
+    """Per-photon RNG order rtheta, rphi, rand from the global MT19937 stream (__init__.py:606-619)."""
+    z = golden("g2_iso_" + tag)
+    rs = np.random.RandomState(int(z["seed"]))
+    for k in range(int(z["K"])):
+        rt, rp, ra = orc.reference_draws(len(z["k%d_rand" % k]), rs)
+        assert np.array_equal(rt, z["k%d_rtheta" % k])
+        assert np.array_equal(rp, z["k%d_rphi" % k])
+        assert np.array_equal(ra, z["k%d_rand" % k])
+
+
+@pytest.mark.parametrize("tag", ["base", "varn"])
+def test_iso_chain_with_newton(golden, tag):
+    """Newton -> scatter chained over K steps from the initial state, using the reference's own
+    kernel outputs for v (so the chain stays bit-exact): r, dr must match exactly."""
+    z = golden("g2_iso_" + tag)
+    n = len(z["k0_rand"])
+    r = cols(z["init_r"])
+    v = [np.full(n, C_LIT), np.zeros(n), np.zeros(n)]
+    dt = float(z["dt"])
+    for k in range(int(z["K"])):
+        r, dr = orc.newton_euler(r, v, dt)
+        assert np.array_equal(np.stack(r, 1), z["k%d_post_r" % k])
+        assert np.array_equal(np.stack(dr, 1), z["k%d_post_dr" % k])
+        v = cols(z["k%d_post_v" % k])
+
+
+# ------------------------------------------------------------------ G5 counters (exact integers)
+@pytest.mark.parametrize("tag", sorted(ISO))
+def test_sign_and_plane_counters(golden, tag):
+    z = golden("g2_iso_" + tag)
+    planes = z["planes"]
+    for k in range(int(z["K"])):
+        v, r, dr = (cols(z["k%d_post_%s" % (k, f)]) for f in ("v", "r", "dr"))
+        row = z["sign_rows"][k]
+        assert row[1] == len(v[0])
+        assert tuple(int(x) for x in row[2:5]) == orc.sign_counts(v)
+        mrow = z["measure_rows"][k]
+        for pi, loc in enumerate(planes):
+            assert int(mrow[2 + pi]) == orc.plane_crossings(r, dr, loc)
+
+
+# ------------------------------------------------------------------ G4 delete + stable compaction
+def test_delete_flags_and_compaction(golden):
+    z = golden("g4_delete")
+    assert list(z["argnames_clprogram"]) == ["d0", "d1", "d2", "rand", "A", "n", "res"]
+    assert list(z["argnames_reference"]) == ["dx", "dy", "dz", "rand", "n", "A", "result"]
+    uid = np.arange(int(z["N"]), dtype=np.int64)
+    rs = np.random.RandomState(int(z["seed"]))
+    A_k, n_k = float(z["n_user"]), float(z["A_user"])  # swapped (light.py:236)
+    for k in range(int(z["K"])):
+        g = lambda nm: z["k%d_%s" % (k, nm)]
+        assert np.array_equal(rs.random_sample(len(uid)), g("rand"))       # one draw per photon
+        flags = orc.delete_flags(g("d0"), g("d1"), g("d2"), g("rand"), A_k, n_k)
+        assert flags.dtype == np.int32 and np.array_equal(flags, g("flags"))
+        keep = orc.survivors(flags)
+        uid = uid[keep]
+        assert np.array_equal(uid, g("survivor_uid"))
+        assert z["measure_rows"][k][1] == len(uid)
+    assert len(uid) == 0
+
+
+def test_delete_full_chain(golden):
+    """Newton + delete from the initial state with the reference's random stream: survivor ids,
+    positions and the plane-crossing rows, all exact."""
+    z = golden("g4_delete")
+    n = int(z["N"])
+    st = {"r": [np.zeros(n)] * 3, "v": [np.full(n, C_LIT), np.zeros(n), np.zeros(n)],
+          "dr": [np.zeros(n)] * 3, "dv": [np.zeros(n)] * 3, "E": np.ones(n), "id": np.arange(n, dtype=np.int64)}
+    rs = np.random.RandomState(int(z["seed"]))
+    for k in range(int(z["K"])):
+        orc.step_newton(st, float(z["dt"]))
+        orc.step_scatter_delete(st, rs.random_sample(len(st["id"])), float(z["n_user"]), float(z["A_user"]))
+        assert np.array_equal(st["id"], z["k%d_survivor_uid" % k])
+        if k < 3:
+            assert np.array_equal(np.stack(st["r"], 1), z["k%d_post_r" % k])
+        row = z["measure_rows"][k]
+        assert row[1] == len(st["id"])
+        for pi, loc in enumerate(z["planes"]):
+            assert int(row[2 + pi]) == orc.plane_crossings(st["r"], st["dr"], loc)
+        srow = z["sign_rows"][k]
+        assert tuple(int(x) for x in srow[2:5]) == orc.sign_counts(st["v"])
+
+
+# ------------------------------------------------------------------ Philox known answers
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10 (Salmon et al., SC'11 distribution)."""
+    kat = [
+        ((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+        ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+        ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+         (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)),
+    ]
+    for ctr, key, want in kat:
+        got = orc.philox4x32_10(*[np.array([x], dtype=np.uint64) for x in ctr], key[0], key[1])
+        assert tuple(int(g[0]) for g in got) == want
+
+
+def test_philox_draws_ranges_and_independence():
+    ids = np.arange(100000, dtype=np.int64)
+    rt, rp, ra = orc.philox_draws(1234, 5, ids)
+    assert 0 <= rt.min() and rt.max() < 2 * np.pi and 0 <= rp.min() and rp.max() < np.pi
+    assert 0 <= ra.min() and ra.max() < 1 and abs(ra.mean() - 0.5) < 5e-3
+    # keyed by id: a shard sees the same numbers as the whole
+    rt2, rp2, ra2 = orc.philox_draws(1234, 5, ids[40000:60000])
+    assert np.array_equal(rt2, rt[40000:60000]) and np.array_equal(ra2, ra[40000:60000])
+    # different step or seed -> different stream
+    assert not np.array_equal(orc.philox_draws(1234, 6, ids)[2], ra)
+    assert not np.array_equal(orc.philox_draws(1235, 5, ids)[2], ra)
+    # ids above 2**32 use the high counter word
+    hi = orc.philox_draws(1, 0, np.array([1 << 32, 0], dtype=np.int64))[2]
+    assert hi[0] != hi[1]
+
+
+def test_planck_table_matches_the_reference_density():
+    """Closed-form bin masses == numerical integration of the reference's planck_distribution formula
+    (physicl/light.py:53-60); sampled energies follow that table."""
+    import scipy.integrate
+    kB, T, lo, hi = 1.380649e-23, 5778.0, 7.9e-20, 9.9e-19
+    cdf, grid = orc.planck_table(lo, hi, T, 40)
+    dens = lambda E: 15 / (np.pi ** 4 * kB * T) * (E / (kB * T)) ** 3 / np.e ** (E / (kB * T))
+    edges = np.linspace(lo, hi, 40)
+    mass = np.array([scipy.integrate.quad(dens, edges[k], edges[k + 1])[0] for k in range(39)])
+    assert np.allclose(np.cumsum(mass / mass.sum()), cdf, rtol=1e-10, atol=1e-13)
+    assert np.array_equal(grid, edges[:-1]) and cdf[-1] == 1.0 and np.all(np.diff(cdf) > 0)
+    E = orc.philox_table_energy(3, np.arange(200000), cdf, grid)
+    counts = np.array([(E == g).sum() for g in grid]) / len(E)
+    assert np.max(np.abs(counts - np.diff(np.concatenate([[0.0], cdf])))) < 4e-3
