@@ -14,7 +14,14 @@ One "step" = one pass of the Simulation loop body (physicl/__init__.py:512-516):
 UpdateTimeStep -> NewtonianKinematicsStep -> ScatterIsotropicStep -> ScatterSignMeasureStep counters,
 then (N > 1) an RCCL all-reduce of the counter vector [N, hits, xp, yp, zp].
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the fused scatter step),
+Default mode "fused" with --steps-per-launch S > 1 runs S consecutive loop bodies per pass over the store
+(pcl_step_fused_multi: photons do not interact, so a photon is loaded once, stepped S times in registers and
+stored once -- bit-identical state and per-step counters, 128/S instead of 104 B of HBM traffic per
+particle-step, which turns the step from HBM-bound into VALU-bound).  The K timed steps are ceil(K/S) launches.
+--steps-per-launch 1 is the one-launch-per-step, HBM-bound path; with N=1 it is also measured in the same run
+and reported under "single_step".
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the timed region,
 timed with HIP event pairs recorded around every launch inside the timed region (pcl_prof_*).
 `cpu_baseline` = the oracle's C/OpenMP port of the same step timed on this box's host cores on a
 bounded sample of the same photons (rank 0, N=1 only).
@@ -46,13 +53,15 @@ PROFILES = {
 }
 
 
-def algorithmic_bytes_per_particle(profile, h, mode="separate"):
+def algorithmic_bytes_per_particle(profile, h, mode="separate", multi=False):
     """fp64 bytes the dominant kernel must move per particle-step (DESIGN.md 'Kernels').
     separate (k_scatter): reads dr (24) + E (8) + the position components the expression names (8 each),
         writes dv (24, always); a hit additionally reads v_old (24) and writes v' (24): 64 + 48h here.
     fused-eager (k_fused = Newton + scatter + counters): reads r (24) + v (24) + E (8); writes r (24) +
         dr (24) + dv (24); a hit additionally writes v' (24): 128 + 24h.
     fused (PCL_FUSED_LAZY): dr and dv stay implicit (derivable from the v double buffer): 104, hit or miss."""
+    if mode == "fused" and multi:   # per LAUNCH of S steps: reads r (24) + v (24) + lam4 (8); writes r (24) + v (24) + v_prev (24)
+        return 128.0
     if mode == "fused":      # lazy: reads r (24) + v (24) + E (8); writes r (24) + v (24, double buffer)
         return 104.0
     if mode == "fused-eager":
@@ -71,6 +80,9 @@ def main():
                     help="fused: the loop body as ONE kernel with dr/dv left implicit (pcl_step_fused, "
                          "PCL_FUSED_LAZY); fused-eager: one kernel, dr/dv written every step; "
                          "separate: one kernel per Step")
+    ap.add_argument("--steps-per-launch", type=int, default=16,
+                    help="fused mode: loop bodies per pass over the store (1 = one launch per step, HBM-bound; "
+                         "1..64; results are bit-identical for every value)")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f64 = the reference's precision (the headline number); f32 = precision-sweep build")
@@ -105,6 +117,7 @@ def main():
 
     sim_t = 0.0
     totals = None
+    S = max(1, min(64, args.steps_per_launch)) if args.mode == "fused" else 1
 
     fused_sc = lambda k: dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
                               n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k)
@@ -130,12 +143,31 @@ def main():
         return np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
                          cnt[_hip.CNT_ZP]], dtype=np.int64)
 
+    def run_multi(k0, k1):
+        """Steps k0..k1-1 as ceil((k1-k0)/S) passes of S loop bodies each; one all-reduce of the S x 5 per-step
+        counters per pass."""
+        nonlocal totals, sim_t
+        hits = 0
+        k = k0
+        while k < k1:
+            ks = min(S, k1 - k)
+            for _ in range(ks):
+                sim_t += prof["dt"]                                      # UpdateTimeStep   __init__.py:337-343
+            rows = dev.step_fused_multi(prof["dt"], ks, fused_sc(k))
+            c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
+            hits += int(c[:, 1].sum())
+            totals = comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
+            k += ks
+        return hits
+
     def run_steps(k0, k1):
         """Steps k0..k1-1, software-pipelined: step k+1 is enqueued BEFORE the host waits for step k's counters
         (two counter banks in the library), so the GPU never idles on Python; the all-reduce of step k's
         counters (RCCL over xGMI when world > 1) runs while the GPU computes step k+1 -- counters are consumed
         one step behind; the last one is read and reduced inside the timed region."""
         nonlocal totals
+        if S > 1:
+            return run_multi(k0, k1)
         hits = 0
         if not args.mode.startswith("fused") or os.environ.get("PCL_BENCH_NOPIPE"):
             for k in range(k0, k1):
@@ -174,10 +206,35 @@ def main():
     kern = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}
     dev.prof_enable(False)
     h_mean = hits_local / float(N * args.steps)
-    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode) * (0.5 if args.dtype == "f32" else 1.0)
-    dominant = "k_fused" if args.mode.startswith("fused") else "k_scatter"
+    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode, S > 1) * (0.5 if args.dtype == "f32" else 1.0)
+    dominant = ("k_multi" if S > 1 else "k_fused") if args.mode.startswith("fused") else "k_scatter"
     sc = kern[dominant]
     achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
+
+    single = None
+    if S > 1 and world == 1:
+        # the one-launch-per-step path on the same store, same run: the HBM-bound kernel's own roofline line
+        S_keep, S = S, 1
+        totals_main = totals
+        k_next = args.warmup + args.steps
+        run_steps(k_next, k_next + 3)
+        dev.prof_enable(True)
+        dev.sync()
+        t1 = time.perf_counter()
+        h1 = run_steps(k_next + 3, k_next + 3 + args.steps)
+        dev.sync()
+        el1 = time.perf_counter() - t1
+        k1 = dev.prof_read(_hip.PROF_FUSED)
+        dev.prof_enable(False)
+        S, totals = S_keep, totals_main
+        b1 = 104.0 * (0.5 if args.dtype == "f32" else 1.0)
+        a1 = N * b1 / (k1["avg_ms"] * 1e-3) / 1e9 if k1["launches"] else 0.0
+        single = {"value": N * args.steps / el1, "unit": "particle-steps/s", "ms_per_step": el1 / args.steps * 1e3,
+                  "steps": args.steps,
+                  "roofline": {"bound": "hbm", "kernel": "k_fused (one launch per step, dr/dv implicit)", "achieved": a1,
+                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBPS,
+                               "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1["avg_ms"],
+                               "launches": k1["launches"], "hit_fraction": h1 / float(N * args.steps)}}
 
     out = None
     if rank == 0:
@@ -187,7 +244,11 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             t = json.load(open(tfile)).get("%s:%s%s:%d" % (args.profile, args.mode, "-f32" if args.dtype == "f32" else "", N))
+            valu = None
             traffic = t.get(dominant + "_bytes_per_launch") if t else None
+            valu = t.get(dominant + "_valu") if t else None
+            if single is not None and t:
+                single["roofline"]["traffic"] = t.get("k_fused_bytes_per_launch")
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -197,16 +258,21 @@ def main():
                                    "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N,
                                       " + %s all-reduce of 5 int64 counters" % ("RCCL" if comm.backend == "nccl" else "gloo") if world > 1 else ""),
-                       "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "variable_n_fn": prof["expr"], "dt": prof["dt"],
+                       "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "steps_per_launch": S,
+                       "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
+                         "kernel": (("k_multi: %d x (Newton + ScatterIsotropic + counters) per pass over the store (hipRTC "
+                                     "variable-n), dr/dv implicit; VALU-bound by construction -- see 'valu' and single_step" % S)
+                                    if S > 1 else
+                                    "k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
                                     % (", dr/dv implicit" if args.mode == "fused" else "")
                                     if args.mode.startswith("fused") else
                                     "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
-                         "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"]},
+                         "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"], "steps_per_launch": S,
+                         "valu": valu},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if v["launches"]},
             "kernels_GBps": {
                 "k_newton": N * 96 / (kern["k_newton"]["avg_ms"] * 1e-3) / 1e9 if kern["k_newton"]["launches"] else None,
@@ -216,6 +282,8 @@ def main():
                                    "yp": int(totals[3]), "zp": int(totals[4])},
             "device": dev.info()["name"],
         }
+        if single is not None:
+            out["single_step"] = single
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
             out["cpu_baseline"] = cpu_baseline(dev, args, prof)
             out["cpu_baseline_python"] = cpu_baseline_python(dev, args, prof)

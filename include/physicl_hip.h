@@ -125,6 +125,7 @@ int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
 #define PCL_PROF_COMPACT     3 /* k_compact                        */
 #define PCL_PROF_COUNTERS    4 /* k_counters                       */
 #define PCL_PROF_FUSED       5 /* k_fused / hipRTC specialisation  */
+#define PCL_PROF_MULTI       6 /* k_multi / hipRTC specialisation  */
 int pcl_prof_enable(pcl_ctx *ctx, int on);
 int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out,
                   double *min_ms_out, double *max_ms_out);
@@ -256,6 +257,23 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
 int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, int flags, double c,
                    double h, const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                    const double *planes_host, int n_planes, int64_t *out_host);
+
+/* 1 if every particle is a photon and ids are implicit (id_base + index: nothing has been compacted or uploaded
+ * with explicit ids/kinds) -- the precondition of pcl_step_fused_multi and of the fast single-step kernel. */
+int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out);
+
+/* k_steps consecutive fused steps (Newton + ScatterIsotropic + sign counters) in ONE pass over the store.  Photons
+ * do not interact, so each one is loaded once, advanced k_steps times in registers -- the very operations of
+ * k_steps calls of pcl_step_fused(dt, 1, ..., PCL_FUSED_LAZY, PCL_RNG_PHILOX, seed, step0 + k) in the same order --
+ * and stored once: results and per-step counters are bit-identical to the step-by-step sequence while the HBM
+ * traffic per particle-step falls from 104 B to 128 / k_steps B (fp64).  It is the device side of a run whose
+ * passes are [UpdateTimeStep][NewtonStep][ScatterIsotropicStep][counting measures] with nothing on the host
+ * looking at the photons in between (physicl/__init__.py:441-448 runs the same steps every pass).
+ * Requirements: all-photon store with implicit ids (no compaction yet), device RNG; dr/dv are left implicit
+ * exactly as after the last single lazy step.  flags: PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N.
+ * out_host (may be NULL): int64[k_steps][5] = { N, xp, yp, zp, hits } per step; 1 <= k_steps <= 64. */
+int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int flags, double c, double h,
+                         const char *n_expr, uint64_t seed, uint32_t step0, int64_t *out_host);
 
 /* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
  * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --

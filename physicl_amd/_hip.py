@@ -21,9 +21,9 @@ DTYPE_F64, DTYPE_F32 = 0, 1
 _NP_DTYPE = {DTYPE_F64: np.float64, DTYPE_F32: np.float32}
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
-PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED = range(6)
+PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED, PROF_MULTI = range(7)
 PROF_NAMES = {PROF_NEWTON: "k_newton", PROF_SCATTER: "k_scatter", PROF_DELETE_MASK: "k_delete_mask",
-              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused"}
+              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused", PROF_MULTI: "k_multi"}
 ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
              -6: "PCL_ERR_NOMEM"}
 
@@ -91,6 +91,9 @@ _PROTOTYPES = {
     "pcl_step_newton": [_vp, c_double],
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
+    "pcl_store_is_uniform": [_vp, POINTER(c_int)],
+    "pcl_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
+                             c_uint32, _vp],
     "pcl_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                        c_uint32, _vp, c_int, _vp],
     "pcl_step_fused_read": [_vp, c_int, _vp],
@@ -439,6 +442,27 @@ class Device:
         if out is None:
             return None
         return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + npl].copy(), "hits": int(out[4 + npl])}
+
+    def is_uniform(self):
+        """All photons with implicit ids: eligible for step_fused_multi."""
+        u = c_int()
+        check(self.lib.pcl_store_is_uniform(self.ctx, byref(u)))
+        return bool(u.value)
+
+    def step_fused_multi(self, dt, k_steps, scatter, sync=True):
+        """``k_steps`` consecutive lazy fused steps (Newton + ScatterIsotropic + sign counters, device RNG, launch
+        indices scatter['step'] .. +k_steps-1) in one pass over the store.  Returns a list of k_steps dicts like
+        step_fused's (or None if not sync)."""
+        sc = scatter
+        out = np.zeros((k_steps, 5), dtype=np.int64) if sync else None
+        expr = sc.get("n_expr")
+        check(self.lib.pcl_step_fused_multi(
+            self.ctx, float(dt), int(k_steps), float(sc["A"]), float(sc["n"]), int(sc.get("flags", 0)),
+            float(sc.get("c", 0.0)), float(sc.get("h", 0.0)), expr.encode() if expr is not None else None,
+            int(sc.get("seed", 0)), int(sc.get("step", 0)) & 0xFFFFFFFF, out.ctypes.data_as(c_void_p) if sync else None))
+        if out is None:
+            return None
+        return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4].copy(), "hits": int(o[4])} for o in out]
 
     def step_fused_read(self, n_planes=0):
         """Counters of the last ``step_fused(..., sync=False)``: same dict as the synchronous call."""

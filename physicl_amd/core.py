@@ -204,6 +204,13 @@ class Simulation(threading.Thread):
                as ONE kernel (bit-identical results)
       comm     a physicl_amd.dist.CounterComm: this process owns one index shard of the particles;
                counters (alive, hits, measure rows) are all-reduced
+      steps_per_launch
+               K > 1 (opt-in, default 1): when every pass of the loop is exactly
+               [UpdateTimeStep][NewtonianKinematicsStep][ScatterIsotropicStep][plane-less counting measures], rng is
+               "philox" and all objects are photons, up to K passes run as ONE pass over the device store
+               (photons do not interact; state, ``hits`` and every measure row are bit-identical to K=1).  The host
+               side of those passes -- the time update and ``exit(sim)`` -- is evaluated ahead of the launch, so
+               ``exit`` may depend on ``t``/``ts``/``dt`` and the object count only, not on measured data.
     """
 
     def __init__(self, *args, **kwargs):
@@ -224,6 +231,7 @@ class Simulation(threading.Thread):
         self.seed = 0
         self.fuse = True
         self.comm = None
+        self.steps_per_launch = 1
         for attr, val in kwargs.items():
             setattr(self, attr, val)
         self.dt = Measurement(np.double(0), "s**1")
@@ -495,6 +503,9 @@ class Simulation(threading.Thread):
         key = tuple(id(s) for s in self.steps.values()) + (self.fuse,)
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan()
+        if self.steps_per_launch > 1 and self._multi_eligible():
+            self._run_multi(self._plan[0][1], self._plan[1][1])
+            return
         for kind, item in self._plan:
             if kind == "fused":
                 self._run_fused(item)
@@ -508,6 +519,54 @@ class Simulation(threading.Thread):
                     item.run(self)
                 finally:
                     self._readonly_scope = False
+
+    def _multi_eligible(self):
+        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + plane-less counting measures], device RNG,
+        uniform photon store: K passes can run as one launch (pcl_step_fused_multi)."""
+        plan = self._plan
+        if len(plan) != 2 or plan[0][0] != "single" or type(plan[0][1]) is not UpdateTimeStep or plan[1][0] != "fused":
+            return False
+        group = plan[1][1]
+        roles = [s._fuse_role for s in group]
+        if roles[:2] != ["newton", "scatter_iso"] or any(r != "measure" for r in roles[2:]):
+            return False
+        if any(s._n_planes() for s in group[2:]) or self._rng_mode() != self._hip.RNG_PHILOX:
+            return False
+        self._to_device()
+        return self._dev.is_uniform()
+
+    def _run_multi(self, upd, group):
+        """Up to ``steps_per_launch`` passes of the loop in one launch.  The host part of each pass (time update,
+        then the exit test the outer loop would make before the next pass) runs first; the device then advances the
+        photons through all of them in one pass over the store and returns one counter row per pass."""
+        dev = self._dev
+        times, dt0 = [], None
+        while len(times) < self.steps_per_launch:
+            before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
+            upd.run(self)
+            if dt0 is None:
+                dt0 = self._dt_code()
+            elif self._dt_code() != dt0:              # the time step changed: that pass belongs to the next launch
+                self.t, self.dt = before
+                self.ts.pop()
+                break
+            times.append((copy.deepcopy(self.t), self.dt))
+            if len(times) < self.steps_per_launch and self.exit(self):
+                break
+        k = len(times)
+        scatter, measures = group[1], group[2:]
+        sc = scatter._kernel_params(self)
+        sc.update(rng_mode=self._hip.RNG_PHILOX, seed=self.seed, step=self._launch + 1)
+        self._launch += k
+        self._scattered = True
+        rows = dev.step_fused_multi(dt0, k, sc)
+        flat = np.array([[o["N"], o["hits"]] + list(o["sign"]) for o in rows], dtype=np.int64)
+        glob = self._global(flat.reshape(-1)).reshape(k, 5)
+        for (t, dt), g in zip(times, glob):
+            self.t, self.dt = t, dt                   # each row carries its own pass's time
+            for m in measures:
+                m._record(self, int(g[0]), g[2:5], g[5:5])
+        self.hits = int(glob[-1][1])
 
     def _run_fused(self, group):
         self._to_device()

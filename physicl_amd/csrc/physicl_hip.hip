@@ -185,6 +185,10 @@ template <typename T, bool USE_E>
 __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
     pcl_fast_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
 }
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
+    pcl_multi_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
+}
 
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
 // store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
@@ -724,6 +728,7 @@ struct rtc_entry {
     hipFunction_t scatter[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [dtype][USE_E]
     hipFunction_t fused[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t fast[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 
 } // namespace
@@ -776,6 +781,7 @@ struct pcl_ctx {
     bool hits_on_host = true; // h_cnt[0] holds the hit count of the most recent scatter step
     // two counter banks for pcl_step_fused calls that do not synchronise: step k+1 is enqueued before the host
     // reads step k's counters, so the GPU never waits for Python (pcl_step_fused_read drains them in order)
+    uint64_t *d_multi = nullptr, *h_multi = nullptr; // 4 * PCL_MULTI_MAX counters of a K-step pass
     uint64_t *d_bank[2] = {nullptr, nullptr};
     uint64_t *h_bank[2] = {nullptr, nullptr};
     hipEvent_t bank_ev[2] = {nullptr, nullptr};
@@ -1014,8 +1020,9 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
     std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
-    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+    const char *extra = getenv("PCL_RTC_DEFINE"); // timing experiments only: e.g. -DPCL_ABLATE_TRIG
+    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra};
+    r = hiprtcCompileProgram(prog, (extra && *extra) ? 5 : 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -1052,6 +1059,8 @@ int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &cod
             PCL_HIP(hipModuleGetFunction(&ent.fused[d][e], ent.module, nm));
             snprintf(nm, sizeof nm, "pcl_rtc_fast_%se%d", dt_tag[d], e);
             PCL_HIP(hipModuleGetFunction(&ent.fast[d][e], ent.module, nm));
+            snprintf(nm, sizeof nm, "pcl_rtc_multi_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.multi[d][e], ent.module, nm));
         }
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
@@ -1228,6 +1237,41 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
         else
             hipLaunchKernelGGL((k_fast<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
         PCL_TRY(launch_check("k_fast"));
+    }
+    prof_end(ctx, ps);
+    return PCL_OK;
+}
+
+template <typename T>
+int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c,
+                 double h, uint64_t seed, uint32_t step) {
+    const int64_t N = ctx->count;
+    if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
+    pcl_multi_args<T> f{};
+    f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
+    f.v0 = F<T>(ctx, PCL_V0); f.v1 = F<T>(ctx, PCL_V1); f.v2 = F<T>(ctx, PCL_V2);
+    f.vp0 = static_cast<T *>(ctx->vprev[0]); f.vp1 = static_cast<T *>(ctx->vprev[1]); f.vp2 = static_cast<T *>(ctx->vprev[2]);
+    f.lam4 = static_cast<const T *>(ctx->lam4);
+    f.E = F<T>(ctx, PCL_E);
+    f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_multi);
+    f.id_base = ctx->id_base;
+    f.N = N;
+    f.ts = tile_stride(ctx);
+    f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
+    f.seed = seed;
+    f.step = step;
+    f.K = k_steps;
+    const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    const int ps = prof_begin(ctx, PCL_PROF_MULTI);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL((k_multi<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        else
+            hipLaunchKernelGGL((k_multi<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        PCL_TRY(launch_check("k_multi"));
     }
     prof_end(ctx, ps);
     return PCL_OK;
@@ -1476,6 +1520,11 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
             return fail(PCL_ERR_HIP, "context resource allocation failed");
         }
     }
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_multi), 4 * PCL_MULTI_MAX * sizeof(uint64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_multi), 4 * PCL_MULTI_MAX * sizeof(uint64_t)) != hipSuccess) {
+        pcl_ctx_destroy(c);
+        return fail(PCL_ERR_HIP, "context resource allocation failed");
+    }
     c->cnt_target = c->d_cnt;
     *ctx_out = c;
     return PCL_OK;
@@ -1490,6 +1539,8 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
         if (kv.second.module) (void)hipModuleUnload(kv.second.module);
     if (ctx->d_cnt) (void)hipFree(ctx->d_cnt);
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
+    if (ctx->d_multi) (void)hipFree(ctx->d_multi);
+    if (ctx->h_multi) (void)hipHostFree(ctx->h_multi);
     for (int b = 0; b < 2; ++b) {
         if (ctx->d_bank[b]) (void)hipFree(ctx->d_bank[b]);
         if (ctx->h_bank[b]) (void)hipHostFree(ctx->h_bank[b]);
@@ -2096,6 +2147,54 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
         ctx->hits_on_host = true;
         for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
         out_host[4 + np] = (int64_t)ctx->h_cnt[0];
+    }
+    return PCL_OK;
+}
+
+int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out) {
+    PCL_TRY(need_store_raw(ctx));
+    if (!uniform_out) return fail(PCL_ERR_ARG, "uniform_out is NULL");
+    *uniform_out = (!ctx->kind && ctx->ids_iota) ? 1 : 0;
+    return PCL_OK;
+}
+
+int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int flags, double c, double h,
+                         const char *n_expr, uint64_t seed, uint32_t step0, int64_t *out_host) {
+    PCL_TRY(need_store_raw(ctx));
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (k_steps < 1 || k_steps > PCL_MULTI_MAX) return fail(PCL_ERR_ARG, "k_steps outside [1, %d]", PCL_MULTI_MAX);
+    if (ctx->kind || !ctx->ids_iota)
+        return fail(PCL_ERR_STATE, "pcl_step_fused_multi needs an all-photon store with implicit ids (use pcl_step_fused)");
+    if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    const int64_t N = ctx->count;
+    if (out_host)
+        for (int k = 0; k < k_steps; ++k) {
+            out_host[5 * k] = N;
+            for (int j = 1; j < 5; ++j) out_host[5 * k + j] = 0;
+        }
+    if (N == 0) return PCL_OK;
+    // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)4 * k_steps * sizeof(uint64_t), ctx->stream));
+    ctx->hits_on_host = false;
+    ctx->last_async_bank = -1;
+    PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0),
+                         step_multi_t<float>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0)));
+    ctx->lazy_dv = true; // vprev rows = v before the last step
+    ctx->lazy_dr = true;
+    ctx->lazy_dt = dt;
+    // pcl_store_last_scatter_hits() reports the last of the K steps
+    PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + 4 * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (out_host) {
+        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)4 * k_steps * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < k_steps; ++k) {
+            for (int j = 0; j < 3; ++j) out_host[5 * k + 1 + j] = (int64_t)ctx->h_multi[4 * k + 1 + j];
+            out_host[5 * k + 4] = (int64_t)ctx->h_multi[4 * k];
+        }
     }
     return PCL_OK;
 }

@@ -1,0 +1,157 @@
+"""GPU parity of pcl_step_fused_multi: K fused steps in one pass over the store.
+
+Bars: bit-identical -- state (r, v, dr, dv, E) and every per-step counter -- to K calls of the single-step
+lazy fused path (itself pinned to the reference / the oracle in test_gpu_parity.py), for fp64 and fp32,
+every scatter variant and ragged sizes; and, against the CPU oracle run K steps on its own, equal hit /
+sign counters per step with positions within K * dt * 4 ulp(c) (the oracle's libm sin/cos differ from
+OCML's by <= 4 ulp of c in a scattered velocity, which then feeds the later Euler steps).
+"""
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+H_LIT = 6.62607015e-34
+V_ABS_TOL = 4 * np.spacing(C_LIT)
+EXPR_EX = "0.000000001 * exp(r0[gid] - 5)"
+EXPR_RAD = "2.5 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - 6.0)/(3.5))"
+CASES = {
+    # tag: (use_E, expr, A, n, dt)
+    "base": (False, None, 1e-3, 1e-3, 1e-3),
+    "lambda": (True, None, 1e-15, 1e-19, 5e-3),
+    "varn": (True, EXPR_EX, 1e-15, 1e-19, 1e-9),
+    "varn_radial": (False, EXPR_RAD, 1e-9, 1.0, 1e-9),
+}
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from physicl_amd import _hip
+    return _hip
+
+
+@pytest.fixture()
+def make_store(hip):
+    devs = []
+
+    def make(capacity, dtype="f64"):
+        d = hip.Device(0)
+        d.store_alloc(capacity, dtype)
+        devs.append(d)
+        return d
+    yield make
+    for d in devs:
+        d.close()
+
+
+def scatter_dict(hip, tag, seed, step):
+    use_e, expr, A, n, dt = CASES[tag]
+    flags = (hip.SCATTER_WAVELENGTH if use_e else 0) | (hip.SCATTER_VARIABLE_N if expr else 0)
+    return dict(A=A, n=n, flags=flags, c=C_LIT, h=H_LIT, n_expr=expr, rng_mode=hip.RNG_PHILOX, seed=seed, step=step), dt
+
+
+def initial(N, dtype, seed):
+    rs = np.random.RandomState(seed)
+    npdt = np.float64 if dtype == "f64" else np.float32
+    return {"r": rs.uniform(-8, 8, (N, 3)).astype(npdt), "v": np.tile([C_LIT, 0.0, 0.0], (N, 1)).astype(npdt),
+            "E": rs.uniform(2.8e-19, 9.9e-19, N).astype(npdt), "id_base": 7_000_000_001}
+
+
+def state_equal(a, b):
+    assert np.array_equal(a["E"], b["E"])
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(a[f][k], b[f][k]), (f, k)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag", sorted(CASES))
+@pytest.mark.parametrize("N,K", [(1, 1), (2, 3), (777, 5), (2049, 2), (200_001, 7), (65_537, 64)])
+def test_multi_is_bit_identical_to_single_steps(make_store, hip, tag, N, K, dtype):
+    init = initial(N, dtype, N + K)
+    seed, step0 = 0xC0FFEE1234, 11
+    a = make_store(N, dtype)
+    a.upload_state(init)
+    single = []
+    for k in range(K):
+        sc, dt = scatter_dict(hip, tag, seed, step0 + k)
+        o = a.step_fused(dt, sc, [], lazy=True)
+        single.append((o["N"], o["hits"], list(o["sign"])))
+    b = make_store(N, dtype)
+    b.upload_state(init)
+    sc, dt = scatter_dict(hip, tag, seed, step0)
+    rows = b.step_fused_multi(dt, K, sc)
+    assert [(o["N"], o["hits"], list(o["sign"])) for o in rows] == single
+    assert b.last_scatter_hits() == single[-1][1]
+    state_equal(a.download_state(), b.download_state())         # includes the implicit dr / dv of the last step
+
+
+def test_multi_chains_with_single_steps_and_consumers(make_store, hip):
+    """multi -> single lazy step -> multi -> delete: the implicit dr/dv hand-over works in every direction."""
+    N, tag = 30_011, "varn"
+    init = initial(N, "f64", 5)
+    seed = 99
+    out = []
+    for use_multi in (False, True):
+        d = make_store(N)
+        d.upload_state(init)
+        log, step = [], 0
+        for chunk in (4, 1, 3):
+            sc, dt = scatter_dict(hip, tag, seed, step)
+            if use_multi and chunk > 1:
+                log += [(o["hits"], list(o["sign"])) for o in d.step_fused_multi(dt, chunk, sc)]
+            else:
+                for k in range(chunk):
+                    sc, dt = scatter_dict(hip, tag, seed, step + k)
+                    o = d.step_fused(dt, sc, [], lazy=True)
+                    log.append((o["hits"], list(o["sign"])))
+            step += chunk
+        mid = d.download_state()
+        alive, removed = d.step_scatter_delete(1e-3, 1e-3, hip.RNG_PHILOX, seed, 1000)   # reads the real dr
+        out.append((log, mid, alive, removed, d.download_state()))
+    assert out[0][0] == out[1][0] and out[0][2:4] == out[1][2:4]
+    state_equal(out[0][1], out[1][1])
+    state_equal(out[0][4], out[1][4])
+    assert np.array_equal(out[0][4]["id"], out[1][4]["id"])
+
+
+@pytest.mark.parametrize("tag", ["base", "varn"])
+def test_multi_vs_oracle_chain(make_store, hip, tag):
+    N, K = 1000, 6
+    init = initial(N, "f64", 42)
+    use_e, expr, A, n, dt = CASES[tag]
+    st = {"r": [np.ascontiguousarray(init["r"][:, k]) for k in range(3)],
+          "v": [np.ascontiguousarray(init["v"][:, k]) for k in range(3)],
+          "dr": [np.zeros(N)] * 3, "dv": [np.zeros(N)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64) + init["id_base"]}
+    seed, step0 = 2024, 3
+    ref = []
+    for k in range(K):
+        orc.step_newton(st, dt)
+        hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, step0 + k, st["id"]), A, n, C_LIT, h=H_LIT,
+                                         use_E=use_e, n_expr=expr)
+        ref.append((int(hit.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+    d = make_store(N)
+    d.upload_state(init)
+    sc, _ = scatter_dict(hip, tag, seed, step0)
+    rows = d.step_fused_multi(dt, K, sc)
+    assert [(o["hits"], list(o["sign"])) for o in rows] == ref
+    s = d.download_state()
+    assert np.max(np.abs(np.stack(s["v"], 1) - np.stack(st["v"], 1))) <= V_ABS_TOL
+    assert np.max(np.abs(np.stack(s["r"], 1) - np.stack(st["r"], 1))) <= K * dt * V_ABS_TOL + 1e-15
+
+
+def test_multi_state_errors(make_store, hip):
+    d = make_store(100)
+    d.upload_state({"v": np.ones((100, 3)), "E": np.ones(100)})
+    sc, dt = scatter_dict(hip, "base", 1, 0)
+    with pytest.raises(hip.HipError):
+        d.step_fused_multi(dt, 0, sc)
+    with pytest.raises(hip.HipError):
+        d.step_fused_multi(dt, 65, sc)
+    d.upload_kind(np.zeros(100, dtype=np.uint8))                   # a store with plain Objects: not eligible
+    with pytest.raises(hip.HipError):
+        d.step_fused_multi(dt, 2, sc)

@@ -364,3 +364,58 @@ def test_user_step_built_on_clprogram(golden):
         bad = phys.CLProgram(sim, "broken", "int gid = get_global_id(0); res[gid] = undefined_symbol;")
         bad.prep_metadata, bad.output_metadata = [phys.CLInput(name="d0", type="obj", obj_attr="dr[0]")], [phys.CLOutput(name="res")]
         bad.build_kernel()
+
+
+# ============================================================================ steps_per_launch (K passes per launch)
+def _batch_sim(n, K, t_end, dt_fn=lambda s: np.double(0.001), **kw):
+    sim = phys.Simulation(cl_on=True, seed=77, exit=lambda s: s.t >= t_end, steps_per_launch=K, **kw)
+    sim.add_objs(phys.light.generate_photons_bulk(n, min=phys.light.E_from_wavelength(700e-9),
+                                                  max=phys.light.E_from_wavelength(200e-9), seed=5))
+    sim.add_step(0, phys.UpdateTimeStep(dt_fn))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.002), wavelength_dep_scattering=False))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    count = phys.light.ScatterMeasureStep(None, True, [])
+    sim.add_step(3, sign)
+    sim.add_step(4, count)
+    return sim, sign, count
+
+
+@pytest.mark.parametrize("K", [2, 5, 64])
+def test_steps_per_launch_is_bit_identical_to_one_pass_per_launch(K):
+    """13 passes in launches of K: same ts, same measure rows (each with its own pass's t), same hits, same state."""
+    n, t_end = 300_001, 0.0125
+    ref, ref_sign, ref_count = _batch_sim(n, 1, t_end)
+    run(ref)
+    sim, sign, count = _batch_sim(n, K, t_end)
+    run(sim)
+    assert len(ref.ts) == 13 and [float(t) for t in sim.ts] == [float(t) for t in ref.ts] and float(sim.t) == float(ref.t)
+    assert len(sign.data) == 13 and len(count.data) == 13
+    for a, b in zip(sign.data + count.data, ref_sign.data + ref_count.data):
+        assert [float(x) for x in a] == [float(x) for x in b]
+    assert sim.hits == ref.hits
+    for f in ("r", "v", "dr", "dv", "E", "id"):
+        assert np.array_equal(sim.download(f), ref.download(f)), f
+
+
+def test_steps_per_launch_with_changing_dt_and_ineligible_plans():
+    """A time step that changes mid-run splits the launch at the change; a pass with a host plugin, host randoms or
+    plane measures is simply run one launch per pass."""
+    n = 50_001
+    dt_fn = lambda s: np.double(0.001 if len(s.ts) < 4 else 0.0005)
+    ref, ref_sign, _ = _batch_sim(n, 1, 0.0073, dt_fn)
+    run(ref)
+    sim, sign, _ = _batch_sim(n, 8, 0.0073, dt_fn)
+    run(sim)
+    assert [float(t) for t in sim.ts] == [float(t) for t in ref.ts] and len(ref.ts) == 11
+    assert [[float(x) for x in r] for r in sign.data] == [[float(x) for x in r] for r in ref_sign.data]
+    assert np.array_equal(sim.download("r"), ref.download("r")) and np.array_equal(sim.download("dv"), ref.download("dv"))
+    # plane measure in the pass: not eligible, still correct
+    out = []
+    for K in (1, 8):
+        s, sg, _ = _batch_sim(n, K, 0.0045)
+        pl = phys.light.ScatterMeasureStep(None, True, [[100.0, np.nan, np.nan]])
+        s.add_step(5, pl)
+        run(s)
+        out.append(([[float(x) for x in r] for r in pl.data], s.download("v")))
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
