@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s and achieved HBM GB/s of the photon time-step hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 64 --warmup 32        (the defaults: warm-up and timed launches all 32 steps long)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -72,15 +72,15 @@ def algorithmic_bytes_per_particle(profile, h, mode="separate", multi=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--photons", type=float, default=1e8, help="photons PER GPU (weak scaling)")
     ap.add_argument("--profile", choices=sorted(PROFILES), default="example")
     ap.add_argument("--mode", choices=("fused", "fused-eager", "separate"), default="fused",
                     help="fused: the loop body as ONE kernel with dr/dv left implicit (pcl_step_fused, "
                          "PCL_FUSED_LAZY); fused-eager: one kernel, dr/dv written every step; "
                          "separate: one kernel per Step")
-    ap.add_argument("--steps-per-launch", type=int, default=16,
+    ap.add_argument("--steps-per-launch", type=int, default=32,
                     help="fused mode: loop bodies per pass over the store (1 = one launch per step, HBM-bound; "
                          "1..64; results are bit-identical for every value)")
     ap.add_argument("--seed", type=int, default=1234)

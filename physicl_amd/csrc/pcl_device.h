@@ -5,7 +5,8 @@
 // Arithmetic contract (see DESIGN.md "Numerics"): everything the reference kernels compute with
 // + - * / sqrt is evaluated left to right in IEEE arithmetic with NO fma contraction (the library is
 // built with -ffp-contract=off and hiprtc gets the same flag), so fp64 results are bit-identical
-// to the CPU oracle.  sin/cos/exp/pow come from ROCm's OCML.  The reference is fp64-only
+// to the CPU oracle.  exp/pow come from ROCm's OCML; fp64 sin/cos of the scatter angles from pcl_sincos.h
+// (< 1 ulp, OCML outside [0, 6.5]); fp32 sin/cos from OCML.  The reference is fp64-only
 // (physicl/__init__.py:613); the fp32 instantiations (T = float) exist for the precision sweep of
 // BASELINE.json configs[4] and are bit-exact against the oracle's float32 restatement.
 #ifndef PCL_DEVICE_H
@@ -14,6 +15,9 @@
 typedef long long pcl_i64;
 typedef unsigned long long pcl_u64;
 typedef unsigned int pcl_u32;
+
+#define PCL_SC_FN __device__ __forceinline__
+#include "pcl_sincos.h" /* build.py splices the file in here for the hipRTC copy of this text */
 
 #define PCL_PI 3.141592653589793 /* == numpy.pi */
 #define PCL_RNG_IN 0
@@ -89,7 +93,21 @@ template <> struct pcl_rt<double> {
         s = x * 0.1;
         c = 1.0 - s;
 #else
-        sincos(x, &s, &c);
+        // the step's own angles lie in [0, 2*pi] (light.py:285): short reduction, < 1 ulp (pcl_sincos.h); anything
+        // else a caller of the reference-ABI kernels may pass -- negative, huge, NaN -- goes to the library
+        if (x >= 0.0 && x <= PCL_SINCOS_XMAX)
+            pcl_sincos_2pi(x, &s, &c);
+        else
+            sincos(x, &s, &c);
+#endif
+    }
+    // an angle the kernel itself built from a uniform draw (u*2*pi or u*pi): always inside [0, 2*pi]
+    static __device__ __forceinline__ void sincos_angle_(double x, double &s, double &c) {
+#ifdef PCL_ABLATE_TRIG /* timing experiment only */
+        s = x * 0.1;
+        c = 1.0 - s;
+#else
+        pcl_sincos_2pi(x, &s, &c);
 #endif
     }
     // uniform in [0,1) from two Philox words: all 53 bits
@@ -107,6 +125,7 @@ template <> struct pcl_rt<float> {
     static __device__ __forceinline__ float sqrt_(float a) { return __fsqrt_rn(a); }
     static __device__ __forceinline__ float pow_m4(float x) { return powf(x, -4.0f); }
     static __device__ __forceinline__ void sincos_(float x, float &s, float &c) { sincosf(x, &s, &c); }
+    static __device__ __forceinline__ void sincos_angle_(float x, float &s, float &c) { sincosf(x, &s, &c); }
     // the top 24 bits of the SAME words the fp64 path uses: u32 <= u64 < u32 + 2^-24, so both
     // precisions follow the same random stream (hit decisions differ only within that sliver)
     static __device__ __forceinline__ float uniform(pcl_u32 a, pcl_u32 b) {
@@ -182,12 +201,19 @@ __device__ __forceinline__ T pcl_wavelength_term(T h, T c, T E) {
 
 // res0 = c * sin(rtheta) * cos(rphi); res1 = c * sin(rtheta) * sin(rphi); res2 = c * cos(rtheta)
 //                                                     physicl/light.py:309-311
-template <typename T>
+// OWN_ANGLES: rtheta/rphi were drawn by the kernel itself (device RNG), so they are inside [0, 2*pi] and the
+// range test + library fallback of sincos_ is not compiled in at all; same values either way.
+template <typename T, bool OWN_ANGLES = false>
 __device__ __forceinline__ void pcl_new_velocity(T c, T rtheta, T rphi, T &o0, T &o1, T &o2) {
     typedef pcl_rt<T> R;
     T st, ct, sp, cp;
-    R::sincos_(rtheta, st, ct);
-    R::sincos_(rphi, sp, cp);
+    if constexpr (OWN_ANGLES) {
+        R::sincos_angle_(rtheta, st, ct);
+        R::sincos_angle_(rphi, sp, cp);
+    } else {
+        R::sincos_(rtheta, st, ct);
+        R::sincos_(rphi, sp, cp);
+    }
     const T cs = R::mul(c, st);
     o0 = R::mul(cs, cp);
     o1 = R::mul(cs, sp);
@@ -227,10 +253,10 @@ __device__ __forceinline__ T pcl_n_expr_val(T r0v, T r1v, T r2v, T d0v, T d1v, T
 
 // pcoll exactly as the generated kernel text multiplies it            physicl/light.py:299-306
 //   A * n * norm  |  A * (<expr>) * norm  [ * pow((h*c)/E, -4) ]   -- left to right
+// (the norm is passed in: a K-step pass keeps it in a register between the photon's hits)
 template <typename T, bool USE_E, bool VAR_N>
-__device__ __forceinline__ T pcl_pcoll(T A, T n, T h, T c, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
+__device__ __forceinline__ T pcl_pcoll_norm(T A, T n, T h, T c, T norm, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
     typedef pcl_rt<T> R;
-    const T norm = pcl_step_norm<T>(d0, d1, d2);
     T p;
     if constexpr (VAR_N) {
 #ifdef PCL_N_EXPR
@@ -243,6 +269,10 @@ __device__ __forceinline__ T pcl_pcoll(T A, T n, T h, T c, T d0, T d1, T d2, T r
     }
     if constexpr (USE_E) p = R::mul(p, pcl_wavelength_term<T>(h, c, E));
     return p;
+}
+template <typename T, bool USE_E, bool VAR_N>
+__device__ __forceinline__ T pcl_pcoll(T A, T n, T h, T c, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
+    return pcl_pcoll_norm<T, USE_E, VAR_N>(A, n, h, c, pcl_step_norm<T>(d0, d1, d2), d0, d1, d2, r0, r1, r2, E);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,7 +699,7 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
                 const T rtheta = pcl_rtheta<T>(w.z, w.w);
                 const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 1u, k0, k1);
                 const T rphi = pcl_rphi<T>(w2.x, w2.y);
-                pcl_new_velocity<T>(a.c, rtheta, rphi, cur.V[0][e], cur.V[1][e], cur.V[2][e]);
+                pcl_new_velocity<T, true>(a.c, rtheta, rphi, cur.V[0][e], cur.V[1][e], cur.V[2][e]);
             }
             w_hits += (pcl_u32)__popcll(__ballot(hit));
             w_sx += (pcl_u32)__popcll(__ballot(live && cur.V[0][e] > (T)0));
@@ -733,7 +763,7 @@ template <typename T, int VEC>
 struct pcl_hit_queue {
     pcl_u32 owner[256 * VEC]; // thread * VEC + e of the photon that hit
     pcl_u32 wz[256 * VEC], ww[256 * VEC]; // its rtheta words (Philox block 0)
-    T out[3][256 * VEC];      // the new velocity
+    T out[4][256 * VEC];      // the new velocity and its step length |v' * dt|
 };
 
 template <typename T, bool USE_E, bool VAR_N, int VEC>
@@ -755,7 +785,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
         const pcl_i64 qs = pcl_tq<VEC>(live_q ? q : 0, a.ts);
-        T Rr[3][VEC], V[3][VEC], VP[3][VEC], L4[VEC], Ev[VEC];
+        T Rr[3][VEC], V[3][VEC], VP[3][VEC], L4[VEC], Ev[VEC], NM[VEC];
         VV::ld(a.r0, qs, Rr[0]);
         VV::ld(a.r1, qs, Rr[1]);
         VV::ld(a.r2, qs, Rr[2]);
@@ -764,7 +794,13 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         VV::ld(a.v2, qs, V[2]);
         if constexpr (USE_E) VV::ld(a.lam4, qs, L4);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) Ev[e] = a.E[pcl_tix((live_q && q * VEC + e < a.N) ? q * VEC + e : 0, a.ts)];
+        for (int e = 0; e < VEC; ++e) {
+            Ev[e] = a.E[pcl_tix((live_q && q * VEC + e < a.N) ? q * VEC + e : 0, a.ts)];
+            // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
+            NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) VP[j][e] = V[j][e];
+        }
         for (int k = 0; k < a.K; ++k, ++it) {
             const pcl_u32 st = a.step + (pcl_u32)k;
             pcl_u32 *nh = &s_nh[it & 1];
@@ -775,16 +811,14 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             for (int e = 0; e < VEC; ++e) {
                 const pcl_i64 i = q * VEC + e;
                 const bool live = live_q && i < a.N;
-                VP[0][e] = V[0][e];
-                VP[1][e] = V[1][e];
-                VP[2][e] = V[2][e];
                 // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
                 const T d0 = R::mul(V[0][e], a.dt), d1 = R::mul(V[1][e], a.dt), d2 = R::mul(V[2][e], a.dt);
                 Rr[0][e] = R::add(Rr[0][e], d0);
                 Rr[1][e] = R::add(Rr[1][e], d1);
                 Rr[2][e] = R::add(Rr[2][e], d2);
                 // scatter decision                                                       light.py:303-308
-                T pc = pcl_pcoll<T, false, VAR_N>(a.A, a.n, (T)0, a.c, d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e], Ev[e]);
+                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e],
+                                                       Ev[e]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
                 const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 0u, k0, k1);
@@ -824,19 +858,26 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 1u, k0, k1);
                 const T rphi = pcl_rphi<T>(w2.x, w2.y);
                 T o0, o1, o2;
-                pcl_new_velocity<T>(a.c, rtheta, rphi, o0, o1, o2);
+                pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
                 s_q.out[0][j] = o0;
                 s_q.out[1][j] = o1;
                 s_q.out[2][j] = o2;
+                s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
             }
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const bool live = live_q && q * VEC + e < a.N;
+                if (k + 1 == a.K) { // the velocity before the LAST step is what dv = v - v_prev needs
+                    VP[0][e] = V[0][e];
+                    VP[1][e] = V[1][e];
+                    VP[2][e] = V[2][e];
+                }
                 if (hit[e]) {
                     V[0][e] = s_q.out[0][slot[e]];
                     V[1][e] = s_q.out[1][slot[e]];
                     V[2][e] = s_q.out[2][slot[e]];
+                    NM[e] = s_q.out[3][slot[e]];
                 }
                 w_sx += (pcl_u32)__popcll(__ballot(live && V[0][e] > (T)0));
                 w_sy += (pcl_u32)__popcll(__ballot(live && V[1][e] > (T)0));

@@ -18,15 +18,26 @@ def main():
     ap.add_argument("--profile", default="example")
     ap.add_argument("--ks", default="1,2,4,8,16,32,64")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--plain-p", type=float, default=None,
+                    help="no variable-n / wavelength: constant hit probability p for every photon (AOT kernel)")
+    ap.add_argument("--expr", default=None, help="override the profile's variable_n_fn (e.g. 1.0E+300: every photon hits)")
+    ap.add_argument("--a-kernel", type=float, default=None, help="override the kernel's A (0: no photon hits)")
     args = ap.parse_args()
     from physicl_amd import _hip
     N = int(args.photons)
-    prof = PROFILES[args.profile]
+    prof = dict(PROFILES[args.profile])
+    if args.expr is not None:
+        prof["expr"] = args.expr
+    if args.a_kernel is not None:
+        prof["A_kernel"] = args.a_kernel
     dev = _hip.Device(0)
     dev.store_alloc(N, args.dtype)
     fill = lambda: dev.fill_photons(N, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, 1234)
     fill()
     flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
+    if args.plain_p is not None:                   # pcoll = A * n * |v| dt = p
+        flags = 0
+        prof.update(A_kernel=args.plain_p / (C_LIT * prof["dt"]), n_kernel=1.0, expr=None)
     sc = lambda k: dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT, n_expr=prof["expr"],
                         rng_mode=_hip.RNG_PHILOX, seed=1234, step=k)
     rows = []

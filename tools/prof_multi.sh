@@ -5,8 +5,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_multi
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o pmc -- python3 $REPO/tools/bench_multi.py --ks ${1:-16} --reps 2 > $OUT/sq1.json 2> $OUT/sq1.err || { tail -5 $OUT/sq1.err; exit 1; }
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq2 -o pmc -- python3 $REPO/tools/bench_multi.py --ks ${1:-16} --reps 2 > $OUT/sq2.json 2> $OUT/sq2.err || { tail -5 $OUT/sq2.err; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq1 -o pmc -- python3 $REPO/tools/bench_multi.py --ks ${1:-16} --reps 2 "${@:2}" > $OUT/sq1.json 2> $OUT/sq1.err || { tail -5 $OUT/sq1.err; exit 1; }
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/sq2 -o pmc -- python3 $REPO/tools/bench_multi.py --ks ${1:-16} --reps 2 "${@:2}" > $OUT/sq2.json 2> $OUT/sq2.err || { tail -5 $OUT/sq2.err; exit 1; }
 cd $REPO
 python3 - <<'PY'
 import csv, glob, collections
