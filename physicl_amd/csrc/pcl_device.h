@@ -45,7 +45,8 @@ __device__ __forceinline__ pcl_u32x4 pcl_philox4x32_10(pcl_u32 c0, pcl_u32 c1, p
         const pcl_u64 p0 = (pcl_u64)0xD2511F53u * (pcl_u64)c0, p1 = (pcl_u64)0xCD9E8D57u * (pcl_u64)c2;
         const pcl_u32 hi0 = (pcl_u32)(p0 >> 32), lo0 = (pcl_u32)p0;
         const pcl_u32 hi1 = (pcl_u32)(p1 >> 32), lo1 = (pcl_u32)p1;
-        const pcl_u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        // three-input XOR in one instruction (gfx950 v_bitop3_b32, truth table 0x96 = a ^ b ^ c)
+        const pcl_u32 n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
         c0 = n0;
         c1 = lo1;
         c2 = n2;
@@ -803,6 +804,11 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         }
         for (int k = 0; k < a.K; ++k, ++it) {
             const pcl_u32 st = a.step + (pcl_u32)k;
+            // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push
+            // other scalars into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler
+            // rebuild them per iteration on the otherwise idle scalar unit instead.
+            pcl_u32 kk0 = k0, kk1 = k1;
+            asm volatile("" : "+s"(kk0), "+s"(kk1));
             pcl_u32 *nh = &s_nh[it & 1];
             pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
             bool hit[VEC];
@@ -821,7 +827,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                                                        Ev[e]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
-                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 0u, k0, k1);
+                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 0u, kk0, kk1);
                 const T rand = R::uniform(w.x, w.y);
                 hit[e] = live && (pc >= rand);
                 wz[e] = w.z;
@@ -855,7 +861,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 const pcl_u32 o = s_q.owner[j];
                 const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(o / VEC)) * VEC + (pcl_i64)(o % VEC));
                 const T rtheta = pcl_rtheta<T>(s_q.wz[j], s_q.ww[j]);
-                const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 1u, k0, k1);
+                const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 1u, kk0, kk1);
                 const T rphi = pcl_rphi<T>(w2.x, w2.y);
                 T o0, o1, o2;
                 pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
