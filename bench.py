@@ -257,7 +257,8 @@ def main():
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N,
-                                      " + %s all-reduce of 5 int64 counters" % ("RCCL" if comm.backend == "nccl" else "gloo") if world > 1 else ""),
+                                      " + %s all-reduce of the %s int64 counters" % ("RCCL" if comm.backend == "nccl" else "gloo",
+                                                                                   "%d x 5 per-launch" % S if S > 1 else "5") if world > 1 else ""),
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "steps_per_launch": S,
                        "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
