@@ -90,16 +90,16 @@ int64_t orc_scatter_isotropic(const double *d0, const double *d1, const double *
         if (ra) {
             rand = ra[i];
         } else {
-            philox((uint32_t)id, (uint32_t)(id >> 32), step, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-            rand = u53(w[0], w[1]);
+            philox((uint32_t)id, (uint32_t)(id >> 32), step >> 1, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            rand = (step & 1u) ? u53(w[2], w[3]) : u53(w[0], w[1]);
         }
         if (p >= rand) {
             if (ra) {
                 rtheta = rt[i]; rphi = rp[i];
             } else {
-                rtheta = u53(w[2], w[3]) * 2 * PI;
                 philox((uint32_t)id, (uint32_t)(id >> 32), step, 1u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-                rphi = u53(w[0], w[1]) * PI;
+                rtheta = u53(w[0], w[1]) * 2 * PI;
+                rphi = u53(w[2], w[3]) * PI;
             }
             const double st = sin(rtheta), ct = cos(rtheta), sp = sin(rphi), cp = cos(rphi);
             const double n0 = (c * st) * cp, n1 = (c * st) * sp, n2 = c * ct;

@@ -237,24 +237,27 @@ def philox_draws(seed, step, ids, dtype=np.float64):
     """Device-RNG equivalent of ``reference_draws``: keyed by (seed, step, global particle id), so the
     stream of a photon does not depend on how particles are sharded over GPUs or compacted.
 
-    counter = (id_lo, id_hi, step, block) ; key = (seed_lo, seed_hi)
-    block 0 -> words w0..w3 : rand = u53(w0,w1), rtheta = u53(w2,w3) * 2 * pi
-    block 1 -> words w0..w1 : rphi = u53(w0,w1) * pi
+    key = (seed_lo, seed_hi)
+    decision block  counter (id_lo, id_hi, step >> 1, 0): rand of an even step = u53(w0,w1), of an odd step = u53(w2,w3)
+                    (one block serves the hit decisions of two consecutive steps)
+    direction block counter (id_lo, id_hi, step, 1):      rtheta = u53(w0,w1) * 2 * pi, rphi = u53(w2,w3) * pi
     """
     ids = np.asarray(ids, dtype=np.uint64)
     lo, hi = ids & _U32, ids >> np.uint64(32)
     k0, k1 = int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF
     st = np.uint64(int(step) & 0xFFFFFFFF)
-    a = philox4x32_10(lo, hi, st, np.uint64(0), k0, k1)
+    odd = int(step) & 1
+    a = philox4x32_10(lo, hi, np.uint64((int(step) & 0xFFFFFFFF) >> 1), np.uint64(0), k0, k1)
     b = philox4x32_10(lo, hi, st, np.uint64(1), k0, k1)
+    ra, rb = (a[2], a[3]) if odd else (a[0], a[1])
     if dtype == np.float32:
         # the top 24 bits of the same words: u32 <= u64 < u32 + 2**-24, so both precisions follow one stream
         u24 = lambda w: (w >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
         pi32 = np.float32(np.pi)
-        return (u24(a[2]) * np.float32(2)) * pi32, u24(b[0]) * pi32, u24(a[0])
-    rand = u53(a[0], a[1])
-    rtheta = u53(a[2], a[3]) * 2 * np.pi
-    rphi = u53(b[0], b[1]) * np.pi
+        return (u24(b[0]) * np.float32(2)) * pi32, u24(b[2]) * pi32, u24(ra)
+    rand = u53(ra, rb)
+    rtheta = u53(b[0], b[1]) * 2 * np.pi
+    rphi = u53(b[2], b[3]) * np.pi
     return rtheta, rphi, rand
 
 

@@ -233,6 +233,23 @@ __device__ __forceinline__ T pcl_rphi(pcl_u32 a, pcl_u32 b) {
     return R::mul(R::uniform(a, b), R::pi());
 }
 
+// Device random stream of a light step (DESIGN.md "Device RNG"), keyed by (seed, launch number ``step``, photon id):
+//   decision block  Philox(id_lo, id_hi, step >> 1, 0):  rand of an even step = u(w0, w1), of an odd step = u(w2, w3)
+//                   -- one block serves the hit decisions of two consecutive steps (a K-step pass computes it once);
+//   direction block Philox(id_lo, id_hi, step, 1), hit only:  rtheta = u(w0, w1) * 2 * pi, rphi = u(w2, w3) * pi.
+template <typename T>
+__device__ __forceinline__ T pcl_draw_rand(pcl_u64 id, pcl_u32 step, pcl_u32 k0, pcl_u32 k1) {
+    typedef pcl_rt<T> R;
+    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), step >> 1, 0u, k0, k1);
+    return (step & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+}
+template <typename T>
+__device__ __forceinline__ void pcl_draw_angles(pcl_u64 id, pcl_u32 step, pcl_u32 k0, pcl_u32 k1, T &rtheta, T &rphi) {
+    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), step, 1u, k0, k1);
+    rtheta = pcl_rtheta<T>(w.x, w.y);
+    rphi = pcl_rphi<T>(w.z, w.w);
+}
+
 // The number-density factor of pcoll.  Under hipRTC, PCL_N_EXPR is the user's OpenCL-C expression
 // (variable_n_fn, physicl/light.py:299), which names the kernel arrays r0,r1,r2,d0,d1,d2,E and the
 // work-item index gid; those names are bound here to this particle's values (one-element arrays,
@@ -360,22 +377,17 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
             if (i >= a.N || !photon[j]) continue;
             const pcl_i64 ti = pcl_tix(i, a.ts);
             T rand, rtheta = (T)0, rphi = (T)0;
-            pcl_u32 c0 = 0, c1 = 0;
+            pcl_u64 id = 0;
             if (a.rng_mode == PCL_RNG_PHX) {
-                const pcl_u64 id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
-                c0 = (pcl_u32)id;
-                c1 = (pcl_u32)(id >> 32);
-                const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 0u, k0, k1);
-                rand = R::uniform(w.x, w.y);
-                rtheta = pcl_rtheta<T>(w.z, w.w);
+                id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
+                rand = pcl_draw_rand<T>(id, a.step, k0, k1);
             } else {
                 rand = a.rand[i];
             }
             // NaN pcoll compares false, +inf compares true: same as the reference's ``pcoll >= rand``
             if (pcoll[j] >= rand) {
                 if (a.rng_mode == PCL_RNG_PHX) {
-                    const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 1u, k0, k1);
-                    rphi = pcl_rphi<T>(w.x, w.y);
+                    pcl_draw_angles<T>(id, a.step, k0, k1, rtheta, rphi);
                 } else {
                     rtheta = a.rtheta[i];
                     rphi = a.rphi[i];
@@ -506,15 +518,11 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
                 const T pc = pcl_pcoll<T, USE_E, VAR_N>(a.A, a.n, a.h, a.c, D[0][e], D[1][e], D[2][e], Rr[0][e],
                                                         Rr[1][e], Rr[2][e], Ev[e]);
                 T rand = (T)0, rtheta = (T)0, rphi = (T)0;
-                pcl_u32 c0 = 0, c1 = 0;
+                pcl_u64 id = 0;
                 if (photon[e]) {
                     if (a.rng_mode == PCL_RNG_PHX) {
-                        const pcl_u64 id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
-                        c0 = (pcl_u32)id;
-                        c1 = (pcl_u32)(id >> 32);
-                        const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 0u, k0, k1);
-                        rand = R::uniform(w.x, w.y);
-                        rtheta = pcl_rtheta<T>(w.z, w.w);
+                        id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
+                        rand = pcl_draw_rand<T>(id, a.step, k0, k1);
                     } else {
                         rand = a.rand[i];
                     }
@@ -523,8 +531,7 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
                 T n0 = (T)0, n1 = (T)0, n2 = (T)0;
                 if (hit[e]) {
                     if (a.rng_mode == PCL_RNG_PHX) {
-                        const pcl_u32x4 w = pcl_philox4x32_10(c0, c1, a.step, 1u, k0, k1);
-                        rphi = pcl_rphi<T>(w.x, w.y);
+                        pcl_draw_angles<T>(id, a.step, k0, k1, rtheta, rphi);
                     } else {
                         rtheta = a.rtheta[i];
                         rphi = a.rphi[i];
@@ -693,13 +700,11 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
                                               a.E[pcl_tix(live ? i : 0, a.ts)]);
             if constexpr (USE_E) pc = R::mul(pc, cur.L4[e]);
             const pcl_u64 id = (pcl_u64)(a.id_base + i);
-            const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u, k0, k1);
-            const T rand = R::uniform(w.x, w.y);
+            const T rand = pcl_draw_rand<T>(id, a.step, k0, k1);
             const bool hit = live && (pc >= rand);
             if (hit) {
-                const T rtheta = pcl_rtheta<T>(w.z, w.w);
-                const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 1u, k0, k1);
-                const T rphi = pcl_rphi<T>(w2.x, w2.y);
+                T rtheta, rphi;
+                pcl_draw_angles<T>(id, a.step, k0, k1, rtheta, rphi);
                 pcl_new_velocity<T, true>(a.c, rtheta, rphi, cur.V[0][e], cur.V[1][e], cur.V[2][e]);
             }
             w_hits += (pcl_u32)__popcll(__ballot(hit));
@@ -763,7 +768,6 @@ struct pcl_multi_args {
 template <typename T, int VEC>
 struct pcl_hit_queue {
     pcl_u32 owner[256 * VEC]; // thread * VEC + e of the photon that hit
-    pcl_u32 wz[256 * VEC], ww[256 * VEC]; // its rtheta words (Philox block 0)
     T out[4][256 * VEC];      // the new velocity and its step length |v' * dt|
 };
 
@@ -787,6 +791,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         const bool live_q = q < nq;
         const pcl_i64 qs = pcl_tq<VEC>(live_q ? q : 0, a.ts);
         T Rr[3][VEC], V[3][VEC], VP[3][VEC], L4[VEC], Ev[VEC], NM[VEC];
+        pcl_u32 wodd0[VEC], wodd1[VEC]; // the decision block's second half, waiting for the odd step
         VV::ld(a.r0, qs, Rr[0]);
         VV::ld(a.r1, qs, Rr[1]);
         VV::ld(a.r2, qs, Rr[2]);
@@ -812,7 +817,8 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             pcl_u32 *nh = &s_nh[it & 1];
             pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
             bool hit[VEC];
-            pcl_u32 slot[VEC], wz[VEC], ww[VEC];
+            pcl_u32 slot[VEC];
+            const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const pcl_i64 i = q * VEC + e;
@@ -827,11 +833,16 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                                                        Ev[e]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
-                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 0u, kk0, kk1);
-                const T rand = R::uniform(w.x, w.y);
+                T rand;
+                if (new_block) { // decision block of steps (st & ~1, st | 1): computed once for the pair
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
+                    rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    wodd0[e] = w.z;
+                    wodd1[e] = w.w;
+                } else {
+                    rand = R::uniform(wodd0[e], wodd1[e]);
+                }
                 hit[e] = live && (pc >= rand);
-                wz[e] = w.z;
-                ww[e] = w.w;
             }
             // queue slots: one LDS atomic per wave for all its VEC ballots
             pcl_u64 ballot[VEC];
@@ -847,11 +858,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             for (int e = 0; e < VEC; ++e) {
                 slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(ballot[e] >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)ballot[e], 0u));
                 wbase += (pcl_u32)__popcll(ballot[e]);
-                if (hit[e]) {
-                    s_q.owner[slot[e]] = threadIdx.x * VEC + e;
-                    s_q.wz[slot[e]] = wz[e];
-                    s_q.ww[slot[e]] = ww[e];
-                }
+                if (hit[e]) s_q.owner[slot[e]] = threadIdx.x * VEC + e;
             }
             __syncthreads();
             const pcl_u32 n_hit = *nh;
@@ -860,9 +867,8 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             for (pcl_u32 j = threadIdx.x; j < n_hit; j += blockDim.x) {
                 const pcl_u32 o = s_q.owner[j];
                 const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(o / VEC)) * VEC + (pcl_i64)(o % VEC));
-                const T rtheta = pcl_rtheta<T>(s_q.wz[j], s_q.ww[j]);
-                const pcl_u32x4 w2 = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st, 1u, kk0, kk1);
-                const T rphi = pcl_rphi<T>(w2.x, w2.y);
+                T rtheta, rphi;
+                pcl_draw_angles<T>(id, st, kk0, kk1, rtheta, rphi);
                 T o0, o1, o2;
                 pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
                 s_q.out[0][j] = o0;

@@ -244,9 +244,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
                 T rand;
                 if (a.rng_mode == PCL_RNG_PHX) {
                     const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
-                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u,
-                                                          (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                    rand = R::uniform(w.x, w.y);
+                    rand = pcl_draw_rand<T>(id, a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
                 } else {
                     rand = a.rand[i];
                 }
@@ -390,9 +388,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
             T rand;
             if (a.rng_mode == PCL_RNG_PHX) {
                 const uint64_t id = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
-                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), a.step, 0u, (pcl_u32)a.seed,
-                                                      (pcl_u32)(a.seed >> 32));
-                rand = R::uniform(w.x, w.y);
+                rand = pcl_draw_rand<T>(id, a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
             } else {
                 rand = a.rand[i];
             }
