@@ -301,6 +301,15 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
 int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags, int rng_mode, uint64_t seed,
                           uint32_t step, const double *planes_host, int n_planes, int64_t *out_host);
 
+/* k_steps consecutive delete loop bodies (Newton + ScatterDelete + the counters of the measure steps) in one pass
+ * and ONE compaction: a photon of a delete run never changes its velocity, so per step only r += v*dt, the
+ * decision draw and the compare remain until it is removed.  State and per-step rows are identical to k_steps
+ * calls of pcl_step_fused_delete(dt, A, n, PCL_FUSED_LAZY, PCL_RNG_PHILOX, seed, step0 + k, ...); dr is left
+ * implicit.  Device RNG only.  out_host (may be NULL): int64[k_steps][5 + n_planes] =
+ * { N alive after the step, xp, yp, zp, plane counts..., removed in the step }; n_planes = -1: alive/removed only. */
+int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step0,
+                                const double *planes_host, int n_planes, int64_t *out_host);
+
 /* The int32 flag array of the most recent pcl_step_scatter_delete / pcl_step_fused_delete, in PRE-compaction order
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */
 int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n);

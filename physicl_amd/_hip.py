@@ -91,6 +91,7 @@ _PROTOTYPES = {
     "pcl_step_newton": [_vp, c_double],
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
+    "pcl_step_fused_delete_multi": [_vp, c_double, c_int, c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_store_is_uniform": [_vp, POINTER(c_int)],
     "pcl_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
                              c_uint32, _vp],
@@ -497,6 +498,21 @@ class Device:
                                              int(rng_mode), int(seed), int(step) & 0xFFFFFFFF, pp, npl,
                                              out.ctypes.data_as(c_void_p)))
         return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + k].copy(), "removed": int(out[4 + k])}
+
+    def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None):
+        """``k_steps`` delete loop bodies (Newton + ScatterDelete + counters on the survivors) in one pass and one
+        compaction.  Returns a list of k_steps dicts {'N','removed','sign','planes'}."""
+        if planes is None:
+            npl, pp = -1, None
+        else:
+            pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+            npl = len(pl)
+            pp = pl.ctypes.data_as(c_void_p) if npl else None
+        k = max(npl, 0)
+        out = np.zeros((k_steps, 5 + k), dtype=np.int64)
+        check(self.lib.pcl_step_fused_delete_multi(self.ctx, float(dt), int(k_steps), float(A), float(n), int(seed),
+                                                   int(step) & 0xFFFFFFFF, pp, npl, out.ctypes.data_as(c_void_p)))
+        return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + k].copy(), "removed": int(o[4 + k])} for o in out]
 
     def last_delete_flags(self, n):
         out = np.empty(n, dtype=np.int32)

@@ -521,25 +521,28 @@ class Simulation(threading.Thread):
                     self._readonly_scope = False
 
     def _multi_eligible(self):
-        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + plane-less counting measures], device RNG,
-        uniform photon store: K passes can run as one launch (pcl_step_fused_multi)."""
+        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + plane-less counting measures] on a uniform
+        photon store, or [UpdateTimeStep][Newton + ScatterDelete + counting measures], with the device RNG: K passes
+        can run as one launch (pcl_step_fused_multi / pcl_step_fused_delete_multi)."""
         plan = self._plan
         if len(plan) != 2 or plan[0][0] != "single" or type(plan[0][1]) is not UpdateTimeStep or plan[1][0] != "fused":
             return False
         group = plan[1][1]
         roles = [s._fuse_role for s in group]
-        if roles[:2] != ["newton", "scatter_iso"] or any(r != "measure" for r in roles[2:]):
+        if roles[0] != "newton" or len(roles) < 2 or any(r != "measure" for r in roles[2:]):
             return False
-        if any(s._n_planes() for s in group[2:]) or self._rng_mode() != self._hip.RNG_PHILOX:
+        if self._rng_mode() != self._hip.RNG_PHILOX:
+            return False
+        if roles[1] == "scatter_delete":
+            return True
+        if roles[1] != "scatter_iso" or any(s._n_planes() for s in group[2:]):
             return False
         self._to_device()
         return self._dev.is_uniform()
 
-    def _run_multi(self, upd, group):
-        """Up to ``steps_per_launch`` passes of the loop in one launch.  The host part of each pass (time update,
-        then the exit test the outer loop would make before the next pass) runs first; the device then advances the
-        photons through all of them in one pass over the store and returns one counter row per pass."""
-        dev = self._dev
+    def _plan_passes(self, upd):
+        """Host part of up to ``steps_per_launch`` passes, ahead of the launch: the time update of each pass, then
+        the exit test the outer loop would make before the next one.  Returns [(t, dt)] per pass and the code dt."""
         times, dt0 = [], None
         while len(times) < self.steps_per_launch:
             before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
@@ -553,6 +556,16 @@ class Simulation(threading.Thread):
             times.append((copy.deepcopy(self.t), self.dt))
             if len(times) < self.steps_per_launch and self.exit(self):
                 break
+        return times, dt0
+
+    def _run_multi(self, upd, group):
+        """Up to ``steps_per_launch`` passes of the loop in one launch.  The host part of each pass runs first
+        (_plan_passes); the device then advances the photons through all of them in one pass over the store and
+        returns one counter row per pass."""
+        if group[1]._fuse_role == "scatter_delete":
+            return self._run_multi_delete(upd, group)
+        dev = self._dev
+        times, dt0 = self._plan_passes(upd)
         k = len(times)
         scatter, measures = group[1], group[2:]
         sc = scatter._kernel_params(self)
@@ -567,6 +580,38 @@ class Simulation(threading.Thread):
             for m in measures:
                 m._record(self, int(g[0]), g[2:5], g[5:5])
         self.hits = int(glob[-1][1])
+
+    def _run_multi_delete(self, upd, group):
+        """K delete passes per launch, one compaction.  ``exit`` usually waits for the store to empty, which the host
+        cannot know ahead of the launch: the rows are replayed afterwards and the run is cut at the first pass whose
+        exit test is true -- valid because that can only be a pass that left nothing alive (checked)."""
+        self._to_device()
+        dev = self._dev
+        n_ts = len(self.ts)
+        times, dt0 = self._plan_passes(upd)
+        k = len(times)
+        delete, measures = group[1], group[2:]
+        planes = [p for m in measures for p in m._plane_rows()]
+        A_k, n_k = delete._kernel_consts()
+        rows = dev.step_fused_delete_multi(dt0, k, A_k, n_k, self.seed, self._launch + 1, planes if measures else None)
+        self._launch += k
+        flat = np.array([np.concatenate([[o["N"], o["removed"]], o["sign"], o["planes"]]) for o in rows], dtype=np.int64)
+        glob = self._global(flat.reshape(-1)).reshape(k, flat.shape[1])
+        for i, ((t, dt), g) in enumerate(zip(times, glob)):
+            self.t, self.dt = t, dt
+            self._alive, delete.removed = int(g[0]), int(g[1])
+            j = 5
+            for m in measures:
+                npl = m._n_planes()
+                m._record(self, int(g[0]), g[2:5], g[j:j + npl])
+                j += npl
+            if i + 1 < k and self.exit(self):         # the outer loop would have stopped here
+                if int(g[0]) != 0:
+                    raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
+                                       "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
+                                       "the store being empty only" % (i + 1, k, int(g[0])))
+                del self.ts[n_ts + i + 1:]
+                break
 
     def _run_fused(self, group):
         self._to_device()

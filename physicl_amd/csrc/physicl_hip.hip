@@ -75,6 +75,7 @@ constexpr int kBlock = 256;           // 4 wave64 per workgroup
 constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particles
 constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
+constexpr int kMultiSlots = PCL_MULTI_MAX * (4 + PCL_MAX_PLANES); // per-step counter rows of a K-step pass
 constexpr int kRows = PCL_NFIELDS + 4;       // rows per tile of the store slab: 13 fields + vprev0..2 + lam4
 constexpr int kRowVprev = PCL_NFIELDS, kRowLam4 = PCL_NFIELDS + 3;
 constexpr int64_t kTileT = PCL_T;            // particles per tile (rows of 2048 elements)
@@ -401,6 +402,114 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
     if (lane == 0) s_cnt[wave] = kept;
     __syncthreads();
     if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// ---- K delete loop bodies in one pass: Newton + delete test K times per photon, ONE mask at the end -------
+//   A photon of a delete simulation never changes its velocity, so dr = v*dt, |dr| and pcoll = A*n*|dr| are constants
+//   of the photon: per step only r += dr (3 adds), the decision draw and the compare remain, until the photon is
+//   removed.  The per-step rows of the measure steps (alive count, sign counts, plane crossings of the survivors,
+//   physicl/light.py:385-399, 414-431) are tallied as the steps go; survivors of all K steps get their final r and a
+//   mask bit, and the usual scan + compaction runs once.  Identical to K rounds of k_newton_mask / scan /
+//   k_compact_count (tests/test_gpu_multi.py).  dr is left implicit (= v*dt, PCL_FUSED_LAZY).
+template <typename T>
+struct newtonmask_multi_args {
+    const T *v[3];
+    T *r[3];
+    const int64_t *ids;
+    const unsigned char *kind;
+    uint64_t *masks;
+    int32_t *tile_keep;
+    uint64_t *cnt; // [K][4 + n_planes]: alive, sign x/y/z, plane crossings -- of the survivors of each step
+    int64_t id_base, N;
+    int64_t ts;
+    T dt, An;
+    uint64_t seed;
+    uint32_t step;
+    int K, n_planes;
+    T plane_L[PCL_MAX_PLANES];
+    int plane_ax[PCL_MAX_PLANES];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_args<T> a) {
+    typedef pcl_rt<T> R;
+    __shared__ uint32_t s_cnt[PCL_MULTI_MAX * (4 + PCL_MAX_PLANES)];
+    __shared__ int s_keep[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = a.n_planes > 0 ? a.n_planes : 0, nslots = 4 + np;
+    for (int j = threadIdx.x; j < a.K * nslots; j += blockDim.x) s_cnt[j] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const int64_t tile = blockIdx.x;
+    int kept = 0;
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        const bool in = i < a.N;
+        const int64_t ti = pcl_tix(in ? i : 0, a.ts);
+        T rv[3], d[3];
+        uint64_t sgn[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T vk = a.v[k][ti];
+            rv[k] = a.r[k][ti];
+            d[k] = R::mul(vk, a.dt);                                  // newton.py:15
+            sgn[k] = __ballot(in && vk > (T)0);
+        }
+        const bool photon = in && (a.kind ? (a.kind[in ? i : 0] != 0) : true);
+        const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])); // light.py:241-244
+        const pcl_u64 id = (pcl_u64)(a.ids ? a.ids[in ? i : 0] : a.id_base + i);
+        bool alive = in;
+        pcl_u32 wodd0 = 0, wodd1 = 0;
+        for (int k = 0; k < a.K; ++k) {
+            if (!__ballot(alive)) break; // nobody of this row is left: the remaining rows of the counters stay 0
+            const pcl_u32 st = a.step + (pcl_u32)k;
+            rv[0] = R::add(rv[0], d[0]);                              // newton.py:16
+            rv[1] = R::add(rv[1], d[1]);
+            rv[2] = R::add(rv[2], d[2]);
+            T rand;
+            if ((st & 1u) == 0u || k == 0) { // decision block of the step pair (pcl_draw_rand)
+                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, k0, k1);
+                rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                wodd0 = w.z;
+                wodd1 = w.w;
+            } else {
+                rand = R::uniform(wodd0, wodd1);
+            }
+            alive = alive && !(photon && (pcoll >= rand));
+            const uint64_t m = __ballot(alive);
+            uint32_t *c = &s_cnt[k * nslots];
+            if (lane == 0 && m) {
+                atomicAdd(&c[0], (uint32_t)__popcll(m));
+                if (a.n_planes >= 0) {
+                    atomicAdd(&c[1], (uint32_t)__popcll(m & sgn[0]));
+                    atomicAdd(&c[2], (uint32_t)__popcll(m & sgn[1]));
+                    atomicAdd(&c[3], (uint32_t)__popcll(m & sgn[2]));
+                }
+            }
+            for (int p = 0; p < np; ++p) {
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
+                const T prev = R::sub(x, pcl_pick<T>(ax, d[0], d[1], d[2]));
+                const uint32_t nc = (uint32_t)__popcll(__ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                if (lane == 0 && nc) atomicAdd(&c[4 + p], nc);
+            }
+        }
+        if (alive) {
+            a.r[0][ti] = rv[0];
+            a.r[1][ti] = rv[1];
+            a.r[2][ti] = rv[2];
+        }
+        const uint64_t m = __ballot(alive);
+        if (lane == 0) a.masks[tile * kTileRows + row] = m;
+        kept += __popcll(m);
+    }
+    if (lane == 0) s_keep[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    for (int j = threadIdx.x; j < a.K * nslots; j += blockDim.x)
+        if (s_cnt[j]) atomicAdd(reinterpret_cast<unsigned long long *>(&a.cnt[j]), (unsigned long long)s_cnt[j]);
 }
 
 // ---- pass 3 with the measure counters folded in: the survivors' r, v (and dr) pass through registers anyway ----
@@ -777,7 +886,7 @@ struct pcl_ctx {
     bool hits_on_host = true; // h_cnt[0] holds the hit count of the most recent scatter step
     // two counter banks for pcl_step_fused calls that do not synchronise: step k+1 is enqueued before the host
     // reads step k's counters, so the GPU never waits for Python (pcl_step_fused_read drains them in order)
-    uint64_t *d_multi = nullptr, *h_multi = nullptr; // 4 * PCL_MULTI_MAX counters of a K-step pass
+    uint64_t *d_multi = nullptr, *h_multi = nullptr; // kMultiSlots counters of a K-step pass
     uint64_t *d_bank[2] = {nullptr, nullptr};
     uint64_t *h_bank[2] = {nullptr, nullptr};
     hipEvent_t bank_ev[2] = {nullptr, nullptr};
@@ -1444,6 +1553,69 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int r
     return launch_check("k_compact_count");
 }
 
+template <typename T>
+int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step,
+                         const double *planes_host, int n_planes) {
+    const int64_t N = ctx->count;
+    const int tiles = (int)div_up(N, kTile);
+    newtonmask_multi_args<T> m{};
+    for (int k = 0; k < 3; ++k) {
+        m.v[k] = F<T>(ctx, PCL_V0 + k);
+        m.r[k] = F<T>(ctx, PCL_R0 + k);
+    }
+    m.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    m.kind = ctx->kind;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.cnt = ctx->d_multi;
+    m.id_base = ctx->id_base;
+    m.N = N;
+    m.ts = tile_stride(ctx);
+    m.dt = (T)dt;
+    m.An = (T)A * (T)n;
+    m.seed = seed;
+    m.step = step;
+    m.K = k_steps;
+    m.n_planes = n_planes;
+    for (int p = 0; p < (n_planes > 0 ? n_planes : 0); ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        m.plane_ax[p] = ax;
+        m.plane_L[p] = (T)loc[ax];
+    }
+    const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
+    hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    prof_end(ctx, ps);
+    PCL_TRY(launch_check("k_newton_mask_multi"));
+    PCL_TRY(scan_tiles(ctx, N));
+    compact_args ca{};
+    int nf = 0;
+    for (int f = 0; f < PCL_NFIELDS; ++f) {
+        if (f >= PCL_DR0 && f <= PCL_DR2) continue; // implicit: dr = v*dt, nothing to move
+        ca.src[nf] = ctx->field[f];
+        ca.dst[nf] = ctx->field_alt[f];
+        ++nf;
+    }
+    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
+    ca.ids_dst = ctx->ids_alt;
+    ca.ksrc = ctx->kind;
+    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.id_base = ctx->id_base;
+    ca.N = N;
+    ca.ts = tile_stride(ctx);
+    compact_counter_args<T> cc{};
+    cc.cnt = ctx->d_cnt;
+    cc.n_planes = -1; // the counters were taken step by step in pass 1
+    cc.dt = (T)dt;
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+    const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
+    hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    prof_end(ctx, pc);
+    return launch_check("k_compact_count");
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1516,8 +1688,8 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
             return fail(PCL_ERR_HIP, "context resource allocation failed");
         }
     }
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_multi), 4 * PCL_MULTI_MAX * sizeof(uint64_t)) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&c->h_multi), 4 * PCL_MULTI_MAX * sizeof(uint64_t)) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_multi), kMultiSlots * sizeof(uint64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_multi), kMultiSlots * sizeof(uint64_t)) != hipSuccess) {
         pcl_ctx_destroy(c);
         return fail(PCL_ERR_HIP, "context resource allocation failed");
     }
@@ -2326,6 +2498,55 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
         out_host[0] = alive;
         for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
         out_host[4 + np] = N - alive;
+    }
+    return PCL_OK;
+}
+
+int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step0,
+                                const double *planes_host, int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store_raw(ctx));
+    if (k_steps < 1 || k_steps > PCL_MULTI_MAX) return fail(PCL_ERR_ARG, "k_steps outside [1, %d]", PCL_MULTI_MAX);
+    if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
+    if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
+    if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    if (ctx->lazy_dv) PCL_TRY(materialize(ctx)); // a pending implicit dv has to become real before the state is moved
+    ctx->lazy_dr = false;                          // an implicit dr is superseded by these steps' own moves
+    const int64_t N = ctx->count;
+    const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;
+    if (out_host)
+        for (int k = 0; k < k_steps * (5 + np); ++k) out_host[k] = 0;
+    if (N == 0) return PCL_OK;
+    PCL_TRY(ensure_scratch(ctx, N));
+    PCL_TRY(ensure_alt(ctx));
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)k_steps * nslots * sizeof(uint64_t), ctx->stream));
+    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, seed, step0, planes_host, n_planes),
+                         fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, seed, step0, planes_host, n_planes)));
+    PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)k_steps * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (alive < 0 || alive > N || alive != (int64_t)ctx->h_multi[(k_steps - 1) * nslots])
+        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
+    std::swap(ctx->slab, ctx->slab_alt);
+    refresh_rows(ctx);
+    std::swap(ctx->ids, ctx->ids_alt);
+    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
+    ctx->ids_iota = false;
+    ctx->count = alive;
+    ctx->last_delete_n = -1; // the masks describe K steps at once: no per-step flag array to hand out
+    ctx->lam4_valid = false;
+    ctx->lazy_dr = true;     // dr = v*dt with the (unchanged) velocities of the survivors
+    ctx->lazy_dt = dt;
+    if (out_host) {
+        int64_t before = N;
+        for (int k = 0; k < k_steps; ++k) {
+            int64_t *o = out_host + (int64_t)k * (5 + np);
+            const uint64_t *c = ctx->h_multi + (int64_t)k * nslots;
+            o[0] = (int64_t)c[0];
+            for (int j = 0; j < 3 + np; ++j) o[1 + j] = (int64_t)c[1 + j];
+            o[4 + np] = before - (int64_t)c[0];
+            before = (int64_t)c[0];
+        }
     }
     return PCL_OK;
 }

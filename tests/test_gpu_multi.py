@@ -155,3 +155,53 @@ def test_multi_state_errors(make_store, hip):
     d.upload_kind(np.zeros(100, dtype=np.uint8))                   # a store with plain Objects: not eligible
     with pytest.raises(hip.HipError):
         d.step_fused_multi(dt, 2, sc)
+
+
+# ============================================================================ K delete loop bodies per pass
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N,K", [(1, 1), (64, 3), (2049, 2), (100_003, 9), (500_003, 40)])
+def test_delete_multi_is_bit_identical_to_single_fused_delete_steps(make_store, hip, N, K, dtype):
+    """pcl_step_fused_delete_multi == K x pcl_step_fused_delete (lazy, Philox): per-step rows (alive, sign counts,
+    plane crossings, removed) and the survivors' whole state, ids and kinds included; mixed kinds, a previous
+    compaction (explicit ids) and an odd first launch number on the way."""
+    npdt = np.float64 if dtype == "f64" else np.float32
+    rs = np.random.RandomState(N + K)
+    vdir = rs.normal(size=(N, 3))
+    vdir /= np.linalg.norm(vdir, axis=1)[:, None]
+    init = {"r": rs.uniform(-3, 3, (N, 3)).astype(npdt), "v": (vdir * C_LIT).astype(npdt),
+            "dv": rs.normal(size=(N, 3)).astype(npdt), "E": rs.uniform(1, 2, N).astype(npdt), "id_base": 123,
+            "kind": (rs.random_sample(N) < 0.9).astype(np.uint8)}
+    A, n, dt, seed, step0 = 1e-3, 0.4e-3, 1e-3, 777, 5          # pcoll ~ 0.12 per step
+    planes = [[0.5, np.nan, np.nan], [np.nan, -1.0, np.nan]]
+    out = []
+    for multi in (False, True):
+        d = make_store(N, dtype)
+        d.upload_state(init)
+        first = d.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, step0 - 1, planes, lazy=True)   # ids become explicit
+        if multi:
+            rows = d.step_fused_delete_multi(dt, K, A, n, seed, step0, planes)
+        else:
+            rows = [d.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, step0 + k, planes, lazy=True) for k in range(K)]
+        log = [(o["N"], o["removed"], list(o["sign"]), list(o["planes"])) for o in rows]
+        st = d.download_state() if d.count else None
+        kind = d.download_kind(d.count) if d.count else None
+        out.append((first["N"], log, d.count, st, kind))
+    a, b = out
+    assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+    if a[3] is not None:
+        state_equal(a[3], b[3])
+        assert np.array_equal(a[3]["id"], b[3]["id"]) and np.array_equal(a[4], b[4])
+        assert np.all(np.diff(a[3]["id"]) > 0)
+
+
+def test_delete_multi_until_empty_and_without_counters(make_store, hip):
+    N = 20_000
+    d = make_store(N)
+    d.upload_state({"v": np.tile([C_LIT, 0.0, 0.0], (N, 1)), "E": np.ones(N)})
+    rows = d.step_fused_delete_multi(1e-3, 64, 1e-3, 1e-3, seed=3, step=0, planes=None)     # survival 0.70 per step
+    alive = [o["N"] for o in rows]
+    assert alive[-1] == 0 and d.count == 0 and all(x >= y for x, y in zip(alive, alive[1:]))
+    assert sum(o["removed"] for o in rows) == N and all(o["sign"].sum() == 0 for o in rows)
+    assert abs(alive[0] - 0.7002 * N) < 6 * np.sqrt(N * 0.21)
+    rows = d.step_fused_delete_multi(1e-3, 3, 1e-3, 1e-3, seed=3, step=64)                   # empty store: all zeros
+    assert all(o["N"] == 0 and o["removed"] == 0 for o in rows)

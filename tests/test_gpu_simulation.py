@@ -419,3 +419,41 @@ def test_steps_per_launch_with_changing_dt_and_ineligible_plans():
         run(s)
         out.append(([[float(x) for x in r] for r in pl.data], s.download("v")))
     assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
+
+
+@pytest.mark.parametrize("K", [3, 64])
+def test_steps_per_launch_delete_until_empty_matches_one_pass_per_launch(K):
+    """test/test_light.py:47-66's delete run through the K-passes-per-launch path: same alive sequence, same measure
+    rows, same ts (the run is cut at the pass that empties the store), same survivors' state."""
+    def build(k):
+        n = 40_000
+        sim = phys.Simulation(cl_on=True, seed=21, steps_per_launch=k)           # default exit: len(objects) == 0
+        sim.add_objs(phys.light.generate_photons_bulk(n, min=1.0, max=1.0, seed=2))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        m = phys.light.ScatterMeasureStep(None, True, [[C_LIT * 0.0035, np.nan, np.nan]])
+        sg = phys.light.ScatterSignMeasureStep(None, True)
+        sim.add_step(3, m)
+        sim.add_step(4, sg)
+        return sim, m, sg
+    ref, rm, rs = build(1)
+    run(ref)
+    sim, m, sg = build(K)
+    run(sim)
+    assert len(ref.ts) > 15 and [float(t) for t in sim.ts] == [float(t) for t in ref.ts]
+    assert [[float(x) for x in r] for r in m.data] == [[float(x) for x in r] for r in rm.data]
+    assert [[float(x) for x in r] for r in sg.data] == [[float(x) for x in r] for r in rs.data]
+    assert len(sim.objects) == 0 and float(sim.t) == float(ref.t)
+    assert rm.data[3][2] > 0                                                    # the plane at 3.5 steps is crossed in pass 4
+
+    # an exit on time leaves survivors: their state must agree too
+    out = []
+    for k in (1, K):
+        s, _, _ = build(k)
+        s.exit = lambda x: x.t >= 0.0045
+        run(s)
+        out.append((len(s.objects), s.download("r"), s.download("id"), s.download("dr")))
+    assert out[0][0] == out[1][0] > 0
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert np.array_equal(a, b)
