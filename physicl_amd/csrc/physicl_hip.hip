@@ -442,6 +442,8 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const int64_t tile = blockIdx.x;
     int kept = 0;
+    // per-step tallies of this wave, lane k holding step k's (K <= 64): one add per step instead of an LDS atomic
+    uint32_t t_alive = 0, t_sx = 0, t_sy = 0, t_sz = 0;
     for (int rr = 0; rr < kTileRows / 4; ++rr) {
         const int row = wave * (kTileRows / 4) + rr;
         const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
@@ -479,14 +481,11 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
             alive = alive && !(photon && (pcoll >= rand));
             const uint64_t m = __ballot(alive);
             uint32_t *c = &s_cnt[k * nslots];
-            if (lane == 0 && m) {
-                atomicAdd(&c[0], (uint32_t)__popcll(m));
-                if (a.n_planes >= 0) {
-                    atomicAdd(&c[1], (uint32_t)__popcll(m & sgn[0]));
-                    atomicAdd(&c[2], (uint32_t)__popcll(m & sgn[1]));
-                    atomicAdd(&c[3], (uint32_t)__popcll(m & sgn[2]));
-                }
-            }
+            const bool mine = lane == k;
+            t_alive += mine ? (uint32_t)__popcll(m) : 0u;
+            t_sx += mine ? (uint32_t)__popcll(m & sgn[0]) : 0u;
+            t_sy += mine ? (uint32_t)__popcll(m & sgn[1]) : 0u;
+            t_sz += mine ? (uint32_t)__popcll(m & sgn[2]) : 0u;
             for (int p = 0; p < np; ++p) {
                 const int ax = a.plane_ax[p];
                 const T L = a.plane_L[p];
@@ -504,6 +503,14 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
         const uint64_t m = __ballot(alive);
         if (lane == 0) a.masks[tile * kTileRows + row] = m;
         kept += __popcll(m);
+    }
+    if (lane < a.K) {
+        if (t_alive) atomicAdd(&s_cnt[lane * nslots + 0], t_alive);
+        if (a.n_planes >= 0) {
+            if (t_sx) atomicAdd(&s_cnt[lane * nslots + 1], t_sx);
+            if (t_sy) atomicAdd(&s_cnt[lane * nslots + 2], t_sy);
+            if (t_sz) atomicAdd(&s_cnt[lane * nslots + 3], t_sz);
+        }
     }
     if (lane == 0) s_keep[wave] = kept;
     __syncthreads();

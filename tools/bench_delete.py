@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--mode", choices=("multi", "fused", "fused-eager", "separate"), default="multi",
                     help="multi: --steps-per-launch loop bodies per pass and one compaction (pcl_step_fused_delete_multi)")
     ap.add_argument("--steps-per-launch", type=int, default=8)
+    ap.add_argument("--no-counters", action="store_true", help="multi mode: alive counts only (timing experiment)")
     a = ap.parse_args()
     N = int(a.photons)
     dev = _hip.Device(0)
@@ -43,7 +44,7 @@ def main():
         while a.mode == "multi" and k < a.steps:
             ks = min(a.steps_per_launch, a.steps - k)
             n_before = dev.count
-            for o in dev.step_fused_delete_multi(1e-3, ks, 1e-3, 1e-3, a.seed, k, plane):
+            for o in dev.step_fused_delete_multi(1e-3, ks, 1e-3, 1e-3, a.seed, k, None if a.no_counters else plane):
                 work += n_before
                 per_step.append((n_before, o["N"]))
                 n_before = o["N"]
