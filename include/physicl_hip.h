@@ -271,9 +271,11 @@ int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out);
  * looking at the photons in between (physicl/__init__.py:441-448 runs the same steps every pass).
  * Requirements: all-photon store with implicit ids (no compaction yet), device RNG; dr/dv are left implicit
  * exactly as after the last single lazy step.  flags: PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N.
- * out_host (may be NULL): int64[k_steps][5] = { N, xp, yp, zp, hits } per step; 1 <= k_steps <= 64. */
+ * planes_host / n_planes (0..12) as in pcl_step_fused.  out_host (may be NULL): int64[k_steps][5 + n_planes] =
+ * { N, xp, yp, zp, plane counts..., hits } per step; 1 <= k_steps <= 64. */
 int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int flags, double c, double h,
-                         const char *n_expr, uint64_t seed, uint32_t step0, int64_t *out_host);
+                         const char *n_expr, uint64_t seed, uint32_t step0, const double *planes_host, int n_planes,
+                         int64_t *out_host);
 
 /* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
  * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --

@@ -94,7 +94,7 @@ _PROTOTYPES = {
     "pcl_step_fused_delete_multi": [_vp, c_double, c_int, c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_store_is_uniform": [_vp, POINTER(c_int)],
     "pcl_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
-                             c_uint32, _vp],
+                             c_uint32, _vp, c_int, _vp],
     "pcl_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                        c_uint32, _vp, c_int, _vp],
     "pcl_step_fused_read": [_vp, c_int, _vp],
@@ -450,20 +450,23 @@ class Device:
         check(self.lib.pcl_store_is_uniform(self.ctx, byref(u)))
         return bool(u.value)
 
-    def step_fused_multi(self, dt, k_steps, scatter, sync=True):
-        """``k_steps`` consecutive lazy fused steps (Newton + ScatterIsotropic + sign counters, device RNG, launch
-        indices scatter['step'] .. +k_steps-1) in one pass over the store.  Returns a list of k_steps dicts like
+    def step_fused_multi(self, dt, k_steps, scatter, planes=(), sync=True):
+        """``k_steps`` consecutive lazy fused steps (Newton + ScatterIsotropic + sign / plane counters, device RNG,
+        launch indices scatter['step'] .. +k_steps-1) in one pass over the store.  Returns a list of k_steps dicts like
         step_fused's (or None if not sync)."""
         sc = scatter
-        out = np.zeros((k_steps, 5), dtype=np.int64) if sync else None
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        npl = len(pl)
+        out = np.zeros((k_steps, 5 + npl), dtype=np.int64) if sync else None
         expr = sc.get("n_expr")
         check(self.lib.pcl_step_fused_multi(
             self.ctx, float(dt), int(k_steps), float(sc["A"]), float(sc["n"]), int(sc.get("flags", 0)),
             float(sc.get("c", 0.0)), float(sc.get("h", 0.0)), expr.encode() if expr is not None else None,
-            int(sc.get("seed", 0)), int(sc.get("step", 0)) & 0xFFFFFFFF, out.ctypes.data_as(c_void_p) if sync else None))
+            int(sc.get("seed", 0)), int(sc.get("step", 0)) & 0xFFFFFFFF, pl.ctypes.data_as(c_void_p) if npl else None, npl,
+            out.ctypes.data_as(c_void_p) if sync else None))
         if out is None:
             return None
-        return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4].copy(), "hits": int(o[4])} for o in out]
+        return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + npl].copy(), "hits": int(o[4 + npl])} for o in out]
 
     def step_fused_read(self, n_planes=0):
         """Counters of the last ``step_fused(..., sync=False)``: same dict as the synchronous call."""

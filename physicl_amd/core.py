@@ -206,7 +206,7 @@ class Simulation(threading.Thread):
                counters (alive, hits, measure rows) are all-reduced
       steps_per_launch
                K > 1 (opt-in, default 1): when every pass of the loop is exactly
-               [UpdateTimeStep][NewtonianKinematicsStep][ScatterIsotropicStep][plane-less counting measures], rng is
+               [UpdateTimeStep][NewtonianKinematicsStep][ScatterIsotropicStep | ScatterDeleteStep][counting measures], rng is
                "philox" and all objects are photons, up to K passes run as ONE pass over the device store
                (photons do not interact; state, ``hits`` and every measure row are bit-identical to K=1).  The host
                side of those passes -- the time update and ``exit(sim)`` -- is evaluated ahead of the launch, so
@@ -521,7 +521,7 @@ class Simulation(threading.Thread):
                     self._readonly_scope = False
 
     def _multi_eligible(self):
-        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + plane-less counting measures] on a uniform
+        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + counting measures] on a uniform
         photon store, or [UpdateTimeStep][Newton + ScatterDelete + counting measures], with the device RNG: K passes
         can run as one launch (pcl_step_fused_multi / pcl_step_fused_delete_multi)."""
         plan = self._plan
@@ -535,7 +535,7 @@ class Simulation(threading.Thread):
             return False
         if roles[1] == "scatter_delete":
             return True
-        if roles[1] != "scatter_iso" or any(s._n_planes() for s in group[2:]):
+        if roles[1] != "scatter_iso":
             return False
         self._to_device()
         return self._dev.is_uniform()
@@ -572,13 +572,17 @@ class Simulation(threading.Thread):
         sc.update(rng_mode=self._hip.RNG_PHILOX, seed=self.seed, step=self._launch + 1)
         self._launch += k
         self._scattered = True
-        rows = dev.step_fused_multi(dt0, k, sc)
-        flat = np.array([[o["N"], o["hits"]] + list(o["sign"]) for o in rows], dtype=np.int64)
-        glob = self._global(flat.reshape(-1)).reshape(k, 5)
+        planes = [p for m in measures for p in m._plane_rows()]
+        rows = dev.step_fused_multi(dt0, k, sc, planes)
+        flat = np.array([np.concatenate([[o["N"], o["hits"]], o["sign"], o["planes"]]) for o in rows], dtype=np.int64)
+        glob = self._global(flat.reshape(-1)).reshape(k, flat.shape[1])
         for (t, dt), g in zip(times, glob):
             self.t, self.dt = t, dt                   # each row carries its own pass's time
+            j = 5
             for m in measures:
-                m._record(self, int(g[0]), g[2:5], g[5:5])
+                npl = m._n_planes()
+                m._record(self, int(g[0]), g[2:5], g[j:j + npl])
+                j += npl
         self.hits = int(glob[-1][1])
 
     def _run_multi_delete(self, upd, group):

@@ -740,7 +740,7 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
 // operations in the same order per photon -- while the HBM traffic per particle-step drops from 104 B to
 // 128/K B (fp64).  The velocity is updated in place and the velocity before the LAST step goes to the vp
 // rows, so dr = vp*dt and dv = v - vp stay implicit exactly as after a single lazy step.
-// cnt[4*k + {0: hits, 1..3: sign counts}] for k = 0..K-1.
+// cnt[(4 + n_planes)*k + {0: hits, 1..3: sign counts, 4..: plane crossings}] for k = 0..K-1.
 // ------------------------------------------------------------------------------------------------
 #define PCL_MULTI_MAX 64
 template <typename T>
@@ -750,13 +750,16 @@ struct pcl_multi_args {
     T *vp0, *vp1, *vp2; // written: v before the last of the K steps
     const T *lam4;      // pow((h*c)/E, -4) per photon            (USE_E)
     const T *E;         // only dereferenced if the expression names E[gid]
-    pcl_u64 *cnt;       // [4 * K]
+    pcl_u64 *cnt;       // [K][4 + n_planes]: hits, sign x/y/z, plane crossings
     pcl_i64 id_base, N;
     pcl_i64 ts;
     T dt, A, n, c;
     pcl_u64 seed;
     pcl_u32 step; // launch index of the first of the K steps
     int K;
+    int n_planes;             // 0..PCL_MAXPL measure planes (physicl/light.py:385-399)
+    int plane_ax[PCL_MAXPL];
+    T plane_L[PCL_MAXPL];
 };
 
 // The scatter branch (second Philox block, two sincos, the new velocity) is ~half of a step's arithmetic but
@@ -775,10 +778,11 @@ template <typename T, bool USE_E, bool VAR_N, int VEC>
 __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
-    __shared__ pcl_u32 s_cnt[4 * PCL_MULTI_MAX];
+    __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
+    const int nslots = 4 + a.n_planes;
     __shared__ pcl_u32 s_nh[2];
     __shared__ pcl_hit_queue<T, VEC> s_q;
-    for (int k = threadIdx.x; k < 4 * a.K; k += blockDim.x) s_cnt[k] = 0;
+    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
     if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
@@ -828,6 +832,15 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 Rr[0][e] = R::add(Rr[0][e], d0);
                 Rr[1][e] = R::add(Rr[1][e], d1);
                 Rr[2][e] = R::add(Rr[2][e], d2);
+                // plane crossings of this step's move (r - dr, r)                        light.py:385-399
+                for (int p = 0; p < a.n_planes; ++p) {
+                    const int ax = a.plane_ax[p];
+                    const T L = a.plane_L[p];
+                    const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
+                    const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
+                    const pcl_u32 nc = (pcl_u32)__popcll(__ballot(live && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + p], nc);
+                }
                 // scatter decision                                                       light.py:303-308
                 T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e],
                                                        Ev[e]);
@@ -896,10 +909,10 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 w_sz += (pcl_u32)__popcll(__ballot(live && V[2][e] > (T)0));
             }
             if (lane0) {
-                if (w_hits) atomicAdd(&s_cnt[4 * k + 0], w_hits);
-                if (w_sx) atomicAdd(&s_cnt[4 * k + 1], w_sx);
-                if (w_sy) atomicAdd(&s_cnt[4 * k + 2], w_sy);
-                if (w_sz) atomicAdd(&s_cnt[4 * k + 3], w_sz);
+                if (w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
+                if (w_sx) atomicAdd(&s_cnt[nslots * k + 1], w_sx);
+                if (w_sy) atomicAdd(&s_cnt[nslots * k + 2], w_sy);
+                if (w_sz) atomicAdd(&s_cnt[nslots * k + 3], w_sz);
             }
         }
         if (live_q) {
@@ -915,7 +928,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < 4 * a.K; k += blockDim.x)
+    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
 }
 

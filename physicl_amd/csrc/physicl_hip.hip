@@ -1356,7 +1356,7 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
 
 template <typename T>
 int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c,
-                 double h, uint64_t seed, uint32_t step) {
+                 double h, uint64_t seed, uint32_t step, const double *planes_host, int n_planes) {
     const int64_t N = ctx->count;
     if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
     pcl_multi_args<T> f{};
@@ -1373,6 +1373,13 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     f.seed = seed;
     f.step = step;
     f.K = k_steps;
+    f.n_planes = n_planes > 0 ? n_planes : 0;
+    for (int p = 0; p < f.n_planes; ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        f.plane_ax[p] = ax;
+        f.plane_L[p] = (T)loc[ax];
+    }
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
@@ -2334,10 +2341,14 @@ int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out) {
 }
 
 int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int flags, double c, double h,
-                         const char *n_expr, uint64_t seed, uint32_t step0, int64_t *out_host) {
+                         const char *n_expr, uint64_t seed, uint32_t step0, const double *planes_host, int n_planes,
+                         int64_t *out_host) {
     PCL_TRY(need_store_raw(ctx));
     if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
     if (k_steps < 1 || k_steps > PCL_MULTI_MAX) return fail(PCL_ERR_ARG, "k_steps outside [1, %d]", PCL_MULTI_MAX);
+    if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
+    if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
+    const int np = n_planes, nslots = 4 + np;
     if (ctx->kind || !ctx->ids_iota)
         return fail(PCL_ERR_STATE, "pcl_step_fused_multi needs an all-photon store with implicit ids (use pcl_step_fused)");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
@@ -2347,28 +2358,29 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     const int64_t N = ctx->count;
     if (out_host)
         for (int k = 0; k < k_steps; ++k) {
-            out_host[5 * k] = N;
-            for (int j = 1; j < 5; ++j) out_host[5 * k + j] = 0;
+            out_host[(5 + np) * k] = N;
+            for (int j = 1; j < 5 + np; ++j) out_host[(5 + np) * k + j] = 0;
         }
     if (N == 0) return PCL_OK;
     // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
-    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)4 * k_steps * sizeof(uint64_t), ctx->stream));
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)nslots * k_steps * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
-    PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0),
-                         step_multi_t<float>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0)));
+    PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np),
+                         step_multi_t<float>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np)));
     ctx->lazy_dv = true; // vprev rows = v before the last step
     ctx->lazy_dr = true;
     ctx->lazy_dt = dt;
     // pcl_store_last_scatter_hits() reports the last of the K steps
-    PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + 4 * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + nslots * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                           ctx->stream));
     if (out_host) {
-        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)4 * k_steps * sizeof(uint64_t), hipMemcpyDeviceToHost,
+        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)nslots * k_steps * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < k_steps; ++k) {
-            for (int j = 0; j < 3; ++j) out_host[5 * k + 1 + j] = (int64_t)ctx->h_multi[4 * k + 1 + j];
-            out_host[5 * k + 4] = (int64_t)ctx->h_multi[4 * k];
+            for (int j = 0; j < 3 + np; ++j) out_host[(5 + np) * k + 1 + j] = (int64_t)ctx->h_multi[nslots * k + 1 + j];
+            out_host[(5 + np) * k + 4 + np] = (int64_t)ctx->h_multi[nslots * k];
         }
     }
     return PCL_OK;

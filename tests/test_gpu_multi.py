@@ -73,18 +73,22 @@ def state_equal(a, b):
 def test_multi_is_bit_identical_to_single_steps(make_store, hip, tag, N, K, dtype):
     init = initial(N, dtype, N + K)
     seed, step0 = 0xC0FFEE1234, 11
+    # measure planes (light.py:385-399) ride along in half of the cases; the single steps then take the generic kernel
+    planes = [[0.5, np.nan, np.nan], [np.nan, np.nan, -2.0], [np.nan, 1e-3, np.nan]] if N in (777, 200_001) else []
     a = make_store(N, dtype)
     a.upload_state(init)
     single = []
     for k in range(K):
         sc, dt = scatter_dict(hip, tag, seed, step0 + k)
-        o = a.step_fused(dt, sc, [], lazy=True)
-        single.append((o["N"], o["hits"], list(o["sign"])))
+        o = a.step_fused(dt, sc, planes, lazy=True)
+        single.append((o["N"], o["hits"], list(o["sign"]), list(o["planes"])))
     b = make_store(N, dtype)
     b.upload_state(init)
     sc, dt = scatter_dict(hip, tag, seed, step0)
-    rows = b.step_fused_multi(dt, K, sc)
-    assert [(o["N"], o["hits"], list(o["sign"])) for o in rows] == single
+    rows = b.step_fused_multi(dt, K, sc, planes)
+    assert [(o["N"], o["hits"], list(o["sign"]), list(o["planes"])) for o in rows] == single
+    if planes and tag == "base":
+        assert sum(sum(o["planes"]) for o in rows) > 0
     assert b.last_scatter_hits() == single[-1][1]
     state_equal(a.download_state(), b.download_state())         # includes the implicit dr / dv of the last step
 
