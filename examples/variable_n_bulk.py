@@ -2,7 +2,10 @@
 """Variable number density + wavelength-dependent scattering (the physics of the reference's
 examples/variable_n_scattering.ipynb) on 1e8 photons that never exist as Python objects.
 
-    python examples/variable_n_bulk.py [n_photons]
+    python examples/variable_n_bulk.py [n_photons] [steps_per_launch]
+
+steps_per_launch > 1 (default 25) runs that many passes of the loop per pass over the device store -- same rows,
+same final state, ~2.5x the particle-steps/s of one launch per pass.
 """
 import os
 import sys
@@ -16,9 +19,10 @@ import physicl.light as light   # noqa: E402
 import physicl.newton as newton  # noqa: E402
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+spl = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 cl_n = "0.000000001 * exp(r0[gid] - 5)"                      # OpenCL-C expression, compiled into the kernel by hipRTC
 
-sim = phys.Simulation(cl_on=True, seed=1234, exit=lambda cond: cond.t >= 0.2495)
+sim = phys.Simulation(cl_on=True, seed=1234, exit=lambda cond: cond.t >= 0.2495, steps_per_launch=spl)
 sim.add_step(2, phys.UpdateTimeStep(lambda c: 0.005))
 sim.add_step(1, newton.NewtonianKinematicsStep())
 sim.add_step(3, light.ScatterIsotropicStep(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True,
