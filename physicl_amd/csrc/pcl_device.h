@@ -764,10 +764,11 @@ struct pcl_multi_args {
 
 // The scatter branch (second Philox block, two sincos, the new velocity) is ~half of a step's arithmetic but
 // only the hit photons need it; executed in place it costs every wave the full branch however few of its
-// lanes hit.  So the hits of a workgroup's 256*VEC photons are queued in LDS (wave-aggregated slot
-// allocation), processed densely -- item j by thread j, whole waves skip when the queue is short -- and the
-// new velocities handed back through LDS.  Same operations on the same operands per photon, so nothing changes
-// in the results; only which lane executes them.
+// lanes hit.  So each wave queues the hits of its 64*VEC photons in its own slice of an LDS queue (slots from
+// the ballots' prefix counts), processes them densely -- item j by lane j, ceil(hits/64) passes instead of VEC --
+// and hands the new velocities back through LDS.  Same operations on the same operands per photon, so nothing
+// changes in the results; only which lane executes them.  (A workgroup-wide queue packs better -- 0.75 instead
+// of 1.0 passes per wave at 26 % hits -- but its two barriers per step cost more than that: measured 7 % slower.)
 template <typename T, int VEC>
 struct pcl_hit_queue {
     pcl_u32 owner[256 * VEC]; // thread * VEC + e of the photon that hit
@@ -780,16 +781,13 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     typedef pcl_vec<T, VEC> VV;
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
-    __shared__ pcl_u32 s_nh[2];
     __shared__ pcl_hit_queue<T, VEC> s_q;
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
-    if (threadIdx.x < 2) s_nh[threadIdx.x] = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
-    pcl_u32 it = 0; // k-iterations this workgroup has run: parity selects the queue counter
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
@@ -811,14 +809,13 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) VP[j][e] = V[j][e];
         }
-        for (int k = 0; k < a.K; ++k, ++it) {
+        for (int k = 0; k < a.K; ++k) {
             const pcl_u32 st = a.step + (pcl_u32)k;
             // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push
             // other scalars into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler
             // rebuild them per iteration on the otherwise idle scalar unit instead.
             pcl_u32 kk0 = k0, kk1 = k1;
             asm volatile("" : "+s"(kk0), "+s"(kk1));
-            pcl_u32 *nh = &s_nh[it & 1];
             pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
             bool hit[VEC];
             pcl_u32 slot[VEC];
@@ -857,27 +854,28 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 }
                 hit[e] = live && (pc >= rand);
             }
-            // queue slots: one LDS atomic per wave for all its VEC ballots
+            // queue slots from the wave's own ballots
             pcl_u64 ballot[VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 ballot[e] = __ballot(hit[e]);
                 w_hits += (pcl_u32)__popcll(ballot[e]);
             }
-            pcl_u32 wbase = 0;
-            if (lane0 && w_hits) wbase = atomicAdd(nh, w_hits);
-            wbase = (pcl_u32)__builtin_amdgcn_readfirstlane((int)wbase);
+            const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
+            pcl_u32 wbase = qbase;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(ballot[e] >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)ballot[e], 0u));
                 wbase += (pcl_u32)__popcll(ballot[e]);
                 if (hit[e]) s_q.owner[slot[e]] = threadIdx.x * VEC + e;
             }
-            __syncthreads();
-            const pcl_u32 n_hit = *nh;
-            if (threadIdx.x == 0) s_nh[(it + 1) & 1] = 0; // nobody touches the other counter until the next barrier
-            // the scatter itself, densely: item j by thread j                              light.py:309-311
-            for (pcl_u32 j = threadIdx.x; j < n_hit; j += blockDim.x) {
+            // the queue is private to the wave: LDS executes a wave's accesses in order, so a compiler-level fence
+            // is all the hand-over needs -- no workgroup barrier anywhere in the K loop
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const pcl_u32 n_hit = qbase + w_hits;
+            // the scatter itself, densely: item j by lane j                                light.py:309-311
+            for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
                 const pcl_u32 o = s_q.owner[j];
                 const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(o / VEC)) * VEC + (pcl_i64)(o % VEC));
                 T rtheta, rphi;
@@ -889,7 +887,8 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                 s_q.out[2][j] = o2;
                 s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const bool live = live_q && q * VEC + e < a.N;
