@@ -949,8 +949,15 @@ PCL_RTC_KERNEL(pcl_rtc_fused_f_e0, pcl_fused_args<float>, (pcl_fused_body<float,
 PCL_RTC_KERNEL(pcl_rtc_fused_f_e1, pcl_fused_args<float>, (pcl_fused_body<float, true, true>))
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e0, pcl_fast_args<float>, (pcl_fast_body<float, false, true, 4>))
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e1, pcl_fast_args<float>, (pcl_fast_body<float, true, true, 4>))
-PCL_RTC_KERNEL(pcl_rtc_multi_e0, pcl_multi_args<double>, (pcl_multi_body<double, false, true, 2>))
-PCL_RTC_KERNEL(pcl_rtc_multi_e1, pcl_multi_args<double>, (pcl_multi_body<double, true, true, 2>))
+#ifndef PCL_MULTI_ATTR /* timing experiments: e.g. -DPCL_MULTI_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) */
+#define PCL_MULTI_ATTR
+#endif
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e0(pcl_multi_args<double> a) {
+    pcl_multi_body<double, false, true, 2>(a);
+}
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e1(pcl_multi_args<double> a) {
+    pcl_multi_body<double, true, true, 2>(a);
+}
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float, false, true, 4>))
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
 #endif
