@@ -69,6 +69,20 @@ def algorithmic_bytes_per_particle(profile, h, mode="separate", multi=False):
     return 8 * len(PROFILES[profile]["arrays_read"]) + 24 + 48.0 * h
 
 
+VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12    # CUs x SIMDs x lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s
+
+
+def valu_roofline(v, per_gpu_rate):
+    """The K-step kernel is bound by vector-ALU issue, not by HBM: VALU instructions per particle-step (rocprofv3
+    SQ_INSTS_VALU x 64 / particle-steps, profiles/) x the measured particle-steps/s of one GPU, against the chip's
+    issue peak of one VALU instruction per lane per clock (fp64 FMA included: 78.6 TFLOP/s = 2 x 39.3)."""
+    out = dict(v)
+    ach = v["valu_insts_per_particle_step"] * per_gpu_rate / 1e12
+    out.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
+                "frac": ach / VALU_PEAK_TLANE})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -273,7 +287,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
                          "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"], "steps_per_launch": S,
-                         "valu": valu},
+                         "valu": valu_roofline(valu, value / world) if valu else None},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if v["launches"]},
             "kernels_GBps": {
                 "k_newton": N * 96 / (kern["k_newton"]["avg_ms"] * 1e-3) / 1e9 if kern["k_newton"]["launches"] else None,

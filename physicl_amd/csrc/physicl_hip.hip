@@ -2,7 +2,9 @@
 // include/physicl_hip.h.  Build: see __graft_entry__.build() (hipcc --offload-arch=gfx950 -O3
 // -ffp-contract=off).  No PyOpenCL, no CUDA compatibility layer, no Triton.
 //
-// Kernel inventory (all HBM-bandwidth-bound streaming kernels; roofline and bytes in DESIGN.md).
+// Kernel inventory (HBM-bandwidth-bound streaming kernels, except the K-step passes, which trade HBM bytes for
+// arithmetic and are VALU-bound; roofline and bytes in DESIGN.md).  The resident store is one tiled slab
+// ([tile][17 rows][2048 particles], pcl_tix / pcl_tq).
 // <T> = double (the reference's precision) or float (precision sweep, BASELINE.json configs[4]):
 //   k_newton<T>           NewtonianKinematicsStep.run                 physicl/newton.py:10-16
 //   k_delete_flags        light_scatter_step_del / "test"             physicl/light.py:146-158, 239-249
@@ -10,9 +12,13 @@
 //   k_scatter<T,E>        ScatterIsotropicStep.__run_cl as one step   physicl/light.py:281-331
 //   k_fused<T,E>          Newton + scatter + counters in one pass     (pcl_device.h)
 //   k_fast<T,E>           the same, fast path                         (pcl_device.h)
+//   k_multi<T,E>          K of those loop bodies per pass over the store (pcl_device.h)
 //   k_lam4<T>             cache of pow((h*c)/E, -4)                   physicl/light.py:301
 //   k_materialize<T>      dr, dv after lazy fused steps               physicl/newton.py:15, light.py:329-331
 //   k_delete_mask<T>      delete-flag kernel -> wave64 ballot masks   physicl/light.py:239-249
+//   k_newton_mask<T>      Newton + delete flag -> masks (fused delete pipeline, pass 1)
+//   k_newton_mask_multi<T> K delete loop bodies per pass -> one mask + per-step measure rows
+//   k_compact_count<T,W>  compaction with the measure counters folded in (pass 3)
 //   k_tile_scan           exclusive scan of per-tile survivor counts
 //   k_compact<W,NF>       stable compaction of the SoA state          physicl/light.py:258-260,
 //                                                                      physicl/__init__.py:455-459
