@@ -792,7 +792,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
         const pcl_i64 qs = pcl_tq<VEC>(live_q ? q : 0, a.ts);
-        T Rr[3][VEC], V[3][VEC], VP[3][VEC], L4[VEC], Ev[VEC], NM[VEC];
+        T Rr[3][VEC], V[3][VEC], L4[VEC], Ev[VEC], NM[VEC];
         pcl_u32 wodd0[VEC], wodd1[VEC]; // the decision block's second half, waiting for the odd step
         VV::ld(a.r0, qs, Rr[0]);
         VV::ld(a.r1, qs, Rr[1]);
@@ -806,8 +806,6 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             Ev[e] = a.E[pcl_tix((live_q && q * VEC + e < a.N) ? q * VEC + e : 0, a.ts)];
             // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
             NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
-#pragma unroll
-            for (int j = 0; j < 3; ++j) VP[j][e] = V[j][e];
         }
         for (int k = 0; k < a.K; ++k) {
             const pcl_u32 st = a.step + (pcl_u32)k;
@@ -889,14 +887,14 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            if (k + 1 == a.K && live_q) { // the velocity before the LAST step is what dv = v - v_prev needs: stored
+                VV::st(a.vp0, qs, V[0]);  // straight from the v registers (wave-uniform branch), no copy kept
+                VV::st(a.vp1, qs, V[1]);
+                VV::st(a.vp2, qs, V[2]);
+            }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const bool live = live_q && q * VEC + e < a.N;
-                if (k + 1 == a.K) { // the velocity before the LAST step is what dv = v - v_prev needs
-                    VP[0][e] = V[0][e];
-                    VP[1][e] = V[1][e];
-                    VP[2][e] = V[2][e];
-                }
                 if (hit[e]) {
                     V[0][e] = s_q.out[0][slot[e]];
                     V[1][e] = s_q.out[1][slot[e]];
@@ -921,9 +919,6 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             VV::st(a.v0, qs, V[0]);
             VV::st(a.v1, qs, V[1]);
             VV::st(a.v2, qs, V[2]);
-            VV::st(a.vp0, qs, VP[0]);
-            VV::st(a.vp1, qs, VP[1]);
-            VV::st(a.vp2, qs, VP[2]);
         }
     }
     __syncthreads();
