@@ -21,11 +21,12 @@ sys.path.insert(0, %(root)r)
 import physicl as phys, physicl.light, physicl.newton
 from physicl_amd.dist import CounterComm
 comm = CounterComm.from_env(backend="gloo")
-kind = %(kind)r
-sim = phys.Simulation(cl_on=True, device=0, comm=comm if comm.world > 1 else None, seed=21, rng="philox",
-                      exit=(lambda s: len(s.objects) < 2000) if kind == "delete" else (lambda s: s.t >= 0.0055))
+kind, spl = %(kind)r, %(spl)d
+sim = phys.Simulation(cl_on=True, device=0, comm=comm if comm.world > 1 else None, seed=21, rng="philox", steps_per_launch=spl,
+                      exit=(lambda s: len(s.objects) < 2000) if kind == "delete" else
+                           (lambda s: len(s.objects) == 0) if kind == "delete_empty" else (lambda s: s.t >= 0.0055))
 N = 150001
-if kind == "batch" or kind == "delete":
+if kind in ("batch", "delete", "delete_empty"):
     sim.add_objs(phys.light.generate_photons_bulk(N, min=phys.light.E_from_wavelength(700e-9),
                                                   max=phys.light.E_from_wavelength(200e-9), seed=21))
 else:
@@ -33,7 +34,7 @@ else:
                   for i in range(3001)])
 sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
 sim.add_step(1, phys.newton.NewtonianKinematicsStep())
-if kind == "delete":
+if kind.startswith("delete"):
     sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
 else:
     sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001), wavelength_dep_scattering=False))
@@ -56,13 +57,13 @@ def free_port():
     return p
 
 
-def run_world(world, kind):
+def run_world(world, kind, spl=1):
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "kind": kind}], env=env,
+        procs.append(subprocess.Popen([sys.executable, "-c", WORKER % {"root": ROOT, "kind": kind, "spl": spl}], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
@@ -81,3 +82,16 @@ def test_two_shards_reproduce_the_single_process_rows(kind):
         assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
     assert two[0]["local"] + two[1]["local"] == one["local"]
     assert len(one["m1"]) >= 5 and one["m1"][0][1] > 0
+
+
+@pytest.mark.parametrize("kind", ["batch", "delete_empty"])
+def test_two_shards_with_several_passes_per_launch_reproduce_the_single_process_rows(kind):
+    """Simulation(steps_per_launch=4) on two shards == one pass per launch on one process: the K x counters of a
+    launch are all-reduced at once, and the cut at the pass that empties the GLOBAL store is taken by both ranks."""
+    one = run_world(1, kind, 1)[0]
+    two = run_world(2, kind, 4)
+    for rank in two:
+        assert rank["m1"] == one["m1"] and rank["m2"] == one["m2"]
+        assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
+    assert two[0]["local"] + two[1]["local"] == one["local"]
+    assert len(one["m1"]) >= 5
