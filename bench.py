@@ -203,7 +203,9 @@ def main():
             totals = comm.allreduce_sum(c)
         return hits
 
+    dev.prof_enable(True)
     run_steps(0, args.warmup)
+    warm = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}   # rocprofv3 --stats averages these in too
 
     dev.prof_enable(True)
     comm.barrier()
@@ -287,6 +289,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
                          "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"], "steps_per_launch": S,
+                         "warmup_launches": warm[dominant]["launches"], "warmup_avg_launch_ms": warm[dominant]["avg_ms"],
+                         "avg_launch_ms_incl_warmup": ((sc["avg_ms"] * sc["launches"] + warm[dominant]["avg_ms"] * warm[dominant]["launches"])
+                                                       / max(1, sc["launches"] + warm[dominant]["launches"])),
                          "valu": valu_roofline(valu, value / world) if valu else None},
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if v["launches"]},
             "kernels_GBps": {

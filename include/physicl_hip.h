@@ -165,6 +165,8 @@ int pcl_k_compact_indices(pcl_ctx *ctx, const int32_t *flags, int64_t N, int64_t
  * numbers, + - * / ( ) , the functions exp sqrt pow log log2 log10 exp2 sin cos tanh fabs fmin fmax,
  * and the array reads r0[gid] r1[gid] r2[gid] d0[gid] d1[gid] d2[gid] E[gid].                     */
 int pcl_expr_validate(const char *n_expr);
+/* (The hipRTC code objects of an expression are cached in $PCL_RTC_CACHE -- a directory, "off" disables -- default
+ * ~/.cache/physicl_amd/rtc, checksummed; a second process loads them instead of compiling.) */
 
 /* User kernels -- the role of CLProgram.build_kernel()/run() (physicl/__init__.py:583-597, 648-656): the
  * caller supplies the parameter list it generated from its CLInput/CLOutput metadata (e.g.

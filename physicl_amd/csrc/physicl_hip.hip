@@ -27,6 +27,9 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1099,6 +1102,92 @@ std::map<std::string, std::vector<char>> g_code_cache;
 
 int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &code, rtc_entry **out);
 
+// ---- on-disk cache of hipRTC code objects: $PCL_RTC_CACHE (a directory; "off" disables), default ~/.cache/physicl_amd/rtc
+uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+    for (unsigned char c : s) {
+        h ^= c;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+
+std::string rtc_cache_path(const std::string &src, const std::string &arch, const std::string &extra) {
+    const char *dir_env = getenv("PCL_RTC_CACHE");
+    std::string dir;
+    if (dir_env && *dir_env) {
+        if (!strcmp(dir_env, "off") || !strcmp(dir_env, "0")) return "";
+        dir = dir_env;
+    } else {
+        const char *home = getenv("HOME");
+        if (!home || !*home) return "";
+        dir = std::string(home) + "/.cache/physicl_amd/rtc";
+    }
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    char tag[64];
+    snprintf(tag, sizeof tag, "|%d.%d|abi%d", major, minor, PCL_ABI_VERSION);
+    const uint64_t h1 = fnv1a(src + "|" + arch + "|" + extra + tag);
+    const uint64_t h2 = fnv1a(arch + tag + "|" + extra + "|" + src, 0x9E3779B97F4A7C15ull);
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)h1, (unsigned long long)h2);
+    // mkdir -p (two levels are enough for the default; a user-supplied directory must exist or be creatable in one step)
+    std::string partial;
+    for (size_t i = 0; i <= dir.size(); ++i) {
+        if (i == dir.size() || (dir[i] == '/' && i > 0)) {
+            partial = dir.substr(0, i);
+            if (!partial.empty()) (void)mkdir(partial.c_str(), 0755);
+        }
+    }
+    return dir + name;
+}
+
+bool read_file(const std::string &path, std::vector<char> *out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<char> buf;
+    char chunk[65536];
+    size_t n;
+    while ((n = fread(chunk, 1, sizeof chunk, f)) > 0) buf.insert(buf.end(), chunk, chunk + n);
+    const bool ok = !ferror(f);
+    fclose(f);
+    if (ok) out->swap(buf);
+    return ok;
+}
+
+void write_file_atomic(const std::string &path, const std::vector<char> &data) {
+    char tmp[32];
+    snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
+    const std::string t = path + tmp;
+    FILE *f = fopen(t.c_str(), "wb");
+    if (!f) return; // read-only home, full disk ...: the cache is an optimisation only
+    const bool ok = fwrite(data.data(), 1, data.size(), f) == data.size();
+    if (fclose(f) != 0 || !ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
+}
+
+// cache file = "PCLRTC01" | payload size (u64) | FNV-1a of the payload (u64) | payload.  A file that fails any of the
+// three checks is treated as absent: the module loader must never see a truncated or foreign code object.
+bool read_cached_code(const std::string &path, std::vector<char> *code) {
+    std::vector<char> raw;
+    if (!read_file(path, &raw) || raw.size() < 24 || memcmp(raw.data(), "PCLRTC01", 8) != 0) return false;
+    uint64_t size = 0, sum = 0;
+    memcpy(&size, raw.data() + 8, 8);
+    memcpy(&sum, raw.data() + 16, 8);
+    if (size == 0 || size != raw.size() - 24) return false;
+    if (fnv1a(std::string(raw.data() + 24, (size_t)size)) != sum) return false;
+    code->assign(raw.begin() + 24, raw.end());
+    return true;
+}
+
+void write_cached_code(const std::string &path, const std::vector<char> &code) {
+    std::vector<char> raw(24 + code.size());
+    const uint64_t size = code.size(), sum = fnv1a(std::string(code.data(), code.size()));
+    memcpy(raw.data(), "PCLRTC01", 8);
+    memcpy(raw.data() + 8, &size, 8);
+    memcpy(raw.data() + 16, &sum, 8);
+    memcpy(raw.data() + 24, code.data(), code.size());
+    write_file_atomic(path, raw);
+}
+
 int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     std::string expr_f32;
     PCL_TRY(validate_expr(expr, &expr_f32));
@@ -1134,11 +1223,27 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     src += expr_f32;
     src += ")\n";
     src += pcl_rtc_source;
+    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
+    const char *extra = getenv("PCL_RTC_DEFINE"); // timing experiments only: e.g. -DPCL_ABLATE_TRIG
+    // code objects are kept on disk, keyed by a hash of everything that determines them (the whole specialised source
+    // text, target, options, hipRTC version): a second process starts without the ~2 s compile
+    const std::string disk = rtc_cache_path(src, arch, extra ? extra : "");
+    if (!disk.empty()) {
+        std::vector<char> cached;
+        if (read_cached_code(disk, &cached)) {
+            rtc_entry *e = nullptr;
+            if (load_rtc_module(ctx, expr, cached, &e) == PCL_OK) {
+                std::lock_guard<std::mutex> lock(g_code_mutex);
+                g_code_cache[code_key] = cached;
+                *out = e;
+                return PCL_OK;
+            }
+            ctx->rtc.erase(expr); // unreadable / stale file: compile again and overwrite it
+        }
+    }
     hiprtcProgram prog;
     hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
     if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
-    std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
-    const char *extra = getenv("PCL_RTC_DEFINE"); // timing experiments only: e.g. -DPCL_ABLATE_TRIG
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra};
     r = hiprtcCompileProgram(prog, (extra && *extra) ? 5 : 4, opts);
     if (r != HIPRTC_SUCCESS) {
@@ -1159,6 +1264,7 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
         std::lock_guard<std::mutex> lock(g_code_mutex);
         g_code_cache[code_key] = code;
     }
+    if (!disk.empty()) write_cached_code(disk, code);
     return load_rtc_module(ctx, expr, code, out);
 }
 

@@ -766,3 +766,44 @@ def test_async_fused_steps_are_pipelined_and_read_in_order(store, hip):
     with pytest.raises(hip.HipError, match="outstanding"):
         d.step_fused(1e-3, sc(7), (), sync=False, lazy=True)
     d.step_fused_read(0), d.step_fused_read(0)
+
+
+# ============================================================================ on-disk cache of hipRTC code objects
+_RTC_CACHE_WORKER = r"""
+import sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from physicl_amd import _hip
+d = _hip.Device(0)
+d.store_alloc(1000)
+d.upload_state({"v": np.tile([299792458.0, 0.0, 0.0], (1000, 1)), "E": np.full(1000, 3e-19)})
+t0 = time.perf_counter()
+hits = d.step_scatter_isotropic(1e-3, 1.0, _hip.SCATTER_VARIABLE_N, 299792458.0, 6.62607015e-34, %(expr)r, _hip.RNG_PHILOX, 3, 0)
+print(hits, time.perf_counter() - t0)
+d.close()
+"""
+
+
+def test_rtc_code_objects_are_cached_on_disk_and_survive_a_corrupt_file(tmp_path):
+    """A second process finds the specialised kernels of an expression in $PCL_RTC_CACHE instead of recompiling them;
+    a truncated cache file is ignored (recompiled and overwritten), never trusted."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    expr = "0.5 * exp(-1 * pow(r0[gid], 2) / %d.0)" % (1000 + os.getpid() % 1000)     # not compiled by anyone before
+    env = dict(os.environ, PCL_RTC_CACHE=str(tmp_path))
+
+    def run():
+        out = subprocess.check_output([sys.executable, "-c", _RTC_CACHE_WORKER % {"root": root, "expr": expr}], env=env)
+        h, t = out.decode().split()[-2:]
+        return int(h), float(t)
+    h1, t1 = run()
+    files = list(tmp_path.glob("*.hsaco"))
+    assert len(files) == 1 and files[0].stat().st_size > 10_000
+    h2, t2 = run()
+    assert h2 == h1 and t2 < 0.5 * t1, (t1, t2)                    # no compile the second time
+    size = files[0].stat().st_size
+    files[0].write_bytes(files[0].read_bytes()[: size // 3])        # corrupt it
+    h3, _ = run()
+    assert h3 == h1 and files[0].stat().st_size == size and len(list(tmp_path.glob("*"))) == 1
