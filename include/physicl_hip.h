@@ -12,9 +12,11 @@
  *   Level 1  "reference-ABI kernels"  (pcl_k_*): same argument lists as the three OpenCL kernels
  *            the reference builds at run time, on raw device pointers.  One call == one
  *            ``prog.<kernel>(queue, (N,), None, *args)``.
- *   Level 2  "particle store" (pcl_store_*, pcl_step_*): particles stay resident in HBM as
- *            structure-of-arrays for the whole simulation and a Step is one fused kernel launch;
- *            replaces gather + H2D + launch + D2H + Python write-back.
+ *   Level 2  "particle store" (pcl_store_*, pcl_step_*): particles stay resident in HBM (one tiled
+ *            slab, see pcl_store_alloc) for the whole simulation; a Step, a whole loop body
+ *            (pcl_step_fused, pcl_step_fused_delete) or K loop bodies (pcl_step_fused_multi,
+ *            pcl_step_fused_delete_multi) are one pass over it; replaces gather + H2D + launch + D2H +
+ *            Python write-back.
  *
  * Conventions: plain C types only; every function returns 0 (PCL_OK) or a negative PCL_ERR_* code
  * and never throws; pcl_last_error() gives the calling thread's last message.  Unless a parameter
@@ -44,8 +46,7 @@ extern "C" {
 #define PCL_ERR_NOMEM  (-6) /* device or host allocation failed */
 
 /* Per-particle state = the fields of physicl.Object / PhotonObject that a Step reads or writes
- * (physicl/__init__.py:390-394, physicl/light.py:26-35), one contiguous array per component, of the
- * store's dtype. */
+ * (physicl/__init__.py:390-394, physicl/light.py:26-35), one row per component, of the store's dtype. */
 enum pcl_field {
     PCL_R0 = 0, PCL_R1, PCL_R2,      /* Object.r   position                    */
     PCL_V0, PCL_V1, PCL_V2,          /* Object.v   velocity                    */
@@ -69,7 +70,9 @@ enum pcl_field {
 /* where a step's three random numbers per photon come from */
 #define PCL_RNG_INPUT  0 /* arrays uploaded with pcl_store_upload_rand: the reference's contract
                             ("randoms are kernel inputs", light.py:285, __init__.py:606-619)       */
-#define PCL_RNG_PHILOX 1 /* generated in-kernel: Philox4x32-10 keyed by (seed, step, particle id)  */
+#define PCL_RNG_PHILOX 1 /* generated in-kernel: Philox4x32-10 keyed by (seed, step, particle id):
+                            decision block (id, step >> 1, 0) shared by two steps, direction block
+                            (id, step, 1) on a hit (DESIGN.md "Device RNG")                         */
 
 /* kind[] values (pcl_store_upload_kind) */
 #define PCL_KIND_OBJECT 0 /* plain physicl.Object: moved by Newton, skipped by the light steps
