@@ -544,7 +544,8 @@ class Simulation(threading.Thread):
         """Host part of up to ``steps_per_launch`` passes, ahead of the launch: the time update of each pass, then
         the exit test the outer loop would make before the next one.  Returns [(t, dt)] per pass and the code dt."""
         times, dt0 = [], None
-        while len(times) < self.steps_per_launch:
+        k_max = max(1, min(int(self.steps_per_launch), 64))        # PCL_MULTI_MAX
+        while len(times) < k_max:
             before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
             upd.run(self)
             if dt0 is None:
@@ -554,7 +555,7 @@ class Simulation(threading.Thread):
                 self.ts.pop()
                 break
             times.append((copy.deepcopy(self.t), self.dt))
-            if len(times) < self.steps_per_launch and self.exit(self):
+            if len(times) < k_max and self.exit(self):
                 break
         return times, dt0
 

@@ -381,7 +381,7 @@ def _batch_sim(n, K, t_end, dt_fn=lambda s: np.double(0.001), **kw):
     return sim, sign, count
 
 
-@pytest.mark.parametrize("K", [2, 5, 64])
+@pytest.mark.parametrize("K", [2, 5, 1000])       # 1000: clamped to the library maximum of 64
 def test_steps_per_launch_is_bit_identical_to_one_pass_per_launch(K):
     """13 passes in launches of K: same ts, same measure rows (each with its own pass's t), same hits, same state."""
     n, t_end = 300_001, 0.0125
