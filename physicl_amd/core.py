@@ -250,6 +250,7 @@ class Simulation(threading.Thread):
         self._scattered = False       # a device scatter step has replaced velocities since the upload
         self._launch = 0              # Philox "step" word: one per light-step launch
         self._plan_key, self._plan = None, None
+        self._upload_gen, self._multi_key, self._multi_ok = 0, None, False   # steps_per_launch eligibility cache
         self._readonly_scope = False  # inside a host step that promises not to modify objects
         self._dev_lock = threading.RLock()   # one device call in flight per context (include/physicl_hip.h)
         self._uploaded, self._upload_lo = [], 0
@@ -346,6 +347,7 @@ class Simulation(threading.Thread):
             self._all_photons = True
             self._alive = b.n
             self._residency = DEVICE
+            self._upload_gen += 1
             return
         items = self._objects._items
         lo, hi = self._shard(len(items))
@@ -373,6 +375,7 @@ class Simulation(threading.Thread):
         self._alive = len(items)
         self._scattered = False
         self._residency = DEVICE
+        self._upload_gen += 1
 
     def _to_host(self, mutate=True):
         """Bring the state back into Python objects.  mutate=False keeps the device copy valid."""
@@ -503,7 +506,7 @@ class Simulation(threading.Thread):
         key = tuple(id(s) for s in self.steps.values()) + (self.fuse,)
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan()
-        if self.steps_per_launch > 1 and self._multi_eligible():
+        if self.steps_per_launch > 1 and self._multi_agreed():
             self._run_multi(self._plan[0][1], self._plan[1][1])
             return
         for kind, item in self._plan:
@@ -519,6 +522,18 @@ class Simulation(threading.Thread):
                     item.run(self)
                 finally:
                     self._readonly_scope = False
+
+    def _multi_agreed(self):
+        """_multi_eligible(), decided once per (plan, upload) and -- with ``comm`` -- agreed by all ranks: a shard whose
+        store is not uniform (a plain Object among its photons) must not leave the others waiting in a collective of a
+        different launch schedule."""
+        key = (self._plan_key, self._upload_gen)
+        if key != self._multi_key:
+            ok = 1 if self._multi_eligible() else 0
+            if self.comm is not None:
+                ok = -int(self.comm.allreduce_sum([-ok])[0]) == self.comm.world      # all ranks eligible
+            self._multi_key, self._multi_ok = (self._plan_key, self._upload_gen), bool(ok)
+        return self._multi_ok
 
     def _multi_eligible(self):
         """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + counting measures] on a uniform
