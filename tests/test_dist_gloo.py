@@ -28,7 +28,7 @@ ids = np.arange(lo, hi, dtype=np.int64)
 n = hi - lo
 st = {"r": [np.zeros(n)] * 3, "v": [np.full(n, C), np.zeros(n), np.zeros(n)], "dr": [np.zeros(n)] * 3,
       "dv": [np.zeros(n)] * 3, "E": orc.philox_energy(seed, ids, 2.8e-19, 9.9e-19), "id": ids}
-rows = []
+rows, locals_ = [], []
 for step in range(4):
     orc.step_newton(st, 1e-3)
     hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, step, st["id"]), 1e-3, 1e-3, C)
@@ -36,9 +36,12 @@ for step in range(4):
     local = [len(st["id"]), int(hit.sum())] + list(orc.sign_counts(st["v"])) + \
             [orc.plane_crossings(st["r"], st["dr"], [6e5, np.nan, np.nan])]
     rows.append(comm.allreduce_sum(local).tolist())
+    locals_.append(local)
+# K steps per launch: the K x counters of a launch go through ONE all-reduce (bench.py run_multi, Simulation._run_multi)
+batched = comm.allreduce_sum(np.array(locals_, dtype=np.int64).reshape(-1)).reshape(4, -1).tolist()
 tmax = comm.allreduce_max(float(comm.rank))
 comm.barrier()
-print(json.dumps({"rank": comm.rank, "rows": rows, "ids": st["id"].tolist(), "tmax": tmax}))
+print(json.dumps({"rank": comm.rank, "rows": rows, "batched": batched, "ids": st["id"].tolist(), "tmax": tmax}))
 comm.close()
 """
 
@@ -87,6 +90,7 @@ def test_world2_gloo_counters_equal_unsharded_run():
     one = run_world(1)[0]
     two = run_world(2)
     assert two[0]["rows"] == two[1]["rows"] == one["rows"]          # every rank sees the global counters
+    assert two[0]["batched"] == two[1]["batched"] == one["rows"]     # ... also when K steps' rows are reduced at once
     assert two[0]["ids"] + two[1]["ids"] == one["ids"]               # survivors: concatenation of the shards
     assert two[0]["tmax"] == two[1]["tmax"] == 1.0
     assert one["rows"][-1][0] == len(one["ids"]) > 0
