@@ -85,6 +85,8 @@ constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particl
 constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
 constexpr int kMultiSlots = PCL_MULTI_MAX * (4 + PCL_MAX_PLANES); // per-step counter rows of a K-step pass
+static_assert(PCL_MAXPL == PCL_MAX_PLANES, "device header and C ABI disagree on the number of measure planes");
+static_assert(PCL_MULTI_MAX <= 64, "per-step tallies are kept one per lane of a wave64");
 constexpr int kRows = PCL_NFIELDS + 4;       // rows per tile of the store slab: 13 fields + vprev0..2 + lam4
 constexpr int kRowVprev = PCL_NFIELDS, kRowLam4 = PCL_NFIELDS + 3;
 constexpr int64_t kTileT = PCL_T;            // particles per tile (rows of 2048 elements)
