@@ -321,6 +321,11 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */
 int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n);
 
+/* ScatterMeasureStep(measure_E=True) (physicl/light.py:383-399): the energies of the photons whose last move
+ * crossed the plane (one 3-vector, NaN in the coordinates that do not define it), in particle order.  *n_out =
+ * number of crossing photons; the first min(n, cap) energies (store dtype) are copied to E_out_host (host pointers). */
+int pcl_step_plane_energies(pcl_ctx *ctx, const double *plane_host, void *E_out_host, int64_t cap, int64_t *n_out);
+
 /* ScatterSignMeasureStep.run + the counting part of ScatterMeasureStep.run
  * (physicl/light.py:414-431, 374-400).  planes_host: n_planes x 3 doubles, NaN = coordinate not
  * defining the plane.  out_host: int64[PCL_CNT_PLANE0 + n_planes].  Synchronises. */

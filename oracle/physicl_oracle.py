@@ -200,6 +200,19 @@ def plane_crossings(r, dr, loc):
     return int(np.count_nonzero(((p <= L) & (L <= x)) | ((p >= L) & (L >= x))))
 
 
+def plane_crossing_energies(r, dr, E, loc, kind=None):
+    """``ScatterMeasureStep(measure_E=True)``: the energies of the photons whose last move crossed ``loc``, in object
+    order (light.py:383-399; plain Objects carry no E and are left out)."""
+    ax = 0 if not math.isnan(loc[0]) else (1 if not math.isnan(loc[1]) else 2)
+    L = np.float64(loc[ax])
+    x = np.asarray(r[ax], dtype=np.float64)
+    p = x - np.asarray(dr[ax], dtype=np.float64)
+    m = ((p <= L) & (L <= x)) | ((p >= L) & (L >= x))
+    if kind is not None:
+        m &= np.asarray(kind) != 0
+    return np.asarray(E)[m]
+
+
 # ----------------------------------------------------------------------------------------------
 # device RNG mode (NEW functionality; defines what the HIP Philox path must reproduce bit-exactly)
 # Philox4x32-10: Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3", SC'11.

@@ -92,6 +92,7 @@ _PROTOTYPES = {
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
     "pcl_step_fused_delete_multi": [_vp, c_double, c_int, c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
+    "pcl_step_plane_energies": [_vp, _vp, _vp, c_int64, POINTER(c_int64)],
     "pcl_store_is_uniform": [_vp, POINTER(c_int)],
     "pcl_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
                              c_uint32, _vp, c_int, _vp],
@@ -521,6 +522,19 @@ class Device:
         out = np.empty(n, dtype=np.int32)
         check(self.lib.pcl_store_last_delete_flags(self.ctx, out.ctypes.data_as(c_void_p), n))
         return out
+
+    def plane_energies(self, plane, n_hint=None):
+        """Energies of the photons that crossed ``plane`` ([x, y, z] with NaN in the free coordinates) in the last
+        move, in particle order (ScatterMeasureStep(measure_E=True)).  ``n_hint``: the crossing count if the caller
+        already has it from step_counters (sizes the host buffer)."""
+        pl = np.ascontiguousarray(np.asarray(plane, dtype=np.float64).reshape(3))
+        n = c_int64()
+        cap = self.count if n_hint is None else min(int(n_hint), self.count)
+        out = np.empty(max(cap, 1), dtype=self.np_dtype)
+        check(self.lib.pcl_step_plane_energies(self.ctx, pl.ctypes.data_as(c_void_p), out.ctypes.data_as(c_void_p), cap, byref(n)))
+        if n.value > cap:
+            raise HipError("plane_energies: %d photons crossed, n_hint was %d" % (n.value, cap))
+        return out[:n.value].copy()
 
     def step_counters(self, planes=()):
         planes = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))

@@ -306,6 +306,45 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     if (t == 1023) *total = s_wave[15];
 }
 
+// ---- ScatterMeasureStep(measure_E=True): which photons crossed a plane in this step's move ----------------
+//   (r - dr <= L <= r) or (r - dr >= L >= r) on the plane's axis, physicl/light.py:385-399; mask bit = crossed.
+//   The energies of those photons are then gathered in particle order with the compaction kernels.
+template <typename T>
+struct crossmask_args {
+    const T *x, *dx;           // the plane's axis of r and of dr
+    const unsigned char *kind;
+    uint64_t *masks;
+    int32_t *tile_keep;
+    int64_t N, ts;
+    T L;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_cross_mask(crossmask_args<T> a) {
+    typedef pcl_rt<T> R;
+    __shared__ int s_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    int kept = 0;
+#pragma unroll 4
+    for (int rr = 0; rr < kTileRows / 4; ++rr) {
+        const int row = wave * (kTileRows / 4) + rr;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
+        bool cross = false;
+        if (i < a.N && (a.kind ? (a.kind[i] != 0) : true)) {
+            const int64_t ti = pcl_tix(i, a.ts);
+            const T x = a.x[ti], prev = R::sub(x, a.dx[ti]);
+            cross = (prev <= a.L && a.L <= x) || (prev >= a.L && a.L >= x);
+        }
+        const uint64_t m = __ballot(cross);
+        if (lane == 0) a.masks[tile * kTileRows + row] = m;
+        kept += __popcll(m);
+    }
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
 // ---- delete step, pass 3: stable compaction of NF arrays of W-sized words (+ ids, kind bytes) -----
 // Reads: 1 bit of mask per particle + the survivors' state; writes the survivors densely, in order.
 constexpr int kMaxCompactFields = 16;
@@ -321,6 +360,7 @@ struct compact_args {
     const int64_t *tile_off;
     int64_t id_base, N;
     int64_t ts; // tile stride of BOTH slabs (elements)
+    int dense_dst; // 1: dst[] are plain dense arrays (pcl_step_plane_energies), not rows of a slab
 };
 
 template <typename W, int NF>
@@ -339,7 +379,7 @@ __global__ void __launch_bounds__(kBlock) k_compact(compact_args a) {
         if ((m >> lane) & 1ull) {
             const int64_t o = dest + __popcll(m & below);
             W val[NF > 0 ? NF : 1];
-            const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
+            const int64_t ti = pcl_tix(i, a.ts), to = a.dense_dst ? o : pcl_tix(o, a.ts);
 #pragma unroll
             for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
 #pragma unroll
@@ -905,6 +945,8 @@ struct pcl_ctx {
     // two counter banks for pcl_step_fused calls that do not synchronise: step k+1 is enqueued before the host
     // reads step k's counters, so the GPU never waits for Python (pcl_step_fused_read drains them in order)
     uint64_t *d_multi = nullptr, *h_multi = nullptr; // kMultiSlots counters of a K-step pass
+    void *e_out = nullptr;                           // dense gather buffer of pcl_step_plane_energies
+    int64_t e_out_cap = 0;
     uint64_t *d_bank[2] = {nullptr, nullptr};
     uint64_t *h_bank[2] = {nullptr, nullptr};
     hipEvent_t bank_ev[2] = {nullptr, nullptr};
@@ -1744,6 +1786,35 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     return launch_check("k_compact_count");
 }
 
+template <typename T>
+int plane_energies_t(pcl_ctx *ctx, int ax, double L) {
+    const int64_t N = ctx->count;
+    const int tiles = (int)div_up(N, kTile);
+    crossmask_args<T> m{};
+    m.x = F<T>(ctx, PCL_R0 + ax);
+    m.dx = F<T>(ctx, PCL_DR0 + ax);
+    m.kind = ctx->kind;
+    m.masks = ctx->masks;
+    m.tile_keep = ctx->tile_keep;
+    m.N = N;
+    m.ts = tile_stride(ctx);
+    m.L = (T)L;
+    hipLaunchKernelGGL(k_cross_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    PCL_TRY(launch_check("k_cross_mask"));
+    PCL_TRY(scan_tiles(ctx, N));
+    compact_args ca{};
+    ca.src[0] = ctx->field[PCL_E];
+    ca.dst[0] = ctx->e_out;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.N = N;
+    ca.ts = tile_stride(ctx);
+    ca.dense_dst = 1;
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+    hipLaunchKernelGGL((k_compact<W, 1>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca);
+    return launch_check("k_compact");
+}
+
 } // namespace
 
 // =================================================================================================
@@ -2159,6 +2230,8 @@ int pcl_store_free(pcl_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     dev_free(ctx->slab);
     dev_free(ctx->slab_alt);
+    dev_free(ctx->e_out);
+    ctx->e_out_cap = 0;
     ctx->tiles = 0;
     refresh_rows(ctx); // all row addresses -> NULL
     ctx->lazy_dr = ctx->lazy_dv = false;
@@ -2696,6 +2769,31 @@ int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n) {
     if (rc == PCL_OK) rc = pcl_d2h(ctx, flags_host, d, n * (int64_t)sizeof(int32_t));
     (void)hipFree(d);
     return rc;
+}
+
+int pcl_step_plane_energies(pcl_ctx *ctx, const double *plane_host, void *E_out_host, int64_t cap, int64_t *n_out) {
+    PCL_TRY(need_store(ctx)); // reads the real dr: a lazy step's implicit one is materialised first
+    if (!plane_host || !n_out || cap < 0 || (cap > 0 && !E_out_host)) return fail(PCL_ERR_ARG, "bad argument");
+    *n_out = 0;
+    const int64_t N = ctx->count;
+    if (N == 0) return PCL_OK;
+    const int ax = !std::isnan(plane_host[0]) ? 0 : (!std::isnan(plane_host[1]) ? 1 : 2); // light.py:385-396
+    PCL_TRY(ensure_scratch(ctx, N));
+    ctx->last_delete_n = -1; // scratch masks no longer describe a delete
+    if (ctx->e_out_cap < N) {
+        dev_free(ctx->e_out);
+        ctx->e_out_cap = 0;
+        PCL_TRY(dev_alloc_bytes(&ctx->e_out, ctx->capacity, ctx->esz));
+        ctx->e_out_cap = ctx->capacity;
+    }
+    PCL_TRY(PCL_DISPATCH(ctx, plane_energies_t<double>(ctx, ax, plane_host[ax]), plane_energies_t<float>(ctx, ax, plane_host[ax])));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t n = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (n < 0 || n > N) return fail(PCL_ERR_HIP, "gather produced an impossible count %lld of %lld", (long long)n, (long long)N);
+    *n_out = n;
+    const int64_t take = n < cap ? n : cap;
+    if (take > 0) PCL_TRY(pcl_d2h(ctx, E_out_host, ctx->e_out, take * (int64_t)ctx->esz));
+    return PCL_OK;
 }
 
 int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int64_t *out_host) {

@@ -218,15 +218,36 @@ class _CountingMeasure(DeviceStep, MeasureStep):
 
 class ScatterMeasureStep(_CountingMeasure):
     """Row per step: ``[t, N, crossings of plane 0, ...]`` (physicl/light.py:361-404).  A plane is a
-    3-vector with NaN in the coordinates that do not define it.  ``measure_E`` (per-plane lists of the
-    crossing photons' energies) is not provided by this build."""
+    3-vector with NaN in the coordinates that do not define it.  With ``measure_E`` each plane's count is followed
+    by the list of the crossing photons' energies (object order), gathered on the device."""
 
     def __init__(self, out_fn, measure_n=True, measure_locs=[], measure_E=False):
         MeasureStep.__init__(self, out_fn)
-        if measure_E:
-            raise NotImplementedError("ScatterMeasureStep(measure_E=True): variable-length energy lists are outside "
-                                      "the device path of this build")
         self.measure_locs, self.measure_n, self.measure_E = measure_locs, measure_n, measure_E
+        if measure_E:
+            # rows carry variable-length energy lists: a separate gather per plane after the counters, outside the
+            # fused kernels (this instance takes no part in step fusion / steps_per_launch)
+            self._fuse_role = None
+
+    def _device_run(self, sim):
+        if not self.measure_E:
+            return _CountingMeasure._device_run(self, sim)
+        if sim.comm is not None and sim.comm.world > 1:
+            raise NotImplementedError("ScatterMeasureStep(measure_E=True) on a sharded Simulation: the energy lists are "
+                                      "not gathered across ranks by this build")
+        dev = sim._dev
+        cnt = dev.step_counters(self._plane_rows())
+        hip = sim._hip
+        row = [sim.t]
+        if self.measure_n:
+            row.append(int(cnt[hip.CNT_N]))
+        for p, loc in enumerate(self._plane_rows()):                        # physicl/light.py:378-402
+            nl = int(cnt[hip.CNT_PLANE0 + p])
+            row.append(nl)
+            row.append(dev.plane_energies(loc, n_hint=nl).tolist())          # crossing photons' E, object order
+        out = np.empty(len(row), dtype=object)                               # ragged row, as the reference's np.array(out)
+        out[:] = row
+        self.data.append(out)
 
     def _n_planes(self):
         return len(self.measure_locs)

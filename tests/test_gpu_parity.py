@@ -807,3 +807,35 @@ def test_rtc_code_objects_are_cached_on_disk_and_survive_a_corrupt_file(tmp_path
     files[0].write_bytes(files[0].read_bytes()[: size // 3])        # corrupt it
     h3, _ = run()
     assert h3 == h1 and files[0].stat().st_size == size and len(list(tmp_path.glob("*"))) == 1
+
+
+# ============================================================================ ScatterMeasureStep(measure_E=True)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N", [1, 64, 2049, 300_001])
+def test_plane_energies_match_oracle_in_particle_order(dev, hip, N, dtype):
+    npdt = np.float64 if dtype == "f64" else np.float32
+    rs = np.random.RandomState(N)
+    r = rs.uniform(-2, 2, (N, 3)).astype(npdt)
+    dr = rs.uniform(-1, 1, (N, 3)).astype(npdt)
+    E = rs.uniform(1, 2, N).astype(npdt)
+    kind = (rs.random_sample(N) < 0.8).astype(np.uint8)
+    d = hip.Device(0)
+    try:
+        d.store_alloc(N, dtype)
+        d.upload_state({"r": r, "dr": dr, "v": np.zeros((N, 3)), "E": E, "kind": kind})
+        for loc in ([0.25, np.nan, np.nan], [np.nan, -0.5, np.nan], [np.nan, np.nan, 1.0], [0.1, 0.2, np.nan], [50.0, np.nan, np.nan]):
+            want = orc.plane_crossing_energies([r[:, k].astype(np.float64) for k in range(3)],
+                                               [dr[:, k].astype(np.float64) for k in range(3)], E, loc, kind)
+            if dtype == "f32":                       # the device subtracts in float32
+                ax = 0 if not np.isnan(loc[0]) else (1 if not np.isnan(loc[1]) else 2)
+                x, L = r[:, ax], np.float32(loc[ax])
+                p = x - dr[:, ax]
+                want = E[(((p <= L) & (L <= x)) | ((p >= L) & (L >= x))) & (kind != 0)]
+            got = d.plane_energies(loc)
+            assert got.dtype == npdt and np.array_equal(got, want), (loc, len(got), len(want))
+            cnt = d.step_counters([loc])
+            if kind.all():
+                assert cnt[hip.CNT_PLANE0] == len(want)
+            assert np.array_equal(d.plane_energies(loc, n_hint=len(want)), want)
+    finally:
+        d.close()

@@ -457,3 +457,25 @@ def test_steps_per_launch_delete_until_empty_matches_one_pass_per_launch(K):
     assert out[0][0] == out[1][0] > 0
     for a, b in zip(out[0][1:], out[1][1:]):
         assert np.array_equal(a, b)
+
+
+def test_scatter_measure_step_with_energies():
+    """ScatterMeasureStep(measure_E=True), the row layout of physicl/light.py:374-404: [t, N, n_plane0, [E...], ...]."""
+    n = 500
+    sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= 0.0055, rng="philox", seed=1)
+    Es = np.linspace(1.0, 2.0, n)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(Es[i]), uid=i)
+                  for i in range(n)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    m = phys.light.ScatterMeasureStep(None, True, [[2.5e-3 * C_LIT, np.nan, np.nan], [np.nan, 1.0, np.nan]], measure_E=True)
+    sim.add_step(2, m)
+    run(sim)
+    assert len(m.data) == 6
+    for k, row in enumerate(m.data):
+        assert len(row) == 6 and row[1] == n and float(row[0]) == float(sim.ts[k])
+        if k == 2:                                   # the third move takes every photon across x = 2.5 c dt
+            assert row[2] == n and np.array_equal(np.array(row[3]), Es)
+        else:
+            assert row[2] == 0 and row[3] == []
+        assert row[4] == 0 and row[5] == []
