@@ -151,8 +151,8 @@ def test_measure_step_csv_and_kernel_glue_stubs(tmp_path):
     assert prog._signature() == [("double", "d0", True), ("double", "A", False), ("int", "res", True)]
     with pytest.raises(RuntimeError, match="no CPU implementation"):
         prog.build_kernel()
-    with pytest.raises(NotImplementedError):
-        light.ScatterMeasureStep(None, True, [], measure_E=True)
+    m_e = light.ScatterMeasureStep(None, True, [[1.0, np.nan, np.nan]], measure_E=True)
+    assert m_e._fuse_role is None and light.ScatterMeasureStep(None, True, [])._fuse_role == "measure"   # ragged rows: not fused
 
 
 def test_kernel_constants_follow_the_reference_swap_and_code_scale():
