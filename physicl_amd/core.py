@@ -396,9 +396,13 @@ class Simulation(threading.Thread):
         if self._batch is not None:
             self._materialise_batch()
         s = dev.download_state()
-        ids = s["id"] - self._upload_lo
         shells = self._uploaded
-        keep = [shells[i] for i in ids]
+        if isinstance(shells, dict):                          # materialised batch: keyed by photon id
+            ids = s["id"]
+            keep = [shells[int(i)] for i in ids]
+        else:                                                 # uploaded objects: index == device id - lo
+            ids = s["id"] - self._upload_lo
+            keep = [shells[i] for i in ids]
         r, v, dr, dv = (np.stack(s[g], 1) if len(ids) else np.zeros((0, 3)) for g in ("r", "v", "dr", "dv"))
         for k, o in enumerate(keep):
             o.r = Measurement._from_code(r[k], like=o.r, units="m**1")
@@ -410,10 +414,8 @@ class Simulation(threading.Thread):
                 o.v = Measurement._from_code(v[k], like=o.v, units="m**1 s**-1") if isinstance(o.v, Measurement) \
                     else np.array(v[k], dtype=np.double)
         self._objects._items[:] = keep
-        self._uploaded = keep
-        self._upload_lo = 0
-        if len(keep):
-            dev.upload_ids(np.arange(len(keep), dtype=np.int64))     # ids == positions in the shell list again
+        # the device keeps its ids (a photon's random stream is keyed by them: looking at the objects must not change
+        # the run) and ``_uploaded`` keeps every shell ever uploaded, removed ones included
         self._residency = HOST if mutate else BOTH
 
     def _materialise_batch(self):
@@ -425,13 +427,11 @@ class Simulation(threading.Thread):
         cval = np.asarray(_c)
         ids = self._dev.download_ids()
         E = self._dev.download(self._hip.E)
-        self._uploaded = {}
         shells = [PhotonObject.__new__(PhotonObject) for _ in range(n)]
         for o, e, i in zip(shells, E, ids):
             Object.__init__(o, E=np.double(e), v=Measurement._from_code([cval, 0, 0], units="m**1 s**-1"), uid=int(i))
-        self._uploaded = shells
+        self._uploaded = {int(i): o for i, o in zip(ids, shells)}    # the photons keep their ids (and random streams)
         self._upload_lo = 0
-        self._dev.upload_ids(np.arange(n, dtype=np.int64))
         self._batch = None
 
     # ------------------------------------------------------------------ helpers for the device-native steps

@@ -280,8 +280,10 @@ class ScatterSignMeasureStep(_CountingMeasure):
 
 class TracePathMeasureStep(MeasureStep):
     """Records every object's position at every step (physicl/light.py:433-483): O(N*T) host memory, a
-    diagnostic for small N.  Host plugin: the particle state is copied back into the Python objects each
-    step (read-only, so nothing is re-uploaded)."""
+    diagnostic for small N.  Host plugin.  The first time an object is seen it is looked at as a Python object
+    (``id_info_fn(obj)``, exactly as in the reference); after that, while the particles live on the device, a step
+    costs three array downloads (ids, r, dv) instead of rebuilding every Python object: the positions are filed
+    under the objects' trace ids when the table is built."""
     _reads_only = True
 
     def __init__(self, out_fn, trace_type=Object, id_info_fn=lambda x: str(type(x)), trace_dv=False):
@@ -289,8 +291,50 @@ class TracePathMeasureStep(MeasureStep):
         self.trace_type, self.id_info_fn, self.trace_dv = trace_type, id_info_fn, trace_dv
         self.id_counter = 0
         self.id_dict, self.pos_dict = {}, {}
+        self._tid_map, self._map_gen, self._log = None, None, []
+
+    def _device_rows(self, sim):
+        """(trace ids, positions, moved flags) of the resident particles straight from the device, or None when some
+        particle has not been seen as an object yet / the state is not on the device / the run is sharded."""
+        dev = getattr(sim, "_dev", None)
+        if dev is None or sim._batch is not None or sim.comm is not None or sim._residency == "host" or not isinstance(sim._uploaded, list) or not sim._uploaded:
+            return None
+        if self._tid_map is None or self._map_gen != sim._upload_gen:
+            self._tid_map = np.array([o.__dict__.get("__trace_path_id", -1) for o in sim._uploaded], dtype=np.int64)
+            self._map_gen = sim._upload_gen
+        with sim._dev_lock:
+            n = dev.count
+            idx = dev.download_ids(n) - sim._upload_lo
+            if n and (idx.min() < 0 or idx.max() >= len(self._tid_map)):
+                return None
+            tids = self._tid_map[idx]
+            if n and tids.min() < 0:
+                return None
+            hip = sim._hip
+            r = np.stack([dev.download(f, n) for f in (hip.R0, hip.R1, hip.R2)], 1) if n else np.zeros((0, 3))
+            moved = None
+            if self.trace_dv:
+                moved = np.zeros(n, dtype=bool)
+                for f in (hip.DV0, hip.DV1, hip.DV2):
+                    moved |= dev.download(f, n) != 0
+        return tids, r, moved
+
+    def _flush(self):
+        for tids, r, moved in self._log:
+            for k, tid in enumerate(tids.tolist()):
+                self.pos_dict[tid]["pos"].append(r[k])
+            if moved is not None:
+                for tid in tids[moved].tolist():
+                    self.pos_dict[tid]["freq"] += 1
+        self._log = []
 
     def run(self, sim):
+        rows = self._device_rows(sim)
+        if rows is not None:
+            self._log.append(rows)
+            return
+        self._flush()
+        self._tid_map = None
         for obj in sim.objects:
             tid = obj.__dict__.get("__trace_path_id")
             if tid is None:
@@ -306,6 +350,7 @@ class TracePathMeasureStep(MeasureStep):
 
     def terminate(self, sim):
         """data[0] = ["t", t0, t1, ...]; data[1+i] = [id info, (freq,) NaN-padded positions of object i]."""
+        self._flush()
         cols = len(sim.ts)
         table = [["t"] + copy.deepcopy(sim.ts)]
         for i in range(len(self.id_dict)):

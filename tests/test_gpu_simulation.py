@@ -479,3 +479,41 @@ def test_scatter_measure_step_with_energies():
         else:
             assert row[2] == 0 and row[3] == []
         assert row[4] == 0 and row[5] == []
+
+
+@pytest.mark.parametrize("kind", ["scatter", "delete"])
+def test_trace_path_from_device_arrays_equals_the_per_object_walk(kind, monkeypatch):
+    """TracePathMeasureStep reads ids / r / dv arrays from the device once every object has been seen; the table is the
+    one the per-object walk of the reference (light.py:447-483) builds -- also when a delete step thins the list."""
+    def build():
+        sim = phys.Simulation(cl_on=True, rng="philox", seed=4, exit=lambda s: s.t >= 0.0075 or len(s.objects) == 0)
+        sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0 + i), uid=i)
+                      for i in range(300)])
+        tp = phys.light.TracePathMeasureStep(None, id_info_fn=lambda o: str(o.E), trace_dv=True)
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: 0.001))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        if kind == "scatter":
+            sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+        else:
+            sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        sim.add_step(3, tp)
+        return sim, tp
+    fast, tf = build()
+    calls = []
+    orig = phys.light.TracePathMeasureStep._device_rows
+    monkeypatch.setattr(phys.light.TracePathMeasureStep, "_device_rows",
+                        lambda self, sim: calls.append(orig(self, sim)) or calls[-1])
+    run(fast)
+    assert sum(c is not None for c in calls) >= len(fast.ts) - 1 and calls[0] is None      # only the first sight is a walk
+    monkeypatch.setattr(phys.light.TracePathMeasureStep, "_device_rows", lambda self, sim: None)
+    slow, tsl = build()
+    run(slow)
+    # (with the delete step ahead of the trace step, photons removed in the very first pass are never seen)
+    assert len(tf.data) == len(tsl.data) and (len(tf.data) == 301 if kind == "scatter" else 150 < len(tf.data) < 301)
+    assert [float(t) for t in tf.data[0][1:]] == [float(t) for t in tsl.data[0][1:]]
+    for a, b in zip(tf.data[1:], tsl.data[1:]):
+        assert a[0] == b[0] and a[1] == b[1] and len(a) == len(b)
+        for x, y in zip(a[2:], b[2:]):
+            assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
+    if kind == "delete":
+        assert any(np.isscalar(x) and np.isnan(x) for row in tf.data[1:] for x in row[2:])      # NaN padding after removal
