@@ -368,7 +368,7 @@ def cpu_baseline_numpy(dev, args, prof):
     """Third CPU figure: the numpy-vectorised oracle (oracle/physicl_oracle.py) on the first 1e6 photons, 1 core
     (BASELINE.md section 4, item 2)."""
     from oracle import physicl_oracle as orc
-    n = 1_000_000
+    n = int(min(1_000_000, args.photons))
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     st = {g: [dev.download(f, n) for f in fids] for g, fids in
           (("r", (0, 1, 2)), ("v", (3, 4, 5)), ("dr", (6, 7, 8)), ("dv", (9, 10, 11)))}
@@ -392,7 +392,7 @@ def cpu_baseline_python(dev, args, prof):
     from oracle import pyloop
     if prof["c_profile"] is None:
         return None
-    n = 10000
+    n = int(min(10000, args.photons))
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     E = dev.download(12, n)
     value, steps, el = pyloop.time_steps(E, prof["dt"], prof["A_kernel"], prof["n_kernel"], True, prof["c_profile"], 3.0)
