@@ -109,6 +109,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU baseline duration")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when it
+    # initialises): everything but the final line goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -323,7 +329,8 @@ def main():
     dev.close()
     comm.close()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def cpu_baseline(dev, args, prof):
