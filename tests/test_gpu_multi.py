@@ -209,3 +209,26 @@ def test_delete_multi_until_empty_and_without_counters(make_store, hip):
     assert abs(alive[0] - 0.7002 * N) < 6 * np.sqrt(N * 0.21)
     rows = d.step_fused_delete_multi(1e-3, 3, 1e-3, 1e-3, seed=3, step=64)                   # empty store: all zeros
     assert all(o["N"] == 0 and o["removed"] == 0 for o in rows)
+
+
+def test_full_size_multi_equals_single_steps_at_1e8(make_store, hip):
+    """BASELINE configs[2] size: 1e8 photons filled on the device, the bench's expression; 6 steps in one pass give the
+    counters of 6 single launches, and the far ends of the store hold the same positions / velocities / implicit dv."""
+    N, K, seed = 100_000_000, 6, 1234
+    sc = lambda k: dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=C_LIT, h=H_LIT,
+                        n_expr=EXPR_EX, rng_mode=hip.RNG_PHILOX, seed=seed, step=k)
+    out = []
+    for multi in (True, False):
+        d = make_store(N)
+        d.fill_photons(N, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, seed)
+        if multi:
+            rows = d.step_fused_multi(5e-3, K, sc(3))
+        else:
+            rows = [d.step_fused(5e-3, sc(3 + k), [], lazy=True) for k in range(K)]
+        log = [(o["N"], o["hits"], list(o["sign"])) for o in rows]
+        ends = [d.download(f, 4096, off) for f in (hip.R0, hip.R1, hip.V2, hip.DV0, hip.DR1) for off in (0, N // 2 + 77, N - 4096)]
+        out.append((log, ends))
+        d.close()
+    assert out[0][0] == out[1][0]
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))
+    assert out[0][0][0][1] == N and 0.3 * N < out[0][0][-1][1] < 0.9 * N          # step 1: every photon at x > 0 scatters
