@@ -232,3 +232,27 @@ def test_full_size_multi_equals_single_steps_at_1e8(make_store, hip):
     assert out[0][0] == out[1][0]
     assert all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))
     assert out[0][0][0][1] == N and 0.3 * N < out[0][0][-1][1] < 0.9 * N          # step 1: every photon at x > 0 scatters
+
+
+def test_full_size_delete_multi_equals_single_steps_at_1e8(make_store, hip):
+    """BASELINE configs[1](ii) at 1e8 photons: 5 delete loop bodies in one pass + one compaction == 5 fused delete
+    launches (alive / removed / sign / plane rows, survivor ids and positions at both ends of the store)."""
+    N, K, seed = 100_000_000, 5, 99
+    plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]
+    out = []
+    for multi in (True, False):
+        d = make_store(N)
+        d.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
+        if multi:
+            rows = d.step_fused_delete_multi(1e-3, K, 1e-3, 1e-3, seed, 0, plane)
+        else:
+            rows = [d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, seed, k, plane, lazy=True) for k in range(K)]
+        log = [(o["N"], o["removed"], list(o["sign"]), list(o["planes"])) for o in rows]
+        n = d.count
+        ends = [d.download_ids(4096, off) for off in (0, n // 2, n - 4096)] + \
+               [d.download(f, 4096, off) for f in (hip.R0, hip.DR0, hip.E) for off in (0, n - 4096)]
+        out.append((log, n, ends))
+        d.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    assert abs(out[0][1] / N - 0.7002 ** K) < 1e-3
