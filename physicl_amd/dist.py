@@ -96,6 +96,17 @@ class CounterComm:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self._group)
         return t.cpu().numpy()
 
+    def allgather_concat(self, values):
+        """Concatenation, in rank order, of every rank's 1-D array (variable lengths) -- the energy lists of
+        ScatterMeasureStep(measure_E=True): shards are contiguous index blocks, so rank order is particle order.
+        Goes over the gloo control plane (these lists are diagnostics, not a per-step hot path)."""
+        a = np.ascontiguousarray(values)
+        if self.world == 1:
+            return a.copy()
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, a)                       # default (gloo) group
+        return np.concatenate([np.asarray(p, dtype=a.dtype) for p in parts]) if parts else a
+
     def allreduce_max(self, x):
         if self.world == 1:
             return float(x)

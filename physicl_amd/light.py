@@ -232,19 +232,19 @@ class ScatterMeasureStep(_CountingMeasure):
     def _device_run(self, sim):
         if not self.measure_E:
             return _CountingMeasure._device_run(self, sim)
-        if sim.comm is not None and sim.comm.world > 1:
-            raise NotImplementedError("ScatterMeasureStep(measure_E=True) on a sharded Simulation: the energy lists are "
-                                      "not gathered across ranks by this build")
         dev = sim._dev
         cnt = dev.step_counters(self._plane_rows())
+        glob = sim._global(cnt)                                              # counts over all shards
         hip = sim._hip
         row = [sim.t]
         if self.measure_n:
-            row.append(int(cnt[hip.CNT_N]))
+            row.append(int(glob[hip.CNT_N]))
         for p, loc in enumerate(self._plane_rows()):                        # physicl/light.py:378-402
-            nl = int(cnt[hip.CNT_PLANE0 + p])
-            row.append(nl)
-            row.append(dev.plane_energies(loc, n_hint=nl).tolist())          # crossing photons' E, object order
+            row.append(int(glob[hip.CNT_PLANE0 + p]))
+            Es = dev.plane_energies(loc, n_hint=int(cnt[hip.CNT_PLANE0 + p]))
+            if sim.comm is not None:
+                Es = sim.comm.allgather_concat(Es)                           # rank order == particle order
+            row.append(Es.tolist())                                          # crossing photons' E, object order
         out = np.empty(len(row), dtype=object)                               # ragged row, as the reference's np.array(out)
         out[:] = row
         self.data.append(out)

@@ -39,9 +39,10 @@ for step in range(4):
     locals_.append(local)
 # K steps per launch: the K x counters of a launch go through ONE all-reduce (bench.py run_multi, Simulation._run_multi)
 batched = comm.allreduce_sum(np.array(locals_, dtype=np.int64).reshape(-1)).reshape(4, -1).tolist()
+gathered = comm.allgather_concat(np.arange(comm.rank + 2, dtype=np.float64) + 10 * comm.rank).tolist()
 tmax = comm.allreduce_max(float(comm.rank))
 comm.barrier()
-print(json.dumps({"rank": comm.rank, "rows": rows, "batched": batched, "ids": st["id"].tolist(), "tmax": tmax}))
+print(json.dumps({"rank": comm.rank, "rows": rows, "batched": batched, "gathered": gathered, "ids": st["id"].tolist(), "tmax": tmax}))
 comm.close()
 """
 
@@ -93,4 +94,5 @@ def test_world2_gloo_counters_equal_unsharded_run():
     assert two[0]["batched"] == two[1]["batched"] == one["rows"]     # ... also when K steps' rows are reduced at once
     assert two[0]["ids"] + two[1]["ids"] == one["ids"]               # survivors: concatenation of the shards
     assert two[0]["tmax"] == two[1]["tmax"] == 1.0
+    assert two[0]["gathered"] == two[1]["gathered"] == [0.0, 1.0, 10.0, 11.0, 12.0] and one["gathered"] == [0.0, 1.0]
     assert one["rows"][-1][0] == len(one["ids"]) > 0

@@ -30,7 +30,7 @@ if kind in ("batch", "delete", "delete_empty"):
     sim.add_objs(phys.light.generate_photons_bulk(N, min=phys.light.E_from_wavelength(700e-9),
                                                   max=phys.light.E_from_wavelength(200e-9), seed=21))
 else:
-    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(3e-19), uid=i)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(3e-19 * (1 + 1e-4 * i)), uid=i)
                   for i in range(3001)])
 sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
 sim.add_step(1, phys.newton.NewtonianKinematicsStep())
@@ -38,12 +38,13 @@ if kind.startswith("delete"):
     sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
 else:
     sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001), wavelength_dep_scattering=False))
-m1 = phys.light.ScatterMeasureStep(None, True, [[6e5, np.nan, np.nan], [np.nan, 0.0, np.nan]])
+m1 = phys.light.ScatterMeasureStep(None, True, [[6e5, np.nan, np.nan], [np.nan, 0.0, np.nan]], measure_E=(kind == "objects"))
 m2 = phys.light.ScatterSignMeasureStep(None, True)
 sim.add_step(3, m1)
 sim.add_step(4, m2)
 sim.run()
-print(json.dumps({"rank": comm.rank, "m1": [[float(x) for x in r] for r in m1.data], "m2": [[float(x) for x in r] for r in m2.data],
+flat = lambda r: [x if isinstance(x, list) else float(x) for x in r]       # measure_E rows carry energy lists
+print(json.dumps({"rank": comm.rank, "m1": [flat(r) for r in m1.data], "m2": [[float(x) for x in r] for r in m2.data],
                   "alive": len(sim.objects), "hits": int(sim.hits), "local": int(sim._dev.count)}))
 comm.close()
 """
@@ -82,6 +83,9 @@ def test_two_shards_reproduce_the_single_process_rows(kind):
         assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
     assert two[0]["local"] + two[1]["local"] == one["local"]
     assert len(one["m1"]) >= 5 and one["m1"][0][1] > 0
+    if kind == "objects":          # measure_E: the crossing photons' energies, gathered across the shards in object order
+        lists = [x for r in one["m1"] for x in r if isinstance(x, list) and x]
+        assert lists and all(len(set(l)) == len(l) for l in lists)
 
 
 @pytest.mark.parametrize("kind", ["batch", "delete_empty"])
