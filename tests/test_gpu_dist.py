@@ -99,3 +99,12 @@ def test_two_shards_with_several_passes_per_launch_reproduce_the_single_process_
         assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
     assert two[0]["local"] + two[1]["local"] == one["local"]
     assert len(one["m1"]) >= 5
+
+
+def test_rccl_group_comes_up_with_one_rank():
+    """The RCCL leg of CounterComm (new_group("nccl") on top of the gloo control plane, the probe, an all-reduce of
+    a K x 5 counter block on a device tensor) -- with the single rank a one-GPU box allows."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "rccl_single_rank.py")],
+                                  env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stderr=subprocess.STDOUT, timeout=300)
+    text = out.decode()
+    assert "backend after init: nccl" in text and "allreduce ok: [0 1 2 3 4] 12720" in text, text[-2000:]
