@@ -156,6 +156,10 @@ def test_multi_state_errors(make_store, hip):
         d.step_fused_multi(dt, 0, sc)
     with pytest.raises(hip.HipError):
         d.step_fused_multi(dt, 65, sc)
+    d.set_count(0, 0)                                              # an empty store: K rows of zeros, nothing launched
+    rows = d.step_fused_multi(dt, 3, sc, [[0.0, np.nan, np.nan]])
+    assert [(o["N"], o["hits"], list(o["sign"]), list(o["planes"])) for o in rows] == [(0, 0, [0, 0, 0], [0])] * 3
+    d.set_count(100, 0)
     d.upload_kind(np.zeros(100, dtype=np.uint8))                   # a store with plain Objects: not eligible
     with pytest.raises(hip.HipError):
         d.step_fused_multi(dt, 2, sc)
