@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s and achieved HBM GB/s of the photon time-step hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 64 --warmup 32        (the defaults: warm-up and timed launches all 32 steps long)
+    python bench.py                                        (N=1; 64 steps per block, 5 blocks, 32 warm-up steps)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W          (same thing, ranks started by torchrun)
 
 Workload (BASELINE.json configs[2], the config the metric is quoted on; weak-scaled = configs[3]):
 1e8 photons per GPU, r = 0, v = (c,0,0), E power-law between E(700 nm) and E(200 nm)
@@ -14,23 +15,31 @@ One "step" = one pass of the Simulation loop body (physicl/__init__.py:512-516):
 UpdateTimeStep -> NewtonianKinematicsStep -> ScatterIsotropicStep -> ScatterSignMeasureStep counters,
 then (N > 1) an RCCL all-reduce of the counter vector [N, hits, xp, yp, zp].
 
+Timing: W warm-up steps, then the block of exactly K steps is timed R times (--repeats, default 5), each block
+bracketed by barrier + device synchronise on both sides and reduced with MAX over ranks; `value` uses the MEDIAN
+block (every block's time is in `repeat_ms_per_step`).  The simulation simply keeps running from block to block.
+
 Default mode "fused" with --steps-per-launch S > 1 runs S consecutive loop bodies per pass over the store
 (pcl_step_fused_multi: photons do not interact, so a photon is loaded once, stepped S times in registers and
 stored once -- bit-identical state and per-step counters, 128/S instead of 104 B of HBM traffic per
 particle-step, which turns the step from HBM-bound into VALU-bound).  The K timed steps are ceil(K/S) launches.
 --steps-per-launch 1 is the one-launch-per-step, HBM-bound path; with N=1 it is also measured in the same run
-and reported under "single_step".
+and reported under "single_step", and the delete/compaction path (BASELINE configs[1](ii)) under "delete".
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel of the timed region,
-timed with HIP event pairs recorded around every launch inside the timed region (pcl_prof_*).
+Prints ONE JSON line on rank 0.  Every number in `roofline`, `single_step` and `delete` is measured in THIS run
+(HIP event pairs recorded on the library's stream around every launch, pcl_prof_*); PMC-counter figures from
+committed rocprofv3 profiles appear only under `static_profile`, labelled with their source.
 `cpu_baseline` = the oracle's C/OpenMP port of the same step timed on this box's host cores on a
 bounded sample of the same photons (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # before anything can initialise HIP (RCCL needs dmabuf IPC)
 
 import numpy as np
 
@@ -69,25 +78,12 @@ def algorithmic_bytes_per_particle(profile, h, mode="separate", multi=False):
     return 8 * len(PROFILES[profile]["arrays_read"]) + 24 + 48.0 * h
 
 
-VALU_PEAK_TLANE = 256 * 4 * 16 * 2.4e9 / 1e12    # CUs x SIMDs x lanes/clk x 2.4 GHz = 39.3 T lane-instructions/s
-
-
-def valu_roofline(v, per_gpu_rate):
-    """The K-step kernel is bound by vector-ALU issue, not by HBM: VALU instructions per particle-step (rocprofv3
-    SQ_INSTS_VALU x 64 / particle-steps, profiles/) x the measured particle-steps/s of one GPU, against the chip's
-    issue peak of one VALU instruction per lane per clock (fp64 FMA included: 78.6 TFLOP/s = 2 x 39.3)."""
-    out = dict(v)
-    ach = v["valu_insts_per_particle_step"] * per_gpu_rate / 1e12
-    out.update({"bound": "valu", "achieved": ach, "peak": VALU_PEAK_TLANE, "unit": "T lane-instr/s",
-                "frac": ach / VALU_PEAK_TLANE})
-    return out
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the block of --steps steps is timed (median reported)")
     ap.add_argument("--photons", type=float, default=1e8, help="photons PER GPU (weak scaling)")
     ap.add_argument("--profile", choices=sorted(PROFILES), default="example")
     ap.add_argument("--mode", choices=("fused", "fused-eager", "separate"), default="fused",
@@ -101,252 +97,454 @@ def main():
     ap.add_argument("--dtype", choices=("f64", "f32"), default="f64",
                     help="f64 = the reference's precision (the headline number); f32 = precision-sweep build")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
-                    help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = rehearsal on CPU tensors")
+                    help="collective backend for N > 1: nccl = RCCL over xGMI (default; failing to bring it up is an "
+                         "error); gloo = rehearsal on CPU tensors, must be asked for")
     ap.add_argument("--device", type=int, default=None,
-                    help="HIP device index for this rank (default LOCAL_RANK); rehearsals put every rank on device 0")
+                    help="HIP device index for EVERY rank (default LOCAL_RANK); rehearsals put all ranks on device 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-photons", type=float, default=1e7)
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU baseline duration")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the single_step, delete and api legs (N=1)")
+    ap.add_argument("--cpu-photons", type=float, default=1e8)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the OpenMP CPU baseline")
+    ap.add_argument("--delete-photons", type=str, default="1e7,1e8", help="sizes of the delete leg (comma separated)")
+    return ap.parse_args(argv)
 
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Launched directly: start the ranks ourselves.  Nothing above has touched the GPU (no torch, no
+        # libphysicl_hip), the children are fresh interpreters, and this process only waits for them.
+        from physicl_amd.launch import spawn_ranks
+        rc, out = spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        lines = [ln for ln in out.splitlines() if ln.strip()]
+        if rc == 0 and len(lines) != 1:
+            sys.stderr.write("bench.py: rank 0 printed %d lines instead of one JSON line\n" % len(lines))
+            rc = 1
+        if rc == 0:
+            sys.stdout.write(lines[0] + "\n")
+            sys.stdout.flush()
+        else:
+            sys.stderr.write("bench.py: a rank failed (exit code %d); no result line\n" % rc)
+        sys.exit(rc)
+    run_rank(args)
+
+
+class Bench:
+    """One rank's store, step functions and timing helpers."""
+
+    def __init__(self, args):
+        from physicl_amd import _hip
+        from physicl_amd.dist import CounterComm
+        self.args, self.hip = args, _hip
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        self.comm = CounterComm.from_env(backend=args.backend, device_index=args.device)   # no-op when world == 1
+        self.N = int(args.photons)
+        self.prof = PROFILES[args.profile]
+        self.flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
+        self.e_lo, self.e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9   # E_from_wavelength, light.py:39-43
+        self.dev_index = self.local_rank if args.device is None else args.device
+        self.dev = _hip.Device(self.dev_index)
+        self.S = max(1, min(64, args.steps_per_launch)) if args.mode == "fused" else 1
+        self.sim_t = 0.0
+        self.totals = None
+
+    def fill(self):
+        self.dev.store_alloc(self.N, self.args.dtype)
+        self.dev.fill_photons(self.N, self.rank * self.N, C_LIT, self.e_lo, self.e_hi, self.args.seed)   # global ids
+
+    def sc(self, k):
+        p, a = self.prof, self.args
+        return dict(A=p["A_kernel"], n=p["n_kernel"], flags=self.flags, c=C_LIT, h=H_LIT, n_expr=p["expr"],
+                    rng_mode=self.hip.RNG_PHILOX, seed=a.seed, step=k)
+
+    def launch(self, k):
+        """Enqueue step k (no host synchronisation)."""
+        a, dev, p = self.args, self.dev, self.prof
+        self.sim_t += p["dt"]                                          # UpdateTimeStep   __init__.py:337-343
+        if a.mode.startswith("fused"):
+            # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles
+            dev.step_fused(p["dt"], self.sc(k), planes=(), sync=False, lazy=(a.mode == "fused"))
+        else:
+            dev.step_newton(p["dt"])                                  # newton.py:10-16
+            dev.step_scatter_isotropic(p["A_kernel"], p["n_kernel"], self.flags, C_LIT, H_LIT, p["expr"],
+                                       self.hip.RNG_PHILOX, a.seed, k, want_hits=False)   # light.py:281-331
+
+    def collect(self):
+        """Wait for the enqueued step and fetch its local counters [N, hits, xp, yp, zp] (one sync)."""
+        dev, hip = self.dev, self.hip
+        if self.args.mode.startswith("fused"):
+            o = dev.step_fused_read(0)
+            return np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
+        cnt = dev.step_counters()                                        # light.py:414-431
+        return np.array([cnt[hip.CNT_N], dev.last_scatter_hits(), cnt[hip.CNT_XP], cnt[hip.CNT_YP],
+                         cnt[hip.CNT_ZP]], dtype=np.int64)
+
+    def run_multi(self, k0, k1, S):
+        """Steps k0..k1-1 as ceil((k1-k0)/S) passes of S loop bodies each; one all-reduce of the S x 5 per-step
+        counters per pass."""
+        hits, k = 0, k0
+        while k < k1:
+            ks = min(S, k1 - k)
+            self.sim_t += ks * self.prof["dt"]                           # UpdateTimeStep   __init__.py:337-343
+            rows = self.dev.step_fused_multi(self.prof["dt"], ks, self.sc(k))
+            c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
+            hits += int(c[:, 1].sum())
+            self.totals = self.comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
+            k += ks
+        return hits
+
+    def run_steps(self, k0, k1, S=None):
+        """Steps k0..k1-1.  S == 1 in fused mode is software-pipelined: step k+1 is enqueued BEFORE the host waits
+        for step k's counters (two counter banks in the library), so the GPU never idles on Python; the all-reduce
+        of step k's counters (RCCL over xGMI when world > 1) runs while the GPU computes step k+1 -- counters are
+        consumed one step behind; the last one is read and reduced inside the timed region."""
+        S = self.S if S is None else S
+        if S > 1:
+            return self.run_multi(k0, k1, S)
+        hits = 0
+        if not self.args.mode.startswith("fused") or os.environ.get("PCL_BENCH_NOPIPE"):
+            for k in range(k0, k1):
+                self.launch(k)
+                c = self.collect()
+                hits += int(c[1])
+                self.totals = self.comm.allreduce_sum(c)
+            return hits
+        if k1 > k0:
+            self.launch(k0)
+        for k in range(k0 + 1, k1):
+            self.launch(k)
+            c = self.collect()                      # counters of step k-1
+            hits += int(c[1])
+            self.totals = self.comm.allreduce_sum(c)
+        if k1 > k0:
+            c = self.collect()
+            hits += int(c[1])
+            self.totals = self.comm.allreduce_sum(c)
+        return hits
+
+    def timed_blocks(self, k_start, steps, repeats, S=None):
+        """``repeats`` consecutive blocks of ``steps`` steps, each bracketed by barrier + synchronise on both sides.
+        Returns per-block wall seconds (MAX over ranks), local hit counts and per-kernel HIP-event samples."""
+        comm, dev = self.comm, self.dev
+        el, hits, kern = [], [], []
+        k = k_start
+        for _ in range(repeats):
+            dev.prof_enable(True)                   # clears the samples; synchronises (outside the timed region)
+            comm.barrier()
+            dev.sync()
+            comm.device_synchronize()
+            t0 = time.perf_counter()
+            h = self.run_steps(k, k + steps, S)
+            dev.sync()
+            comm.device_synchronize()
+            comm.barrier()
+            dt = time.perf_counter() - t0
+            el.append(comm.allreduce_max(dt))
+            hits.append(h)
+            kern.append({name: dev.prof_read(kid) for kid, name in self.hip.PROF_NAMES.items()})
+            k += steps
+        dev.prof_enable(False)
+        return el, hits, kern, k
+
+
+def kernel_summary(kern_blocks, name):
+    """All timed launches of one kernel over the blocks: launches, average / min / max launch ms."""
+    n = sum(b[name]["launches"] for b in kern_blocks)
+    tot = sum(b[name]["total_ms"] for b in kern_blocks)
+    live = [b[name] for b in kern_blocks if b[name]["launches"]]
+    return {"launches": n, "avg_ms": tot / n if n else 0.0, "min_ms": min((b["min_ms"] for b in live), default=0.0),
+            "max_ms": max((b["max_ms"] for b in live), default=0.0),
+            "per_block_avg_ms": [round(b[name]["avg_ms"], 5) for b in kern_blocks]}
+
+
+def median_index(xs):
+    """Index of the median element (the lower one for even lengths): the block every per-block figure refers to."""
+    order = sorted(range(len(xs)), key=lambda i: xs[i])
+    return order[(len(xs) - 1) // 2]
+
+
+def static_profile(profile, mode, dtype, N, S, steps):
+    """PMC-counter figures of a COMMITTED rocprofv3 run of this configuration (profiles/pmc_traffic.json): HBM bytes
+    per launch and the SQ (VALU) counters.  Not measured by this process -- nested here with their source, the K and
+    the hit fraction they were taken at; nothing in the line is derived from them."""
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    try:
+        table = json.load(open(tfile))
+    except ValueError:
+        return None
+    for key in ("%s:%s%s:%d:K%d:steps%d" % (profile, mode, "-f32" if dtype == "f32" else "", N, S, steps),
+                "%s:%s%s:%d" % (profile, mode, "-f32" if dtype == "f32" else "", N)):
+        if key in table:
+            return dict(table[key], key=key, file="profiles/pmc_traffic.json",
+                        note="from a committed rocprofv3 --pmc run of this configuration, not from this process")
+    return None
+
+
+def run_rank(args):
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when it
     # initialises): everything but the final line goes to stderr.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
-                         % (args.gpus, world))
+    b = Bench(args)
+    comm, dev, N, S, prof, world, rank = b.comm, b.dev, b.N, b.S, b.prof, b.world, b.rank
+    hip = b.hip
+    f32 = args.dtype == "f32"
+    bscale = 0.5 if f32 else 1.0
+    b.fill()
 
-    from physicl_amd import _hip
-    from physicl_amd.dist import CounterComm
-
-    comm = CounterComm.from_env(backend=args.backend, device_index=args.device)   # no-op communicator when world == 1
-    N = int(args.photons)
-    prof = PROFILES[args.profile]
-    flags = _hip.SCATTER_WAVELENGTH | _hip.SCATTER_VARIABLE_N
-    e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9   # E_from_wavelength, light.py:39-43
-
-    dev = _hip.Device(local_rank if args.device is None else args.device)
-    dev.store_alloc(N, args.dtype)
-    dev.fill_photons(N, rank * N, C_LIT, e_lo, e_hi, args.seed)      # ids are global: shard-independent RNG
-
-    sim_t = 0.0
-    totals = None
-    S = max(1, min(64, args.steps_per_launch)) if args.mode == "fused" else 1
-
-    fused_sc = lambda k: dict(A=prof["A_kernel"], n=prof["n_kernel"], flags=flags, c=C_LIT, h=H_LIT,
-                              n_expr=prof["expr"], rng_mode=_hip.RNG_PHILOX, seed=args.seed, step=k)
-
-    def launch(k):
-        """Enqueue step k (no host synchronisation)."""
-        nonlocal sim_t
-        sim_t += prof["dt"]                                          # UpdateTimeStep   __init__.py:337-343
-        if args.mode.startswith("fused"):
-            # newton.py:10-16 + light.py:281-331 + light.py:414-431 in one pass over the particles
-            dev.step_fused(prof["dt"], fused_sc(k), planes=(), sync=False, lazy=(args.mode == "fused"))
-        else:
-            dev.step_newton(prof["dt"])                                  # newton.py:10-16
-            dev.step_scatter_isotropic(prof["A_kernel"], prof["n_kernel"], flags, C_LIT, H_LIT, prof["expr"],
-                                       _hip.RNG_PHILOX, args.seed, k, want_hits=False)   # light.py:281-331
-
-    def collect():
-        """Wait for the enqueued step and fetch its local counters [N, hits, xp, yp, zp] (one sync)."""
-        if args.mode.startswith("fused"):
-            o = dev.step_fused_read(0)
-            return np.array([o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]], dtype=np.int64)
-        cnt = dev.step_counters()                                        # light.py:414-431
-        return np.array([cnt[_hip.CNT_N], dev.last_scatter_hits(), cnt[_hip.CNT_XP], cnt[_hip.CNT_YP],
-                         cnt[_hip.CNT_ZP]], dtype=np.int64)
-
-    def run_multi(k0, k1):
-        """Steps k0..k1-1 as ceil((k1-k0)/S) passes of S loop bodies each; one all-reduce of the S x 5 per-step
-        counters per pass."""
-        nonlocal totals, sim_t
-        hits = 0
-        k = k0
-        while k < k1:
-            ks = min(S, k1 - k)
-            for _ in range(ks):
-                sim_t += prof["dt"]                                      # UpdateTimeStep   __init__.py:337-343
-            rows = dev.step_fused_multi(prof["dt"], ks, fused_sc(k))
-            c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
-            hits += int(c[:, 1].sum())
-            totals = comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
-            k += ks
-        return hits
-
-    def run_steps(k0, k1):
-        """Steps k0..k1-1, software-pipelined: step k+1 is enqueued BEFORE the host waits for step k's counters
-        (two counter banks in the library), so the GPU never idles on Python; the all-reduce of step k's
-        counters (RCCL over xGMI when world > 1) runs while the GPU computes step k+1 -- counters are consumed
-        one step behind; the last one is read and reduced inside the timed region."""
-        nonlocal totals
-        if S > 1:
-            return run_multi(k0, k1)
-        hits = 0
-        if not args.mode.startswith("fused") or os.environ.get("PCL_BENCH_NOPIPE"):
-            for k in range(k0, k1):
-                launch(k)
-                c = collect()
-                hits += int(c[1])
-                totals = comm.allreduce_sum(c)
-            return hits
-        if k1 > k0:
-            launch(k0)
-        for k in range(k0 + 1, k1):
-            launch(k)
-            c = collect()                      # counters of step k-1
-            hits += int(c[1])
-            totals = comm.allreduce_sum(c)
-        if k1 > k0:
-            c = collect()
-            hits += int(c[1])
-            totals = comm.allreduce_sum(c)
-        return hits
+    # every rank reports which physical device it drives: N ranks on N distinct devices is what RCCL needs
+    devices = comm.allgather_object({"rank": rank, "device": b.dev_index, "pci": dev.info().get("pci_bus_id")})
 
     dev.prof_enable(True)
-    run_steps(0, args.warmup)
-    warm = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}   # rocprofv3 --stats averages these in too
+    b.run_steps(0, args.warmup)
+    warm = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
 
-    dev.prof_enable(True)
-    comm.barrier()
-    dev.sync()
-    comm.device_synchronize()
-    t0 = time.perf_counter()
-    hits_local = run_steps(args.warmup, args.warmup + args.steps)
-    dev.sync()
-    comm.device_synchronize()
-    comm.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = comm.allreduce_max(elapsed)
-
-    kern = {name: dev.prof_read(kid) for kid, name in _hip.PROF_NAMES.items()}
-    dev.prof_enable(False)
-    h_mean = hits_local / float(N * args.steps)
-    bpp = algorithmic_bytes_per_particle(args.profile, h_mean, args.mode, S > 1) * (0.5 if args.dtype == "f32" else 1.0)
+    R = max(1, args.repeats)
+    el, hits, kern, k_next = b.timed_blocks(args.warmup, args.steps, R)
+    totals_main = b.totals
+    mi = median_index(el)
+    elapsed = el[mi]
     dominant = ("k_multi" if S > 1 else "k_fused") if args.mode.startswith("fused") else "k_scatter"
-    sc = kern[dominant]
-    achieved = N * bpp / (sc["avg_ms"] * 1e-3) / 1e9 if sc["launches"] else 0.0
-    # what the same steps would have to move one launch per step (104 B per particle-step) over the time they took:
-    # > HBM peak is possible for the K-step pass precisely because it does not move those bytes
-    eff_steps = args.steps / max(1, sc["launches"]) if S > 1 else 1.0
-    effective = N * 104.0 * (0.5 if args.dtype == "f32" else 1.0) * eff_steps / (sc["avg_ms"] * 1e-3) / 1e9 \
-        if (S > 1 and sc["launches"]) else None
+    ks = kernel_summary(kern, dominant)
+    h_blocks = [h / float(N * args.steps) for h in hits]
+    bpp = algorithmic_bytes_per_particle(args.profile, h_blocks[mi], args.mode, S > 1) * bscale
+    achieved = N * bpp / (ks["avg_ms"] * 1e-3) / 1e9 if ks["launches"] else 0.0
+    steps_per_timed_launch = args.steps * R / max(1, ks["launches"]) if S > 1 else 1.0
 
-    single = None
-    if S > 1 and world == 1:
+    single = delete = api = None
+    extra = world == 1 and not args.no_extra
+    if extra and S > 1:
         # the one-launch-per-step path on the same store, same run: the HBM-bound kernel's own roofline line
-        S_keep, S = S, 1
-        totals_main = totals
-        k_next = args.warmup + args.steps
-        run_steps(k_next, k_next + 3)
-        dev.prof_enable(True)
-        dev.sync()
-        t1 = time.perf_counter()
-        h1 = run_steps(k_next + 3, k_next + 3 + args.steps)
-        dev.sync()
-        el1 = time.perf_counter() - t1
-        k1 = dev.prof_read(_hip.PROF_FUSED)
-        dev.prof_enable(False)
-        S, totals = S_keep, totals_main
-        b1 = 104.0 * (0.5 if args.dtype == "f32" else 1.0)
+        b.run_steps(k_next, k_next + 3, S=1)
+        el1, hits1, kern1, k_next = b.timed_blocks(k_next + 3, args.steps, R, S=1)
+        m1 = median_index(el1)
+        k1 = kernel_summary(kern1, "k_fused")
+        b1 = 104.0 * bscale
         a1 = N * b1 / (k1["avg_ms"] * 1e-3) / 1e9 if k1["launches"] else 0.0
-        single = {"value": N * args.steps / el1, "unit": "particle-steps/s", "ms_per_step": el1 / args.steps * 1e3,
-                  "steps": args.steps,
-                  "roofline": {"bound": "hbm", "kernel": "k_fused (one launch per step, dr/dv implicit)", "achieved": a1,
-                               "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBPS,
-                               "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1["avg_ms"],
-                               "launches": k1["launches"], "hit_fraction": h1 / float(N * args.steps)}}
+        single = {"value": N * args.steps / el1[m1], "unit": "particle-steps/s", "ms_per_step": el1[m1] / args.steps * 1e3,
+                  "steps": args.steps, "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el1],
+                  "roofline": {"bound": "hbm", "kernel": "k_fast (pcl_rtc_fast_e1): one launch per step, dr/dv implicit",
+                               "achieved": a1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBPS,
+                               "traffic": None, "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1["avg_ms"],
+                               "min_launch_ms": k1["min_ms"], "max_launch_ms": k1["max_ms"], "launches": k1["launches"],
+                               "hit_fraction": hits1[m1] / float(N * args.steps)}}
+        b.totals = totals_main
+
+    info = dev.info()
+    dev.store_free()
+    if extra and not f32:
+        delete = delete_leg(dev, hip, [int(float(x)) for x in args.delete_photons.split(",") if x.strip()], args.seed)
+    dev.close()
+    if extra and not f32:
+        api = api_leg(args, prof)
 
     out = None
     if rank == 0:
-        total_particles = N * world
-        value = total_particles * args.steps / elapsed
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            t = json.load(open(tfile)).get("%s:%s%s:%d" % (args.profile, args.mode, "-f32" if args.dtype == "f32" else "", N))
-            valu = None
-            traffic = t.get(dominant + "_bytes_per_launch") if t else None
-            valu = t.get(dominant + "_valu") if t else None
-            if single is not None and t:
-                single["roofline"]["traffic"] = t.get("k_fused_bytes_per_launch")
+        value = N * world * args.steps / elapsed
+        if world > 1:
+            coll_txt = " + %s all-reduce of the %s int64 counters" % (
+                "RCCL" if comm.backend == "nccl" else "gloo", "%d x 5 per-launch" % S if S > 1 else "5")
+        else:
+            coll_txt = ""
         out = {
             "metric": "particle-steps/sec", "value": value, "unit": "particle-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el],
+            "repeat_hit_fraction": [round(h, 6) for h in h_blocks], "timing": "median of %d blocks of %d steps" % (R, args.steps),
             "config": {"workload": "BASELINE configs[2]%s: %.0e photons/GPU, variable-n + wavelength isotropic "
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
-                                   % ("/[3] weak-scaled" if world > 1 else "", N,
-                                      " + %s all-reduce of the %s int64 counters" % ("RCCL" if comm.backend == "nccl" else "gloo",
-                                                                                   "%d x 5 per-launch" % S if S > 1 else "5") if world > 1 else ""),
+                                   % ("/[3] weak-scaled" if world > 1 else "", N, coll_txt),
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "steps_per_launch": S,
                        "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
+            "collective": dict(comm.info(), devices=devices) if world > 1 else None,
             "roofline": {"bound": "hbm",
-                         "kernel": (("k_multi: %d x (Newton + ScatterIsotropic + counters) per pass over the store (hipRTC "
-                                     "variable-n), dr/dv implicit; VALU-bound by construction -- see 'valu' and single_step" % S)
+                         "kernel": (("k_multi (pcl_rtc_multi_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "
+                                     "store, dr/dv implicit; arithmetic-bound by construction -- the HBM-bound formulation "
+                                     "is single_step" % S)
                                     if S > 1 else
-                                    "k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
+                                    "k_fast/k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
                                     % (", dr/dv implicit" if args.mode == "fused" else "")
                                     if args.mode.startswith("fused") else
                                     "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "algorithmic_bytes_per_particle": bpp, "hit_fraction": h_mean,
-                         "avg_launch_ms": sc["avg_ms"], "launches": sc["launches"], "steps_per_launch": S,
-                         "effective_GBps_at_104B_per_step": effective,
-                         "warmup_launches": warm[dominant]["launches"], "warmup_avg_launch_ms": warm[dominant]["avg_ms"],
-                         "avg_launch_ms_incl_warmup": ((sc["avg_ms"] * sc["launches"] + warm[dominant]["avg_ms"] * warm[dominant]["launches"])
-                                                       / max(1, sc["launches"] + warm[dominant]["launches"])),
-                         "valu": valu_roofline(valu, value / world) if valu else None},
+                         "traffic": None, "algorithmic_bytes_per_particle": bpp,
+                         "algorithmic_bytes_note": "per LAUNCH of the K-step pass (r, v, lam4 read; r, v, vprev written)" if S > 1
+                                                   else "per particle-step",
+                         "hit_fraction": h_blocks[mi], "avg_launch_ms": ks["avg_ms"], "min_launch_ms": ks["min_ms"],
+                         "max_launch_ms": ks["max_ms"], "launches": ks["launches"],
+                         "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch": S,
+                         "steps_per_timed_launch": steps_per_timed_launch,
+                         # SURVEY 8(d)'s per-step form: what the same particle-steps would have had to move one launch per
+                         # step (104 B each).  > peak is possible precisely because the pass does not move those bytes.
+                         "per_step_form": ({"bytes_per_particle_step": 104.0 * bscale,
+                                            "GBps": N * 104.0 * bscale * steps_per_timed_launch / (ks["avg_ms"] * 1e-3) / 1e9,
+                                            "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (ks["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                                           if (S > 1 and ks["launches"]) else None),
+                         "warmup_launches": warm[dominant]["launches"], "warmup_avg_launch_ms": warm[dominant]["avg_ms"]},
+            "static_profile": static_profile(args.profile, args.mode, args.dtype, N, S, args.steps),
             # north_star target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons): carried by the
             # one-launch-per-step kernel, measured in this same run (single_step); the K-step pass trades those bytes away
-            "hbm_target": ({"kernel": "k_fused, one launch per step", "frac": single["roofline"]["frac"], "target": 0.6,
+            "hbm_target": ({"kernel": "k_fast, one launch per step", "frac": single["roofline"]["frac"], "target": 0.6,
                             "met": single["roofline"]["frac"] >= 0.6} if single is not None else None),
-            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in kern.items() if v["launches"]},
-            "kernels_GBps": {
-                "k_newton": N * 96 / (kern["k_newton"]["avg_ms"] * 1e-3) / 1e9 if kern["k_newton"]["launches"] else None,
-                "k_counters": N * 24 / (kern["k_counters"]["avg_ms"] * 1e-3) / 1e9 if kern["k_counters"]["launches"] else None,
-            },
-            "counters_last_step": {"N": int(totals[0]), "hits": int(totals[1]), "xp": int(totals[2]),
-                                   "yp": int(totals[3]), "zp": int(totals[4])},
-            "device": dev.info()["name"],
+            "kernels_ms": {k: round(kernel_summary(kern, k)["avg_ms"], 4) for k in kern[0] if kernel_summary(kern, k)["launches"]},
+            "counters_last_step": {"N": int(totals_main[0]), "hits": int(totals_main[1]), "xp": int(totals_main[2]),
+                                   "yp": int(totals_main[3]), "zp": int(totals_main[4])},
+            "device": info["name"],
         }
         if single is not None:
             out["single_step"] = single
-        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64":
-            out["cpu_baseline"] = cpu_baseline(dev, args, prof)
-            out["cpu_baseline_python"] = cpu_baseline_python(dev, args, prof)
-            out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev, args, prof)
+        if delete is not None:
+            out["delete"] = delete
+        if api is not None:
+            out["api"] = api
+        if world == 1 and not args.no_cpu_baseline and not f32:
+            dev2 = hip.Device(b.dev_index)
+            try:
+                out["cpu_baseline"] = cpu_baseline(dev2, args, prof)
+                out["cpu_baseline_python"] = cpu_baseline_python(dev2, args, prof)
+                out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev2, args, prof)
+            finally:
+                dev2.close()
 
-    dev.store_free()
-    dev.close()
     comm.close()
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[1](ii): Newton + ScatterDeleteStep(A = n = 1e-3) + plane counter until no photon is left
+# (test/test_light.py:52-59; physicl/light.py:231-260, physicl/__init__.py:455-459)
+# ---------------------------------------------------------------------------------------------------------------------
+def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
+    """Delete-until-empty at each size, two formulations: "per_step" = one pipeline (k_newton_mask -> scan ->
+    k_compact_count) per loop body, the HBM-bound form whose kernels get a roofline figure each; "multi" = K loop
+    bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation(steps_per_launch=K) runs.
+    A "particle-step" is one photon alive at the start of one loop body.  Algorithmic bytes (DESIGN.md section 4,
+    fp64): pass 1 reads r, v (48), writes r (24) + 1 mask bit; pass 3 reads 1 bit per particle and moves
+    r, v, dv, E + the id of every survivor ((80 + 8) x 2 per survivor; dr stays implicit)."""
+    plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]          # test/test_light.py:58
+    dt, A, n = 1e-3, 1e-3, 1e-3
+    out = {"workload": "BASELINE configs[1](ii): Newton + ScatterDelete(A=n=1e-3) + plane counter until empty, E = 1, "
+                       "v = (c,0,0), dt = 1e-3, Philox", "repeats": repeats, "sizes": {}}
+    for N in sizes:
+        dev.store_alloc(N)
+        rec = {}
+        for mode in ("per_step", "multi"):
+            runs = []
+            for rep in range(repeats + 1):                    # rep 0 = warm-up (allocations of the second slab, first touch)
+                dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
+                dev.prof_enable(True)
+                dev.sync()
+                t0 = time.perf_counter()
+                work, per_step, k = 0, [], 0
+                while dev.count > 0 and k < 4096:
+                    nb = dev.count
+                    if mode == "multi":
+                        for o in dev.step_fused_delete_multi(dt, K, A, n, seed, k, plane):
+                            work += nb
+                            per_step.append((nb, o["N"]))
+                            nb = o["N"]
+                        k += K
+                    else:
+                        o = dev.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, k, plane, lazy=True)
+                        work += nb
+                        per_step.append((nb, o["N"]))
+                        k += 1
+                dev.sync()
+                el = time.perf_counter() - t0
+                kern = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
+                dev.prof_enable(False)
+                if rep:
+                    runs.append((el, work, per_step, kern))
+            runs.sort(key=lambda r: r[0])
+            el, work, per_step, kern = runs[(len(runs) - 1) // 2]
+            tot = sum(nb for nb, _ in per_step if nb)
+            surv = sum(al for nb, al in per_step if nb)
+            r = {"value": work / el, "unit": "particle-steps/s", "ms_total": el * 1e3, "loop_bodies": len([1 for nb, _ in per_step if nb]),
+                 "particle_steps": work, "survivor_fraction": surv / float(tot) if tot else 0.0,
+                 "run_ms": [round(x[0] * 1e3, 4) for x in runs],
+                 "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
+                 "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
+            if mode == "per_step":
+                p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
+                b1 = tot * 72.125                              # r, v read; r written; one mask bit
+                b3 = tot * 0.125 + surv * 2.0 * 88.0           # mask bit; survivors' 10 fields + id read and written
+                g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
+                g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
+                r["roofline"] = {"bound": "hbm", "kernel": "k_compact_count (stable compaction, pass 3)", "achieved": g3,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS, "traffic": None,
+                                 "algorithmic_bytes": b3, "total_ms": p3_ms}
+                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_newton_mask (Newton + delete flag -> ballot masks, pass 1)",
+                                       "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
+                                       "traffic": None, "algorithmic_bytes": b1, "total_ms": p1_ms}
+            else:
+                r["steps_per_launch"] = K
+            rec[mode] = r
+        out["sizes"]["%.0e" % N] = rec
+        dev.store_free()
+    return out
+
+
+def api_leg(args, prof):
+    """The same workload through the public API (physicl_amd.Simulation + the reference's step classes), so that the
+    Simulation / ObjectList / UpdateTimeStep / measure-step overhead is part of a measured number: particle-steps/s
+    over sim.run_time (start() .. join()), with steps_per_launch 32 and 1."""
+    import physicl_amd as phys
+    import physicl_amd.light as light
+    import physicl_amd.newton as newton
+    N, steps = int(args.photons), args.steps
+    out = {"what": "Simulation(steps_per_launch=S) with [UpdateTimeStep, NewtonianKinematicsStep, ScatterIsotropicStep, "
+                   "ScatterSignMeasureStep], exit at t >= %d * dt; whole run incl. upload/fill, hipRTC lookup, terminate" % steps}
+    for S in (32, 1):
+        sim = phys.Simulation(exit=lambda s: len(s.ts) >= steps, steps_per_launch=S, seed=args.seed)
+        sim.add_objs(light.generate_photons_bulk(N, min=light.E_from_wavelength(700e-9), max=light.E_from_wavelength(200e-9),
+                                                 seed=args.seed))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(prof["dt"])))
+        sim.add_step(1, newton.NewtonianKinematicsStep())
+        sim.add_step(2, light.ScatterIsotropicStep(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True,
+                                                   variable_n=True, variable_n_fn=prof["expr"]))
+        m = light.ScatterSignMeasureStep(None, True)
+        sim.add_step(3, m)
+        sim._to_device()                       # creation of the photons is set-up, not stepping
+        sim._dev.sync()
+        sim.start()
+        sim.join()
+        if sim.error is not None:
+            raise sim.error
+        out["steps_per_launch_%d" % S] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s",
+                                          "steps": len(sim.ts), "run_time_s": sim.run_time, "rows": len(m.data)}
+        sim.close(download=False)
+    return out
+
+
 def cpu_baseline(dev, args, prof):
     """The oracle's C/OpenMP port of the same step (newton + fused scatter + sign counters) on the first
-    `cpu_photons` photons of the SAME initial workload, all host cores.  Checker code timed as a
-    baseline: never part of the GPU path."""
+    `cpu_photons` photons of the SAME initial workload, all host cores this process may use (BASELINE.md section 4
+    item 3: 1e8 photons).  Checker code timed as a baseline: never part of the GPU path."""
     from oracle import c_oracle as co
     if prof["c_profile"] is None:
         return {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
                 "sample": "C port implements the example profile only"}
     n = int(min(args.cpu_photons, args.photons))
-    # same photons as the GPU run: regenerate the initial state of ids [0, n) on the device and download it
+    # same photons as the GPU run: regenerate the initial energies of ids [0, n) on the device and download them;
+    # every other field of the initial state is a constant (r = dr = dv = 0, v = (c, 0, 0))
+    dev.store_alloc(n)
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
-    st = {g: [dev.download(f, n) for f in fids] for g, fids in
-          (("r", (0, 1, 2)), ("v", (3, 4, 5)), ("dr", (6, 7, 8)), ("dv", (9, 10, 11)))}
-    st["E"] = dev.download(12, n)
+    st = {"r": [np.zeros(n) for _ in range(3)], "v": [np.full(n, C_LIT), np.zeros(n), np.zeros(n)],
+          "dr": [np.zeros(n) for _ in range(3)], "dv": [np.zeros(n) for _ in range(3)], "E": dev.download(12, n)}
+    dev.store_free()
     co.set_threads(co.usable_cores())          # the box's CPU share, not every core of the host
     cores = co.threads()
     profile, pk, poff = prof["c_profile"]
@@ -357,7 +555,7 @@ def cpu_baseline(dev, args, prof):
                              ids=None, id_base=0)
         co.counters(st)
 
-    step(0)                                   # warm-up + calibration
+    step(0)                                   # warm-up (first touch of the pages) + calibration
     t0 = time.perf_counter()
     step(1)
     one = time.perf_counter() - t0
@@ -366,9 +564,9 @@ def cpu_baseline(dev, args, prof):
     for k in range(2, 2 + steps):
         step(k)
     el = time.perf_counter() - t0
-    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads, "
-                      "%.1f s)" % (n, steps, cores, el)}
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+            "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads of %d "
+                      "CPUs on the box, %.1f s)" % (n, steps, cores, os.cpu_count() or 0, el)}
 
 
 def cpu_baseline_numpy(dev, args, prof):
@@ -376,10 +574,12 @@ def cpu_baseline_numpy(dev, args, prof):
     (BASELINE.md section 4, item 2)."""
     from oracle import physicl_oracle as orc
     n = int(min(1_000_000, args.photons))
+    dev.store_alloc(n)
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     st = {g: [dev.download(f, n) for f in fids] for g, fids in
           (("r", (0, 1, 2)), ("v", (3, 4, 5)), ("dr", (6, 7, 8)), ("dv", (9, 10, 11)))}
     st["E"], st["id"] = dev.download(12, n), np.arange(n, dtype=np.int64)
+    dev.store_free()
     steps, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < 4.0:
         orc.step_newton(st, prof["dt"])
@@ -400,8 +600,10 @@ def cpu_baseline_python(dev, args, prof):
     if prof["c_profile"] is None:
         return None
     n = int(min(10000, args.photons))
+    dev.store_alloc(n)
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     E = dev.download(12, n)
+    dev.store_free()
     value, steps, el = pyloop.time_steps(E, prof["dt"], prof["A_kernel"], prof["n_kernel"], True, prof["c_profile"], 3.0)
     return {"value": value, "unit": "particle-steps/s", "cores": 1, "kind": "port",
             "sample": "%d photons x %d steps, per-object Python loops (oracle/pyloop.py), %.1f s" % (n, steps, el)}

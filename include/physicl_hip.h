@@ -104,6 +104,9 @@ int pcl_ctx_stream(pcl_ctx *ctx, void **stream_out);
 /* name: host buffer of name_len bytes.  Replaces Simulation.get_device_info (__init__.py:470-499). */
 int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_bytes, int *n_cu,
                         int *wavefront);
+/* PCI bus id of the context's device ("0000:05:00.0"; host buffer of >= 16 bytes): lets N ranks show that they
+ * drive N different GPUs (bench.py "collective"). */
+int pcl_ctx_device_pci(pcl_ctx *ctx, char *pci, int pci_len);
 
 /* raw device memory for Level 1 callers: replaces cl_array.to_device / cl_array.empty / .get()
  * (physicl/__init__.py:614, 653, 662).  Copies are ordered on the context stream and return when
@@ -199,7 +202,8 @@ int pcl_store_dtype(pcl_ctx *ctx, int *dtype_out);
 int pcl_store_free(pcl_ctx *ctx);
 int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out);
 int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, no sync */
-/* Set the particle count (<= capacity) and declare ids = id_base + index (no id array is read). */
+/* Set the particle count (<= capacity) and declare a new population: ids = id_base + index (no id array is read) and
+ * every particle a photon (a kind array of an earlier upload is dropped) until pcl_store_upload_ids / _kind. */
 int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base);
 
 int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, int64_t n);
@@ -264,7 +268,8 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
                    const double *planes_host, int n_planes, int64_t *out_host);
 
 /* 1 if every particle is a photon and ids are implicit (id_base + index: nothing has been compacted or uploaded
- * with explicit ids/kinds) -- the precondition of pcl_step_fused_multi and of the fast single-step kernel. */
+ * with explicit ids/kinds) -- the precondition of pcl_step_fused_multi.  (Any other store takes pcl_step_mixed_multi;
+ * the fast single-step kernel has a variant that reads the explicit ids and the kind bytes.) */
 int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out);
 
 /* k_steps consecutive fused steps (Newton + ScatterIsotropic + sign counters) in ONE pass over the store.  Photons
@@ -316,6 +321,24 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
  * { N alive after the step, xp, yp, zp, plane counts..., removed in the step }; n_planes = -1: alive/removed only. */
 int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step0,
                                 const double *planes_host, int n_planes, int64_t *out_host);
+
+/* k_passes whole passes of a loop whose body holds one isotropic-scatter phase and/or one delete phase, each phase =
+ * NewtonianKinematicsStep + the light step + the counters of the measure steps that follow it:
+ *   {ISOTROPIC}          [Newton, ScatterIsotropic]                      on ANY store (explicit ids, plain Objects)
+ *   {DELETE}             [Newton, ScatterDelete]
+ *   {ISOTROPIC, DELETE}  [Newton, ScatterIsotropic, Newton, ScatterDelete]   (BASELINE.json configs[4]; or the reverse)
+ * in ONE pass over the store and, with a delete phase, ONE stable compaction afterwards.  Phase j of pass p uses launch
+ * index step0 + p * n_phases + j, so state, survivor order and rows are identical to the same passes run one launch at
+ * a time (pcl_step_fused / pcl_step_fused_delete with PCL_FUSED_LAZY, PCL_RNG_PHILOX).  A photon removed by a delete
+ * phase takes no further part (physicl/__init__.py:455-459).  dr and dv are left implicit.  A, n, flags, c, h, n_expr:
+ * the isotropic phase, as pcl_step_fused_multi; A_del, n_del: the delete phase.  Device RNG only.
+ * out_host (may be NULL): int64[k_passes * n_phases][5 + n_planes] = { N alive after the phase, xp, yp, zp, plane
+ * counts..., hits (isotropic phase) | removed (delete phase) }; k_passes * n_phases <= 64. */
+#define PCL_PHASE_ISOTROPIC 0
+#define PCL_PHASE_DELETE    1
+int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int *phase_kinds_host, double A, double n,
+                         int flags, double c, double h, const char *n_expr, double A_del, double n_del, uint64_t seed,
+                         uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host);
 
 /* The int32 flag array of the most recent pcl_step_scatter_delete / pcl_step_fused_delete, in PRE-compaction order
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */

@@ -16,6 +16,7 @@ R0, R1, R2, V0, V1, V2, DR0, DR1, DR2, DV0, DV1, DV2, E, NFIELDS = range(14)
 FIELD_GROUPS = {"r": (R0, R1, R2), "v": (V0, V1, V2), "dr": (DR0, DR1, DR2), "dv": (DV0, DV1, DV2)}
 SCATTER_WAVELENGTH, SCATTER_VARIABLE_N, FUSED_LAZY = 1, 2, 4
 RNG_INPUT, RNG_PHILOX = 0, 1
+PHASE_ISOTROPIC, PHASE_DELETE = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
 DTYPE_F64, DTYPE_F32 = 0, 1
 _NP_DTYPE = {DTYPE_F64: np.float64, DTYPE_F32: np.float32}
@@ -52,6 +53,7 @@ _PROTOTYPES = {
     "pcl_ctx_sync": [_vp],
     "pcl_ctx_stream": [_vp, POINTER(_vp)],
     "pcl_ctx_device_info": [_vp, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int)],
+    "pcl_ctx_device_pci": [_vp, c_char_p, c_int],
     "pcl_dev_alloc": [_vp, c_int64, POINTER(_vp)],
     "pcl_dev_free": [_vp, _vp],
     "pcl_h2d": [_vp, _vp, _vp, c_int64],
@@ -98,6 +100,8 @@ _PROTOTYPES = {
                              c_uint32, _vp, c_int, _vp],
     "pcl_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                        c_uint32, _vp, c_int, _vp],
+    "pcl_step_mixed_multi": [_vp, c_double, c_int, c_int, _vp, c_double, c_double, c_int, c_double, c_double, c_char_p,
+                             c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_step_fused_read": [_vp, c_int, _vp],
     "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
@@ -252,8 +256,10 @@ class Device:
         name = ctypes.create_string_buffer(256)
         hbm, cu, wf = c_int64(), c_int(), c_int()
         check(self.lib.pcl_ctx_device_info(self.ctx, name, 256, byref(hbm), byref(cu), byref(wf)))
+        pci = ctypes.create_string_buffer(64)
+        check(self.lib.pcl_ctx_device_pci(self.ctx, pci, 64))
         return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cu.value,
-                "wavefront": wf.value, "device": self.device}
+                "wavefront": wf.value, "device": self.device, "pci_bus_id": pci.value.decode()}
 
     def timer_start(self):
         check(self.lib.pcl_timer_start(self.ctx))
@@ -469,6 +475,32 @@ class Device:
             return None
         return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + npl].copy(), "hits": int(o[4 + npl])} for o in out]
 
+    def step_mixed_multi(self, dt, k_passes, phases, scatter=None, delete=None, planes=(), seed=0, step=0):
+        """``k_passes`` passes of a loop whose body holds the phases ``phases`` -- a sequence of "iso" / "delete", at
+        most one of each -- every phase being Newton + the light step + the counters of the measure steps behind it;
+        one pass over the store and (with a delete phase) one compaction.  ``scatter``: dict A, n, flags, c, h, n_expr
+        (kernel constants) of the isotropic phase; ``delete``: (A, n) of the delete phase.  Device RNG; phase j of
+        pass p uses launch index ``step + p * len(phases) + j``.  Returns one dict per phase, in order:
+        {'phase', 'N' (alive after it), 'sign', 'planes', 'hits' | 'removed'}."""
+        kinds = np.array([{"iso": PHASE_ISOTROPIC, "delete": PHASE_DELETE}[p] for p in phases], dtype=np.int32)
+        sc = scatter or {}
+        A_d, n_d = delete if delete is not None else (0.0, 0.0)
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        npl = len(pl)
+        out = np.zeros((k_passes * len(kinds), 5 + npl), dtype=np.int64)
+        expr = sc.get("n_expr")
+        check(self.lib.pcl_step_mixed_multi(
+            self.ctx, float(dt), int(k_passes), len(kinds), kinds.ctypes.data_as(c_void_p), float(sc.get("A", 0.0)),
+            float(sc.get("n", 0.0)), int(sc.get("flags", 0)), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
+            expr.encode() if expr is not None else None, float(A_d), float(n_d), int(seed), int(step) & 0xFFFFFFFF,
+            pl.ctypes.data_as(c_void_p) if npl else None, npl, out.ctypes.data_as(c_void_p)))
+        rows = []
+        for k, o in enumerate(out):
+            ph = phases[k % len(kinds)]
+            rows.append({"phase": ph, "N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + npl].copy(),
+                         ("hits" if ph == "iso" else "removed"): int(o[4 + npl])})
+        return rows
+
     def step_fused_read(self, n_planes=0):
         """Counters of the last ``step_fused(..., sync=False)``: same dict as the synchronous call."""
         out = np.zeros(5 + n_planes, dtype=np.int64)
@@ -533,7 +565,7 @@ class Device:
         out = np.empty(max(cap, 1), dtype=self.np_dtype)
         check(self.lib.pcl_step_plane_energies(self.ctx, pl.ctypes.data_as(c_void_p), out.ctypes.data_as(c_void_p), cap, byref(n)))
         if n.value > cap:
-            raise HipError("plane_energies: %d photons crossed, n_hint was %d" % (n.value, cap))
+            raise HipError(-2, "plane_energies: %d photons crossed, n_hint was %d" % (n.value, cap))
         return out[:n.value].copy()
 
     def step_counters(self, planes=()):

@@ -466,7 +466,14 @@ class Simulation(threading.Thread):
             dev.upload_rand(2, full)
 
     def _rng_mode(self):
-        return self._hip.RNG_PHILOX if (self.rng or "numpy") == "philox" else self._hip.RNG_INPUT
+        if (self.rng or "numpy") == "philox":
+            return self._hip.RNG_PHILOX
+        if self.comm is not None and self.comm.world > 1:
+            # every rank would draw the SAME np.random stream for its own shard (scripts seed it once): correlated
+            # shards, and never the unsharded run's numbers.  Only the id-keyed device RNG is shard-independent.
+            raise ValueError("a sharded Simulation (comm.world = %d) needs rng='philox'; rng=%r draws host randoms per "
+                             "rank" % (self.comm.world, self.rng or "numpy"))
+        return self._hip.RNG_INPUT
 
     def _global(self, values):
         return self.comm.allreduce_sum(values) if self.comm is not None else np.asarray(values, dtype=np.int64)
@@ -507,7 +514,7 @@ class Simulation(threading.Thread):
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan()
         if self.steps_per_launch > 1 and self._multi_agreed():
-            self._run_multi(self._plan[0][1], self._plan[1][1])
+            self._run_multi(self._plan[0][1], [item for _, item in self._plan[1:]])
             return
         for kind, item in self._plan:
             if kind == "fused":
@@ -524,9 +531,8 @@ class Simulation(threading.Thread):
                     self._readonly_scope = False
 
     def _multi_agreed(self):
-        """_multi_eligible(), decided once per (plan, upload) and -- with ``comm`` -- agreed by all ranks: a shard whose
-        store is not uniform (a plain Object among its photons) must not leave the others waiting in a collective of a
-        different launch schedule."""
+        """_multi_eligible(), decided once per (plan, upload) and -- with ``comm`` -- agreed by all ranks: every rank
+        must follow the same launch schedule, or the collectives of different schedules would wait for each other."""
         key = (self._plan_key, self._upload_gen)
         if key != self._multi_key:
             ok = 1 if self._multi_eligible() else 0
@@ -536,30 +542,29 @@ class Simulation(threading.Thread):
         return self._multi_ok
 
     def _multi_eligible(self):
-        """The whole pass is [UpdateTimeStep][Newton + ScatterIsotropic + counting measures] on a uniform
-        photon store, or [UpdateTimeStep][Newton + ScatterDelete + counting measures], with the device RNG: K passes
-        can run as one launch (pcl_step_fused_multi / pcl_step_fused_delete_multi)."""
+        """The whole pass is [UpdateTimeStep] followed by one or two groups [Newton + light step + counting measures]
+        -- at most one ScatterIsotropicStep and one ScatterDeleteStep, either order -- with the device RNG: K passes can
+        run as one launch (pcl_step_fused_multi / pcl_step_fused_delete_multi / pcl_step_mixed_multi)."""
         plan = self._plan
-        if len(plan) != 2 or plan[0][0] != "single" or type(plan[0][1]) is not UpdateTimeStep or plan[1][0] != "fused":
+        if not (2 <= len(plan) <= 3) or plan[0][0] != "single" or type(plan[0][1]) is not UpdateTimeStep:
             return False
-        group = plan[1][1]
-        roles = [s._fuse_role for s in group]
-        if roles[0] != "newton" or len(roles) < 2 or any(r != "measure" for r in roles[2:]):
+        seen = []
+        for kind, group in plan[1:]:
+            if kind != "fused":
+                return False
+            roles = [s._fuse_role for s in group]
+            if roles[0] != "newton" or len(roles) < 2 or roles[1] not in ("scatter_iso", "scatter_delete") or \
+                    any(r != "measure" for r in roles[2:]) or roles[1] in seen:
+                return False
+            seen.append(roles[1])
+        if sum(m._n_planes() for _, group in plan[1:] for m in group[2:]) > 12:
             return False
-        if self._rng_mode() != self._hip.RNG_PHILOX:
-            return False
-        if roles[1] == "scatter_delete":
-            return True
-        if roles[1] != "scatter_iso":
-            return False
-        self._to_device()
-        return self._dev.is_uniform()
+        return self._rng_mode() == self._hip.RNG_PHILOX
 
-    def _plan_passes(self, upd):
-        """Host part of up to ``steps_per_launch`` passes, ahead of the launch: the time update of each pass, then
+    def _plan_passes(self, upd, k_max):
+        """Host part of up to ``k_max`` passes, ahead of the launch: the time update of each pass, then
         the exit test the outer loop would make before the next one.  Returns [(t, dt)] per pass and the code dt."""
         times, dt0 = [], None
-        k_max = max(1, min(int(self.steps_per_launch), 64))        # PCL_MULTI_MAX
         while len(times) < k_max:
             before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
             upd.run(self)
@@ -574,62 +579,67 @@ class Simulation(threading.Thread):
                 break
         return times, dt0
 
-    def _run_multi(self, upd, group):
+    def _run_multi(self, upd, groups):
         """Up to ``steps_per_launch`` passes of the loop in one launch.  The host part of each pass runs first
-        (_plan_passes); the device then advances the photons through all of them in one pass over the store and
-        returns one counter row per pass."""
-        if group[1]._fuse_role == "scatter_delete":
-            return self._run_multi_delete(upd, group)
-        dev = self._dev
-        times, dt0 = self._plan_passes(upd)
-        k = len(times)
-        scatter, measures = group[1], group[2:]
-        sc = scatter._kernel_params(self)
-        sc.update(rng_mode=self._hip.RNG_PHILOX, seed=self.seed, step=self._launch + 1)
-        self._launch += k
-        self._scattered = True
-        planes = [p for m in measures for p in m._plane_rows()]
-        rows = dev.step_fused_multi(dt0, k, sc, planes)
-        flat = np.array([np.concatenate([[o["N"], o["hits"]], o["sign"], o["planes"]]) for o in rows], dtype=np.int64)
-        glob = self._global(flat.reshape(-1)).reshape(k, flat.shape[1])
-        for (t, dt), g in zip(times, glob):
-            self.t, self.dt = t, dt                   # each row carries its own pass's time
-            j = 5
-            for m in measures:
-                npl = m._n_planes()
-                m._record(self, int(g[0]), g[2:5], g[j:j + npl])
-                j += npl
-        self.hits = int(glob[-1][1])
-
-    def _run_multi_delete(self, upd, group):
-        """K delete passes per launch, one compaction.  ``exit`` usually waits for the store to empty, which the host
-        cannot know ahead of the launch: the rows are replayed afterwards and the run is cut at the first pass whose
-        exit test is true -- valid because that can only be a pass that left nothing alive (checked)."""
-        self._to_device()
-        dev = self._dev
+        (_plan_passes); the device then advances the particles through all of them in one pass over the store (and one
+        compaction if a ScatterDeleteStep is in the loop) and returns one counter row per light step per pass.
+        ``exit`` usually waits for the store to empty, which the host cannot know ahead of the launch: the rows are
+        replayed afterwards and the run is cut at the first pass whose exit test is true -- valid because that can only
+        be a pass that left nothing alive (checked)."""
+        self._to_device()             # a host plugin or another thread may have taken the objects back since the last pass
+        dev, hip = self._dev, self._hip
+        P = len(groups)
+        lights = [g[1] for g in groups]
+        phases = ["iso" if s._fuse_role == "scatter_iso" else "delete" for s in lights]
+        has_delete = "delete" in phases
         n_ts = len(self.ts)
-        times, dt0 = self._plan_passes(upd)
+        times, dt0 = self._plan_passes(upd, max(1, min(int(self.steps_per_launch), 64 // P)))     # PCL_MULTI_MAX rows
         k = len(times)
-        delete, measures = group[1], group[2:]
-        planes = [p for m in measures for p in m._plane_rows()]
-        A_k, n_k = delete._kernel_consts()
-        rows = dev.step_fused_delete_multi(dt0, k, A_k, n_k, self.seed, self._launch + 1, planes if measures else None)
-        self._launch += k
-        flat = np.array([np.concatenate([[o["N"], o["removed"]], o["sign"], o["planes"]]) for o in rows], dtype=np.int64)
-        glob = self._global(flat.reshape(-1)).reshape(k, flat.shape[1])
-        for i, ((t, dt), g) in enumerate(zip(times, glob)):
-            self.t, self.dt = t, dt
-            self._alive, delete.removed = int(g[0]), int(g[1])
-            j = 5
-            for m in measures:
-                npl = m._n_planes()
-                m._record(self, int(g[0]), g[2:5], g[j:j + npl])
-                j += npl
-            if i + 1 < k and self.exit(self):         # the outer loop would have stopped here
-                if int(g[0]) != 0:
+        planes, span = [], []
+        for g in groups:
+            pl = [p for m in g[2:] for p in m._plane_rows()]
+            span.append((len(planes), len(pl)))
+            planes += pl
+        sc = dl = None
+        for s in lights:
+            if s._fuse_role == "scatter_iso":
+                sc = s._kernel_params(self)
+            else:
+                dl = s._kernel_consts()
+        step0 = self._launch + 1
+        self._launch += k * P
+        if phases == ["iso"] and dev.is_uniform():
+            sc.update(rng_mode=hip.RNG_PHILOX, seed=self.seed, step=step0)
+            rows = [dict(o, evt=o["hits"]) for o in dev.step_fused_multi(dt0, k, sc, planes)]
+        elif phases == ["delete"]:
+            rows = [dict(o, evt=o["removed"]) for o in
+                    dev.step_fused_delete_multi(dt0, k, dl[0], dl[1], self.seed, step0, planes if groups[0][2:] else None)]
+        else:
+            rows = [dict(o, evt=o["hits"] if o["phase"] == "iso" else o["removed"]) for o in
+                    dev.step_mixed_multi(dt0, k, phases, sc, dl, planes, self.seed, step0)]
+        npl = len(planes)
+        flat = np.array([np.concatenate([[o["N"], o["evt"]], o["sign"], o["planes"] if len(o["planes"]) else np.zeros(npl, np.int64)])
+                         for o in rows], dtype=np.int64)
+        glob = self._global(flat.reshape(-1)).reshape(k * P, flat.shape[1])
+        for i, (t, dt) in enumerate(times):
+            self.t, self.dt = t, dt                   # each row carries its own pass's time
+            for j, g in enumerate(groups):
+                row = glob[i * P + j]
+                if phases[j] == "iso":
+                    self.hits = int(row[1])
+                    self._scattered = True
+                else:
+                    self._alive, lights[j].removed = int(row[0]), int(row[1])
+                at = 5 + span[j][0]
+                for m in g[2:]:
+                    n_m = m._n_planes()
+                    m._record(self, int(row[0]), row[2:5], row[at:at + n_m])
+                    at += n_m
+            if has_delete and i + 1 < k and self.exit(self):         # the outer loop would have stopped here
+                if self._alive != 0:
                     raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
                                        "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
-                                       "the store being empty only" % (i + 1, k, int(g[0])))
+                                       "the store being empty only" % (i + 1, k, self._alive))
                 del self.ts[n_ts + i + 1:]
                 break
 
@@ -728,10 +738,11 @@ class Simulation(threading.Thread):
             return d.download_ids()
         return np.stack([d.download(f) for f in self._hip.FIELD_GROUPS[field]], 1)
 
-    def close(self):
-        """Free the device store and context (also happens at garbage collection)."""
+    def close(self, download=True):
+        """Free the device store and context (also happens at garbage collection).  ``download=False`` drops the
+        device state instead of bringing it back into the Python objects first."""
         if self._dev is not None:
-            if self._residency == DEVICE and self._batch is None:
+            if download and self._residency == DEVICE and self._batch is None:
                 self._to_host(True)
             self._dev.close()
             self._dev = None

@@ -646,15 +646,22 @@ struct pcl_fast_args {
     T dt, A, n, c;
     pcl_u64 seed;
     pcl_u32 step;
+    // GEN variants only (stores that have been compacted or hold plain Objects): explicit photon ids and the kind
+    // bytes, dense arrays padded to whole 64-element groups; NULL = implicit ids / every particle is a photon
+    const pcl_i64 *ids;
+    const unsigned char *kind;
 };
 
 template <typename T, int VEC>
 struct pcl_fast_tile {
     T R[3][VEC], V[3][VEC], L4[VEC];
+    pcl_i64 ID[VEC];          // GEN only
+    unsigned char KD[VEC];    // GEN only
 };
 
-template <typename T, bool USE_E, int VEC>
-__device__ __forceinline__ void pcl_fast_load(const pcl_fast_args<T> &a, pcl_i64 q, pcl_fast_tile<T, VEC> &t) {
+// q = the lane's group in the tiled rows, qd = the same group in the dense id / kind arrays (GEN)
+template <typename T, bool USE_E, int VEC, bool GEN>
+__device__ __forceinline__ void pcl_fast_load(const pcl_fast_args<T> &a, pcl_i64 q, pcl_i64 qd, pcl_fast_tile<T, VEC> &t) {
     typedef pcl_vec<T, VEC> VV;
     VV::ld(a.r0, q, t.R[0]);
     VV::ld(a.r1, q, t.R[1]);
@@ -663,9 +670,16 @@ __device__ __forceinline__ void pcl_fast_load(const pcl_fast_args<T> &a, pcl_i64
     VV::ld(a.vi1, q, t.V[1]);
     VV::ld(a.vi2, q, t.V[2]);
     if constexpr (USE_E) VV::ld(a.lam4, q, t.L4);
+    if constexpr (GEN) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { // consecutive elements of whole (padded) groups: the compiler merges the loads
+            t.ID[e] = a.ids ? a.ids[qd * VEC + e] : (pcl_i64)0;
+            t.KD[e] = a.kind ? a.kind[qd * VEC + e] : (unsigned char)1;
+        }
+    }
 }
 
-template <typename T, bool USE_E, bool VAR_N, int VEC>
+template <typename T, bool USE_E, bool VAR_N, int VEC, bool GEN = false>
 __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
@@ -679,13 +693,19 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
     pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x;
     // register double buffer: the next trip's loads are in flight while this trip computes
     pcl_fast_tile<T, VEC> cur;
-    if (base < nq) pcl_fast_load<T, USE_E, VEC>(a, pcl_tq<VEC>(base + threadIdx.x < nq ? base + threadIdx.x : 0, a.ts), cur);
+    if (base < nq) {
+        const pcl_i64 q0 = base + threadIdx.x < nq ? base + threadIdx.x : 0;
+        pcl_fast_load<T, USE_E, VEC, GEN>(a, pcl_tq<VEC>(q0, a.ts), q0, cur);
+    }
     for (; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
         pcl_fast_tile<T, VEC> nxt;
         const pcl_i64 nb = base + stride;
-        if (nb < nq) pcl_fast_load<T, USE_E, VEC>(a, pcl_tq<VEC>(nb + threadIdx.x < nq ? nb + threadIdx.x : 0, a.ts), nxt);
+        if (nb < nq) {
+            const pcl_i64 q1 = nb + threadIdx.x < nq ? nb + threadIdx.x : 0;
+            pcl_fast_load<T, USE_E, VEC, GEN>(a, pcl_tq<VEC>(q1, a.ts), q1, nxt);
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const pcl_i64 i = q * VEC + e;
@@ -699,9 +719,14 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
             T pc = pcl_pcoll<T, false, VAR_N>(a.A, a.n, (T)0, a.c, d0, d1, d2, cur.R[0][e], cur.R[1][e], cur.R[2][e],
                                               a.E[pcl_tix(live ? i : 0, a.ts)]);
             if constexpr (USE_E) pc = R::mul(pc, cur.L4[e]);
-            const pcl_u64 id = (pcl_u64)(a.id_base + i);
+            pcl_u64 id = (pcl_u64)(a.id_base + i);
+            bool photon = true;
+            if constexpr (GEN) { // explicit ids after a compaction; plain Objects are moved but never scattered (light.py:283)
+                if (a.ids) id = (pcl_u64)cur.ID[e];
+                photon = cur.KD[e] != 0;
+            }
             const T rand = pcl_draw_rand<T>(id, a.step, k0, k1);
-            const bool hit = live && (pc >= rand);
+            const bool hit = live && photon && (pc >= rand);
             if (hit) {
                 T rtheta, rphi;
                 pcl_draw_angles<T>(id, a.step, k0, k1, rtheta, rphi);
@@ -926,6 +951,238 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Level 2, K whole passes of a loop whose body holds an isotropic-scatter phase and/or a delete phase --
+//   [Newton, ScatterIsotropic] | [Newton, ScatterDelete] | [Newton, ScatterIsotropic, Newton, ScatterDelete] (either order)
+// -- in ONE pass over the store and (with a delete phase) ONE compaction afterwards.  It is the general form of
+// pcl_multi_body: any store (explicit ids after earlier compactions, plain Objects mixed in), photons that are removed
+// stop where the reference's list.remove takes them out (physicl/__init__.py:455-459), and every phase tallies its
+// own measure row on the particles alive after it.  Per particle the operations are those of the single steps
+// (pcl_fast_body / k_newton_mask) in the same order with launch index step + phase number, so state, masks and rows
+// are bit-identical to running the passes one launch at a time (tests/test_gpu_mixed.py).
+// Geometry: one workgroup per 2048-particle tile, wave w owns rows 8w..8w+7 of 64 particles, two rows per trip
+// (lane == particle within a row, so a ballot IS the row's keep-mask in particle order).
+// cnt[(5 + n_planes) * phase + {0: alive after the phase, 1: hits | removed, 2..4: sign counts, 5..: plane crossings}].
+// ------------------------------------------------------------------------------------------------
+#define PCL_MIXED_MAXPH 2
+template <typename T>
+struct pcl_mixed_args {
+    T *r0, *r1, *r2;    // read + written
+    T *v0, *v1, *v2;    // read + written
+    T *vp0, *vp1, *vp2; // written: v before the LAST isotropic-scatter phase (dv = v - vp stays implicit)
+    const T *lam4;      // pow((h*c)/E, -4) per photon            (USE_E)
+    const T *E;         // only dereferenced if the expression names E[gid]
+    const pcl_i64 *ids;        // NULL: id = id_base + index
+    const unsigned char *kind; // NULL: every particle is a photon
+    pcl_u64 *masks;     // [tiles * 32] keep-masks, written when the loop has a delete phase
+    int *tile_keep;     // [tiles]
+    pcl_u64 *cnt;
+    pcl_i64 id_base, N;
+    pcl_i64 ts;
+    T dt, A, n, c;      // isotropic phase: kernel constants after the reference's swap (light.py:287)
+    T An_del;           // delete phase: A * n rounded once (light.py:243)
+    pcl_u64 seed;
+    pcl_u32 step;       // launch index of the first phase
+    int K;              // passes
+    int P;              // phases per pass (1..PCL_MIXED_MAXPH)
+    int phase_del[PCL_MIXED_MAXPH]; // 1: ScatterDeleteStep phase, 0: ScatterIsotropicStep phase
+    int has_delete;
+    int last_iso;       // index (0 .. K*P-1) of the last isotropic phase, -1 if the loop has none
+    int n_planes;
+    int plane_ax[PCL_MAXPL];
+    T plane_L[PCL_MAXPL];
+};
+
+template <typename T>
+struct pcl_mixed_queue {
+    pcl_u64 id[256 * 2]; // photon id of the queued hit
+    T out[4][256 * 2];   // the new velocity and its step length |v' * dt|
+};
+
+template <typename T, bool USE_E, bool VAR_N>
+__device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
+    typedef pcl_rt<T> R;
+    constexpr int NE = 2; // rows (particles per lane) per trip
+    __shared__ pcl_u32 s_cnt[(5 + PCL_MAXPL) * PCL_MULTI_MAX];
+    __shared__ pcl_mixed_queue<T> s_q;
+    __shared__ int s_keep[4];
+    const int nslots = 5 + a.n_planes;
+    const int n_ph = a.K * a.P;
+    for (int k = threadIdx.x; k < nslots * n_ph; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool lane0 = lane == 0;
+    const pcl_i64 tile = blockIdx.x;
+    const pcl_u32 qbase = (pcl_u32)wave * 64u * NE; // this wave's part of the hit queue
+    int kept = 0;
+    for (int trip = 0; trip < 4; ++trip) {
+        const int row0 = wave * 8 + trip * NE;
+        T Rr[3][NE], V[3][NE], L4[NE], Ev[NE], NM[NE];
+        pcl_u32 wodd0[NE], wodd1[NE];
+        pcl_u64 id[NE];
+        pcl_i64 ti[NE];
+        bool in[NE], photon[NE], alive[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
+            in[e] = i < a.N;
+            const pcl_i64 is = in[e] ? i : 0;
+            ti[e] = pcl_tix(is, a.ts);
+            Rr[0][e] = a.r0[ti[e]];
+            Rr[1][e] = a.r1[ti[e]];
+            Rr[2][e] = a.r2[ti[e]];
+            V[0][e] = a.v0[ti[e]];
+            V[1][e] = a.v1[ti[e]];
+            V[2][e] = a.v2[ti[e]];
+            L4[e] = (T)1;
+            if constexpr (USE_E) L4[e] = a.lam4[ti[e]];
+            Ev[e] = a.E[ti[e]];
+            id[e] = (pcl_u64)(a.ids ? a.ids[is] : a.id_base + i);
+            photon[e] = in[e] && (a.kind ? (a.kind[is] != 0) : true);
+            alive[e] = in[e];
+            wodd0[e] = wodd1[e] = 0u;
+            // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
+            NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
+        }
+        for (int ph = 0; ph < n_ph; ++ph) {
+            if (!(__ballot(alive[0]) | __ballot(alive[1]))) break; // nobody of these rows is left: their rows stay 0
+            const pcl_u32 st = a.step + (pcl_u32)ph;
+            const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
+            pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body: keeps the round keys off the VGPR spills
+            asm volatile("" : "+s"(kk0), "+s"(kk1));
+            const bool new_block = (st & 1u) == 0u || ph == 0;
+            T d[3][NE], rand[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
+                d[0][e] = R::mul(V[0][e], a.dt);
+                d[1][e] = R::mul(V[1][e], a.dt);
+                d[2][e] = R::mul(V[2][e], a.dt);
+                Rr[0][e] = R::add(Rr[0][e], d[0][e]);
+                Rr[1][e] = R::add(Rr[1][e], d[1][e]);
+                Rr[2][e] = R::add(Rr[2][e], d[2][e]);
+                if (new_block) { // decision block of the launch pair (st & ~1, st | 1): computed once for both
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
+                    rand[e] = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    wodd0[e] = w.z;
+                    wodd1[e] = w.w;
+                } else {
+                    rand[e] = R::uniform(wodd0[e], wodd1[e]);
+                }
+            }
+            pcl_u32 w_evt = 0; // hits (isotropic phase) or removals (delete phase) of this wave
+            if (is_del) {
+                // ScatterDeleteStep: flag = (A*n*norm >= rand), flagged photons leave the list      light.py:239-260
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const T pc = R::mul(a.An_del, NM[e]);
+                    const bool gone = alive[e] && photon[e] && (pc >= rand[e]);
+                    w_evt += (pcl_u32)__popcll(__ballot(gone));
+                    alive[e] = alive[e] && !gone;
+                }
+            } else {
+                // ScatterIsotropicStep: decision in place, the hits densely through the wave's queue   light.py:303-331
+                bool hit[NE];
+                pcl_u32 slot[NE];
+                pcl_u32 wbase = qbase;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[e], d[0][e], d[1][e], d[2][e], Rr[0][e],
+                                                           Rr[1][e], Rr[2][e], Ev[e]);
+                    if constexpr (USE_E) pc = R::mul(pc, L4[e]);
+                    hit[e] = alive[e] && photon[e] && (pc >= rand[e]);
+                    const pcl_u64 b = __ballot(hit[e]);
+                    slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u));
+                    wbase += (pcl_u32)__popcll(b);
+                    if (hit[e]) s_q.id[slot[e]] = id[e];
+                }
+                w_evt = wbase - qbase;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // wave-private queue: ordering only, no barrier
+                __builtin_amdgcn_wave_barrier();
+                for (pcl_u32 j = qbase + (pcl_u32)lane; j < wbase; j += 64) {
+                    T rtheta, rphi, o0, o1, o2;
+                    pcl_draw_angles<T>(s_q.id[j], st, kk0, kk1, rtheta, rphi);
+                    pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
+                    s_q.out[0][j] = o0;
+                    s_q.out[1][j] = o1;
+                    s_q.out[2][j] = o2;
+                    s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (ph == a.last_iso) { // the velocity before the LAST scatter phase is what dv = v - v_prev needs
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        if (in[e]) {
+                            a.vp0[ti[e]] = V[0][e];
+                            a.vp1[ti[e]] = V[1][e];
+                            a.vp2[ti[e]] = V[2][e];
+                        }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; ++e)
+                    if (hit[e]) {
+                        V[0][e] = s_q.out[0][slot[e]];
+                        V[1][e] = s_q.out[1][slot[e]];
+                        V[2][e] = s_q.out[2][slot[e]];
+                        NM[e] = s_q.out[3][slot[e]];
+                    }
+            }
+            // this phase's measure row, on the particles alive after it            light.py:385-399, 414-431
+            pcl_u32 w_n = 0, w_sx = 0, w_sy = 0, w_sz = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                w_n += (pcl_u32)__popcll(__ballot(alive[e]));
+                w_sx += (pcl_u32)__popcll(__ballot(alive[e] && V[0][e] > (T)0));
+                w_sy += (pcl_u32)__popcll(__ballot(alive[e] && V[1][e] > (T)0));
+                w_sz += (pcl_u32)__popcll(__ballot(alive[e] && V[2][e] > (T)0));
+            }
+            pcl_u32 *c = &s_cnt[nslots * ph];
+            for (int p = 0; p < a.n_planes; ++p) {
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                pcl_u32 nc = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
+                    const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
+                    nc += (pcl_u32)__popcll(__ballot(alive[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                }
+                if (lane0 && nc) atomicAdd(&c[5 + p], nc);
+            }
+            if (lane0) {
+                if (w_n) atomicAdd(&c[0], w_n);
+                if (w_evt) atomicAdd(&c[1], w_evt);
+                if (w_sx) atomicAdd(&c[2], w_sx);
+                if (w_sy) atomicAdd(&c[3], w_sy);
+                if (w_sz) atomicAdd(&c[4], w_sz);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if (alive[e]) {
+                a.r0[ti[e]] = Rr[0][e];
+                a.r1[ti[e]] = Rr[1][e];
+                a.r2[ti[e]] = Rr[2][e];
+                a.v0[ti[e]] = V[0][e];
+                a.v1[ti[e]] = V[1][e];
+                a.v2[ti[e]] = V[2][e];
+            }
+            if (a.has_delete) {
+                const pcl_u64 m = __ballot(alive[e]);
+                if (lane0) a.masks[tile * 32 + row0 + e] = m;
+                kept += (int)__popcll(m);
+            }
+        }
+    }
+    if (a.has_delete && lane0) s_keep[wave] = kept;
+    __syncthreads();
+    if (a.has_delete && threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    for (int k = threadIdx.x; k < nslots * n_ph; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
+}
+
 #ifdef PCL_RTC
 // hipRTC translation unit: one expression; both wavelength variants of every kernel, fp64 and fp32.
 #define PCL_RTC_KERNEL(name, argtype, call) \
@@ -944,6 +1201,14 @@ PCL_RTC_KERNEL(pcl_rtc_fused_f_e0, pcl_fused_args<float>, (pcl_fused_body<float,
 PCL_RTC_KERNEL(pcl_rtc_fused_f_e1, pcl_fused_args<float>, (pcl_fused_body<float, true, true>))
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e0, pcl_fast_args<float>, (pcl_fast_body<float, false, true, 4>))
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e1, pcl_fast_args<float>, (pcl_fast_body<float, true, true, 4>))
+PCL_RTC_KERNEL(pcl_rtc_fastg_e0, pcl_fast_args<double>, (pcl_fast_body<double, false, true, 2, true>))
+PCL_RTC_KERNEL(pcl_rtc_fastg_e1, pcl_fast_args<double>, (pcl_fast_body<double, true, true, 2, true>))
+PCL_RTC_KERNEL(pcl_rtc_fastg_f_e0, pcl_fast_args<float>, (pcl_fast_body<float, false, true, 4, true>))
+PCL_RTC_KERNEL(pcl_rtc_fastg_f_e1, pcl_fast_args<float>, (pcl_fast_body<float, true, true, 4, true>))
+PCL_RTC_KERNEL(pcl_rtc_mixed_e0, pcl_mixed_args<double>, (pcl_mixed_body<double, false, true>))
+PCL_RTC_KERNEL(pcl_rtc_mixed_e1, pcl_mixed_args<double>, (pcl_mixed_body<double, true, true>))
+PCL_RTC_KERNEL(pcl_rtc_mixed_f_e0, pcl_mixed_args<float>, (pcl_mixed_body<float, false, true>))
+PCL_RTC_KERNEL(pcl_rtc_mixed_f_e1, pcl_mixed_args<float>, (pcl_mixed_body<float, true, true>))
 #ifndef PCL_MULTI_ATTR /* timing experiments: e.g. -DPCL_MULTI_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) */
 #define PCL_MULTI_ATTR
 #endif

@@ -84,7 +84,7 @@ constexpr int kBlock = 256;           // 4 wave64 per workgroup
 constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particles
 constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
-constexpr int kMultiSlots = PCL_MULTI_MAX * (4 + PCL_MAX_PLANES); // per-step counter rows of a K-step pass
+constexpr int kMultiSlots = PCL_MULTI_MAX * (5 + PCL_MAX_PLANES); // per-step counter rows of a K-step pass
 static_assert(PCL_MAXPL == PCL_MAX_PLANES, "device header and C ABI disagree on the number of measure planes");
 static_assert(PCL_MULTI_MAX <= 64, "per-step tallies are kept one per lane of a wave64");
 constexpr int kRows = PCL_NFIELDS + 4;       // rows per tile of the store slab: 13 fields + vprev0..2 + lam4
@@ -138,15 +138,16 @@ __global__ void __launch_bounds__(kBlock) k_newton(newton_args<T> a) {
     }
 }
 
-// ---- materialise what a lazy fused step left implicit: dr = v_in*dt, dv = v_out - v_in -----------
-// (v_out - v_in is +0 for a particle that was not scattered: exactly the reference's dv = 0)
+// ---- materialise what lazy steps left implicit: dr = v_move*dt, dv = v - v_prev ---------------------
+// v_move = the velocity the LAST Newton move used (the vprev rows if the last step was a lazy Newton + scatter pass,
+// else the current v rows); v - v_prev is +0 for a photon that was not scattered: exactly the reference's dv = 0.
 template <typename T>
 struct materialize_args {
-    const T *vin[3], *vout[3];
+    const T *vmove[3], *vprev[3], *v[3];
     T *dr[3], *dv[3];
     const unsigned char *kind;
     T dt;
-    int do_dv;
+    int do_dr, do_dv;
     int64_t N;
     int64_t ts;
 };
@@ -160,9 +161,8 @@ __global__ void __launch_bounds__(kBlock) k_materialize(materialize_args<T> a) {
         const int64_t ti = pcl_tix(i, a.ts);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const T vi = a.vin[k][ti];
-            a.dr[k][ti] = R::mul(vi, a.dt);
-            if (a.do_dv && photon) a.dv[k][ti] = R::sub(a.vout[k][ti], vi);
+            if (a.do_dr) a.dr[k][ti] = R::mul(a.vmove[k][ti], a.dt);
+            if (a.do_dv && photon) a.dv[k][ti] = R::sub(a.v[k][ti], a.vprev[k][ti]);
         }
     }
 }
@@ -200,6 +200,14 @@ __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
 template <typename T, bool USE_E>
 __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
     pcl_multi_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
+}
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
+    pcl_fast_body<T, USE_E, false, pcl_rt<T>::VEC, true>(a);
+}
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
+    pcl_mixed_body<T, USE_E, false>(a);
 }
 
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
@@ -892,6 +900,8 @@ struct rtc_entry {
     hipFunction_t fused[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t fast[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
 };
 
 } // namespace
@@ -902,6 +912,7 @@ struct pcl_ctx {
     bool own_stream = false;
     hipDeviceProp_t prop;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_count = nullptr; // recorded behind the D2H copy of a compaction's survivor count (scan_tiles)
     int grid_cap = 2048; // workgroups for grid-stride kernels: 8 per CU
 
     // particle store.  Every array holds elements of the store's dtype (8 or 4 bytes).
@@ -921,7 +932,9 @@ struct pcl_ctx {
     unsigned char *kind = nullptr, *kind_alt = nullptr;
     // lazy fused steps: second half of the v double buffer + what is still implicit
     void *vprev[3] = {nullptr, nullptr, nullptr};
-    bool lazy_dr = false; // dr not materialised: dr = (lazy_dv ? vprev : v) * lazy_dt
+    void *vprev_alt[3] = {nullptr, nullptr, nullptr}; // the same rows of the compaction slab
+    bool lazy_dr = false; // dr not materialised: dr = (lazy_dr_vprev ? vprev : v) * lazy_dt
+    bool lazy_dr_vprev = false; // the last Newton move used the velocities now in the vprev rows (a scatter followed it)
     bool lazy_dv = false; // dv not materialised: dv = v - vprev (photons)
     double lazy_dt = 0.0;
     // cache of pow((h*c)/E, -4) per photon for the fast fused path
@@ -981,7 +994,10 @@ void refresh_rows(pcl_ctx *c) {
         c->field[f] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[f] : nullptr;
         c->field_alt[f] = c->slab_alt ? static_cast<char *>(c->slab_alt) + rowb * c->row[f] : nullptr;
     }
-    for (int k = 0; k < 3; ++k) c->vprev[k] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[kRowVprev + k] : nullptr;
+    for (int k = 0; k < 3; ++k) {
+        c->vprev[k] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[kRowVprev + k] : nullptr;
+        c->vprev_alt[k] = c->slab_alt ? static_cast<char *>(c->slab_alt) + rowb * c->row[kRowVprev + k] : nullptr;
+    }
     c->lam4 = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[kRowLam4] : nullptr;
 }
 
@@ -1095,13 +1111,15 @@ int materialize_t(pcl_ctx *ctx) {
     if (N > 0) {
         materialize_args<T> a{};
         for (int k = 0; k < 3; ++k) {
-            a.vin[k] = static_cast<const T *>(ctx->lazy_dv ? ctx->vprev[k] : ctx->field[PCL_V0 + k]);
-            a.vout[k] = F<T>(ctx, PCL_V0 + k);
+            a.vmove[k] = static_cast<const T *>(ctx->lazy_dr_vprev ? ctx->vprev[k] : ctx->field[PCL_V0 + k]);
+            a.vprev[k] = static_cast<const T *>(ctx->vprev[k]);
+            a.v[k] = F<T>(ctx, PCL_V0 + k);
             a.dr[k] = F<T>(ctx, PCL_DR0 + k);
             a.dv[k] = F<T>(ctx, PCL_DV0 + k);
         }
         a.kind = ctx->kind;
         a.dt = (T)ctx->lazy_dt;
+        a.do_dr = ctx->lazy_dr ? 1 : 0;
         a.do_dv = ctx->lazy_dv ? 1 : 0;
         a.N = N;
         a.ts = tile_stride(ctx);
@@ -1114,7 +1132,7 @@ int materialize_t(pcl_ctx *ctx) {
 int materialize(pcl_ctx *ctx) {
     if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
     PCL_TRY(PCL_DISPATCH(ctx, materialize_t<double>(ctx), materialize_t<float>(ctx)));
-    ctx->lazy_dr = ctx->lazy_dv = false;
+    ctx->lazy_dr = ctx->lazy_dv = ctx->lazy_dr_vprev = false;
     return PCL_OK;
 }
 
@@ -1240,8 +1258,9 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
         *out = &it->second;
         return PCL_OK;
     }
-    const char *extra_env = getenv("PCL_RTC_EXTRA");
-    const std::string code_key = std::string(ctx->prop.gcnArchName) + "|" + (extra_env ? extra_env : "") + "|" + expr;
+    const char *extra_env = getenv("PCL_RTC_EXTRA"), *define_env = getenv("PCL_RTC_DEFINE");
+    const std::string code_key = std::string(ctx->prop.gcnArchName) + "|" + (extra_env ? extra_env : "") + "|" +
+                                 (define_env ? define_env : "") + "|" + expr;
     {
         std::lock_guard<std::mutex> lock(g_code_mutex);
         auto ci = g_code_cache.find(code_key);
@@ -1329,6 +1348,10 @@ int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &cod
             PCL_HIP(hipModuleGetFunction(&ent.fast[d][e], ent.module, nm));
             snprintf(nm, sizeof nm, "pcl_rtc_multi_%se%d", dt_tag[d], e);
             PCL_HIP(hipModuleGetFunction(&ent.multi[d][e], ent.module, nm));
+            snprintf(nm, sizeof nm, "pcl_rtc_fastg_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.fastg[d][e], ent.module, nm));
+            snprintf(nm, sizeof nm, "pcl_rtc_mixed_%se%d", dt_tag[d], e);
+            PCL_HIP(hipModuleGetFunction(&ent.mixed[d][e], ent.module, nm));
         }
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
@@ -1371,7 +1394,32 @@ int scan_tiles(pcl_ctx *ctx, int64_t n) {
     PCL_TRY(launch_check("k_tile_scan"));
     PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 1, ctx->d_cnt + kCounterSlots - 1, sizeof(uint64_t),
                            hipMemcpyDeviceToHost, ctx->stream));
+    // the host needs the survivor count (next launch geometry, exit tests), not the end of the compaction that follows:
+    // it waits for this event and prepares the next step while pass 3 is still moving the survivors
+    PCL_HIP(hipEventRecord(ctx->ev_count, ctx->stream));
     return PCL_OK;
+}
+
+// survivor count of the scan most recently enqueued by scan_tiles
+int wait_count(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
+    PCL_HIP(hipEventSynchronize(ctx->ev_count));
+    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (alive < 0 || alive > before)
+        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)before);
+    *alive_out = alive;
+    return PCL_OK;
+}
+
+// the store after a compaction into the other slab
+void adopt_compacted(pcl_ctx *ctx, int64_t alive, int64_t last_delete_n) {
+    std::swap(ctx->slab, ctx->slab_alt);
+    refresh_rows(ctx);
+    std::swap(ctx->ids, ctx->ids_alt);
+    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
+    ctx->ids_iota = false;
+    ctx->count = alive;
+    ctx->last_delete_n = last_delete_n;
+    ctx->lam4_valid = false;
 }
 
 // ---- typed implementations of the Level-2 steps ------------------------------------------------------
@@ -1494,16 +1542,28 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
     f.seed = seed;
     f.step = step;
+    // a store that has been compacted (explicit ids) or holds plain Objects takes the GEN variant: same arithmetic,
+    // two more streams (8 B of id, 1 B of kind per particle)
+    f.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    f.kind = ctx->kind;
+    const bool gen = f.ids || f.kind;
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_FUSED);
     if (var_n) {
-        PCL_TRY(launch_module(ctx, ent->fast[d][use_e ? 1 : 0], grid, f, "step_fused fast path (hipRTC)"));
+        PCL_TRY(launch_module(ctx, (gen ? ent->fastg : ent->fast)[d][use_e ? 1 : 0], grid, f, "step_fused fast path (hipRTC)"));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL((k_fast<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-        else
-            hipLaunchKernelGGL((k_fast<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        if (gen) {
+            if (use_e)
+                hipLaunchKernelGGL((k_fastg<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+            else
+                hipLaunchKernelGGL((k_fastg<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        } else {
+            if (use_e)
+                hipLaunchKernelGGL((k_fast<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+            else
+                hipLaunchKernelGGL((k_fast<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        }
         PCL_TRY(launch_check("k_fast"));
     }
     prof_end(ctx, ps);
@@ -1656,9 +1716,68 @@ int counters_t(pcl_ctx *ctx, const double *planes_host, int n_planes) {
     return launch_check("k_counters");
 }
 
+// Fields a compaction has to move.  r, v and E always; dr unless it is implicit after the call (dr = v*dt); dv -- or,
+// while dv is implicit (dv = v - vprev, all-photon stores), the vprev rows in its place.  Order: r v [dr] dv|vprev E
+// (k_compact_count reads r, v and dr at fixed positions for the measure counters).
+int compact_fields(pcl_ctx *ctx, compact_args &ca, bool move_dr, bool dv_implicit) {
+    int nf = 0;
+    for (int f = PCL_R0; f <= PCL_V2; ++f) {
+        ca.src[nf] = ctx->field[f];
+        ca.dst[nf++] = ctx->field_alt[f];
+    }
+    if (move_dr)
+        for (int f = PCL_DR0; f <= PCL_DR2; ++f) {
+            ca.src[nf] = ctx->field[f];
+            ca.dst[nf++] = ctx->field_alt[f];
+        }
+    for (int k = 0; k < 3; ++k) {
+        ca.src[nf] = dv_implicit ? ctx->vprev[k] : ctx->field[PCL_DV0 + k];
+        ca.dst[nf++] = dv_implicit ? ctx->vprev_alt[k] : ctx->field_alt[PCL_DV0 + k];
+    }
+    ca.src[nf] = ctx->field[PCL_E];
+    ca.dst[nf++] = ctx->field_alt[PCL_E];
+    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
+    ca.ids_dst = ctx->ids_alt;
+    ca.ksrc = ctx->kind;
+    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
+    ca.masks = ctx->masks;
+    ca.tile_off = ctx->tile_off;
+    ca.id_base = ctx->id_base;
+    ca.N = ctx->count;
+    ca.ts = tile_stride(ctx);
+    return nf;
+}
+
 template <typename T>
-int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int rng_mode, uint64_t seed, uint32_t step,
-                   const double *planes_host, int n_planes) {
+void plane_table(const double *planes_host, int n_planes, int *ax_out, T *L_out) {
+    for (int p = 0; p < (n_planes > 0 ? n_planes : 0); ++p) {
+        const double *loc = planes_host + 3 * p;
+        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
+        ax_out[p] = ax;
+        L_out[p] = (T)loc[ax];
+    }
+}
+
+// pass 3 of a delete pipeline: stable compaction of the store into the other slab (+ the measure counters when
+// cc.n_planes >= 0); has_dr says whether the dr rows travel (13 fields) or stay implicit (10)
+template <typename T>
+int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_counter_args<T> &cc) {
+    const int tiles = (int)div_up(ctx->count, kTile);
+    compact_args ca{};
+    compact_fields(ctx, ca, has_dr, dv_implicit);
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+    const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
+    if (has_dr)
+        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    else
+        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    prof_end(ctx, pc);
+    return launch_check("k_compact_count");
+}
+
+template <typename T>
+int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool dv_implicit, int rng_mode, uint64_t seed,
+                   uint32_t step, const double *planes_host, int n_planes) {
     const int64_t N = ctx->count;
     const int tiles = (int)div_up(N, kTile);
     newtonmask_args<T> m{};
@@ -1686,46 +1805,17 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int r
     prof_end(ctx, ps);
     PCL_TRY(launch_check("k_newton_mask"));
     PCL_TRY(scan_tiles(ctx, N));
-    compact_args ca{};
-    int nf = 0;
-    for (int f = 0; f < PCL_NFIELDS; ++f) {
-        if (lazy && f >= PCL_DR0 && f <= PCL_DR2) continue; // implicit: dr = v*dt, nothing to move
-        ca.src[nf] = ctx->field[f];
-        ca.dst[nf] = ctx->field_alt[f];
-        ++nf;
-    }
-    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
-    ca.ids_dst = ctx->ids_alt;
-    ca.ksrc = ctx->kind;
-    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
-    ca.masks = ctx->masks;
-    ca.tile_off = ctx->tile_off;
-    ca.id_base = ctx->id_base;
-    ca.N = N;
-    ca.ts = tile_stride(ctx);
     compact_counter_args<T> cc{};
     cc.cnt = ctx->d_cnt;
     cc.n_planes = n_planes;
     cc.dt = (T)dt;
-    for (int p = 0; p < (n_planes > 0 ? n_planes : 0); ++p) {
-        const double *loc = planes_host + 3 * p;
-        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
-        cc.plane_ax[p] = ax;
-        cc.plane_L[p] = (T)loc[ax];
-    }
-    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
-    const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
-    if (lazy)
-        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    else
-        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    prof_end(ctx, pc);
-    return launch_check("k_compact_count");
+    plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
+    return launch_compact_count<T>(ctx, !lazy, dv_implicit, cc);
 }
 
 template <typename T>
-int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step,
-                         const double *planes_host, int n_planes) {
+int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool dv_implicit, uint64_t seed,
+                         uint32_t step, const double *planes_host, int n_planes) {
     const int64_t N = ctx->count;
     const int tiles = (int)div_up(N, kTile);
     newtonmask_multi_args<T> m{};
@@ -1747,43 +1837,76 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     m.step = step;
     m.K = k_steps;
     m.n_planes = n_planes;
-    for (int p = 0; p < (n_planes > 0 ? n_planes : 0); ++p) {
-        const double *loc = planes_host + 3 * p;
-        const int ax = !std::isnan(loc[0]) ? 0 : (!std::isnan(loc[1]) ? 1 : 2); // light.py:385-396
-        m.plane_ax[p] = ax;
-        m.plane_L[p] = (T)loc[ax];
-    }
+    plane_table<T>(planes_host, n_planes, m.plane_ax, m.plane_L);
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);
     PCL_TRY(launch_check("k_newton_mask_multi"));
     PCL_TRY(scan_tiles(ctx, N));
-    compact_args ca{};
-    int nf = 0;
-    for (int f = 0; f < PCL_NFIELDS; ++f) {
-        if (f >= PCL_DR0 && f <= PCL_DR2) continue; // implicit: dr = v*dt, nothing to move
-        ca.src[nf] = ctx->field[f];
-        ca.dst[nf] = ctx->field_alt[f];
-        ++nf;
-    }
-    ca.ids_src = ctx->ids_iota ? nullptr : ctx->ids;
-    ca.ids_dst = ctx->ids_alt;
-    ca.ksrc = ctx->kind;
-    ca.kdst = ctx->kind ? ctx->kind_alt : nullptr;
-    ca.masks = ctx->masks;
-    ca.tile_off = ctx->tile_off;
-    ca.id_base = ctx->id_base;
-    ca.N = N;
-    ca.ts = tile_stride(ctx);
     compact_counter_args<T> cc{};
     cc.cnt = ctx->d_cnt;
     cc.n_planes = -1; // the counters were taken step by step in pass 1
     cc.dt = (T)dt;
-    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
-    const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
-    hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    prof_end(ctx, pc);
-    return launch_check("k_compact_count");
+    return launch_compact_count<T>(ctx, false, dv_implicit, cc);
+}
+
+// K passes of a loop with an isotropic-scatter phase and/or a delete phase (pcl_mixed_body): the pass itself.
+template <typename T>
+int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int *phase_del, double A, double n, bool use_e,
+                 bool var_n, rtc_entry *ent, double c, double h, double A_del, double n_del, uint64_t seed, uint32_t step,
+                 const double *planes_host, int n_planes, bool has_delete, int last_iso) {
+    const int64_t N = ctx->count;
+    const int tiles = (int)div_up(N, kTile);
+    if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
+    pcl_mixed_args<T> f{};
+    f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
+    f.v0 = F<T>(ctx, PCL_V0); f.v1 = F<T>(ctx, PCL_V1); f.v2 = F<T>(ctx, PCL_V2);
+    f.vp0 = static_cast<T *>(ctx->vprev[0]); f.vp1 = static_cast<T *>(ctx->vprev[1]); f.vp2 = static_cast<T *>(ctx->vprev[2]);
+    f.lam4 = static_cast<const T *>(ctx->lam4);
+    f.E = F<T>(ctx, PCL_E);
+    f.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    f.kind = ctx->kind;
+    f.masks = reinterpret_cast<pcl_u64 *>(ctx->masks);
+    f.tile_keep = ctx->tile_keep;
+    f.cnt = reinterpret_cast<pcl_u64 *>(ctx->d_multi);
+    f.id_base = ctx->id_base;
+    f.N = N;
+    f.ts = tile_stride(ctx);
+    f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
+    f.An_del = (T)A_del * (T)n_del;
+    f.seed = seed;
+    f.step = step;
+    f.K = k_passes;
+    f.P = n_phases;
+    for (int j = 0; j < PCL_MIXED_MAXPH; ++j) f.phase_del[j] = j < n_phases ? phase_del[j] : 0;
+    f.has_delete = has_delete ? 1 : 0;
+    f.last_iso = last_iso;
+    f.n_planes = n_planes > 0 ? n_planes : 0;
+    plane_table<T>(planes_host, n_planes, f.plane_ax, f.plane_L);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    const int ps = prof_begin(ctx, PCL_PROF_MULTI);
+    if (var_n) {
+        PCL_TRY(launch_module(ctx, ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
+    } else {
+        if (use_e)
+            hipLaunchKernelGGL((k_mixed<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
+        else
+            hipLaunchKernelGGL((k_mixed<T, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
+        PCL_TRY(launch_check("k_mixed"));
+    }
+    prof_end(ctx, ps);
+    return PCL_OK;
+}
+
+// scan + stable compaction after a pass that left keep-masks (counters off: the pass tallied them)
+template <typename T>
+int compact_after_pass_t(pcl_ctx *ctx, double dt, bool has_dr, bool dv_implicit) {
+    PCL_TRY(scan_tiles(ctx, ctx->count));
+    compact_counter_args<T> cc{};
+    cc.cnt = ctx->d_cnt;
+    cc.n_planes = -1;
+    cc.dt = (T)dt;
+    return launch_compact_count<T>(ctx, has_dr, dv_implicit, cc);
 }
 
 template <typename T>
@@ -1872,6 +1995,7 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&c->d_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess) {
         pcl_ctx_destroy(c);
@@ -1919,6 +2043,7 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
     }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_count) (void)hipEventDestroy(ctx->ev_count);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCL_OK;
@@ -1942,6 +2067,12 @@ int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_byt
     if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
     if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
     if (wavefront) *wavefront = ctx->prop.warpSize;
+    return PCL_OK;
+}
+
+int pcl_ctx_device_pci(pcl_ctx *ctx, char *pci, int pci_len) {
+    if (!ctx || !pci || pci_len < 16) return fail(PCL_ERR_ARG, "pci buffer must hold at least 16 bytes");
+    PCL_HIP(hipDeviceGetPCIBusId(pci, pci_len, ctx->device));
     return PCL_OK;
 }
 
@@ -2274,6 +2405,11 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
     ctx->lam4_valid = false;
+    // a new population: every particle is a photon again until pcl_store_upload_kind says otherwise (a kind array left
+    // over from an earlier, mixed upload would silently switch the light steps off for whoever sits at those indices)
+    if (ctx->kind || ctx->kind_alt) PCL_HIP(hipStreamSynchronize(ctx->stream));
+    dev_free(ctx->kind);
+    dev_free(ctx->kind_alt);
     return PCL_OK;
 }
 
@@ -2442,9 +2578,9 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
         return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool lazy = flags & PCL_FUSED_LAZY;
     if (lazy) {
+        // a Newton-only pass keeps the dv of a still-implicit scatter step implicit (dv = v - vprev): only the source of
+        // dr changes, to the current v rows
         PCL_TRY(need_store_raw(ctx));
-        // a Newton-only pass must not lose the dv of a still-implicit scatter step
-        if (!do_scatter && ctx->lazy_dv) PCL_TRY(materialize(ctx));
     } else {
         PCL_TRY(need_store(ctx));
     }
@@ -2482,9 +2618,9 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     ctx->hits_on_host = false;
     ctx->last_async_bank = bank;
     static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
-    const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && !ctx->kind && ctx->ids_iota && n_planes <= 0 && !no_fast;
+    const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && n_planes <= 0 && !no_fast;
     if (fast) {
-        // all photons, implicit ids, device RNG, implicit dr/dv, sign counters only
+        // device RNG, implicit dr/dv, sign counters only (any store: explicit ids / plain Objects take k_fastg)
         PCL_TRY(PCL_DISPATCH(ctx, step_fast_t<double>(ctx, dt, A, n, use_e, var_n, ent, c, h, seed, step),
                              step_fast_t<float>(ctx, dt, A, n, use_e, var_n, ent, c, h, seed, step)));
     } else {
@@ -2499,6 +2635,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             ctx->lazy_dv = true;
         }
         ctx->lazy_dr = true;
+        ctx->lazy_dr_vprev = do_scatter != 0; // the move used the velocities that are now in the vprev rows
         ctx->lazy_dt = dt;
     }
     ctx->cnt_target = ctx->d_cnt;
@@ -2557,6 +2694,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
                          step_multi_t<float>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np)));
     ctx->lazy_dv = true; // vprev rows = v before the last step
     ctx->lazy_dr = true;
+    ctx->lazy_dr_vprev = true;
     ctx->lazy_dt = dt;
     // pcl_store_last_scatter_hits() reports the last of the K steps
     PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + nslots * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice,
@@ -2664,10 +2802,12 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     if (flags & ~PCL_FUSED_LAZY) return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool lazy = flags & PCL_FUSED_LAZY;
     PCL_TRY(need_store_raw(ctx));
-    // a still-implicit dv (lazy scatter step) has to become real before the state is moved; an implicit dr is
-    // simply superseded by this step's Newton move
-    if (ctx->lazy_dv) PCL_TRY(materialize(ctx));
-    ctx->lazy_dr = false;
+    // A still-implicit dv (lazy scatter step): an all-photon store keeps it implicit -- the vprev rows travel through the
+    // compaction in place of the dv rows -- anything else makes it real before the state is moved.  An implicit dr is
+    // simply superseded by this step's Newton move.
+    const bool dv_implicit = lazy && ctx->lazy_dv && !ctx->kind;
+    if (ctx->lazy_dv && !dv_implicit) PCL_TRY(materialize(ctx));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false;
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
@@ -2681,28 +2821,24 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
-    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, rng_mode, seed, step, planes_host, n_planes),
-                         fused_delete_t<float>(ctx, dt, A, n, lazy, rng_mode, seed, step, planes_host, n_planes)));
-    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
-    if (alive < 0 || alive > N)
-        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
-    std::swap(ctx->slab, ctx->slab_alt); // (lazy: the dr rows of the new slab are stale -- dr is implicit anyway)
-    refresh_rows(ctx);
-    std::swap(ctx->ids, ctx->ids_alt);
-    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
-    ctx->ids_iota = false;
-    ctx->count = alive;
-    ctx->last_delete_n = N;
-    ctx->lam4_valid = false;
+    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
+                         fused_delete_t<float>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
+    int64_t alive = 0;
+    if (n_planes >= 0 && out_host) {
+        // the measure counters come out of pass 3 itself: wait for it
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    PCL_TRY(wait_count(ctx, N, &alive)); // the count alone is ready before pass 3 has finished
+    adopt_compacted(ctx, alive, N);      // (lazy: the dr rows of the new slab are stale -- dr is implicit anyway)
     if (lazy) {
         ctx->lazy_dr = true; // dr = v*dt with the (unchanged) velocities of the survivors
         ctx->lazy_dt = dt;
     }
     if (out_host) {
         out_host[0] = alive;
-        for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+        if (n_planes >= 0)
+            for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
         out_host[4 + np] = N - alive;
     }
     return PCL_OK;
@@ -2715,8 +2851,9 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
-    if (ctx->lazy_dv) PCL_TRY(materialize(ctx)); // a pending implicit dv has to become real before the state is moved
-    ctx->lazy_dr = false;                          // an implicit dr is superseded by these steps' own moves
+    const bool dv_implicit = ctx->lazy_dv && !ctx->kind;    // see pcl_step_fused_delete
+    if (ctx->lazy_dv && !dv_implicit) PCL_TRY(materialize(ctx));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false;               // an implicit dr is superseded by these steps' own moves
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;
     if (out_host)
@@ -2725,23 +2862,20 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)k_steps * nslots * sizeof(uint64_t), ctx->stream));
-    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, seed, step0, planes_host, n_planes),
-                         fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, seed, step0, planes_host, n_planes)));
+    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, dv_implicit, seed, step0, planes_host, n_planes),
+                         fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, dv_implicit, seed, step0, planes_host, n_planes)));
+    // the per-step rows were complete when pass 1 ended: their copy was enqueued behind the compaction only to keep
+    // one wait; the count event fires before pass 3
     PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)k_steps * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
     PCL_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
-    if (alive < 0 || alive > N || alive != (int64_t)ctx->h_multi[(k_steps - 1) * nslots])
-        return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
-    std::swap(ctx->slab, ctx->slab_alt);
-    refresh_rows(ctx);
-    std::swap(ctx->ids, ctx->ids_alt);
-    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
-    ctx->ids_iota = false;
-    ctx->count = alive;
-    ctx->last_delete_n = -1; // the masks describe K steps at once: no per-step flag array to hand out
-    ctx->lam4_valid = false;
-    ctx->lazy_dr = true;     // dr = v*dt with the (unchanged) velocities of the survivors
+    int64_t alive = 0;
+    PCL_TRY(wait_count(ctx, N, &alive));
+    if (alive != (int64_t)ctx->h_multi[(k_steps - 1) * nslots])
+        return fail(PCL_ERR_HIP, "compaction kept %lld particles, the last step counted %lld", (long long)alive,
+                    (long long)ctx->h_multi[(k_steps - 1) * nslots]);
+    adopt_compacted(ctx, alive, -1); // the masks describe K steps at once: no per-step flag array to hand out
+    ctx->lazy_dr = true;             // dr = v*dt with the (unchanged) velocities of the survivors
     ctx->lazy_dt = dt;
     if (out_host) {
         int64_t before = N;
@@ -2754,6 +2888,97 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
             before = (int64_t)c[0];
         }
     }
+    return PCL_OK;
+}
+
+int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int *phase_kinds_host, double A, double n,
+                         int flags, double c, double h, const char *n_expr, double A_del, double n_del, uint64_t seed,
+                         uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host) {
+    PCL_TRY(need_store_raw(ctx));
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (n_phases < 1 || n_phases > PCL_MIXED_MAXPH || !phase_kinds_host)
+        return fail(PCL_ERR_ARG, "n_phases outside [1, %d]", PCL_MIXED_MAXPH);
+    if (k_passes < 1 || k_passes * n_phases > PCL_MULTI_MAX)
+        return fail(PCL_ERR_ARG, "k_passes * n_phases outside [1, %d]", PCL_MULTI_MAX);
+    if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
+    if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
+    if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    int phase_del[PCL_MIXED_MAXPH] = {0, 0};
+    int n_iso = 0, n_delete = 0, last_iso_in_pass = -1;
+    for (int j = 0; j < n_phases; ++j) {
+        if (phase_kinds_host[j] != PCL_PHASE_ISOTROPIC && phase_kinds_host[j] != PCL_PHASE_DELETE)
+            return fail(PCL_ERR_ARG, "unknown phase kind %d", phase_kinds_host[j]);
+        phase_del[j] = phase_kinds_host[j] == PCL_PHASE_DELETE;
+        if (phase_del[j]) {
+            ++n_delete;
+        } else {
+            ++n_iso;
+            last_iso_in_pass = j;
+        }
+    }
+    if (n_iso > 1 || n_delete > 1) return fail(PCL_ERR_ARG, "at most one isotropic and one delete phase per pass");
+    const bool has_iso = n_iso > 0, has_delete = n_delete > 0;
+    const bool use_e = has_iso && (flags & PCL_SCATTER_WAVELENGTH), var_n = has_iso && (flags & PCL_SCATTER_VARIABLE_N);
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    const int np = n_planes, n_rows = k_passes * n_phases, nslots = 5 + np;
+    const int64_t N = ctx->count;
+    if (out_host)
+        for (int k = 0; k < n_rows * (5 + np); ++k) out_host[k] = 0;
+    if (N == 0) return PCL_OK;
+    // a pending implicit dv: superseded by the pass's own scatter phase; a pass without one (delete only) carries it
+    // through the compaction (all-photon stores) or makes it real first
+    if (!has_iso && ctx->lazy_dv && ctx->kind) PCL_TRY(materialize(ctx));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false; // superseded by the pass's own moves
+    if (has_delete) {
+        PCL_TRY(ensure_scratch(ctx, N));
+        PCL_TRY(ensure_alt(ctx));
+    }
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)n_rows * nslots * sizeof(uint64_t), ctx->stream));
+    ctx->hits_on_host = false;
+    ctx->last_async_bank = -1;
+    const int last_iso = has_iso ? (k_passes - 1) * n_phases + last_iso_in_pass : -1;
+    PCL_TRY(PCL_DISPATCH(ctx,
+                         step_mixed_t<double>(ctx, dt, k_passes, n_phases, phase_del, A, n, use_e, var_n, ent, c, h, A_del, n_del,
+                                              seed, step0, planes_host, np, has_delete, last_iso),
+                         step_mixed_t<float>(ctx, dt, k_passes, n_phases, phase_del, A, n, use_e, var_n, ent, c, h, A_del, n_del,
+                                             seed, step0, planes_host, np, has_delete, last_iso)));
+    PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)n_rows * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    // what is implicit now: dr = (velocity of the last move) * dt; dv = v - vprev once a scatter phase has run
+    if (has_iso) ctx->lazy_dv = true;
+    ctx->lazy_dr = true;
+    ctx->lazy_dr_vprev = has_iso && !phase_del[n_phases - 1]; // last phase scattered: its move used what is now vprev
+    ctx->lazy_dt = dt;
+    if (has_delete) {
+        bool has_dr = false;
+        const bool dv_implicit = ctx->lazy_dv && !ctx->kind;
+        if (ctx->lazy_dv && ctx->kind) { // plain Objects keep real dv rows: make the photons' real too, move everything
+            PCL_TRY(materialize(ctx));
+            has_dr = true;
+        }
+        PCL_TRY(PCL_DISPATCH(ctx, compact_after_pass_t<double>(ctx, dt, has_dr, dv_implicit),
+                             compact_after_pass_t<float>(ctx, dt, has_dr, dv_implicit)));
+    }
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    if (has_delete) {
+        int64_t alive = 0;
+        PCL_TRY(wait_count(ctx, N, &alive));
+        if (alive != (int64_t)ctx->h_multi[(n_rows - 1) * nslots])
+            return fail(PCL_ERR_HIP, "compaction kept %lld particles, the last phase counted %lld", (long long)alive,
+                        (long long)ctx->h_multi[(n_rows - 1) * nslots]);
+        adopt_compacted(ctx, alive, -1);
+    }
+    if (has_iso) // pcl_store_last_scatter_hits() reports the last scatter phase
+        ctx->h_cnt[0] = ctx->h_multi[(int64_t)((k_passes - 1) * n_phases + last_iso_in_pass) * nslots + 1], ctx->hits_on_host = true;
+    if (out_host)
+        for (int k = 0; k < n_rows; ++k) {
+            int64_t *o = out_host + (int64_t)k * (5 + np);
+            const uint64_t *cr = ctx->h_multi + (int64_t)k * nslots;
+            o[0] = (int64_t)cr[0];
+            for (int j = 0; j < 3 + np; ++j) o[1 + j] = (int64_t)cr[2 + j];
+            o[4 + np] = (int64_t)cr[1];
+        }
     return PCL_OK;
 }
 

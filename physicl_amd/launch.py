@@ -1,0 +1,85 @@
+"""Start one process per GPU on this node -- what ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N``
+does, reduced to what the hot path needs (the reference has no launcher: it is single-process).
+
+The parent must not have touched the GPU: on this pool a process that has initialised HIP may neither exec another
+program nor safely fork workers that use the device.  So this module imports nothing but the standard library, the
+children are fresh interpreters started with ``subprocess`` (never a re-exec of the caller), and ``bench.py`` calls
+``spawn_ranks`` before it imports ``physicl_amd._hip`` or torch.
+"""
+import os
+import signal
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(base, rank, world, port):
+    """Environment of rank ``rank``: the variables torch.distributed.run would set, rendezvous on 127.0.0.1
+    (the container hostname may not resolve), dmabuf IPC for RCCL on this driver."""
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return env
+
+
+def spawn_ranks(world, cmd, env=None, poll_s=0.05, grace_s=10.0):
+    """Run ``cmd`` (argv list) ``world`` times, rank r with ``rank_env(env, r, world, port)``.  Rank 0's stdout is
+    captured and returned; every other stream goes to this process's stderr.  Returns (exit code, rank-0 stdout):
+    the code is 0 only if every rank exited 0; as soon as one rank fails the others are terminated (they would wait
+    in a collective forever)."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    base = dict(os.environ if env is None else env)
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(list(cmd), env=rank_env(base, r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    captured = []
+    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        while True:
+            states = [p.poll() for p in procs]
+            bad = [s for s in states if s not in (None, 0)]
+            if bad:
+                rc = bad[0] if bad[0] > 0 else 1          # killed by a signal -> 1
+                break
+            if all(s == 0 for s in states):
+                break
+            time.sleep(poll_s)
+    finally:
+        _stop(procs, grace_s)
+    reader.join(timeout=grace_s)
+    out = captured[0] if captured else b""
+    return rc, out.decode("utf-8", "replace")
+
+
+def _stop(procs, grace_s):
+    """Terminate exactly the processes started here (by PID), then kill what ignores the signal."""
+    live = [p for p in procs if p.poll() is None]
+    for p in live:
+        try:
+            p.send_signal(signal.SIGTERM)
+        except OSError:
+            pass
+    t_end = time.time() + grace_s
+    for p in live:
+        try:
+            p.wait(timeout=max(0.0, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()

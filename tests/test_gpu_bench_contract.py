@@ -10,9 +10,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(*extra):
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--photons", "300000", "--steps", "6",
-                                   "--warmup", "3", "--cpu-photons", "20000", "--cpu-seconds", "0.5", *extra], cwd=ROOT)
+def run_bench(*extra, photons="300000"):
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--photons", photons, "--steps", "6",
+                                   "--warmup", "3", "--repeats", "3", "--cpu-photons", "20000", "--cpu-seconds", "0.5",
+                                   "--delete-photons", "30000", *extra], cwd=ROOT)
     lines = [ln for ln in out.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     return json.loads(lines[0])
@@ -22,27 +23,58 @@ def run_bench(*extra):
 def test_bench_line_has_the_contract_keys(extra):
     d = run_bench(*extra)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "repeats", "repeat_ms_per_step"):
         assert k in d, k
     assert d["metric"] == "particle-steps/sec" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 3
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] * 1e-3 / 300000 - 1.0) < 1e-9      # value = N / time per step
+    assert d["repeats"] == 3 and len(d["repeat_ms_per_step"]) == 3
+    assert min(d["repeat_ms_per_step"]) <= d["ms_per_step"] + 1e-4 <= max(d["repeat_ms_per_step"]) + 2e-4       # the median block
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert d["counters_last_step"]["N"] == 300000
+    assert r["traffic"] is None and "valu" not in r          # nothing from a committed profile inside the measured record
+    assert r["launches"] == (3 if "--mode" not in extra else 18) or "--steps-per-launch" in extra
+    assert d["counters_last_step"]["N"] == 300000 and d["collective"] is None
     if "--dtype" not in extra:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+        for size, rec in d["delete"]["sizes"].items():
+            for mode in ("per_step", "multi"):
+                assert rec[mode]["value"] > 0 and rec[mode]["particle_steps"] >= 30000
+            assert rec["per_step"]["particle_steps"] == rec["multi"]["particle_steps"]       # same photons removed at the same steps
+            assert rec["per_step"]["roofline"]["bound"] == "hbm" and rec["per_step"]["roofline"]["achieved"] > 0
+        assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
     if not extra:
         assert d["config"]["steps_per_launch"] == 32 and d["single_step"]["roofline"]["bound"] == "hbm"
-        assert d["hbm_target"]["target"] == 0.6
+        assert d["hbm_target"]["target"] == 0.6 and d["single_step"]["repeats"] == 3
 
 
 def test_counters_do_not_depend_on_steps_per_launch_or_mode():
-    a = run_bench("--no-cpu-baseline")["counters_last_step"]
-    b = run_bench("--no-cpu-baseline", "--steps-per-launch", "1")["counters_last_step"]
-    c = run_bench("--no-cpu-baseline", "--mode", "separate")["counters_last_step"]
+    a = run_bench("--no-cpu-baseline", "--no-extra")["counters_last_step"]
+    b = run_bench("--no-cpu-baseline", "--no-extra", "--steps-per-launch", "1")["counters_last_step"]
+    c = run_bench("--no-cpu-baseline", "--no-extra", "--mode", "separate")["counters_last_step"]
     assert a == b == c
+
+
+def test_two_ranks_started_by_bench_itself_gloo_rehearsal_on_one_device():
+    """``python bench.py --gpus 2`` launched directly (no torchrun): the parent starts the two ranks, rank 0's line comes
+    back, the line says which collective backend carried the counters, and the global counters are those of one
+    process running both shards' photons (ids are global: results do not depend on the sharding)."""
+    two = run_bench("--gpus", "2", "--backend", "gloo", "--device", "0", photons="150000")
+    assert two["n_gpus"] == 2 and two["collective"]["backend"] == "gloo" and two["collective"]["ranks_seen"] == 2
+    assert [d["rank"] for d in two["collective"]["devices"]] == [0, 1]
+    assert "gloo all-reduce" in two["config"]["workload"] and "cpu_baseline" not in two and "single_step" not in two
+    one = run_bench("--no-cpu-baseline", "--no-extra")
+    assert two["counters_last_step"] == one["counters_last_step"]
+
+
+def test_rccl_backend_on_one_device_is_an_error_not_a_silent_fallback():
+    """Two ranks on ONE device make RCCL refuse; with the default --backend nccl that must fail the whole job."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--device", "0", "--photons", "100000",
+                        "--steps", "2", "--warmup", "1", "--repeats", "1"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    assert "RCCL process group could not be brought up" in p.stderr or "CollectiveError" in p.stderr, p.stderr[-3000:]

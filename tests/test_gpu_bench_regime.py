@@ -1,0 +1,94 @@
+"""GPU: the kernels bench.py actually times, on the bench's own workload, straight against the CPU oracle.
+
+bench.py's headline runs the hipRTC kernels pcl_rtc_multi_e1 (K loop bodies per pass) and pcl_rtc_fast_e1 (one launch
+per step) in the OVERFLOW regime of BASELINE.json configs[2]: the literal constants of
+examples/variable_n_scattering.ipynb:30,52-56 (kernel A = 1e-15, dt = 5e-3, variable_n_fn
+"0.000000001 * exp(r0[gid] - 5)", wavelength term on), where one step moves a photon 1.5e6 m so exp() is +inf for
+almost every photon at x > 0 (always scatters) and 0 for photons that have wandered to x << 0 (never scatter again).
+Here the first 1e5 photons of that workload (ids [0, 1e5), the bench's seed) go through 32 steps
+  (a) as ONE pcl_step_fused_multi pass, and (b) as 32 lazy pcl_step_fused launches,
+and both are compared with 32 steps of the numpy oracle (oracle/physicl_oracle.py, pinned to the reference's goldens;
+the inf / 0 handling itself is pinned by g2_iso_varn_overflow):
+
+* per-step hit counts and sign counters (#v_x>0, #v_y>0, #v_z>0): EXACT.  Tie rule: a decision may
+  differ only where |pcoll - rand| <= 1e-14 * pcoll; in this regime pcoll is inf, 0 or (for the ~1e-5 of photon-steps
+  that land in the 700 m wide transition band) finite with a relative sensitivity of ~1e-7 to the libm differences, so
+  the expected number of flipped decisions in 3.2e6 photon-steps is ~1e-6 and the test asks for equality;
+* velocities within 4 ulp of c per component (sin/cos: pcl_sincos.h / OCML on the device, glibc in the oracle);
+* positions within K * dt * 4 ulp(c) (a scattered velocity feeds every later Euler move);
+* fp32 store: the same against the oracle's float32 restatement (ulp of float32(c)).
+"""
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+H_LIT = 6.62607015e-34
+EXPR = "0.000000001 * exp(r0[gid] - 5)"
+A_KERNEL, N_KERNEL, DT, SEED = 1e-15, 1e-19, 5e-3, 1234       # bench.py PROFILES["example"], --seed default
+N, K = 100_000, 32
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from physicl_amd import _hip
+    return _hip
+
+
+def oracle_chain(E, dtype):
+    ids = np.arange(N, dtype=np.int64)
+    z = lambda: np.zeros(N, dtype=dtype)
+    st = {"r": [z(), z(), z()], "v": [np.full(N, C_LIT, dtype=dtype), z(), z()], "dr": [z(), z(), z()],
+          "dv": [z(), z(), z()], "E": E.astype(dtype), "id": ids}
+    rows = []
+    for k in range(K):
+        orc.step_newton(st, DT, dtype)
+        hit = orc.step_scatter_isotropic(st, orc.philox_draws(SEED, k, ids, dtype), A_KERNEL, N_KERNEL, C_LIT, h=H_LIT,
+                                         use_E=True, n_expr=EXPR, dtype=dtype)
+        rows.append((int(hit.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+    return rows, st
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype):
+    npdt = np.float64 if dtype == "f64" else np.float32
+    sc = lambda k: dict(A=A_KERNEL, n=N_KERNEL, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=C_LIT, h=H_LIT,
+                        n_expr=EXPR, rng_mode=hip.RNG_PHILOX, seed=SEED, step=k)
+    e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9
+    got = {}
+    for how in ("multi", "single"):
+        with hip.Device(0) as d:
+            d.store_alloc(N, dtype)
+            d.fill_photons(N, 0, C_LIT, e_lo, e_hi, SEED)                     # exactly what bench.py does for ids [0, N)
+            assert d.is_uniform()
+            E = d.download(hip.E)
+            if how == "multi":
+                rows = d.step_fused_multi(DT, K, sc(0))
+            else:
+                rows = [d.step_fused(DT, sc(k), [], lazy=True) for k in range(K)]
+            got[how] = ([(o["hits"], list(o["sign"])) for o in rows], d.download_state(), E)
+    # the photons are the bench's: E = e_min + (e_max - e_min) * U^(1/3) from Philox block 2 (device pow vs numpy power)
+    E_orc = orc.philox_energy(SEED, np.arange(N), e_lo, e_hi)
+    assert np.max(np.abs(got["multi"][2].astype(np.float64) - E_orc) / E_orc) <= (4e-16 if dtype == "f64" else 6e-8)
+    ref_rows, st = oracle_chain(got["multi"][2], npdt)
+    ulp_c = float(np.spacing(npdt(C_LIT)))
+    for how in ("multi", "single"):
+        rows, s, _ = got[how]
+        assert rows == ref_rows, how                                           # hits and sign counters of all 32 steps
+        v, r = np.stack(s["v"], 1).astype(np.float64), np.stack(s["r"], 1).astype(np.float64)
+        v_ref, r_ref = np.stack(st["v"], 1).astype(np.float64), np.stack(st["r"], 1).astype(np.float64)
+        assert np.max(np.abs(v - v_ref)) <= 4 * ulp_c
+        # fp32 adds the rounding of 32 position updates at |r| ~ 5e7 (ulp 4): both sides round identically unless the
+        # velocity differs, so the bound stays K * dt * 4 ulp(c) plus one ulp of the largest position per differing step
+        slack = 0.0 if dtype == "f64" else K * float(np.spacing(npdt(np.max(np.abs(r_ref)))))
+        assert np.max(np.abs(r - r_ref)) <= K * DT * 4 * ulp_c + slack + 1e-12
+    # the two device formulations agree bit for bit
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(got["multi"][1][f][k], got["single"][1][f][k]), (f, k)
+    # the regime really is the bench's: every photon scatters in step 1, then a fraction escapes to x << 0 for good
+    hits = [h for h, _ in ref_rows]
+    assert hits[0] == N and 0.25 * N < hits[-1] < 0.9 * N

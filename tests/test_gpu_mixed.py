@@ -1,0 +1,323 @@
+"""GPU parity of the kernels for NON-UNIFORM stores (explicit ids after a compaction, plain Objects mixed in) and of
+pcl_step_mixed_multi -- K whole passes of a loop with an isotropic-scatter phase and/or a delete phase in one pass
+over the store and one compaction (BASELINE.json configs[4]: [Newton, ScatterIsotropic, Newton, ScatterDelete]).
+
+Bars: bit-identical -- every row (alive, hits | removed, sign counts, plane crossings), survivor ids and kinds, and
+the whole state r, v, dr, dv, E -- to the same passes run one launch per light step (pcl_step_fused /
+pcl_step_fused_delete, themselves pinned to the reference's goldens and the oracle in test_gpu_parity.py), fp64 and
+fp32; against the CPU oracle run on its own: equal counters per phase, identical survivor ids, positions within
+K * dt * 4 ulp(c).  Reference semantics exercised: ``type(obj) != PhotonObject`` skips plain objects
+(physicl/light.py:233, 283), stable removal (physicl/__init__.py:455-459).
+"""
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+H_LIT = 6.62607015e-34
+V_ABS_TOL = 4 * np.spacing(C_LIT)
+EXPR_EX = "0.000000001 * exp(r0[gid] - 5)"
+CASES = {
+    # tag: (use_E, expr, A, n, dt)
+    "base": (False, None, 1e-3, 1e-3, 1e-3),
+    "lambda": (True, None, 1e-15, 1e-19, 5e-3),
+    "varn": (True, EXPR_EX, 1e-15, 1e-19, 1e-9),
+}
+A_DEL, N_DEL = 1e-3, 0.4e-3            # pcoll ~ 0.12 per delete phase at dt = 1e-3
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from physicl_amd import _hip
+    return _hip
+
+
+@pytest.fixture()
+def make_store(hip):
+    devs = []
+
+    def make(capacity, dtype="f64"):
+        d = hip.Device(0)
+        d.store_alloc(capacity, dtype)
+        devs.append(d)
+        return d
+    yield make
+    for d in devs:
+        d.close()
+
+
+def scatter_dict(hip, tag, seed, step):
+    use_e, expr, A, n, dt = CASES[tag]
+    flags = (hip.SCATTER_WAVELENGTH if use_e else 0) | (hip.SCATTER_VARIABLE_N if expr else 0)
+    return dict(A=A, n=n, flags=flags, c=C_LIT, h=H_LIT, n_expr=expr, rng_mode=hip.RNG_PHILOX, seed=seed, step=step), dt
+
+
+def initial(N, dtype, seed, store):
+    """store: 'uniform' (all photons, implicit ids), 'ids' (explicit, non-contiguous ids), 'kinds' (plain Objects mixed
+    in, with their own dv), 'both'."""
+    rs = np.random.RandomState(seed)
+    npdt = np.float64 if dtype == "f64" else np.float32
+    vdir = rs.normal(size=(N, 3))
+    vdir /= np.linalg.norm(vdir, axis=1)[:, None]
+    st = {"r": rs.uniform(-8, 8, (N, 3)).astype(npdt), "v": (vdir * C_LIT).astype(npdt),
+          "dv": rs.normal(size=(N, 3)).astype(npdt), "E": rs.uniform(2.8e-19, 9.9e-19, N).astype(npdt), "id_base": 7_000_000_001}
+    if store in ("ids", "both"):
+        st["id"] = np.sort(rs.choice(50 * N + 100, N, replace=False)).astype(np.int64) + (1 << 33)
+    if store in ("kinds", "both"):
+        st["kind"] = (rs.random_sample(N) < 0.85).astype(np.uint8)
+    return st
+
+
+def snapshot(d):
+    if d.count == 0:
+        return None
+    s = d.download_state()
+    s["kind"] = d.download_kind(d.count)
+    return s
+
+
+def state_equal(a, b):
+    assert (a is None) == (b is None)
+    if a is None:
+        return
+    assert np.array_equal(a["E"], b["E"]) and np.array_equal(a["id"], b["id"]) and np.array_equal(a["kind"], b["kind"])
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(a[f][k], b[f][k]), (f, k)
+
+
+# ============================================================================ fast single-step kernel, general stores
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag", sorted(CASES))
+@pytest.mark.parametrize("store", ["ids", "kinds", "both"])
+@pytest.mark.parametrize("N", [1, 130, 4099, 150_001])
+def test_fast_kernel_on_general_stores_equals_the_generic_kernel(make_store, hip, tag, store, N, dtype):
+    """A lazy fused step on a store with explicit ids / plain Objects now takes k_fastg (device RNG, sign counters);
+    the eager call takes the generic k_fused: same counters, same state after every step."""
+    init = initial(N, dtype, N, store)
+    out = []
+    for lazy in (True, False):
+        d = make_store(N, dtype)
+        d.upload_state(init)
+        assert not d.is_uniform()
+        log = []
+        for k in range(4):
+            sc, dt = scatter_dict(hip, tag, 77, 20 + k)
+            o = d.step_fused(dt, sc, [], lazy=lazy)
+            log.append((o["N"], o["hits"], list(o["sign"])))
+        out.append((log, snapshot(d)))
+    assert out[0][0] == out[1][0]
+    state_equal(out[0][1], out[1][1])
+    if store != "ids" and N > 100:           # plain Objects are moved, never scattered: their v and dv are untouched
+        s, k = out[0][1], out[0][1]["kind"] == 0
+        assert k.any() and np.array_equal(np.stack(s["v"], 1)[k], init["v"][k]) and np.array_equal(np.stack(s["dv"], 1)[k], init["dv"][k])
+
+
+def test_fast_kernel_after_a_compaction_matches_a_fresh_store_with_those_ids(make_store, hip):
+    """ids are the key of each photon's random stream: survivors of a delete step, stepped on the compacted store,
+    behave exactly like the same photons uploaded with their ids into a fresh store."""
+    N = 50_000
+    init = initial(N, "f64", 3, "uniform")
+    a = make_store(N)
+    a.upload_state(init)
+    a.step_fused_delete(1e-3, A_DEL, N_DEL, hip.RNG_PHILOX, 5, 1, None, lazy=True)
+    mid = snapshot(a)
+    b = make_store(N)
+    b.upload_state({"r": np.stack(mid["r"], 1), "v": np.stack(mid["v"], 1), "dr": np.stack(mid["dr"], 1),
+                    "dv": np.stack(mid["dv"], 1), "E": mid["E"], "id": mid["id"]})
+    for d in (a, b):
+        for k in range(3):
+            sc, dt = scatter_dict(hip, "varn", 5, 2 + k)
+            d.step_fused(dt, sc, [], lazy=True)
+    state_equal(snapshot(a), snapshot(b))
+
+
+def test_reupload_after_a_mixed_population_forgets_the_old_kinds(make_store, hip):
+    """A mixed Object / photon upload followed by an all-photon upload into the same store: no kind array survives
+    (stale zeros switched the light steps off for whoever sat at those indices)."""
+    N = 10_000
+    mixed = initial(N, "f64", 9, "kinds")
+    photons = initial(N, "f64", 10, "uniform")
+    d = make_store(N)
+    d.upload_state(mixed)
+    assert not d.is_uniform()
+    d.upload_state(photons)
+    assert d.is_uniform() and d.download_kind(N).all()
+    fresh = make_store(N)
+    fresh.upload_state(photons)
+    sc, dt = scatter_dict(hip, "base", 1, 1)
+    assert d.step_fused(dt, sc, [], lazy=True)["hits"] == fresh.step_fused(dt, sc, [], lazy=True)["hits"] > 0
+    state_equal(snapshot(d), snapshot(fresh))
+
+
+# ============================================================================ K passes per launch, any loop, any store
+def single_launches(hip, d, tag, phases, K, seed, step0, planes):
+    log, step = [], step0
+    for _ in range(K):
+        for ph in phases:
+            if ph == "iso":
+                sc, dt = scatter_dict(hip, tag, seed, step)
+                o = d.step_fused(dt, sc, planes, lazy=True)
+                log.append((o["N"], o["hits"], list(o["sign"]), list(o["planes"])))
+            else:
+                dt = CASES[tag][4]
+                o = d.step_fused_delete(dt, A_DEL, N_DEL * 1e-3 / dt, hip.RNG_PHILOX, seed, step, planes, lazy=True)
+                log.append((o["N"], o["removed"], list(o["sign"]), list(o["planes"])))
+            step += 1
+    return log
+
+
+def mixed_launch(hip, d, tag, phases, K, seed, step0, planes):
+    sc, dt = scatter_dict(hip, tag, seed, step0)
+    rows = d.step_mixed_multi(dt, K, phases, sc if "iso" in phases else None,
+                              (A_DEL, N_DEL * 1e-3 / dt) if "delete" in phases else None, planes, seed, step0)
+    return [(o["N"], o["hits"] if o["phase"] == "iso" else o["removed"], list(o["sign"]), list(o["planes"])) for o in rows]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("phases", [("iso",), ("delete",), ("iso", "delete"), ("delete", "iso")])
+@pytest.mark.parametrize("store", ["uniform", "ids", "kinds", "both"])
+@pytest.mark.parametrize("tag,N,K", [("base", 1, 1), ("base", 130, 3), ("lambda", 2049, 2), ("varn", 70_001, 5), ("base", 300_007, 16)])
+def test_mixed_multi_is_bit_identical_to_single_launches(make_store, hip, tag, N, K, store, phases, dtype):
+    init = initial(N, dtype, N + K, store)
+    planes = [[0.5, np.nan, np.nan], [np.nan, np.nan, -2.0]] if N in (130, 70_001) else []
+    seed, step0 = 0xABCDEF0123, 7                 # odd first launch number: the decision block is shared across launches
+    a = make_store(N, dtype)
+    a.upload_state(init)
+    ref = single_launches(hip, a, tag, phases, K, seed, step0, planes)
+    b = make_store(N, dtype)
+    b.upload_state(init)
+    got = mixed_launch(hip, b, tag, phases, K, seed, step0, planes)
+    assert got == ref
+    assert a.count == b.count
+    state_equal(snapshot(a), snapshot(b))          # includes the implicit dr / dv of the last phases
+    if "delete" in phases and N > 1000:
+        assert 0 < b.count < N and np.all(np.diff(b.download_ids()) > 0)
+
+
+def test_mixed_multi_chains_with_everything_else(make_store, hip):
+    """mixed pass -> single lazy steps -> delete-only K-step pass -> mixed pass -> eager consumers: the implicit dr / dv
+    (dv = v - vprev carried through compactions) hand over in every direction."""
+    N, tag, seed = 40_009, "varn", 31
+    init = initial(N, "f64", 8, "uniform")
+    out = []
+    for use_multi in (False, True):
+        d = make_store(N)
+        d.upload_state(init)
+        log, step = [], 1
+        for phases, K in ((("iso", "delete"), 3), (("iso",), 2), (("delete",), 4), (("delete", "iso"), 2)):
+            if use_multi and phases == ("delete",):
+                dt = CASES[tag][4]
+                log += [(o["N"], o["removed"], list(o["sign"]), list(o["planes"]))
+                        for o in d.step_fused_delete_multi(dt, K, A_DEL, N_DEL * 1e-3 / dt, seed, step, [])]
+            elif use_multi:
+                log += mixed_launch(hip, d, tag, phases, K, seed, step, [])
+            else:
+                log += single_launches(hip, d, tag, phases, K, seed, step, [])
+            step += K * len(phases)
+        mid = snapshot(d)
+        d.step_newton(1e-9)                                              # eager steps read the real arrays
+        alive, removed = d.step_scatter_delete(A_DEL, N_DEL, hip.RNG_PHILOX, seed, 1000)
+        out.append((log, mid, alive, removed, snapshot(d)))
+    assert out[0][0] == out[1][0] and out[0][2:4] == out[1][2:4]
+    state_equal(out[0][1], out[1][1])
+    state_equal(out[0][4], out[1][4])
+
+
+@pytest.mark.parametrize("tag", ["base", "varn"])
+def test_mixed_multi_vs_oracle_chain(make_store, hip, tag):
+    """[Newton, ScatterIsotropic, Newton, ScatterDelete] x K against the numpy oracle run step by step."""
+    N, K = 6000, 5
+    init = initial(N, "f64", 42, "ids")
+    use_e, expr, A, n, dt = CASES[tag]
+    st = {"r": [np.ascontiguousarray(init["r"][:, k]) for k in range(3)],
+          "v": [np.ascontiguousarray(init["v"][:, k]) for k in range(3)],
+          "dr": [np.zeros(N)] * 3, "dv": [np.zeros(N)] * 3, "E": init["E"].copy(), "id": init["id"].copy()}
+    seed, step0 = 2024, 4
+    A_d, n_d = A_DEL, N_DEL * 1e-3 / dt
+    ref, step = [], step0
+    for k in range(K):
+        orc.step_newton(st, dt)
+        hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, step, st["id"]), A, n, C_LIT, h=H_LIT, use_E=use_e, n_expr=expr)
+        ref.append((len(st["id"]), int(hit.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+        orc.step_newton(st, dt)
+        flags, keep = orc.step_scatter_delete(st, orc.philox_draws(seed, step + 1, st["id"])[2], A_d, n_d)
+        ref.append((len(st["id"]), int(flags.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+        step += 2
+    d = make_store(N)
+    d.upload_state(init)
+    sc, _ = scatter_dict(hip, tag, seed, step0)
+    rows = d.step_mixed_multi(dt, K, ("iso", "delete"), sc, (A_d, n_d), [], seed, step0)
+    assert [(o["N"], o["hits"] if o["phase"] == "iso" else o["removed"], list(o["sign"])) for o in rows] == ref
+    s = d.download_state()
+    assert np.array_equal(s["id"], st["id"]) and 0 < len(s["id"]) < N
+    assert np.max(np.abs(np.stack(s["v"], 1) - np.stack(st["v"], 1))) <= V_ABS_TOL
+    assert np.max(np.abs(np.stack(s["r"], 1) - np.stack(st["r"], 1))) <= 2 * K * dt * V_ABS_TOL + 1e-15
+    assert np.max(np.abs(np.stack(s["dv"], 1) - np.stack(st["dv"], 1))) <= 2 * V_ABS_TOL
+
+
+def test_mixed_multi_argument_errors(make_store, hip):
+    d = make_store(100)
+    d.upload_state({"v": np.ones((100, 3)), "E": np.ones(100)})
+    sc, dt = scatter_dict(hip, "base", 1, 0)
+    with pytest.raises(hip.HipError):
+        d.step_mixed_multi(dt, 33, ("iso", "delete"), sc, (1e-3, 1e-3))        # 66 rows > 64
+    with pytest.raises(hip.HipError):
+        d.step_mixed_multi(dt, 0, ("iso",), sc)
+    d.set_count(0, 0)                                                         # an empty store: rows of zeros
+    rows = d.step_mixed_multi(dt, 2, ("iso", "delete"), sc, (1e-3, 1e-3), [[0.0, np.nan, np.nan]])
+    assert len(rows) == 4 and all(o["N"] == 0 and list(o["sign"]) == [0, 0, 0] and list(o["planes"]) == [0] for o in rows)
+
+
+# ============================================================================ through the public API
+def _mixed_sim(phys, light, newton, K, n_photons, seed, order, explicit=False):
+    sim = phys.Simulation(exit=lambda s: len(s.ts) >= 12 or len(s.objects) == 0, steps_per_launch=K, seed=seed, rng="philox")
+    if explicit:
+        rs = np.random.RandomState(1)
+        objs = []
+        for i in range(n_photons):
+            if i % 7 == 3:
+                objs.append(phys.Object(v=phys.Measurement(rs.normal(size=3) * 1e8, "m**1 s**-1")))
+            else:
+                objs.append(light.PhotonObject(E=np.double(1.0), v=phys.Measurement([light.c, 0, 0], "m**1 s**-1")))
+        sim.add_objs(objs)
+    else:
+        sim.add_objs(light.generate_photons_bulk(n_photons, min=light.E_from_wavelength(700e-9),
+                                                 max=light.E_from_wavelength(200e-9), seed=seed))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(1e-3)))
+    iso = [newton.NewtonianKinematicsStep(), light.ScatterIsotropicStep(n=np.double(1e-3), A=np.double(1e-3)),
+           light.ScatterSignMeasureStep(None, True)]
+    dele = [newton.NewtonianKinematicsStep(), light.ScatterDeleteStep(np.double(2e-4), np.double(1e-3)),
+            light.ScatterMeasureStep(None, True, [np.array([6e5, np.nan, np.nan])])]
+    idx = 1
+    for s in (iso + dele if order == "iso_first" else dele + iso):
+        sim.add_step(idx, s)
+        idx += 1
+    return sim, iso[2], dele[2], iso[1], dele[1]
+
+
+@pytest.mark.parametrize("order", ["iso_first", "delete_first"])
+@pytest.mark.parametrize("explicit", [False, True])
+def test_simulation_steps_per_launch_covers_the_mixed_loop(order, explicit):
+    """Simulation(steps_per_launch=K) on [UpdateTime, Newton, ScatterIsotropic, sign rows, Newton, ScatterDelete, plane rows]
+    (BASELINE configs[4]'s loop with measure steps): same rows, times, hits, alive count and final state as K = 1."""
+    import physicl_amd as phys
+    import physicl_amd.light as light
+    import physicl_amd.newton as newton
+    out = []
+    for K in (1, 5):
+        sim, m_sign, m_plane, iso, dele = _mixed_sim(phys, light, newton, K, 3000 if explicit else 60_000, 17, order, explicit)
+        sim.start()
+        sim.join()
+        assert sim.error is None
+        out.append(([r.tolist() for r in m_sign.data], [r.tolist() for r in m_plane.data], [float(t) for t in sim.ts],
+                    sim.hits, dele.removed, len(sim.objects), sim.download("r"), sim.download("v"), sim.download("dv"),
+                    sim.download("id")))
+        sim.close(download=False)
+    a, b = out
+    assert a[:6] == b[:6] and len(a[0]) == 12 and a[5] > 0
+    for x, y in zip(a[6:], b[6:]):
+        assert np.array_equal(x, y)
