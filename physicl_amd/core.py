@@ -622,7 +622,9 @@ class Simulation(threading.Thread):
                          for o in rows], dtype=np.int64)
         glob = self._global(flat.reshape(-1)).reshape(k * P, flat.shape[1])
         for i, (t, dt) in enumerate(times):
-            self.t, self.dt = t, dt                   # each row carries its own pass's time
+            self.t, self.dt = t, dt                   # each row carries its own pass's time ...
+            later = self.ts[n_ts + i + 1:]            # ... and sees ``ts`` as it stood after that pass
+            del self.ts[n_ts + i + 1:]
             for j, g in enumerate(groups):
                 row = glob[i * P + j]
                 if phases[j] == "iso":
@@ -640,8 +642,8 @@ class Simulation(threading.Thread):
                     raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
                                        "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
                                        "the store being empty only" % (i + 1, k, self._alive))
-                del self.ts[n_ts + i + 1:]
-                break
+                break                                 # the later passes ran on an empty store: their times are dropped
+            self.ts.extend(later)
 
     def _run_fused(self, group):
         self._to_device()
