@@ -66,6 +66,8 @@ enum pcl_field {
 #define PCL_SCATTER_WAVELENGTH 1 /* wavelength_dep_scattering=True  (light.py:275, 300-301) */
 #define PCL_SCATTER_VARIABLE_N 2 /* variable_n=True                  (light.py:276, 299)     */
 #define PCL_FUSED_LAZY         4 /* pcl_step_fused only: leave dr and dv implicit (see there)  */
+#define PCL_SCATTER_PY_DV      8 /* pcl_step_scatter_isotropic only: a hit leaves dv = v_old, the write-back of the
+                                    reference's CPU path ScatterIsotropicStep.__run_py (light.py:346-348)       */
 
 /* where a step's three random numbers per photon come from */
 #define PCL_RNG_INPUT  0 /* arrays uploaded with pcl_store_upload_rand: the reference's contract
@@ -246,6 +248,16 @@ int pcl_step_newton(pcl_ctx *ctx, double dt);
 int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h,
                                const char *n_expr, int rng_mode, uint64_t seed, uint32_t step,
                                int64_t *hits_out);
+
+/* The reference's CPU paths of the light steps (``cl_on=False``: ScatterIsotropicStep.__run_py light.py:335-350,
+ * ScatterDeleteStepReference.__run_py light.py:216-223) consume np.random in a DATA-DEPENDENT order -- a photon that is
+ * hit draws two more numbers, a removal makes the list iteration skip the next object -- so the host has to see every
+ * photon's collision probability before it can hand the device its randoms / removal flags.  pcl_step_scatter_pcoll
+ * writes pcoll = A * n * |dr| [* pow((h*c)/E, -4)] of every particle (store dtype, constant n only: the CPU path has
+ * no variable_n) to a host array; pcl_step_scatter_isotropic(PCL_RNG_INPUT, flags | PCL_SCATTER_PY_DV) then applies
+ * the scatter with the host's draws, and pcl_step_delete_flags removes the particles whose flag is 1 (stable). */
+int pcl_step_scatter_pcoll(pcl_ctx *ctx, double A, double n, int flags, double c, double h, void *pcoll_out_host);
+int pcl_step_delete_flags(pcl_ctx *ctx, const int32_t *flags_host, int64_t *n_alive_out, int64_t *n_removed_out);
 
 /* The whole Simulation loop body in ONE kernel: NewtonianKinematicsStep, then (do_scatter != 0)
  * ScatterIsotropicStep, then (n_planes >= 0) the counters of ScatterSignMeasureStep /

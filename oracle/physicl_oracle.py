@@ -181,6 +181,81 @@ def reference_draws(n, random_state=None):
 
 
 # ----------------------------------------------------------------------------------------------
+# a3 / a6  the reference's CPU paths of the light steps (``cl_on=False``)
+#          ScatterIsotropicStep.__run_py light.py:335-350, ScatterDeleteStepReference.__run_py light.py:216-223
+# Literal per-object loops: the order in which np.random is consumed depends on the outcome for every earlier object.
+# ``U`` is the np.random stream from where the step finds it (e.g. RandomState(seed).random_sample(big)); every
+# function returns how many numbers it consumed.
+# ----------------------------------------------------------------------------------------------
+def norm_py(d0, d1, d2):
+    """``np_lin.norm(obj.dr)`` (light.py:220, 339): sqrt(dot(x, x)) through BLAS -- NOT the kernels' left-to-right
+    form; the two disagree in the last bit for ~11 % of vectors, which only matters when
+    ``pcoll`` and ``rand`` tie."""
+    return float(np.linalg.norm(np.array([d0, d1, d2], dtype=np.float64)))
+
+
+def step_scatter_isotropic_py(state, U, n_user, A_user, c, *, h=None, use_E=False, is_photon=None):
+    """One ScatterIsotropicStep.__run_py pass over the objects of ``state`` (in place).  Per PhotonObject:
+    ``p = n * A * |dr|`` [``*= ((h*c)/E) ** -4``], one draw; on a hit phi = draw * pi, THEN theta = draw * pi * 2,
+    ``v = c (sin t cos p, sin t sin p, cos t)`` and ``dv = v_old`` (sic, light.py:346-348); on a miss ``dv = 0``.
+    ``variable_n`` does not exist on this path (light.py:334).  Returns (hit mask, numbers consumed)."""
+    N = len(state["E"])
+    v = [np.array(x, dtype=np.float64) for x in state["v"]]
+    dv = [np.array(x, dtype=np.float64) for x in state["dv"]]
+    hit = np.zeros(N, dtype=bool)
+    pos = 0
+    nA = np.float64(n_user) * np.float64(A_user)
+    for i in range(N):
+        if is_photon is not None and not is_photon[i]:
+            continue
+        p = nA * norm_py(state["dr"][0][i], state["dr"][1][i], state["dr"][2][i])
+        if use_E:
+            p = p * np.power((np.float64(h) * np.float64(c)) / np.float64(state["E"][i]), -4)
+        u = U[pos]
+        pos += 1
+        if p >= u:
+            phi = U[pos] * np.pi
+            theta = U[pos + 1] * np.pi * 2
+            pos += 2
+            old = (v[0][i], v[1][i], v[2][i])
+            v[0][i] = c * np.sin(theta) * np.cos(phi)
+            v[1][i] = c * np.sin(theta) * np.sin(phi)
+            v[2][i] = c * np.cos(theta)
+            dv[0][i], dv[1][i], dv[2][i] = old
+            hit[i] = True
+        else:
+            dv[0][i] = dv[1][i] = dv[2][i] = 0.0
+    state["v"], state["dv"] = v, dv
+    return hit, pos
+
+
+def step_scatter_delete_reference_py(state, U, n_user, A_user, is_photon=None):
+    """One ScatterDeleteStepReference.__run_py pass: ``for obj in sim.objects: ... sim.remove_obj(obj)`` removes from
+    the list being iterated, so the object behind every removed photon is skipped -- not tested, no draw.  ``state``
+    is compacted in place.  Returns (removed mask over the incoming objects, numbers consumed)."""
+    N = len(state["id"])
+    removed = np.zeros(N, dtype=bool)
+    nA = np.float64(n_user) * np.float64(A_user)
+    pos, i = 0, 0
+    while i < N:
+        if is_photon is None or is_photon[i]:
+            p = nA * norm_py(state["dr"][0][i], state["dr"][1][i], state["dr"][2][i])
+            u = U[pos]
+            pos += 1
+            if p >= u:
+                removed[i] = True
+                i += 1                      # the list shrank under the iterator: the next object is never visited
+        i += 1
+    keep = np.flatnonzero(~removed)
+    for f in ("r", "v", "dr", "dv"):
+        state[f] = [np.asarray(a)[keep] for a in state[f]]
+    for f in ("E", "id"):
+        if f in state and state[f] is not None:
+            state[f] = np.asarray(state[f])[keep]
+    return removed, pos
+
+
+# ----------------------------------------------------------------------------------------------
 # counters (#10, #11)                                   light.py:414-431 and light.py:374-404
 # ----------------------------------------------------------------------------------------------
 def sign_counts(v):

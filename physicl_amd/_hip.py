@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "_lib", "libphysicl_hip.so")
 # enums of include/physicl_hip.h
 R0, R1, R2, V0, V1, V2, DR0, DR1, DR2, DV0, DV1, DV2, E, NFIELDS = range(14)
 FIELD_GROUPS = {"r": (R0, R1, R2), "v": (V0, V1, V2), "dr": (DR0, DR1, DR2), "dv": (DV0, DV1, DV2)}
-SCATTER_WAVELENGTH, SCATTER_VARIABLE_N, FUSED_LAZY = 1, 2, 4
+SCATTER_WAVELENGTH, SCATTER_VARIABLE_N, FUSED_LAZY, SCATTER_PY_DV = 1, 2, 4, 8
 RNG_INPUT, RNG_PHILOX = 0, 1
 PHASE_ISOTROPIC, PHASE_DELETE = 0, 1
 KIND_OBJECT, KIND_PHOTON = 0, 1
@@ -94,6 +94,8 @@ _PROTOTYPES = {
     "pcl_step_scatter_isotropic": [_vp, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
                                    c_uint32, POINTER(c_int64)],
     "pcl_step_fused_delete_multi": [_vp, c_double, c_int, c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
+    "pcl_step_scatter_pcoll": [_vp, c_double, c_double, c_int, c_double, c_double, _vp],
+    "pcl_step_delete_flags": [_vp, _vp, POINTER(c_int64), POINTER(c_int64)],
     "pcl_step_plane_energies": [_vp, _vp, _vp, c_int64, POINTER(c_int64)],
     "pcl_store_is_uniform": [_vp, POINTER(c_int)],
     "pcl_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
@@ -427,6 +429,23 @@ class Device:
             n_expr.encode() if n_expr is not None else None, int(rng_mode), int(seed), int(step) & 0xFFFFFFFF,
             byref(hits) if want_hits else None))
         return hits.value if want_hits else None
+
+    def scatter_pcoll(self, A, n, flags, c, h):
+        """Collision probability of every particle (constant n; ``flags`` & SCATTER_WAVELENGTH adds the wavelength
+        term), as the scatter kernels compute it: input of the host-side RNG replay of the reference's CPU paths."""
+        out = np.empty(self.count, dtype=self.np_dtype)
+        check(self.lib.pcl_step_scatter_pcoll(self.ctx, float(A), float(n), int(flags), float(c), float(h),
+                                              out.ctypes.data_as(c_void_p)))
+        return out
+
+    def step_delete_flags(self, flags):
+        """Remove the particles whose flag is 1 (stable compaction of the whole state).  Returns (alive, removed)."""
+        f = np.ascontiguousarray(flags, dtype=np.int32)
+        if f.size != self.count:
+            raise ValueError("one flag per particle: got %d for %d" % (f.size, self.count))
+        alive, removed = c_int64(), c_int64()
+        check(self.lib.pcl_step_delete_flags(self.ctx, f.ctypes.data_as(c_void_p), byref(alive), byref(removed)))
+        return alive.value, removed.value
 
     def step_fused(self, dt, scatter=None, planes=None, sync=True, lazy=False):
         """One pass: Newton, then ScatterIsotropic if ``scatter`` (dict: A, n, flags, c, h, n_expr, rng_mode,

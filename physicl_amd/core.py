@@ -16,8 +16,11 @@ scripts written for PhysiCL run unchanged.  What differs is where the particles 
   the state back into the Python objects, and the next device step re-uploads it.  User plugins
   therefore keep working, at the reference's speed; all-native step lists run at HBM speed.
 
-There is no CPU implementation of the device-native steps: with ``cl_on=False`` no device context
-is created (as in the reference) and running such a step raises.
+There is no CPU implementation of the device-native steps.  ``cl_on=False`` -- which in the reference selects its
+Python paths -- selects those paths' SEMANTICS here (the data-dependent np.random order and ``dv = v_old`` of
+ScatterIsotropicStep.__run_py, physicl/light.py:335-350; the skip-after-removal iteration of
+ScatterDeleteStepReference.__run_py, light.py:216-223), still executed by the HIP kernels: the device context is then
+created when the first device step needs it, and ``cl_ctx`` / ``cl_q`` stay None as in the reference.
 """
 import copy
 import threading
@@ -256,13 +259,11 @@ class Simulation(threading.Thread):
         self._uploaded, self._upload_lo = [], 0
         self._all_photons = True
         self.hits = 0                 # photons scattered by the most recent ScatterIsotropicStep
+        self._hip = None
         if self.cl_on:
-            from . import _hip
-            self._hip = _hip
-            dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
-            self._dev = _hip.Device(dev_index)     # raises if there is no GPU / no library: no fallback
-        self.cl_ctx = self._dev                     # reference attribute names (physicl/__init__.py:428-429)
-        self.cl_q = self._dev
+            self._open_device()                     # raises if there is no GPU / no library: no fallback
+        self.cl_ctx = self._dev                     # reference attribute names (physicl/__init__.py:427-432): None when
+        self.cl_q = self._dev                       # cl_on is False
 
     # ------------------------------------------------------------------ objects
     @property
@@ -315,10 +316,21 @@ class Simulation(threading.Thread):
         self.steps.pop(idx)
 
     # ------------------------------------------------------------------ device residency
+    def _open_device(self):
+        from . import _hip
+        self._hip = _hip
+        dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
+        self._dev = _hip.Device(dev_index)
+
+    def _py_semantics(self):
+        """``cl_on=False``: the light steps follow the reference's CPU paths (RNG order, write-back), on the device."""
+        return self.cl_on == False      # noqa: E712 -- the reference's own test (light.py:207, 356)
+
     def _need_device(self, what):
+        """The HIP device every device-native step runs on -- also under ``cl_on=False``, which only selects the
+        reference's CPU-path semantics (there is no CPU implementation of the hot path to fall back to)."""
         if self._dev is None:
-            raise RuntimeError("%s runs on the HIP device only and this Simulation was created with cl_on=False "
-                               "(this build has no CPU implementation of the hot path)" % what)
+            self._open_device()
         return self._dev
 
     def _shard(self, n_global):
@@ -466,7 +478,7 @@ class Simulation(threading.Thread):
             dev.upload_rand(2, full)
 
     def _rng_mode(self):
-        if (self.rng or "numpy") == "philox":
+        if (self.rng or "numpy") == "philox" and not self._py_semantics():
             return self._hip.RNG_PHILOX
         if self.comm is not None and self.comm.world > 1:
             # every rank would draw the SAME np.random stream for its own shard (scripts seed it once): correlated
@@ -486,7 +498,9 @@ class Simulation(threading.Thread):
         plan, i = [], 0
         while i < len(steps):
             s = steps[i]
-            if self.fuse and self._dev is not None and getattr(s, "_fuse_role", None) == "newton":
+            # (cl_on=False: the CPU paths' randoms depend on every photon's own collision probability, which the host has
+            #  to see between the move and the scatter -- nothing is fused)
+            if self.fuse and not self._py_semantics() and getattr(s, "_fuse_role", None) == "newton":
                 group, j = [s], i + 1
                 if j < len(steps) and getattr(steps[j], "_fuse_role", None) in ("scatter_iso", "scatter_delete"):
                     group.append(steps[j])
@@ -513,7 +527,7 @@ class Simulation(threading.Thread):
         key = tuple(id(s) for s in self.steps.values()) + (self.fuse,)
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan()
-        if self.steps_per_launch > 1 and self._multi_agreed():
+        if self.steps_per_launch > 1 and not self._py_semantics() and self._multi_agreed():
             self._run_multi(self._plan[0][1], [item for _, item in self._plan[1:]])
             return
         for kind, item in self._plan:

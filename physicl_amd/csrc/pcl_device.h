@@ -346,6 +346,7 @@ struct pcl_scatter_args {
     pcl_u64 seed;
     pcl_u32 step;
     int rng_mode;
+    int py_dv;                 // 1: a hit leaves dv = v_old (the reference's CPU path, light.py:346-348) instead of v' - v_old
 };
 
 #define PCL_SCATTER_ROWS 4 /* particles per thread per grid-stride trip (memory-level parallelism) */
@@ -398,9 +399,9 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
                 a.v0[ti] = n0;
                 a.v1[ti] = n1;
                 a.v2[ti] = n2;
-                a.dv0[ti] = R::sub(n0, o0);
-                a.dv1[ti] = R::sub(n1, o1);
-                a.dv2[ti] = R::sub(n2, o2);
+                a.dv0[ti] = a.py_dv ? o0 : R::sub(n0, o0);
+                a.dv1[ti] = a.py_dv ? o1 : R::sub(n1, o1);
+                a.dv2[ti] = a.py_dv ? o2 : R::sub(n2, o2);
                 ++my_hits;
             } else {
                 a.dv0[ti] = (T)0;

@@ -222,6 +222,19 @@ __global__ void __launch_bounds__(kBlock) k_lam4(const T *__restrict__ E, T *__r
     }
 }
 
+// collision probability of every particle as the scatter kernels compute it (light.py:299-306, constant n), dense output:
+// what the host needs to replay the data-dependent RNG order of the reference's CPU paths (light.py:216-223, 335-350)
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock) k_pcoll(const T *__restrict__ d0, const T *__restrict__ d1, const T *__restrict__ d2,
+                                                  const T *__restrict__ E, T A, T n, T h, T c, T *__restrict__ out, int64_t N,
+                                                  int64_t ts) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const int64_t ti = pcl_tix(i, ts);
+        out[i] = pcl_pcoll<T, USE_E, false>(A, n, h, c, d0[ti], d1[ti], d2[ti], (T)0, (T)0, (T)0, USE_E ? E[ti] : (T)0);
+    }
+}
+
 // ---- delete step, pass 1: flag -> wave64 ballot keep-mask + per-tile survivor count --------------
 // One workgroup per 2048-particle tile; wave w owns rows 8w..8w+7 (64 consecutive particles per
 // row, lane == particle so the ballot bit order IS the particle order -> stable compaction).
@@ -1475,7 +1488,7 @@ int fill_table_t(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, const doubl
 
 template <typename T>
 int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c, double h,
-                   int rng_mode, uint64_t seed, uint32_t step) {
+                   int rng_mode, uint64_t seed, uint32_t step, bool py_dv) {
     const int64_t N = ctx->count;
     pcl_scatter_args<T> a{};
     a.d0 = F<T>(ctx, PCL_DR0); a.d1 = F<T>(ctx, PCL_DR1); a.d2 = F<T>(ctx, PCL_DR2);
@@ -1496,6 +1509,7 @@ int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc
     a.seed = seed;
     a.step = step;
     a.rng_mode = rng_mode;
+    a.py_dv = py_dv ? 1 : 0;
     const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_SCATTER);
@@ -1907,6 +1921,21 @@ int compact_after_pass_t(pcl_ctx *ctx, double dt, bool has_dr, bool dv_implicit)
     cc.n_planes = -1;
     cc.dt = (T)dt;
     return launch_compact_count<T>(ctx, has_dr, dv_implicit, cc);
+}
+
+template <typename T>
+int scatter_pcoll_t(pcl_ctx *ctx, double A, double n, bool use_e, double c, double h, void *out_dev) {
+    const int64_t N = ctx->count;
+    const int grid = grid_for(ctx, N, kBlock);
+    if (use_e)
+        hipLaunchKernelGGL((k_pcoll<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const T *)F<T>(ctx, PCL_DR0),
+                           (const T *)F<T>(ctx, PCL_DR1), (const T *)F<T>(ctx, PCL_DR2), (const T *)F<T>(ctx, PCL_E), (T)A, (T)n, (T)h,
+                           (T)c, static_cast<T *>(out_dev), N, tile_stride(ctx));
+    else
+        hipLaunchKernelGGL((k_pcoll<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const T *)F<T>(ctx, PCL_DR0),
+                           (const T *)F<T>(ctx, PCL_DR1), (const T *)F<T>(ctx, PCL_DR2), (const T *)F<T>(ctx, PCL_E), (T)A, (T)n, (T)h,
+                           (T)c, static_cast<T *>(out_dev), N, tile_stride(ctx));
+    return launch_check("k_pcoll");
 }
 
 template <typename T>
@@ -2544,9 +2573,9 @@ int pcl_step_newton(pcl_ctx *ctx, double dt) {
 int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, double c, double h, const char *n_expr,
                                int rng_mode, uint64_t seed, uint32_t step, int64_t *hits_out) {
     PCL_TRY(need_store(ctx));
-    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N | PCL_SCATTER_PY_DV)) return fail(PCL_ERR_ARG, "unknown flag bits");
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
-    const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
+    const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N, py_dv = flags & PCL_SCATTER_PY_DV;
     rtc_entry *ent = nullptr;
     if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
     const int64_t N = ctx->count;
@@ -2560,14 +2589,72 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
-    PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step),
-                         step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step)));
+    PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv),
+                         step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv)));
     if (hits_out) {
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt, ctx->d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         ctx->hits_on_host = true;
         *hits_out = (int64_t)ctx->h_cnt[0];
     }
+    return PCL_OK;
+}
+
+int pcl_step_scatter_pcoll(pcl_ctx *ctx, double A, double n, int flags, double c, double h, void *pcoll_out_host) {
+    PCL_TRY(need_store(ctx));
+    if (flags & ~PCL_SCATTER_WAVELENGTH) return fail(PCL_ERR_ARG, "only PCL_SCATTER_WAVELENGTH is meaningful here");
+    const int64_t N = ctx->count;
+    if (N == 0) return PCL_OK;
+    if (!pcoll_out_host) return fail(PCL_ERR_ARG, "pcoll_out_host is NULL");
+    void *tmp = nullptr;
+    PCL_TRY(dev_alloc_bytes(&tmp, N, ctx->esz));
+    int rc = PCL_DISPATCH(ctx, scatter_pcoll_t<double>(ctx, A, n, flags & PCL_SCATTER_WAVELENGTH, c, h, tmp),
+                          scatter_pcoll_t<float>(ctx, A, n, flags & PCL_SCATTER_WAVELENGTH, c, h, tmp));
+    if (rc == PCL_OK) rc = pcl_d2h(ctx, pcoll_out_host, tmp, N * (int64_t)ctx->esz);
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int pcl_step_delete_flags(pcl_ctx *ctx, const int32_t *flags_host, int64_t *n_alive_out, int64_t *n_removed_out) {
+    PCL_TRY(need_store(ctx));
+    const int64_t N = ctx->count;
+    if (n_alive_out) *n_alive_out = N;
+    if (n_removed_out) *n_removed_out = 0;
+    if (N == 0) return PCL_OK;
+    if (!flags_host) return fail(PCL_ERR_ARG, "flags_host is NULL");
+    PCL_TRY(ensure_scratch(ctx, N));
+    PCL_TRY(ensure_alt(ctx));
+    int32_t *d_flags = nullptr;
+    PCL_TRY(dev_alloc(&d_flags, N));
+    int rc = pcl_h2d(ctx, d_flags, flags_host, N * (int64_t)sizeof(int32_t));
+    if (rc == PCL_OK) {
+        delmask_args<double> m{};
+        m.flags_in = d_flags;
+        m.masks = ctx->masks;
+        m.tile_keep = ctx->tile_keep;
+        m.N = N;
+        hipLaunchKernelGGL(k_delete_mask<double>, dim3((int)div_up(N, kTile)), dim3(kBlock), 0, ctx->stream, m);
+        rc = launch_check("k_delete_mask");
+    }
+    if (rc == PCL_OK) rc = scan_tiles(ctx, N);
+    if (rc == PCL_OK) {
+        compact_args ca{};
+        const int nf = compact_fields(ctx, ca, true, false); // every field is real here (need_store materialised)
+        (void)nf;
+        if (ctx->dtype == PCL_DTYPE_F64)
+            hipLaunchKernelGGL((k_compact<uint64_t, PCL_NFIELDS>), dim3((int)div_up(N, kTile)), dim3(kBlock), 0, ctx->stream, ca);
+        else
+            hipLaunchKernelGGL((k_compact<uint32_t, PCL_NFIELDS>), dim3((int)div_up(N, kTile)), dim3(kBlock), 0, ctx->stream, ca);
+        rc = launch_check("k_compact");
+    }
+    if (rc == PCL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PCL_ERR_HIP, "sync failed");
+    (void)hipFree(d_flags);
+    PCL_TRY(rc);
+    int64_t alive = 0;
+    PCL_TRY(wait_count(ctx, N, &alive));
+    adopt_compacted(ctx, alive, N);
+    if (n_alive_out) *n_alive_out = alive;
+    if (n_removed_out) *n_removed_out = N - alive;
     return PCL_OK;
 }
 

@@ -141,7 +141,21 @@ class ScatterDeleteStep(DeviceStep):
 
 class ScatterDeleteStepReference(ScatterDeleteStep):
     """Second statement of the same step in the reference (physicl/light.py:131-223): same kernel maths with
-    the argument order (dx, dy, dz, rand, n, A, result)."""
+    the argument order (dx, dy, dz, rand, n, A, result).  Unlike ScatterDeleteStep it has a CPU path
+    (``__run_py``, light.py:216-223), selected by ``Simulation(cl_on=False)``: that path removes photons from the list
+    it is iterating over, so the object after every removed photon is skipped -- neither tested nor drawing a random
+    number (456 instead of the expected 586 removals of 2000 photons per step at pcoll 0.3).  Reproduced as it is."""
+
+    def _device_run(self, sim):
+        if not sim._py_semantics():
+            return ScatterDeleteStep._device_run(self, sim)
+        from . import pyorder
+        dev = sim._dev
+        A_k, n_k = self._kernel_consts()
+        pcoll = dev.scatter_pcoll(A_k, n_k, 0, 0.0, 0.0)                     # n * A * |dr|   light.py:220
+        photon = None if sim._all_photons else dev.download_kind() != 0
+        alive, removed = dev.step_delete_flags(pyorder.flags_delete_reference_py(pcoll, photon))
+        sim._alive, self.removed = alive, removed
 
 
 # ---------------------------------------------------------------------------------------------- isotropic scatter
@@ -174,7 +188,30 @@ class ScatterIsotropicStep(DeviceStep):
         expr = str(self.variable_n_fn) if self.variable_n else None
         return dict(A=_kernel_const(self.n), n=_kernel_const(self.A), flags=flags, c=c_lit, h=h_lit, n_expr=expr)
 
+    def _run_py_semantics(self, sim):
+        """``Simulation(cl_on=False)``: ScatterIsotropicStep.__run_py (physicl/light.py:335-350) -- per photon one
+        draw for the decision and, only on a hit, phi then theta; a hit leaves ``dv = v_old``; ``variable_n`` is
+        ignored ("this does not support variable n scattering", light.py:334).  The host walks the np.random stream
+        against the device's collision probabilities (physicl_amd/pyorder.py); kernel and write-back run on the device."""
+        from . import pyorder
+        hip, dev = sim._hip, sim._dev
+        flags = hip.SCATTER_WAVELENGTH if self.wavelength_dep_scattering else 0
+        A_k, n_k = _kernel_const(self.n), _kernel_const(self.A)
+        c_val, h_val = float(np.asarray(c)), float(np.asarray(h))            # the path multiplies the Measurements themselves
+        pcoll = dev.scatter_pcoll(A_k, n_k, flags, c_val, h_val)             # n * A * |dr| [* ((h*c)/E)**-4]   light.py:339-341
+        photon = None if sim._all_photons else dev.download_kind() != 0
+        rtheta, rphi, rand, hits = pyorder.draw_isotropic_py(pcoll, photon)
+        for w, arr in enumerate((rtheta, rphi, rand)):
+            dev.upload_rand(w, arr)
+        got = dev.step_scatter_isotropic(A_k, n_k, flags | hip.SCATTER_PY_DV, c_val, h_val, None, hip.RNG_INPUT, 0, 0)
+        if got != hits:
+            raise RuntimeError("cl_on=False scatter: the host walked %d hits, the device applied %d" % (hits, got))
+        sim._scattered = True
+        sim.hits = hits
+
     def _device_run(self, sim):
+        if sim._py_semantics():
+            return self._run_py_semantics(sim)
         hip, dev = sim._hip, sim._dev
         p = self._kernel_params(sim)
         mode = sim._rng_mode()

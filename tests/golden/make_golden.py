@@ -354,6 +354,89 @@ def g4_delete():
 
 
 # ----------------------------------------------------------------------------------------------
+# G3  the reference's CPU paths of the light steps, cl_on=False, unmodified reference code:
+#     ScatterIsotropicStep.__run_py (light.py:335-350): RNG order rand, then -- only on a hit -- phi, then theta;
+#     dv = v_old on a hit; variable_n ignored.   ScatterDeleteStepReference.__run_py (light.py:216-223): removes from
+#     the list it is iterating over, so the element after every removal is skipped (and draws no random number).
+# ----------------------------------------------------------------------------------------------
+def _num(x, shape=None):
+    a = np.asarray(x, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _run_iso_py(tag, N, K, dt, seed, step_kwargs, E_range=None, with_objects=False):
+    out = {}
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=False)
+    objs = _photons(N, rng, *(E_range or (None, None)))
+    if with_objects:                       # plain Objects in between: moved by Newton, skipped by the light step (light.py:337)
+        for i in range(0, N, 5):
+            objs[i] = physicl.Object(v=physicl.Measurement(rng.normal(size=3) * 1e8, "m**1 s**-1"), uid=i)
+    sim.add_objs(objs)
+    out["init_E"] = _state(sim.objects)["E"]
+    out["init_v"] = _state(sim.objects)["v"]
+    out["is_photon"] = np.array([type(o) is light.PhotonObject for o in sim.objects])
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    sc = light.ScatterIsotropicStep(**step_kwargs)
+    sign = light.ScatterSignMeasureStep(None, True)
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    out["seed"], out["dt"], out["K"] = np.int64(seed), np.float64(dt), np.int64(K)
+    out["A_user"], out["n_user"] = np.float64(sc.A), np.float64(sc.n)
+    for k in range(K):
+        upd.run(sim)
+        nk.run(sim)
+        sc.run(sim)
+        sign.run(sim)
+        for f in ("r", "v", "dr", "dv"):
+            out["k%d_post_%s" % (k, f)] = np.array([_num(getattr(o, f), 3) for o in sim.objects])
+    out["sign_rows"] = np.array(sign.data, dtype=np.float64)
+    out["next_draw"] = np.float64(np.random.random())      # where the global MT19937 stream stands after K steps
+    _save("g3_iso_py_" + tag, **out)
+
+
+def g3_iso_py():
+    E_lo = float(light.E_from_wavelength(700e-9))
+    E_hi = float(light.E_from_wavelength(200e-9))
+    _run_iso_py("base", 2048, 4, 1e-3, 31, dict(A=np.double(0.001), n=np.double(0.001)))
+    _run_iso_py("lambda", 1024, 3, 5e-3, 32,
+                dict(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True), E_range=(E_lo, E_hi))
+    # variable_n is silently ignored by the CPU path ("this does not support variable n scattering", light.py:334)
+    _run_iso_py("varn_ignored", 1024, 2, 1e-3, 33,
+                dict(A=np.double(0.001), n=np.double(0.0007), variable_n=True, variable_n_fn="0.000000001 * exp(r0[gid] - 5)"),
+                with_objects=True)
+
+
+def g3_delete_py():
+    N, dt, seed, A, n = 2000, 1e-3, 41, 0.001, 0.001
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=False)
+    objs = _photons(N, rng)
+    for i in range(7, N, 11):
+        objs[i] = physicl.Object(v=physicl.Measurement(rng.normal(size=3) * 1e8, "m**1 s**-1"), uid=i)
+    sim.add_objs(objs)
+    out = {"seed": np.int64(seed), "dt": np.float64(dt), "A_user": np.float64(A), "n_user": np.float64(n), "N": np.int64(N),
+           "is_photon": np.array([type(o) is light.PhotonObject for o in sim.objects]),
+           "init_v": _state(sim.objects)["v"]}
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    sc = light.ScatterDeleteStepReference(np.double(n), np.double(A))
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    K = 6
+    for k in range(K):
+        upd.run(sim)
+        nk.run(sim)
+        sc.run(sim)
+        out["k%d_survivor_uid" % k] = _state(sim.objects)["uid"]
+        out["k%d_post_r" % k] = _state(sim.objects)["r"]
+    out["K"] = np.int64(K)
+    out["next_draw"] = np.float64(np.random.random())
+    _save("g3_delete_py", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -497,6 +580,8 @@ def main():
     g1_newton()
     g2_iso()
     g4_delete()
+    g3_iso_py()
+    g3_delete_py()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

@@ -105,23 +105,34 @@ def test_host_plugins_see_and_modify_real_objects():
     assert sim.objects[0] in sim.objects and sim.objects.index(sim.objects[1]) == 1
 
 
-def test_device_steps_refuse_to_run_without_a_device():
+def _no_gpu_here():
+    from physicl_amd import _hip
+    return _hip.device_count() == 0
+
+
+@pytest.mark.skipif(not _no_gpu_here(), reason="needs a machine WITHOUT a GPU")
+def test_device_steps_fail_loudly_without_a_gpu():
+    """cl_on=False selects the reference's CPU-path semantics, not a CPU implementation: the steps still need the HIP
+    device (created on first use) and raise when there is none -- nothing falls back to the host."""
     sim = phys.Simulation(cl_on=False, exit=lambda s: s.t >= 0.001)
+    assert sim.cl_ctx is None and sim.cl_q is None and sim._dev is None          # as the reference: no context yet
     sim.add_objs(photons(2))
     sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
     sim.add_step(1, newton.NewtonianKinematicsStep())
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
+    with pytest.raises(RuntimeError, match="no ROCm-capable device|PCL_ERR"):
         sim.run()
     assert sim.running is False and isinstance(sim.error, RuntimeError)
     for step in (light.ScatterIsotropicStep(A=1e-3, n=1e-3), light.ScatterDeleteStep(1e-3, 1e-3),
-                 light.ScatterSignMeasureStep(None)):
-        with pytest.raises(RuntimeError, match="no CPU implementation"):
+                 light.ScatterDeleteStepReference(1e-3, 1e-3), light.ScatterSignMeasureStep(None)):
+        with pytest.raises(RuntimeError, match="no ROCm-capable device|PCL_ERR"):
             step.run(sim)
+    with pytest.raises(RuntimeError, match="no ROCm-capable device|PCL_ERR"):
+        phys.Simulation(cl_on=True)                                              # the default creates the context at once
 
 
 def test_fusion_plan_groups_only_adjacent_native_steps():
-    sim = phys.Simulation(cl_on=False)
-    sim._dev = object()                               # planning only looks at whether a device exists
+    sim = phys.Simulation(cl_on=False)                # (no device needed for planning)
+    sim.cl_on = True                                  # cl_on=False would switch fusion off: see the end of this test
     upd, nk = phys.UpdateTimeStep(lambda s: 1e-3), newton.NewtonianKinematicsStep()
     sc = light.ScatterIsotropicStep(A=1e-3, n=1e-3)
     sign = light.ScatterSignMeasureStep(None)
@@ -134,7 +145,8 @@ def test_fusion_plan_groups_only_adjacent_native_steps():
     assert plan[1][1] == [nk, sc, sign, meas] and plan[3][1] == [nk2, dele]   # Newton + Delete: one pipeline
     sim.fuse = False
     assert all(k == "single" for k, _ in sim._build_plan())
-    sim._dev = None
+    sim.fuse, sim.cl_on = True, False                 # the reference's CPU-path semantics: nothing is fused
+    assert all(k == "single" for k, _ in sim._build_plan())
 
 
 def test_measure_step_csv_and_kernel_glue_stubs(tmp_path):
@@ -149,8 +161,9 @@ def test_measure_step_csv_and_kernel_glue_stubs(tmp_path):
     prog = phys.CLProgram(sim, "k", "int gid = get_global_id(0); res[gid] = 1;")
     prog.prep_metadata, prog.output_metadata = [i, phys.CLInput(name="A", type="const", const_value="2.5")], [o]
     assert prog._signature() == [("double", "d0", True), ("double", "A", False), ("int", "res", True)]
-    with pytest.raises(RuntimeError, match="no CPU implementation"):
-        prog.build_kernel()
+    if _no_gpu_here():
+        with pytest.raises(RuntimeError, match="no ROCm-capable device|PCL_ERR"):
+            prog.build_kernel()
     m_e = light.ScatterMeasureStep(None, True, [[1.0, np.nan, np.nan]], measure_E=True)
     assert m_e._fuse_role is None and light.ScatterMeasureStep(None, True, [])._fuse_role == "measure"   # ragged rows: not fused
 

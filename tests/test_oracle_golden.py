@@ -222,3 +222,52 @@ def test_planck_table_matches_the_reference_density():
     E = orc.philox_table_energy(3, np.arange(200000), cdf, grid)
     counts = np.array([(E == g).sum() for g in grid]) / len(E)
     assert np.max(np.abs(counts - np.diff(np.concatenate([[0.0], cdf])))) < 4e-3
+
+
+# ------------------------------------------------------------------ G3 the reference's CPU paths (cl_on=False)
+@pytest.mark.parametrize("tag,use_E", [("base", False), ("lambda", True), ("varn_ignored", False)])
+def test_iso_py_path_bit_exact(golden, tag, use_E):
+    """ScatterIsotropicStep.__run_py (light.py:335-350) restated: the fixture ran the reference unmodified under
+    cl_on=False with numpy's own sin / cos / power, so everything -- hit decisions, new velocities, dv = v_old, the
+    Euler moves fed by them, and the position of the np.random stream afterwards -- is bit-exact."""
+    z = golden("g3_iso_py_" + tag)
+    N, K, dt = len(z["init_E"]), int(z["K"]), float(z["dt"])
+    U = np.random.RandomState(int(z["seed"])).random_sample(3 * N * K + 1)
+    ph = z["is_photon"]
+    st = {"r": [np.zeros(N) for _ in range(3)], "v": cols(z["init_v"]), "dr": [np.zeros(N) for _ in range(3)],
+          "dv": [np.zeros(N) for _ in range(3)], "E": z["init_E"].copy(), "id": np.arange(N)}
+    pos = 0
+    for k in range(K):
+        orc.step_newton(st, dt)
+        before = [x.copy() for x in st["dv"]]
+        hit, used = orc.step_scatter_isotropic_py(st, U[pos:], float(z["n_user"]), float(z["A_user"]), C_LIT, h=H_LIT,
+                                                  use_E=use_E, is_photon=ph)
+        pos += used
+        for f in ("r", "v", "dr"):
+            assert np.array_equal(np.stack(st[f], 1), z["k%d_post_%s" % (k, f)]), (k, f)
+        dv = np.stack(st["dv"], 1)
+        assert np.array_equal(dv[ph], z["k%d_post_dv" % k][ph])          # plain Objects keep their own dv (all zero here)
+        assert hit[~ph].sum() == 0 and 0 < hit.sum() < ph.sum()
+        assert orc.sign_counts(st["v"]) == tuple(int(x) for x in z["sign_rows"][k][2:5])
+    assert U[pos] == float(z["next_draw"])                                # the stream stands where the reference left it
+
+
+def test_delete_reference_py_path_skips_the_object_after_every_removal(golden):
+    """ScatterDeleteStepReference.__run_py (light.py:216-223) restated, survivor ids per step and stream position."""
+    z = golden("g3_delete_py")
+    N, K, dt = int(z["N"]), int(z["K"]), float(z["dt"])
+    U = np.random.RandomState(int(z["seed"])).random_sample(N * K + 1)
+    ph_all = z["is_photon"]
+    st = {"r": [np.zeros(N) for _ in range(3)], "v": cols(z["init_v"]), "dr": [np.zeros(N) for _ in range(3)],
+          "dv": [np.zeros(N) for _ in range(3)], "E": np.ones(N), "id": np.arange(N)}
+    pos = 0
+    for k in range(K):
+        orc.step_newton(st, dt)
+        removed, used = orc.step_scatter_delete_reference_py(st, U[pos:], float(z["n_user"]), float(z["A_user"]),
+                                                             is_photon=ph_all[st["id"]])
+        pos += used
+        assert np.array_equal(st["id"], z["k%d_survivor_uid" % k])
+        assert np.array_equal(np.stack(st["r"], 1), z["k%d_post_r" % k])
+    assert U[pos] == float(z["next_draw"])
+    # the quirk itself: far fewer photons go than pcoll = 0.2998 would remove from 1818 photons in the first step
+    assert N - len(z["k0_survivor_uid"]) < 0.85 * 0.2998 * ph_all.sum()
