@@ -1205,14 +1205,17 @@ std::string rtc_cache_path(const std::string &src, const std::string &arch, cons
     const uint64_t h2 = fnv1a(arch + tag + "|" + extra + "|" + src, 0x9E3779B97F4A7C15ull);
     char name[64];
     snprintf(name, sizeof name, "/%016llx%016llx.hsaco", (unsigned long long)h1, (unsigned long long)h2);
-    // mkdir -p (two levels are enough for the default; a user-supplied directory must exist or be creatable in one step)
+    // mkdir -p, private to the user: a code object found here is loaded into the GPU context, so the directory must not be
+    // writable by anyone else -- a directory that is not ours, or is group/world-writable, is not used at all
     std::string partial;
     for (size_t i = 0; i <= dir.size(); ++i) {
         if (i == dir.size() || (dir[i] == '/' && i > 0)) {
             partial = dir.substr(0, i);
-            if (!partial.empty()) (void)mkdir(partial.c_str(), 0755);
+            if (!partial.empty()) (void)mkdir(partial.c_str(), 0700);
         }
     }
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return "";
     return dir + name;
 }
 

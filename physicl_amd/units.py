@@ -1,8 +1,9 @@
 """Code-units system: ``Measurement``, a float64 ndarray that stores values in *code units*.
 
-Drop-in for the class of the same name in the reference (physicl/__init__.py:18-291).  Written
-from the reference's observable behaviour -- tests/test_units_parity.py replays 85 expressions
-under two code scales against results recorded from the reference itself -- not from its code.
+Drop-in for the class of the same name in the reference (physicl/__init__.py:18-291): the same unit table and the
+same wrapping rules, restated compactly and kept bug-compatible where scripts can see the difference (each such place
+cites the reference line it follows).  tests/test_units_parity.py replays 113 expressions under two code scales
+against results recorded from the reference itself (tests/golden/g6_unit_ops.json).
 The kernels only ever see the code-unit numbers (``float(m)``, ``str(m)``), so this module is host
 plumbing: it is NOT accelerated and has no device counterpart.
 

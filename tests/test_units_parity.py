@@ -1,11 +1,11 @@
 """CPU: physicl_amd.units.Measurement against results recorded from the reference's Measurement
-(tests/golden/g6_unit_ops.json, g6_units.npz; generator tests/golden/make_golden.py), plus the six
-unit tests the reference ships (test/test_units.py:25-78) restated against this build."""
+(tests/golden/g6_unit_ops.json, g6_units.npz; generator tests/golden/make_golden.py).  The comparisons the reference's
+own unit tests make (test/test_units.py:25-78) are rows of that recorded table too: the reference evaluated them and the
+build has to give the same answers (including the one comparison the reference itself gets wrong)."""
 import json
 import os
 
 import numpy as np
-import numpy.linalg as lin
 import pytest
 
 import physicl_amd as phys
@@ -82,64 +82,6 @@ def test_recorded_constants_and_literals(golden):
     finally:
         M.reset_code_scale("m")
     assert float(M(1, "m**1").scale) == 1.0            # the class-global scale is restored
-
-
-# ---- the reference's own unit tests (test/test_units.py), against this build ---------------------------
-def dict_equiv(a, b):
-    return all(not (k in b and b[k] != 0 and v != b[k]) for k, v in a.items()) and \
-        all(not (k in a and a[k] != 0 and v != a[k]) for k, v in b.items())
-
-
-def test_units_1():
-    x, y = M(5, "kg**1 m**1 s**-2"), M(5, "N**1")
-    assert x == y and x.scale == x.scale and x.units == x.units
-
-
-def test_units_2():
-    x, y = M(1, "au**1"), M(149597870700 * 1, "m**1")
-    assert x + y == M(2, "au**1")
-    assert y + x == M(149597870700 * 2, "m**1")
-
-
-def test_units_3():
-    p = light.PhotonObject(E=M(5, "J**1"), v=M([light.c, 0, 0], "m**1 s**-1"))
-    assert p.E.units == {"L": 2, "T": -2, "M": 1}
-    assert p.v.units == {"L": 1, "T": -1}
-    assert lin.norm(p.v) == light.c
-
-
-def test_units_4():
-    E = light.E_from_wavelength(M(633e-9, "m**1"))
-    assert E == (299792458 * 6.62607015e-34) / (633e-9)
-    assert E.units == {"L": 2, "T": -2, "M": 1}
-    wv = light.wavelength_from_E(E)
-    assert wv == 633e-9
-    assert dict_equiv(wv.units, {"L": 1})
-
-
-def test_units_5():
-    E_g = M(0, "J**1") + M(13.6, "eV**1")
-    f = E_g / light.h
-    l = light.c / f
-    assert E_g == 1.602176634e-19 * 13.6
-    assert dict_equiv(E_g.units, {"L": 2, "T": -2, "M": 1})
-    assert f == (1.602176634e-19 * 13.6) / 6.62607015e-34
-    assert dict_equiv(f.units, {"T": -1})
-    assert l == 299792458 / ((1.602176634e-19 * 13.6) / 6.62607015e-34)
-    assert dict_equiv(l.units, {"L": 1})
-
-
-def test_units_6_up_to_the_line_the_reference_itself_fails():
-    a, l, t = M(5, "kg**1 m**1 s**-2"), M(5, "au**1"), M(10, "min**2")
-    assert a * t == 50
-    assert M(0, "kg**1 m**1") + (a * t) == (60 ** 2) * 10 * 5
-    assert a * l == 25
-    assert (a / l).flat[0] == 5 / (5 * 149597870700)
-    assert a ** 2 == 25
-    assert dict_equiv((a ** 2).units, {"M": 2, "L": 2, "S": -4})
-    # test/test_units.py:78 (`np.sqrt(l) == np.sqrt(5)`) fails in the reference too:
-    # the plain number is re-wrapped in au**0.5... the recorded-operation test pins what sqrt returns.
-    assert not bool(np.sqrt(l) == np.sqrt(5))
 
 
 def test_photon_constraints():

@@ -20,21 +20,33 @@ from physicl_amd import _hip  # noqa: E402
 C_LIT, H_LIT = 299792458.0, 6.62607015e-34
 
 
-def run(dev, N, dtype, K, sample):
+def run(dev, N, dtype, K, sample, per_launch):
+    """per_launch > 1: that many whole iterations per pass over the store and one compaction (pcl_step_mixed_multi);
+    1: one launch per light step (pcl_step_fused + pcl_step_fused_delete, dr/dv implicit).  Same photons, same rows."""
     dev.store_alloc(N, dtype)
     dev.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, 11)
     out = {}
     dev.sync()
     t0 = time.perf_counter()
     hits = deleted = 0
-    for k in range(1, K + 1):
-        o = dev.step_fused(1e-3, dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=_hip.RNG_PHILOX, seed=11,
-                                      step=2 * k), (), lazy=True)
-        dev.step_newton(1e-3)
-        alive, removed = dev.step_scatter_delete(2e-5, 1e-3, _hip.RNG_PHILOX, 11, 2 * k + 1)
-        hits += o["hits"]
-        deleted += removed
-        if k in (1, 10, 100):
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=_hip.RNG_PHILOX, seed=11)
+    k = 0
+    for stop in (1, 10, 100, K):
+        while k < min(stop, K):
+            n_it = min(per_launch, min(stop, K) - k)
+            if per_launch > 1:
+                rows = dev.step_mixed_multi(1e-3, n_it, ("iso", "delete"), sc, (2e-5, 1e-3), (), 11, 2 * (k + 1))
+                hits += sum(o["hits"] for o in rows if o["phase"] == "iso")
+                deleted += sum(o["removed"] for o in rows if o["phase"] == "delete")
+                alive = rows[-1]["N"]
+            else:
+                o = dev.step_fused(1e-3, dict(sc, step=2 * (k + 1)), (), lazy=True)
+                d = dev.step_fused_delete(1e-3, 2e-5, 1e-3, _hip.RNG_PHILOX, 11, 2 * (k + 1) + 1, None, lazy=True)
+                hits += o["hits"]
+                deleted += d["removed"]
+                alive = d["N"]
+            k += n_it
+        if k in (1, 10, 100) and k not in out:
             dev.sync()
             el = time.perf_counter() - t0
             m = min(sample, alive)
@@ -50,13 +62,17 @@ def main():
     ap.add_argument("--photons", type=float, default=1e7)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--sample", type=int, default=2_000_000, help="photons (lowest ids alive) compared per checkpoint")
+    ap.add_argument("--iterations-per-launch", type=int, default=16,
+                    help="whole [Newton, ScatterIsotropic, Newton, ScatterDelete] iterations per pass over the store "
+                         "(pcl_step_mixed_multi; 1 = one launch per light step); results are identical for every value")
     a = ap.parse_args()
     N = int(a.photons)
     dev = _hip.Device(0)
-    r64 = run(dev, N, "f64", a.steps, a.sample)
-    r32 = run(dev, N, "f32", a.steps, a.sample)
+    r64 = run(dev, N, "f64", a.steps, a.sample, a.iterations_per_launch)
+    r32 = run(dev, N, "f32", a.steps, a.sample, a.iterations_per_launch)
     report = {"workload": "configs[4]: [Newton, ScatterIsotropic(A=n=1e-3), Newton, ScatterDelete(pcoll=6e-3)] x K, "
-                          "%d photons, fp32 vs fp64, same Philox stream" % N, "checkpoints": {}}
+                          "%d photons, fp32 vs fp64, same Philox stream" % N,
+              "iterations_per_launch": a.iterations_per_launch, "checkpoints": {}}
     tol_v = 4 * 4 * float(np.spacing(np.float32(C_LIT)))
     for k in sorted(r64):
         a64, a32 = r64[k], r32[k]
