@@ -952,6 +952,216 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
 }
 
+// NQ: VEC-wide groups per lane and trip (photons per lane = VEC * NQ).  The dense pass costs the same whether 5 or 64
+// of its lanes carry a hit, so the more photons a wave queues per step the fuller its passes: with NQ = 2 a wave owns
+// 128 * NQ photons per trip and, while their hits fit the queue (<= 64 * VEC), handles them in ONE round of
+// ceil(hits / 64) passes; a busier step falls back to one round per group.  Same operations per photon either way.
+template <typename T, bool USE_E, bool VAR_N, int VEC, int NQ>
+__device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
+    typedef pcl_rt<T> R;
+    typedef pcl_vec<T, VEC> VV;
+    constexpr int NP = VEC * NQ; // photons per lane
+    __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
+    const int nslots = 4 + a.n_planes;
+    __shared__ pcl_hit_queue<T, VEC> s_q;
+    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    const pcl_i64 nq = (a.N + VEC - 1) / VEC;
+    const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x * NQ;
+    const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
+    constexpr pcl_u32 QCAP = 64u * VEC;
+    for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x * NQ; base < nq; base += stride) {
+        pcl_i64 q[NQ], qs[NQ];
+        bool live_q[NQ];
+        T Rr[3][NP], V[3][NP], L4[NP], Ev[NP], NM[NP];
+        pcl_u32 wodd0[NP], wodd1[NP]; // the decision block's second half, waiting for the odd step
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) {
+            q[g] = base + (pcl_i64)g * blockDim.x + threadIdx.x;
+            live_q[g] = q[g] < nq;
+            qs[g] = pcl_tq<VEC>(live_q[g] ? q[g] : 0, a.ts);
+            T t0[VEC], t1[VEC], t2[VEC], t3[VEC], t4[VEC], t5[VEC], t6[VEC];
+            VV::ld(a.r0, qs[g], t0);
+            VV::ld(a.r1, qs[g], t1);
+            VV::ld(a.r2, qs[g], t2);
+            VV::ld(a.v0, qs[g], t3);
+            VV::ld(a.v1, qs[g], t4);
+            VV::ld(a.v2, qs[g], t5);
+            if constexpr (USE_E) VV::ld(a.lam4, qs[g], t6);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int p = g * VEC + e;
+                Rr[0][p] = t0[e];
+                Rr[1][p] = t1[e];
+                Rr[2][p] = t2[e];
+                V[0][p] = t3[e];
+                V[1][p] = t4[e];
+                V[2][p] = t5[e];
+                L4[p] = (T)1;
+                if constexpr (USE_E) L4[p] = t6[e];
+                Ev[p] = a.E[pcl_tix((live_q[g] && q[g] * VEC + e < a.N) ? q[g] * VEC + e : 0, a.ts)];
+                // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
+                NM[p] = pcl_step_norm<T>(R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt), R::mul(V[2][p], a.dt));
+            }
+        }
+        for (int k = 0; k < a.K; ++k) {
+            const pcl_u32 st = a.step + (pcl_u32)k;
+            // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push
+            // other scalars into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler
+            // rebuild them per iteration on the otherwise idle scalar unit instead.
+            pcl_u32 kk0 = k0, kk1 = k1;
+            asm volatile("" : "+s"(kk0), "+s"(kk1));
+            pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
+            bool hit[NP];
+            pcl_u32 slot[NP];
+            pcl_u64 ballot[NP];
+            const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int g = p / VEC, e = p % VEC;
+                const pcl_i64 i = q[g] * VEC + e;
+                const bool live = live_q[g] && i < a.N;
+                // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
+                const T d0 = R::mul(V[0][p], a.dt), d1 = R::mul(V[1][p], a.dt), d2 = R::mul(V[2][p], a.dt);
+                Rr[0][p] = R::add(Rr[0][p], d0);
+                Rr[1][p] = R::add(Rr[1][p], d1);
+                Rr[2][p] = R::add(Rr[2][p], d2);
+                // plane crossings of this step's move (r - dr, r)                        light.py:385-399
+                for (int pl = 0; pl < a.n_planes; ++pl) {
+                    const int ax = a.plane_ax[pl];
+                    const T L = a.plane_L[pl];
+                    const T x = pcl_pick<T>(ax, Rr[0][p], Rr[1][p], Rr[2][p]);
+                    const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
+                    const pcl_u32 nc = (pcl_u32)__popcll(__ballot(live && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
+                }
+                // scatter decision                                                       light.py:303-308
+                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p],
+                                                       Ev[p]);
+                if constexpr (USE_E) pc = R::mul(pc, L4[p]);
+                const pcl_u64 id = (pcl_u64)(a.id_base + i);
+                T rand;
+                if (new_block) { // decision block of steps (st & ~1, st | 1): computed once for the pair
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
+                    rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    wodd0[p] = w.z;
+                    wodd1[p] = w.w;
+                } else {
+                    rand = R::uniform(wodd0[p], wodd1[p]);
+                }
+                hit[p] = live && (pc >= rand);
+                ballot[p] = __ballot(hit[p]);
+                w_hits += (pcl_u32)__popcll(ballot[p]);
+#ifdef PCL_NQ_SCHED_BARRIER
+                __builtin_amdgcn_sched_barrier(0); // one photon's Philox / exp chain at a time: their temporaries do not pile up
+#endif
+            }
+            if (k + 1 == a.K) { // the velocity before the LAST step is what dv = v - v_prev needs: stored straight
+#pragma unroll                  // from the v registers (wave-uniform branch), no copy kept
+                for (int g = 0; g < NQ; ++g)
+                    if (live_q[g]) {
+                        T t3[VEC], t4[VEC], t5[VEC];
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            t3[e] = V[0][g * VEC + e];
+                            t4[e] = V[1][g * VEC + e];
+                            t5[e] = V[2][g * VEC + e];
+                        }
+                        VV::st(a.vp0, qs[g], t3);
+                        VV::st(a.vp1, qs[g], t4);
+                        VV::st(a.vp2, qs[g], t5);
+                    }
+            }
+            // One round for all of the wave's hits when they fit its queue, else one round per group.  The queue is
+            // private to the wave: LDS executes a wave's accesses in order, so a compiler-level fence is all the
+            // hand-over needs -- no workgroup barrier anywhere in the K loop.
+            const int rounds = (NQ == 1 || w_hits <= QCAP) ? 1 : NQ; // wave-uniform
+            for (int rd = 0; rd < rounds; ++rd) {
+                pcl_u32 wbase = qbase;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (rounds == 1 || p / VEC == rd) {
+                        slot[p] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(ballot[p] >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)ballot[p], 0u));
+                        wbase += (pcl_u32)__popcll(ballot[p]);
+                        if (hit[p]) s_q.owner[slot[p]] = threadIdx.x * NP + p;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                // the scatter itself, densely: item j by lane j                                light.py:309-311
+                for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
+                    const pcl_u32 o = s_q.owner[j];
+                    const pcl_u32 ot = o / NP, op = o % NP;
+                    const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(op / VEC) * blockDim.x + (pcl_i64)ot) * VEC + (pcl_i64)(op % VEC));
+                    T rtheta, rphi;
+                    pcl_draw_angles<T>(id, st, kk0, kk1, rtheta, rphi);
+                    T o0, o1, o2;
+                    pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
+                    s_q.out[0][j] = o0;
+                    s_q.out[1][j] = o1;
+                    s_q.out[2][j] = o2;
+                    s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if ((rounds == 1 || p / VEC == rd) && hit[p]) {
+                        V[0][p] = s_q.out[0][slot[p]];
+                        V[1][p] = s_q.out[1][slot[p]];
+                        V[2][p] = s_q.out[2][slot[p]];
+                        NM[p] = s_q.out[3][slot[p]];
+                    }
+                }
+                if (NQ > 1) { // the next round reuses the queue: its reads above come first (same wave, in order)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int g = p / VEC, e = p % VEC;
+                const bool live = live_q[g] && q[g] * VEC + e < a.N;
+                w_sx += (pcl_u32)__popcll(__ballot(live && V[0][p] > (T)0));
+                w_sy += (pcl_u32)__popcll(__ballot(live && V[1][p] > (T)0));
+                w_sz += (pcl_u32)__popcll(__ballot(live && V[2][p] > (T)0));
+            }
+            if (lane0) {
+                if (w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
+                if (w_sx) atomicAdd(&s_cnt[nslots * k + 1], w_sx);
+                if (w_sy) atomicAdd(&s_cnt[nslots * k + 2], w_sy);
+                if (w_sz) atomicAdd(&s_cnt[nslots * k + 3], w_sz);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NQ; ++g)
+            if (live_q[g]) {
+                T t0[VEC], t1[VEC], t2[VEC], t3[VEC], t4[VEC], t5[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const int p = g * VEC + e;
+                    t0[e] = Rr[0][p];
+                    t1[e] = Rr[1][p];
+                    t2[e] = Rr[2][p];
+                    t3[e] = V[0][p];
+                    t4[e] = V[1][p];
+                    t5[e] = V[2][p];
+                }
+                VV::st(a.r0, qs[g], t0);
+                VV::st(a.r1, qs[g], t1);
+                VV::st(a.r2, qs[g], t2);
+                VV::st(a.v0, qs[g], t3);
+                VV::st(a.v1, qs[g], t4);
+                VV::st(a.v2, qs[g], t5);
+            }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Level 2, K whole passes of a loop whose body holds an isotropic-scatter phase and/or a delete phase --
 //   [Newton, ScatterIsotropic] | [Newton, ScatterDelete] | [Newton, ScatterIsotropic, Newton, ScatterDelete] (either order)
@@ -1221,5 +1431,16 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e
 }
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float, false, true, 4>))
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
+#ifdef PCL_MULTI_NQ2 /* experiment: two groups per lane and trip */
+#ifndef PCL_MULTI2_ATTR
+#define PCL_MULTI2_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#endif
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e0(pcl_multi_args<double> a) {
+    pcl_multi_body_nq<double, false, true, 2, 2>(a);
+}
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e1(pcl_multi_args<double> a) {
+    pcl_multi_body_nq<double, true, true, 2, 2>(a);
+}
+#endif
 #endif
 #endif // PCL_DEVICE_H

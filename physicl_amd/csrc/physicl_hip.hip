@@ -915,6 +915,7 @@ struct rtc_entry {
     hipFunction_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t multi2[2] = {nullptr, nullptr}; // experiment (PCL_RTC_EXTRA=PCL_MULTI_NQ2): two groups per lane, fp64
 };
 
 } // namespace
@@ -1369,6 +1370,12 @@ int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &cod
             snprintf(nm, sizeof nm, "pcl_rtc_mixed_%se%d", dt_tag[d], e);
             PCL_HIP(hipModuleGetFunction(&ent.mixed[d][e], ent.module, nm));
         }
+    for (int e = 0; e < 2; ++e) { // optional kernels: absent unless the experiment define was given
+        char nm[64];
+        snprintf(nm, sizeof nm, "pcl_rtc_multi2_e%d", e);
+        if (hipModuleGetFunction(&ent.multi2[e], ent.module, nm) != hipSuccess) ent.multi2[e] = nullptr;
+    }
+    (void)hipGetLastError();
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
     return PCL_OK;
@@ -1613,10 +1620,14 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
         f.plane_ax[p] = ax;
         f.plane_L[p] = (T)loc[ax];
     }
-    const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
+    int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    if (var_n) {
+    static const bool nq2 = getenv("PCL_MULTI_NQ2") != nullptr; // perf-experiment hook
+    if (var_n && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
+        grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
+        PCL_TRY(launch_module(ctx, ent->multi2[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 (hipRTC)"));
+    } else if (var_n) {
         PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
     } else {
         if (use_e)

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (tools/prof_driver_cmd.sh: rocprofv3 of the driver's bench command) into profiles/:
+
+  profiles/<tag>_kernel_stats.csv          rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_kernel_trace.csv          every kernel dispatch of the run: kernel, grid, start, duration (ns)
+  profiles/<tag>_bench_under_rocprof.json  the line bench.py printed in the trace pass
+  profiles/<tag>_pmc.md                    per-dispatch HBM bytes (PMC) and SQ counters of the timed kernels, and the
+                                           recomputation of every roofline fraction in the bench line from the trace
+  profiles/pmc_traffic.json                the entry bench.py shows under "static_profile"
+
+gfx950 counter corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports FETCH_SIZE / WRITE_SIZE in kilobytes
+(x1024 -> bytes); FETCH_SIZE counts 64 B per 128-B request on wide coalesced streams, i.e. exactly HALF the bytes fetched,
+so it is doubled; WRITE_SIZE is exact.  (Calibrated in round 1 on k_newton = 96.0 B and k_counters = 24.0 B per particle;
+8-byte-per-lane kernels -- the delete passes -- are listed with the same correction and marked uncalibrated.)"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK = 8000.0
+
+
+def short(k):
+    k = k.replace("(anonymous namespace)::", "").replace("void ", "")
+    return k.split("(")[0][:48]
+
+
+def read_counter(path):
+    """{kernel: [ {counter: value} per dispatch, in order ]}"""
+    per = collections.defaultdict(dict)
+    order = []
+    for r in csv.DictReader(open(path)):
+        key = (int(r["Dispatch_Id"]), r["Kernel_Name"])
+        if key not in per:
+            order.append(key)
+        per[key][r["Counter_Name"]] = per[key].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    out = collections.defaultdict(list)
+    for key in order:
+        out[short(key[1])].append(per[key])
+    return out
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    args = open(os.path.join(src, "bench_args.txt")).read().strip()
+    shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "trace_bench.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+    line = json.loads([ln for ln in open(os.path.join(src, "trace_bench.json")) if ln.strip()][-1])
+    N, steps, warmup, R = line["config"]["photons_per_gpu"], line["steps"], line["warmup"], line["repeats"]
+    S = line["config"]["steps_per_launch"]
+    # ---- per-dispatch trace
+    rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))))
+    t0 = min(int(r["Start_Timestamp"]) for r in rows)
+    disp = collections.defaultdict(list)
+    with open(os.path.join(dst, tag + "_kernel_trace.csv"), "w") as f:
+        f.write("dispatch,kernel,grid_x,start_ns,duration_ns\n")
+        for r in rows:
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            k = short(r["Kernel_Name"])
+            disp[k].append(d)
+            f.write("%s,%s,%s,%d,%d\n" % (r["Dispatch_Id"], k, r["Grid_Size_X"], int(r["Start_Timestamp"]) - t0, d))
+    fetch = read_counter(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"))
+    write = read_counter(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"))
+    sq = read_counter(os.path.join(src, "pmc_sq", "pmc_counter_collection.csv"))
+    L = ["# %s: rocprofv3 of `python3 bench.py %s`" % (tag, args), "",
+         "Four runs of the same command (`--kernel-trace --stats`; `--kernel-trace --pmc FETCH_SIZE`; `... WRITE_SIZE`; "
+         "`... SQ_*` -- the PMC passes with `--no-cpu-baseline`, which launches no kernel).  Schedule of the run: %d warm-up "
+         "steps (one K = %d launch of the K-step kernel), %d timed blocks of %d steps (one K = %d launch each), then the "
+         "`single_step` leg (3 + %d x %d launches of the one-step kernel), the `delete` legs and the `api` leg."
+         % (warmup, min(S, warmup), R, steps, min(S, steps), R, steps), "",
+         "## K-step kernel `pcl_rtc_multi_e1`, every dispatch (bench.py's own launches; the last two belong to the `api` leg)", "",
+         "Bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); "
+         "lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64); VALU instr / particle-step = SQ_INSTS_VALU x 64 / (N x K).", "",
+         "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
+         "|---|---|---|---|---|---|---|---|---|"]
+    km = "pcl_rtc_multi_e1"
+    ks = [min(S, warmup)] + [min(S, steps)] * R
+    multi_rows = []
+    for i, d in enumerate(disp.get(km, [])):
+        K = ks[i] if i < len(ks) else None
+        fb = fetch[km][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(km, [])) else 0
+        wb = write[km][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(km, [])) else 0
+        c = sq[km][i] if i < len(sq.get(km, [])) else {}
+        busy = c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) if c.get("GRBM_GUI_ACTIVE") else 0
+        util = c.get("SQ_THREAD_CYCLES_VALU", 0) / (c["SQ_ACTIVE_INST_VALU"] * 64) if c.get("SQ_ACTIVE_INST_VALU") else 0
+        per_ps = c.get("SQ_INSTS_VALU", 0) * 64 / (N * K) if K else 0
+        gb = 128.0 * N / (d * 1e-9) / 1e9
+        multi_rows.append((K, d, fb + wb, busy, util, per_ps))
+        L.append("| %d | %s | %.3f | %.1f | %.0f | %.4f | %.3f | %.3f | %s |" % (i, K if K else "api", d * 1e-6, (fb + wb) / N, gb, gb / HBM_PEAK, busy, util,
+                                                                              "%.1f" % per_ps if K else "-"))
+    timed = [r for r in multi_rows[1:1 + R]]
+    if timed:
+        avg = sum(r[1] for r in timed) / len(timed)
+        L += ["", "Timed launches (rows 1..%d): average %.3f ms -> 128 B x N / t = %.0f GB/s = **%.4f** of peak (bench line under rocprof: "
+              "`roofline.avg_launch_ms` %.3f, `frac` %.4f); in the per-step form 104 B x %d x N / t = %.0f GB/s."
+              % (R, avg * 1e-6, 128.0 * N / (avg * 1e-9) / 1e9, 128.0 * N / (avg * 1e-9) / 1e9 / HBM_PEAK, line["roofline"]["avg_launch_ms"],
+                 line["roofline"]["frac"], min(S, steps), 104.0 * min(S, steps) * N / (avg * 1e-9) / 1e9)]
+    # ---- one-step kernel
+    kf = "pcl_rtc_fast_e1"
+    d_f = disp.get(kf, [])
+    n_single = 3 + R * steps
+    single = d_f[:n_single][3:]
+    if single:
+        avg = sum(single) / len(single)
+        fb = [x.get("FETCH_SIZE", 0) * 2 * 1024 for x in fetch.get(kf, [])[:n_single][3:]]
+        wb = [x.get("WRITE_SIZE", 0) * 1024 for x in write.get(kf, [])[:n_single][3:]]
+        c = sq.get(kf, [])[:n_single][3:]
+        tot = (sum(fb) / len(fb) if fb else 0) + (sum(wb) / len(wb) if wb else 0)
+        busy = sum(x.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (x["GRBM_GUI_ACTIVE"] / 8 * 1024) for x in c if x.get("GRBM_GUI_ACTIVE")) / max(1, len(c))
+        L += ["", "## One-step kernel `pcl_rtc_fast_e1` (`single_step` leg: %d timed launches)" % len(single), "",
+              "average %.4f ms (min %.4f, max %.4f) -> 104 B x N / t = %.0f GB/s = **%.4f** of peak (bench line under rocprof: "
+              "`single_step.roofline.frac` %.4f); PMC: %.1f B / photon per launch (algorithmic 104); valu_busy %.3f."
+              % (avg * 1e-6, min(single) * 1e-6, max(single) * 1e-6, 104.0 * N / (avg * 1e-9) / 1e9, 104.0 * N / (avg * 1e-9) / 1e9 / HBM_PEAK,
+                 line["single_step"]["roofline"]["frac"], tot / N, busy)]
+    # ---- delete legs: totals per kernel
+    L += ["", "## Delete legs (`delete` record): kernel totals over the whole run (warm-up repetition included)", "",
+          "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
+    for k in sorted(disp):
+        if any(t in k for t in ("k_newton_mask", "k_compact_count", "k_tile_scan", "k_mixed")):
+            fb = sum(x.get("FETCH_SIZE", 0) for x in fetch.get(k, [])) * 2 * 1024 / 1e9
+            wb = sum(x.get("WRITE_SIZE", 0) for x in write.get(k, [])) * 1024 / 1e9
+            L.append("| `%s` | %d | %.3f | %.2f | %.2f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, fb, wb))
+    dl = line.get("delete", {}).get("sizes", {})
+    for size, rec in dl.items():
+        p = rec["per_step"]
+        L.append("")
+        L.append("`delete` %s photons, per_step: %.4g particle-steps/s; `k_compact_count` %.0f GB/s algorithmic = %.3f of peak, "
+                 "`k_newton_mask` %.0f GB/s = %.3f; multi (K = %d): %.4g particle-steps/s."
+                 % (size, p["value"], p["roofline"]["achieved"], p["roofline"]["frac"], p["roofline_pass1"]["achieved"],
+                    p["roofline_pass1"]["frac"], rec["multi"]["steps_per_launch"], rec["multi"]["value"]))
+    L += ["", "## All kernels of the trace pass (count, total ms)", "", "| kernel | dispatches | total ms | avg ms |", "|---|---|---|---|"]
+    for k in sorted(disp, key=lambda k: -sum(disp[k])):
+        L.append("| `%s` | %d | %.3f | %.4f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, sum(disp[k]) / len(disp[k]) * 1e-6))
+    open(os.path.join(dst, tag + "_pmc.md"), "w").write("\n".join(L) + "\n")
+    # ---- static_profile entry of bench.py
+    tf = os.path.join(dst, "pmc_traffic.json")
+    allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    if timed:
+        t_ok = [r for r in timed if r[0]]
+        ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps),
+               "hit_fraction_of_timed_blocks": line["repeat_hit_fraction"],
+               "k_multi_bytes_per_launch": sum(r[2] for r in t_ok) / len(t_ok),
+               "k_multi_valu": {"busy": round(sum(r[3] for r in t_ok) / len(t_ok), 4),
+                                "lane_utilisation": round(sum(r[4] for r in t_ok) / len(t_ok), 4),
+                                "valu_insts_per_particle_step_per_block": [round(r[5], 1) for r in t_ok]}}
+        if single:
+            ent["k_fast_bytes_per_launch"] = tot
+        allt["%s:%s:%d:K%d:steps%d" % (line["config"]["profile"], line["config"]["mode"], N, S, steps)] = ent
+        json.dump(allt, open(tf, "w"), indent=1, sort_keys=True)
+    print("\n".join(L))
+
+
+if __name__ == "__main__":
+    main()
