@@ -250,38 +250,59 @@ __device__ __forceinline__ void pcl_draw_angles(pcl_u64 id, pcl_u32 step, pcl_u3
     rphi = pcl_rphi<T>(w.z, w.w);
 }
 
-// The number-density factor of pcoll.  Under hipRTC, PCL_N_EXPR is the user's OpenCL-C expression
-// (variable_n_fn, physicl/light.py:299), which names the kernel arrays r0,r1,r2,d0,d1,d2,E and the
-// work-item index gid; those names are bound here to this particle's values (one-element arrays,
-// gid = 0).  hipcc drops the loads of arrays the expression does not mention.  PCL_N_EXPR_F is the
-// same text with an f suffix on every floating literal (fp32 stores).
-#ifdef PCL_N_EXPR
+// The number-density factor of pcoll (variable_n_fn, physicl/light.py:299).
+// Under hipRTC, PCL_N_EXPR is the user's OpenCL-C expression, which names the kernel arrays r0,r1,r2,d0,d1,d2,E and the
+// work-item index gid; those names are bound here to this particle's values (one-element arrays, gid = 0).  hipcc drops
+// the loads of arrays the expression does not mention.  PCL_N_EXPR_F is the same text with an f suffix on every floating
+// literal (fp32 stores).
+// In the ahead-of-time library there is no expression text: its VAR_N kernels evaluate one of three parametrised
+// SHAPES -- the forms the reference's examples use -- with the literals of the user's text as kernel arguments
+// (pcl_nprof), written token for token like the examples so that the compiler sees the same operations as it does
+// under hipRTC.  They serve when hipRTC is not available at run time (DESIGN.md "variable_n_fn").
+//   1  p0 * exp(rA[gid] - p1)                    examples/variable_n_scattering.ipynb:30
+//   2  p0 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - p1)/(p2))
+//                                                examples/presentation_example.ipynb:31, presentation_example_2.ipynb:40
+//   3  p0 * exp(rA[gid] / p1)                    examples/presentation_example_2.ipynb:41
+#define PCL_NPROF_EXP_OFFSET 1
+#define PCL_NPROF_EXP_RADIAL 2
+#define PCL_NPROF_EXP_SCALE 3
 template <typename T>
-__device__ __forceinline__ T pcl_n_expr_val(T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev) {
+struct pcl_nprof {
+    int shape; // 0: none (hipRTC, or constant n)
+    int axis;  // A of rA[gid] (shapes 1 and 3)
+    T p0, p1, p2;
+};
+
+template <typename T>
+__device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev) {
     const T r0[1] = {r0v}, r1[1] = {r1v}, r2[1] = {r2v}, d0[1] = {d0v}, d1[1] = {d1v}, d2[1] = {d2v}, E[1] = {Ev};
     const int gid = 0;
-    (void)r0; (void)r1; (void)r2; (void)d0; (void)d1; (void)d2; (void)E; (void)gid;
+    (void)r0; (void)r1; (void)r2; (void)d0; (void)d1; (void)d2; (void)E; (void)gid; (void)np;
+#ifdef PCL_N_EXPR
     if constexpr (sizeof(T) == 8) {
         return (T)(PCL_N_EXPR);
     } else {
         return (T)(PCL_N_EXPR_F);
     }
-}
+#else
+    const T rA[1] = {np.axis == 0 ? r0v : (np.axis == 1 ? r1v : r2v)};
+    if (np.shape == PCL_NPROF_EXP_OFFSET) return (T)(np.p0 * exp(rA[gid] - np.p1));
+    if (np.shape == PCL_NPROF_EXP_RADIAL)
+        return (T)(np.p0 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - np.p1)/(np.p2)));
+    return (T)(np.p0 * exp(rA[gid] / np.p1));
 #endif
+}
 
 // pcoll exactly as the generated kernel text multiplies it            physicl/light.py:299-306
 //   A * n * norm  |  A * (<expr>) * norm  [ * pow((h*c)/E, -4) ]   -- left to right
 // (the norm is passed in: a K-step pass keeps it in a register between the photon's hits)
 template <typename T, bool USE_E, bool VAR_N>
-__device__ __forceinline__ T pcl_pcoll_norm(T A, T n, T h, T c, T norm, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
+__device__ __forceinline__ T pcl_pcoll_norm(const pcl_nprof<T> &np, T A, T n, T h, T c, T norm, T d0, T d1, T d2, T r0, T r1, T r2,
+                                            T E) {
     typedef pcl_rt<T> R;
     T p;
     if constexpr (VAR_N) {
-#ifdef PCL_N_EXPR
-        p = R::mul(R::mul(A, pcl_n_expr_val<T>(r0, r1, r2, d0, d1, d2, E)), norm);
-#else
-        p = (T)0;
-#endif
+        p = R::mul(R::mul(A, pcl_n_expr_val<T>(np, r0, r1, r2, d0, d1, d2, E)), norm);
     } else {
         p = R::mul(R::mul(A, n), norm);
     }
@@ -289,8 +310,8 @@ __device__ __forceinline__ T pcl_pcoll_norm(T A, T n, T h, T c, T norm, T d0, T 
     return p;
 }
 template <typename T, bool USE_E, bool VAR_N>
-__device__ __forceinline__ T pcl_pcoll(T A, T n, T h, T c, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
-    return pcl_pcoll_norm<T, USE_E, VAR_N>(A, n, h, c, pcl_step_norm<T>(d0, d1, d2), d0, d1, d2, r0, r1, r2, E);
+__device__ __forceinline__ T pcl_pcoll(const pcl_nprof<T> &np, T A, T n, T h, T c, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
+    return pcl_pcoll_norm<T, USE_E, VAR_N>(np, A, n, h, c, pcl_step_norm<T>(d0, d1, d2), d0, d1, d2, r0, r1, r2, E);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -303,14 +324,14 @@ struct pcl_sphere_args {
     double *res0, *res1, *res2;
     pcl_i64 N;
     double c, h;
+    pcl_nprof<double> np; // ahead-of-time VAR_N kernels only
 };
 
 template <bool USE_E, bool VAR_N>
 __device__ __forceinline__ void pcl_sphere_body(const pcl_sphere_args &a) {
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
     for (pcl_i64 gid = (pcl_i64)blockIdx.x * blockDim.x + threadIdx.x; gid < a.N; gid += stride) {
-        const double pcoll = pcl_pcoll<double, USE_E, VAR_N>(
-            a.A, a.n, a.h, a.c, a.d0[gid], a.d1[gid], a.d2[gid], a.r0 ? a.r0[gid] : 0.0, a.r1 ? a.r1[gid] : 0.0,
+        const double pcoll = pcl_pcoll<double, USE_E, VAR_N>(a.np, a.A, a.n, a.h, a.c, a.d0[gid], a.d1[gid], a.d2[gid], a.r0 ? a.r0[gid] : 0.0, a.r1 ? a.r1[gid] : 0.0,
             a.r2 ? a.r2[gid] : 0.0, a.E ? a.E[gid] : 0.0);
         if (pcoll >= a.rand[gid]) {
             double o0, o1, o2;
@@ -347,6 +368,7 @@ struct pcl_scatter_args {
     pcl_u32 step;
     int rng_mode;
     int py_dv;                 // 1: a hit leaves dv = v_old (the reference's CPU path, light.py:346-348) instead of v' - v_old
+    pcl_nprof<T> np;           // ahead-of-time VAR_N kernels only
 };
 
 #define PCL_SCATTER_ROWS 4 /* particles per thread per grid-stride trip (memory-level parallelism) */
@@ -368,7 +390,7 @@ __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
             if (i < a.N) {
                 photon[j] = a.kind ? (a.kind[i] != 0) : true;
                 const pcl_i64 ti = pcl_tix(i, a.ts);
-                pcoll[j] = pcl_pcoll<T, USE_E, VAR_N>(a.A, a.n, a.h, a.c, a.d0[ti], a.d1[ti], a.d2[ti], a.r0[ti],
+                pcoll[j] = pcl_pcoll<T, USE_E, VAR_N>(a.np, a.A, a.n, a.h, a.c, a.d0[ti], a.d1[ti], a.d2[ti], a.r0[ti],
                                                       a.r1[ti], a.r2[ti], a.E[ti]);
             }
         }
@@ -450,6 +472,7 @@ struct pcl_fused_args {
     int n_planes;                // -1: no counters at all
     T plane_L[PCL_MAXPL];
     int plane_ax[PCL_MAXPL];
+    pcl_nprof<T> np;             // ahead-of-time VAR_N kernels only
 };
 
 template <typename T>
@@ -516,7 +539,7 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
             for (int e = 0; e < VEC; ++e) {
                 const pcl_i64 i = q * VEC + e;
                 photon[e] = live[e] && (a.kind ? (a.kind[i] != 0) : true);
-                const T pc = pcl_pcoll<T, USE_E, VAR_N>(a.A, a.n, a.h, a.c, D[0][e], D[1][e], D[2][e], Rr[0][e],
+                const T pc = pcl_pcoll<T, USE_E, VAR_N>(a.np, a.A, a.n, a.h, a.c, D[0][e], D[1][e], D[2][e], Rr[0][e],
                                                         Rr[1][e], Rr[2][e], Ev[e]);
                 T rand = (T)0, rtheta = (T)0, rphi = (T)0;
                 pcl_u64 id = 0;
@@ -651,6 +674,7 @@ struct pcl_fast_args {
     // bytes, dense arrays padded to whole 64-element groups; NULL = implicit ids / every particle is a photon
     const pcl_i64 *ids;
     const unsigned char *kind;
+    pcl_nprof<T> np;          // ahead-of-time VAR_N kernels only
 };
 
 template <typename T, int VEC>
@@ -717,7 +741,7 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
             cur.R[1][e] = R::add(cur.R[1][e], d1);
             cur.R[2][e] = R::add(cur.R[2][e], d2);
             // scatter                                                                light.py:303-315
-            T pc = pcl_pcoll<T, false, VAR_N>(a.A, a.n, (T)0, a.c, d0, d1, d2, cur.R[0][e], cur.R[1][e], cur.R[2][e],
+            T pc = pcl_pcoll<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, d0, d1, d2, cur.R[0][e], cur.R[1][e], cur.R[2][e],
                                               a.E[pcl_tix(live ? i : 0, a.ts)]);
             if constexpr (USE_E) pc = R::mul(pc, cur.L4[e]);
             pcl_u64 id = (pcl_u64)(a.id_base + i);
@@ -786,6 +810,7 @@ struct pcl_multi_args {
     int n_planes;             // 0..PCL_MAXPL measure planes (physicl/light.py:385-399)
     int plane_ax[PCL_MAXPL];
     T plane_L[PCL_MAXPL];
+    pcl_nprof<T> np;          // ahead-of-time VAR_N kernels only
 };
 
 // The scatter branch (second Philox block, two sincos, the new velocity) is ~half of a step's arithmetic but
@@ -863,7 +888,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                     if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + p], nc);
                 }
                 // scatter decision                                                       light.py:303-308
-                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e],
+                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e],
                                                        Ev[e]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
@@ -1038,7 +1063,7 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                     if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
                 }
                 // scatter decision                                                       light.py:303-308
-                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p],
+                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p],
                                                        Ev[p]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[p]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
@@ -1202,6 +1227,7 @@ struct pcl_mixed_args {
     int n_planes;
     int plane_ax[PCL_MAXPL];
     T plane_L[PCL_MAXPL];
+    pcl_nprof<T> np;    // ahead-of-time VAR_N kernels only
 };
 
 template <typename T>
@@ -1299,7 +1325,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 pcl_u32 wbase = qbase;
 #pragma unroll
                 for (int e = 0; e < NE; ++e) {
-                    T pc = pcl_pcoll_norm<T, false, VAR_N>(a.A, a.n, (T)0, a.c, NM[e], d[0][e], d[1][e], d[2][e], Rr[0][e],
+                    T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[e], d[0][e], d[1][e], d[2][e], Rr[0][e],
                                                            Rr[1][e], Rr[2][e], Ev[e]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                     hit[e] = alive[e] && photon[e] && (pc >= rand[e]);

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -180,35 +181,48 @@ __global__ void __launch_bounds__(kBlock) k_delete_flags(const double *__restric
     }
 }
 
-// ---- ahead-of-time variants (constant n) of the kernels whose bodies live in pcl_device.h ---------
-template <bool USE_E>
+// ---- ahead-of-time variants of the kernels whose bodies live in pcl_device.h: constant n (VAR_N = false) and the three
+// parametrised variable-n shapes of the examples (VAR_N = true, pcl_nprof) for machines without hipRTC ---------------
+template <bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_sphere(pcl_sphere_args a) {
-    pcl_sphere_body<USE_E, false>(a);
+    pcl_sphere_body<USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args<T> a) {
-    pcl_scatter_body<T, USE_E, false>(a);
+    pcl_scatter_body<T, USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args<T> a) {
-    pcl_fused_body<T, USE_E, false>(a);
+    pcl_fused_body<T, USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
-    pcl_fast_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
+    pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
-    pcl_multi_body<T, USE_E, false, pcl_rt<T>::VEC>(a);
+    pcl_multi_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
-    pcl_fast_body<T, USE_E, false, pcl_rt<T>::VEC, true>(a);
+    pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC, true>(a);
 }
-template <typename T, bool USE_E>
+template <typename T, bool USE_E, bool VAR_N>
 __global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
-    pcl_mixed_body<T, USE_E, false>(a);
+    pcl_mixed_body<T, USE_E, VAR_N>(a);
 }
+
+// launch K<[T,] USE_E, VAR_N> for run-time use_e / var_n
+#define PCL_AOT_LAUNCH(K, T, use_e, var_n, grid, args)                                                              \
+    do {                                                                                                          \
+        if (use_e) {                                                                                              \
+            if (var_n) hipLaunchKernelGGL((K<T, true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, args);     \
+            else hipLaunchKernelGGL((K<T, true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, args);          \
+        } else {                                                                                                  \
+            if (var_n) hipLaunchKernelGGL((K<T, false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, args);    \
+            else hipLaunchKernelGGL((K<T, false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, args);         \
+        }                                                                                                         \
+    } while (0)
 
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
 // store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
@@ -231,7 +245,8 @@ __global__ void __launch_bounds__(kBlock) k_pcoll(const T *__restrict__ d0, cons
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
         const int64_t ti = pcl_tix(i, ts);
-        out[i] = pcl_pcoll<T, USE_E, false>(A, n, h, c, d0[ti], d1[ti], d2[ti], (T)0, (T)0, (T)0, USE_E ? E[ti] : (T)0);
+        const pcl_nprof<T> none = {0, 0, (T)0, (T)0, (T)0};
+        out[i] = pcl_pcoll<T, USE_E, false>(none, A, n, h, c, d0[ti], d1[ti], d2[ti], (T)0, (T)0, (T)0, USE_E ? E[ti] : (T)0);
     }
 }
 
@@ -907,6 +922,10 @@ int validate_expr(const char *e, std::string *f32_out = nullptr) {
 // context
 // =================================================================================================
 struct rtc_entry {
+    // module == nullptr: hipRTC was not available; the expression matched one of the built-in shapes and runs on the
+    // ahead-of-time VAR_N kernels with these parameters (double and float spellings of the user's literals)
+    pcl_nprof<double> np64 = {0, 0, 0.0, 0.0, 0.0};
+    pcl_nprof<float> np32 = {0, 0, 0.f, 0.f, 0.f};
     hipModule_t module = nullptr;
     hipFunction_t sphere[2] = {nullptr, nullptr};     // [USE_E]           (fp64 only: the reference's ABI)
     hipFunction_t scatter[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // [dtype][USE_E]
@@ -1170,6 +1189,141 @@ int check_range(pcl_ctx *ctx, int64_t offset, int64_t n, const void *host) {
     return PCL_OK;
 }
 
+// ---- hipRTC, loaded at run time -------------------------------------------------------------------------------------
+// libphysicl_hip.so does not link libhiprtc: a machine without it still loads the library and runs everything except
+// user-written kernels and variable_n_fn expressions outside the three built-in shapes (match_nprof below).
+struct hiprtc_api {
+    void *handle = nullptr;
+    decltype(&hiprtcCreateProgram) CreateProgram = nullptr;
+    decltype(&hiprtcCompileProgram) CompileProgram = nullptr;
+    decltype(&hiprtcGetProgramLogSize) GetProgramLogSize = nullptr;
+    decltype(&hiprtcGetProgramLog) GetProgramLog = nullptr;
+    decltype(&hiprtcGetCodeSize) GetCodeSize = nullptr;
+    decltype(&hiprtcGetCode) GetCode = nullptr;
+    decltype(&hiprtcDestroyProgram) DestroyProgram = nullptr;
+    decltype(&hiprtcGetErrorString) GetErrorString = nullptr;
+    decltype(&hiprtcVersion) Version = nullptr;
+    std::string why; // why it is unavailable
+    bool ok = false;
+};
+
+hiprtc_api load_hiprtc() {
+    hiprtc_api a;
+    const char *names[] = {"libhiprtc.so", "libhiprtc.so.7", "libhiprtc.so.6", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char *nm : names) {
+        a.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (a.handle) break;
+    }
+    if (!a.handle) {
+        const char *e = dlerror();
+        a.why = std::string("libhiprtc.so could not be loaded") + (e ? std::string(": ") + e : std::string());
+        return a;
+    }
+#define PCL_RTC_SYM(field, sym)                                                  \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.handle, #sym));        \
+    if (!a.field) {                                                              \
+        a.why = "libhiprtc.so lacks " #sym;                                      \
+        return a;                                                                \
+    }
+    PCL_RTC_SYM(CreateProgram, hiprtcCreateProgram)
+    PCL_RTC_SYM(CompileProgram, hiprtcCompileProgram)
+    PCL_RTC_SYM(GetProgramLogSize, hiprtcGetProgramLogSize)
+    PCL_RTC_SYM(GetProgramLog, hiprtcGetProgramLog)
+    PCL_RTC_SYM(GetCodeSize, hiprtcGetCodeSize)
+    PCL_RTC_SYM(GetCode, hiprtcGetCode)
+    PCL_RTC_SYM(DestroyProgram, hiprtcDestroyProgram)
+    PCL_RTC_SYM(GetErrorString, hiprtcGetErrorString)
+    PCL_RTC_SYM(Version, hiprtcVersion)
+#undef PCL_RTC_SYM
+    a.ok = true;
+    return a;
+}
+
+// PCL_NO_RTC (any value): behave as if libhiprtc were absent -- how the tests exercise the ahead-of-time fallback
+const hiprtc_api &rtc_api() {
+    static const hiprtc_api real = load_hiprtc();
+    static const hiprtc_api off = [] {
+        hiprtc_api a;
+        a.why = "hipRTC switched off by PCL_NO_RTC";
+        return a;
+    }();
+    return getenv("PCL_NO_RTC") ? off : real;
+}
+
+// ---- the three built-in variable_n_fn shapes (pcl_device.h, pcl_nprof) ---------------------------------------------------
+// Token-level match of the user's text (already validated) against
+//   1  NUM * exp ( rA [ gid ] - NUM )
+//   2  NUM * exp ( - 1 * ( sqrt ( pow ( r0 [ gid ] , 2 ) + pow ( r1 [ gid ] , 2 ) + pow ( r2 [ gid ] , 2 ) ) - NUM ) / ( NUM ) )
+//   3  NUM * exp ( rA [ gid ] / NUM )
+// NUM = an unsigned literal of the text; its double value comes from strtod, its float value from strtof of the very
+// characters (what the compiler would have done with the f-suffixed spelling under hipRTC).
+bool match_nprof(const char *expr, rtc_entry *ent) {
+    std::vector<std::string> tok;
+    for (const char *q = expr; *q;) {
+        if (*q == ' ' || *q == '\t' || *q == '\n') {
+            ++q;
+        } else if ((*q >= '0' && *q <= '9') || *q == '.') {
+            const char *b = q;
+            while ((*q >= '0' && *q <= '9') || *q == '.') ++q;
+            if (*q == 'e' || *q == 'E') {
+                ++q;
+                if (*q == '+' || *q == '-') ++q;
+                while (*q >= '0' && *q <= '9') ++q;
+            }
+            tok.push_back(std::string(b, q));
+        } else if ((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || *q == '_') {
+            const char *b = q;
+            while ((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_') ++q;
+            tok.push_back(std::string(b, q));
+        } else {
+            tok.push_back(std::string(1, *q++));
+        }
+    }
+    static const char *const shapes[3] = {
+        "NUM * exp ( AX [ gid ] - NUM )",
+        "NUM * exp ( - 1 * ( sqrt ( pow ( r0 [ gid ] , 2 ) + pow ( r1 [ gid ] , 2 ) + pow ( r2 [ gid ] , 2 ) ) - NUM ) / ( NUM ) )",
+        "NUM * exp ( AX [ gid ] / NUM )"};
+    for (int sh = 0; sh < 3; ++sh) {
+        std::vector<std::string> pat;
+        for (const char *q = shapes[sh]; *q;) {
+            const char *b = q;
+            while (*q && *q != ' ') ++q;
+            pat.push_back(std::string(b, q));
+            while (*q == ' ') ++q;
+        }
+        if (pat.size() != tok.size()) continue;
+        double pd[3] = {0, 0, 0};
+        float pf[3] = {0, 0, 0};
+        int np = 0, axis = 0;
+        bool ok = true;
+        for (size_t i = 0; ok && i < pat.size(); ++i) {
+            const std::string &t = tok[i];
+            if (pat[i] == "NUM") {
+                ok = !t.empty() && ((t[0] >= '0' && t[0] <= '9') || t[0] == '.') && np < 3;
+                if (ok) {
+                    const bool floating = t.find_first_of(".eE") != std::string::npos;
+                    pd[np] = strtod(t.c_str(), nullptr);
+                    pf[np] = floating ? strtof(t.c_str(), nullptr) : (float)strtol(t.c_str(), nullptr, 10); // int literal -> float
+                    ++np;
+                }
+            } else if (pat[i] == "AX") {
+                ok = t == "r0" || t == "r1" || t == "r2";
+                if (ok) axis = t[1] - '0';
+            } else {
+                ok = pat[i] == t;
+            }
+        }
+        if (!ok) continue;
+        ent->np64 = {sh + 1, axis, pd[0], pd[1], pd[2]};
+        ent->np32 = {sh + 1, axis, pf[0], pf[1], pf[2]};
+        return true;
+    }
+    return false;
+}
+
+void set_np(pcl_nprof<double> &np, const rtc_entry *ent) { np = ent ? ent->np64 : pcl_nprof<double>{0, 0, 0.0, 0.0, 0.0}; }
+void set_np(pcl_nprof<float> &np, const rtc_entry *ent) { np = ent ? ent->np32 : pcl_nprof<float>{0, 0, 0.f, 0.f, 0.f}; }
+
 // ---- hipRTC specialisation cache ---------------------------------------------------------------------
 // Two levels: compiled code objects are kept per process (keyed by arch + defines + expression), loaded
 // modules per context.  A second Simulation with the same variable_n_fn only pays hipModuleLoadData.
@@ -1199,7 +1353,7 @@ std::string rtc_cache_path(const std::string &src, const std::string &arch, cons
         dir = std::string(home) + "/.cache/physicl_amd/rtc";
     }
     int major = 0, minor = 0;
-    (void)hiprtcVersion(&major, &minor);
+    if (rtc_api().ok) (void)rtc_api().Version(&major, &minor);
     char tag[64];
     snprintf(tag, sizeof tag, "|%d.%d|abi%d", major, minor, PCL_ABI_VERSION);
     const uint64_t h1 = fnv1a(src + "|" + arch + "|" + extra + tag);
@@ -1267,6 +1421,11 @@ void write_cached_code(const std::string &path, const std::vector<char> &code) {
     write_file_atomic(path, raw);
 }
 
+int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc_entry **out);
+
+// The implementation of a variable_n_fn expression for this context: its hipRTC specialisation, or -- when hipRTC is
+// not available on this machine (or the compile fails) and the text is one of the three built-in shapes -- the
+// ahead-of-time VAR_N kernels with the text's literals as parameters (entry with module == nullptr).
 int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     std::string expr_f32;
     PCL_TRY(validate_expr(expr, &expr_f32));
@@ -1275,6 +1434,23 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
         *out = &it->second;
         return PCL_OK;
     }
+    std::string why = rtc_api().why;
+    if (rtc_api().ok) {
+        if (compile_rtc(ctx, expr, expr_f32, out) == PCL_OK) return PCL_OK;
+        why = g_err;
+        ctx->rtc.erase(expr);
+    }
+    rtc_entry ent;
+    if (!match_nprof(expr, &ent))
+        return fail(PCL_ERR_RTC, "variable_n_fn \"%s\" needs hipRTC (%s) -- without it only the built-in shapes "
+                    "\"K * exp(rA[gid] - X)\", \"K * exp(rA[gid] / X)\" and the radial exponential of the examples run", expr,
+                    why.c_str());
+    auto ins = ctx->rtc.emplace(std::string(expr), ent);
+    *out = &ins.first->second;
+    return PCL_OK;
+}
+
+int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc_entry **out) {
     const char *extra_env = getenv("PCL_RTC_EXTRA"), *define_env = getenv("PCL_RTC_DEFINE");
     const std::string code_key = std::string(ctx->prop.gcnArchName) + "|" + (extra_env ? extra_env : "") + "|" +
                                  (define_env ? define_env : "") + "|" + expr;
@@ -1322,24 +1498,24 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
         }
     }
     hiprtcProgram prog;
-    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
-    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    hiprtcResult r = rtc_api().CreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", rtc_api().GetErrorString(r));
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra};
-    r = hiprtcCompileProgram(prog, (extra && *extra) ? 5 : 4, opts);
+    r = rtc_api().CompileProgram(prog, (extra && *extra) ? 5 : 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
+        rtc_api().GetProgramLogSize(prog, &n);
         std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
-        hiprtcDestroyProgram(&prog);
+        if (n) rtc_api().GetProgramLog(prog, &log[0]);
+        rtc_api().DestroyProgram(&prog);
         return fail(PCL_ERR_RTC, "hipRTC could not compile variable_n_fn \"%s\": %s\n%s", expr,
-                    hiprtcGetErrorString(r), log.c_str());
+                    rtc_api().GetErrorString(r), log.c_str());
     }
     size_t code_n = 0;
-    hiprtcGetCodeSize(prog, &code_n);
+    rtc_api().GetCodeSize(prog, &code_n);
     std::vector<char> code(code_n);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
+    rtc_api().GetCode(prog, code.data());
+    rtc_api().DestroyProgram(&prog);
     {
         std::lock_guard<std::mutex> lock(g_code_mutex);
         g_code_cache[code_key] = code;
@@ -1523,13 +1699,11 @@ int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc
     const int grid = grid_for(ctx, N, kBlock * PCL_SCATTER_ROWS);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_SCATTER);
-    if (var_n) {
+    set_np(a.np, ent);
+    if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->scatter[d][use_e ? 1 : 0], grid, a, "scatter_isotropic (hipRTC)"));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL((k_scatter<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((k_scatter<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_AOT_LAUNCH(k_scatter, T, use_e, var_n, grid, a);
         PCL_TRY(launch_check("k_scatter"));
     }
     prof_end(ctx, ps);
@@ -1574,20 +1748,14 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_FUSED);
-    if (var_n) {
+    set_np(f.np, ent);
+    if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, (gen ? ent->fastg : ent->fast)[d][use_e ? 1 : 0], grid, f, "step_fused fast path (hipRTC)"));
     } else {
-        if (gen) {
-            if (use_e)
-                hipLaunchKernelGGL((k_fastg<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-            else
-                hipLaunchKernelGGL((k_fastg<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-        } else {
-            if (use_e)
-                hipLaunchKernelGGL((k_fast<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-            else
-                hipLaunchKernelGGL((k_fast<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-        }
+        if (gen)
+            PCL_AOT_LAUNCH(k_fastg, T, use_e, var_n, grid, f);
+        else
+            PCL_AOT_LAUNCH(k_fast, T, use_e, var_n, grid, f);
         PCL_TRY(launch_check("k_fast"));
     }
     prof_end(ctx, ps);
@@ -1624,16 +1792,14 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
     static const bool nq2 = getenv("PCL_MULTI_NQ2") != nullptr; // perf-experiment hook
-    if (var_n && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
+    set_np(f.np, ent);
+    if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
         PCL_TRY(launch_module(ctx, ent->multi2[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 (hipRTC)"));
-    } else if (var_n) {
+    } else if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL((k_multi<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
-        else
-            hipLaunchKernelGGL((k_multi<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f);
+        PCL_AOT_LAUNCH(k_multi, T, use_e, var_n, grid, f);
         PCL_TRY(launch_check("k_multi"));
     }
     prof_end(ctx, ps);
@@ -1681,13 +1847,11 @@ int step_fused_t(pcl_ctx *ctx, double dt, bool do_scatter, double A, double n, b
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_FUSED);
-    if (var_n) {
+    set_np(a.np, ent);
+    if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->fused[d][use_e ? 1 : 0], grid, a, "step_fused (hipRTC)"));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL((k_fused<T, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((k_fused<T, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        PCL_AOT_LAUNCH(k_fused, T, use_e, var_n, grid, a);
         PCL_TRY(launch_check("k_fused"));
     }
     prof_end(ctx, ps);
@@ -1913,13 +2077,11 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
     plane_table<T>(planes_host, n_planes, f.plane_ax, f.plane_L);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    if (var_n) {
+    set_np(f.np, ent);
+    if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
     } else {
-        if (use_e)
-            hipLaunchKernelGGL((k_mixed<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
-        else
-            hipLaunchKernelGGL((k_mixed<T, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
+        PCL_AOT_LAUNCH(k_mixed, T, use_e, var_n, tiles, f);
         PCL_TRY(launch_check("k_mixed"));
     }
     prof_end(ctx, ps);
@@ -2241,13 +2403,17 @@ int pcl_k_light_scatter_step_sphere(pcl_ctx *ctx, const double *d0, const double
         return fail(PCL_ERR_ARG, "NULL array argument");
     if (use_e && !E) return fail(PCL_ERR_ARG, "E is NULL but PCL_SCATTER_WAVELENGTH is set");
     if (var_n && (!r0 || !r1 || !r2)) return fail(PCL_ERR_ARG, "r0..r2 NULL but PCL_SCATTER_VARIABLE_N is set");
-    pcl_sphere_args a{d0, d1, d2, rtheta, rphi, rand, A, n, E, r0, r1, r2, res0, res1, res2, N, c, h};
+    pcl_sphere_args a{d0, d1, d2, rtheta, rphi, rand, A, n, E, r0, r1, r2, res0, res1, res2, N, c, h, {0, 0, 0.0, 0.0, 0.0}};
     const int grid = grid_for(ctx, N, kBlock);
-    if (var_n) return launch_module(ctx, ent->sphere[use_e ? 1 : 0], grid, a, "light_scatter_step_sphere (hipRTC)");
-    if (use_e)
-        hipLaunchKernelGGL(k_sphere<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL(k_sphere<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    set_np(a.np, ent);
+    if (var_n && ent->module) return launch_module(ctx, ent->sphere[use_e ? 1 : 0], grid, a, "light_scatter_step_sphere (hipRTC)");
+    if (use_e) {
+        if (var_n) hipLaunchKernelGGL((k_sphere<true, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sphere<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else {
+        if (var_n) hipLaunchKernelGGL((k_sphere<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((k_sphere<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    }
     return launch_check("light_scatter_step_sphere");
 }
 
@@ -2293,6 +2459,7 @@ int pcl_user_kernel_build(pcl_ctx *ctx, const char *name, const char *params, co
     PCL_TRY(bind(ctx));
     if (!name || !params || !body || !kernel_out) return fail(PCL_ERR_ARG, "NULL argument");
     *kernel_out = nullptr;
+    if (!rtc_api().ok) return fail(PCL_ERR_RTC, "user kernels need hipRTC: %s", rtc_api().why.c_str());
     for (const char *q = name; *q; ++q)
         if (!((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_'))
             return fail(PCL_ERR_ARG, "kernel name '%s' is not an identifier", name);
@@ -2314,24 +2481,24 @@ int pcl_user_kernel_build(pcl_ctx *ctx, const char *name, const char *params, co
     src += body;
     src += "\n}\n";
     hiprtcProgram prog;
-    hiprtcResult r = hiprtcCreateProgram(&prog, src.c_str(), "pcl_user_kernel.hip", 0, nullptr, nullptr);
-    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", hiprtcGetErrorString(r));
+    hiprtcResult r = rtc_api().CreateProgram(&prog, src.c_str(), "pcl_user_kernel.hip", 0, nullptr, nullptr);
+    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", rtc_api().GetErrorString(r));
     std::string arch = std::string("--offload-arch=") + ctx->prop.gcnArchName;
     const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
-    r = hiprtcCompileProgram(prog, 4, opts);
+    r = rtc_api().CompileProgram(prog, 4, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
-        hiprtcGetProgramLogSize(prog, &n);
+        rtc_api().GetProgramLogSize(prog, &n);
         std::string log(n, '\0');
-        if (n) hiprtcGetProgramLog(prog, &log[0]);
-        hiprtcDestroyProgram(&prog);
-        return fail(PCL_ERR_RTC, "hipRTC could not compile kernel '%s': %s\n%s", name, hiprtcGetErrorString(r), log.c_str());
+        if (n) rtc_api().GetProgramLog(prog, &log[0]);
+        rtc_api().DestroyProgram(&prog);
+        return fail(PCL_ERR_RTC, "hipRTC could not compile kernel '%s': %s\n%s", name, rtc_api().GetErrorString(r), log.c_str());
     }
     size_t code_n = 0;
-    hiprtcGetCodeSize(prog, &code_n);
+    rtc_api().GetCodeSize(prog, &code_n);
     std::vector<char> code(code_n);
-    hiprtcGetCode(prog, code.data());
-    hiprtcDestroyProgram(&prog);
+    rtc_api().GetCode(prog, code.data());
+    rtc_api().DestroyProgram(&prog);
     pcl_user_kernel *k = new (std::nothrow) pcl_user_kernel();
     if (!k) return fail(PCL_ERR_NOMEM, "out of host memory");
     if (hipModuleLoadData(&k->module, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->module, name) != hipSuccess) {
