@@ -18,7 +18,7 @@ H_LIT = 6.62607015e-34
 SHAPES = {
     "offset": ("0.000000001 * exp(r0[gid] - 5)", 1e-15, 1e-9, True),
     "radial": ("2.5 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - 6.0)/(3.5))", 1.0, 1e-9, False),
-    "scale": ("2.5E+25 * exp(r2[gid] / 8600.0)", 4.08e-56, 1e-5, True),
+    "scale": ("250000.0 * exp(r2[gid] / 8600.0)", 4.08e-36, 1e-5, True),       # "{} * exp(r2[gid] / {})".format(n_0, z_0)
     "offset_spaced": ("  7.5e-10*exp( r1[gid]-2.25 )", 1e-15, 1e-9, True),
 }
 
