@@ -688,6 +688,147 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
     }
 }
 
+// ---- pass 3, LDS-staged: the same stable compaction (+ measure counters) with 16-byte traffic on both sides ----------
+//   k_compact_count moves 8 bytes per lane: a wave reads one 64-particle row and writes its survivors, a segment of
+//   arbitrary length and alignment, straight to the destination.  Here a lane owns TWO consecutive particles (16-byte
+//   loads, a wave covers a 128-particle double row), the workgroup gathers one field of its whole 2048-particle tile into
+//   LDS in survivor order, and writes it out as aligned 16-byte groups of the destination row (the first / last group of
+//   a tile's output range, which it shares with its neighbours, goes element by element).  Fields go one after the
+//   other through two LDS buffers: one barrier per field.  r rows are kept in registers until the v rows arrive, so the
+//   sign / plane counters see the same values as in k_compact_count (dr = v * dt is recomputed: pass 1 wrote exactly that).
+template <typename W> struct w2_of;
+template <> struct w2_of<uint64_t> { typedef ulonglong2 type; };
+template <> struct w2_of<uint32_t> { typedef uint2 type; };
+
+template <typename T, typename W, int NF>
+__global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_counter_args<T> c) {
+    typedef pcl_rt<T> R;
+    typedef typename w2_of<W>::type W2;
+    constexpr int VW = 16 / (int)sizeof(W);      // elements per 16-byte store
+    constexpr int TRIPS = kTile / 128 / (kBlock / 64); // double rows per wave: 4
+    __shared__ uint64_t s_raw[2][kTile];         // two staging buffers (fp32 stores use half of each)
+    __shared__ int s_rowoff[kTileRows + 1];
+    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const uint64_t *tm = a.masks + tile * kTileRows;
+    if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
+    if (wave == 0) { // survivors before each 64-particle row of the tile
+        int inc = lane < kTileRows ? (int)__popcll(tm[lane]) : 0;
+        for (int off = 1; off < kTileRows; off <<= 1) {
+            const int up = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += up;
+        }
+        if (lane < kTileRows) s_rowoff[lane + 1] = inc;
+        if (lane == 0) s_rowoff[0] = 0;
+    }
+    __syncthreads();
+    const int kept = s_rowoff[kTileRows];
+    const int64_t o0 = a.tile_off[tile];
+    // the lane's particle pairs: LDS slots and keep bits
+    int pos[TRIPS];
+    bool k0[TRIPS], k1[TRIPS];
+    int64_t src_pair[TRIPS]; // index of the pair in a tiled row, in 2-element units
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        const int dr = wave * TRIPS + t; // double row of 128 particles
+        const uint64_t m_lo = tm[2 * dr], m_hi = tm[2 * dr + 1];
+        const bool hi = lane >= 32;
+        const uint64_t m = hi ? m_hi : m_lo;
+        const int bit = 2 * (lane & 31);
+        k0[t] = (m >> bit) & 1ull;
+        k1[t] = (m >> (bit + 1)) & 1ull;
+        pos[t] = s_rowoff[2 * dr] + (hi ? (int)__popcll(m_lo) : 0) + (int)__popcll(m & ((1ull << bit) - 1ull));
+        const int64_t i0 = tile * kTile + (int64_t)dr * 128 + 2 * lane;
+        src_pair[t] = pcl_tix(i0, a.ts) >> 1;
+    }
+    const bool counters = c.n_planes >= 0;
+    T rkeep[3][TRIPS][2];
+    uint32_t w_s[3] = {0, 0, 0};
+    auto write_out = [&](void *dst_row, const W *buf, bool dense) {
+        // aligned groups of VW destination elements; group g covers outputs [VW*g, VW*g + VW)
+        const int64_t g0 = o0 / VW, g1 = (o0 + kept + VW - 1) / VW;
+        for (int64_t g = g0 + threadIdx.x; g < g1; g += kBlock) {
+            const int64_t first = g * VW;
+            const int64_t d_el = dense ? first : pcl_tix(first, a.ts);
+            W *d = static_cast<W *>(dst_row) + d_el;
+            const int j = (int)(first - o0);
+            if (j >= 0 && j + VW <= kept) {
+                if constexpr (VW == 2) {
+                    *reinterpret_cast<ulonglong2 *>(d) = make_ulonglong2(buf[j], buf[j + 1]);
+                } else {
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(buf[j], buf[j + 1], buf[j + 2], buf[j + 3]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                    if (j + e >= 0 && j + e < kept) d[e] = buf[j + e];
+            }
+        }
+    };
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        W *buf = reinterpret_cast<W *>(s_raw[f & 1]);
+        const W2 *src = static_cast<const W2 *>(a.src[f]);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const W2 x = src[src_pair[t]];
+            if (k0[t]) buf[pos[t]] = x.x;
+            if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = x.y;
+            if (counters) {
+                if (f < 3) { // r rows: wait for the v rows (plane crossings)
+                    rkeep[f][t][0] = word_as<T, W>(x.x);
+                    rkeep[f][t][1] = word_as<T, W>(x.y);
+                } else if (f < 6) { // v rows: sign counts, and the planes on this axis
+                    const int ax = f - 3;
+                    const T v0 = word_as<T, W>(x.x), v1 = word_as<T, W>(x.y);
+                    w_s[ax] += (uint32_t)__popcll(__ballot(k0[t] && v0 > (T)0)) + (uint32_t)__popcll(__ballot(k1[t] && v1 > (T)0));
+                    for (int p = 0; p < c.n_planes; ++p) {
+                        if (c.plane_ax[p] != ax) continue;
+                        const T L = c.plane_L[p];
+                        const T x0 = rkeep[ax][t][0], x1 = rkeep[ax][t][1];
+                        const T p0 = R::sub(x0, R::mul(v0, c.dt)), p1 = R::sub(x1, R::mul(v1, c.dt));
+                        const uint32_t np = (uint32_t)__popcll(__ballot(k0[t] && ((p0 <= L && L <= x0) || (p0 >= L && L >= x0)))) +
+                                            (uint32_t)__popcll(__ballot(k1[t] && ((p1 <= L && L <= x1) || (p1 >= L && L >= x1))));
+                        if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+                    }
+                }
+            }
+        }
+        __syncthreads(); // field f is complete in its buffer (and the write-out of field f - 1 is behind every thread)
+        write_out(a.dst[f], buf, false);
+    }
+    if (a.ids_dst) { // ids: one more "field", always 8 bytes, dense destination
+        uint64_t *buf = s_raw[NF & 1];
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            const int64_t i0 = tile * kTile + (int64_t)(wave * TRIPS + t) * 128 + 2 * lane;
+            if (k0[t]) buf[pos[t]] = (uint64_t)(a.ids_src ? a.ids_src[i0] : a.id_base + i0);
+            if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = (uint64_t)(a.ids_src ? a.ids_src[i0 + 1] : a.id_base + i0 + 1);
+        }
+        __syncthreads();
+        const int64_t g0 = o0 / 2, g1 = (o0 + kept + 1) / 2;
+        for (int64_t g = g0 + threadIdx.x; g < g1; g += kBlock) {
+            const int j = (int)(g * 2 - o0);
+            uint64_t *d = reinterpret_cast<uint64_t *>(a.ids_dst) + g * 2;
+            if (j >= 0 && j + 2 <= kept) {
+                *reinterpret_cast<ulonglong2 *>(d) = make_ulonglong2(buf[j], buf[j + 1]);
+            } else {
+                if (j >= 0 && j < kept) d[0] = buf[j];
+                if (j + 1 >= 0 && j + 1 < kept) d[1] = buf[j + 1];
+            }
+        }
+    }
+    if (counters) {
+        if (lane == 0)
+            for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
+        __syncthreads();
+        const int nslots = 4 + (c.n_planes > 0 ? c.n_planes : 0);
+        if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+            atomicAdd(&c.cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    }
+}
+
 // expand the keep-masks of the last delete back into the reference's int32 ``res`` array
 __global__ void __launch_bounds__(kBlock) k_masks_to_flags(const uint64_t *__restrict__ masks,
                                                            int32_t *__restrict__ flags, int64_t N) {
@@ -1959,10 +2100,18 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_co
     compact_fields(ctx, ca, has_dr, dv_implicit);
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
     const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
-    if (has_dr)
+    // all-photon stores take the LDS-staged kernel (16-byte traffic); kind bytes only travel in the direct one
+    const bool lds = !ctx->kind && !getenv("PCL_COMPACT_DIRECT");
+    if (lds) {
+        if (has_dr)
+            hipLaunchKernelGGL((k_compact_lds<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        else
+            hipLaunchKernelGGL((k_compact_lds<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    } else if (has_dr) {
         hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    else
+    } else {
         hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    }
     prof_end(ctx, pc);
     return launch_check("k_compact_count");
 }
