@@ -309,8 +309,13 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
 }
 
 // ---- delete step, pass 2: exclusive scan of the per-tile counts (one workgroup) ------------------
+// Also decides which pass-3 kernel runs (``*choice``): both are enqueued behind the scan and the one that was not chosen
+// returns at once -- the survivor fraction is only known here, on the device, and the host must not wait for it.
+//   1  k_compact_lds   (16-byte traffic, whole tile through LDS): wins when most particles survive and the store is large
+//   0  k_compact_count (8 bytes per surviving lane, nothing read for the dead): wins when few survive or the store is small
 __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ tile_keep, int64_t n_tiles,
-                                                    int64_t *__restrict__ tile_off, int64_t *__restrict__ total) {
+                                                    int64_t *__restrict__ tile_off, int64_t *__restrict__ total,
+                                                    int64_t n_particles, int *__restrict__ choice) {
     __shared__ int64_t s_wave[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t per = div_up(n_tiles, 1024);
@@ -339,7 +344,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
         tile_off[k] = run;
         run += tile_keep[k];
     }
-    if (t == 1023) *total = s_wave[15];
+    if (t == 1023) {
+        *total = s_wave[15];
+        *choice = (n_particles >= (int64_t)1 << 22 && s_wave[15] * 20 > n_particles * 7) ? 1 : 0; // > 35 % survive
+    }
 }
 
 // ---- ScatterMeasureStep(measure_E=True): which photons crossed a plane in this step's move ----------------
@@ -397,6 +405,7 @@ struct compact_args {
     int64_t id_base, N;
     int64_t ts; // tile stride of BOTH slabs (elements)
     int dense_dst; // 1: dst[] are plain dense arrays (pcl_step_plane_energies), not rows of a slab
+    const int *choice; // non-NULL: which of the two pass-3 kernels the scan picked (k_tile_scan)
 };
 
 template <typename W, int NF>
@@ -625,6 +634,7 @@ template <typename T, typename W, bool HAS_DR>
 __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compact_counter_args<T> c) {
     typedef pcl_rt<T> R;
     constexpr int NF = HAS_DR ? 13 : 10;
+    if (a.choice && *a.choice != 0) return; // the scan chose k_compact_lds for this launch
     __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
@@ -712,6 +722,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const uint64_t *tm = a.masks + tile * kTileRows;
+    if (a.choice && *a.choice != 1) return; // the scan chose k_compact_count for this launch
     if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
     if (wave == 0) { // survivors before each 64-particle row of the tile
         int inc = lane < kTileRows ? (int)__popcll(tm[lane]) : 0;
@@ -772,7 +783,9 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
         const W2 *src = static_cast<const W2 *>(a.src[f]);
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
-            const W2 x = src[src_pair[t]];
+            W2 x;
+            x.x = x.y = 0;
+            if (k0[t] || k1[t]) x = src[src_pair[t]]; // nothing is read for a pair that is gone
             if (k0[t]) buf[pos[t]] = x.x;
             if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = x.y;
             if (counters) {
@@ -1730,7 +1743,8 @@ int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const ch
 int scan_tiles(pcl_ctx *ctx, int64_t n) {
     const int64_t tiles = div_up(n, kTile);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
-                       reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1));
+                       reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1), n,
+                       reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 2));
     PCL_TRY(launch_check("k_tile_scan"));
     PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 1, ctx->d_cnt + kCounterSlots - 1, sizeof(uint64_t),
                            hipMemcpyDeviceToHost, ctx->stream));
@@ -2100,20 +2114,24 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_co
     compact_fields(ctx, ca, has_dr, dv_implicit);
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
     const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
-    // all-photon stores take the LDS-staged kernel (16-byte traffic); kind bytes only travel in the direct one
-    const bool lds = !ctx->kind && !getenv("PCL_COMPACT_DIRECT");
-    if (lds) {
+    // Two formulations, both enqueued; the scan's verdict (d_cnt[kCounterSlots - 2]) lets exactly one of them work.
+    // Stores with kind bytes (plain Objects) always take the direct kernel -- the staged one does not move them.
+    static const bool direct_only = getenv("PCL_COMPACT_DIRECT") != nullptr; // perf-experiment hook
+    const bool both = !ctx->kind && !direct_only;
+    ca.choice = both ? reinterpret_cast<const int *>(ctx->d_cnt + kCounterSlots - 2) : nullptr;
+    if (has_dr)
+        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    else
+        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    if (both) {
+        PCL_TRY(launch_check("k_compact_count"));
         if (has_dr)
             hipLaunchKernelGGL((k_compact_lds<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
         else
             hipLaunchKernelGGL((k_compact_lds<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    } else if (has_dr) {
-        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    } else {
-        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
     }
     prof_end(ctx, pc);
-    return launch_check("k_compact_count");
+    return launch_check("k_compact");
 }
 
 template <typename T>
