@@ -26,7 +26,7 @@ sim = phys.Simulation(cl_on=True, device=0, comm=comm if comm.world > 1 else Non
                       exit=(lambda s: len(s.objects) < 2000) if kind == "delete" else
                            (lambda s: len(s.objects) == 0) if kind == "delete_empty" else (lambda s: s.t >= 0.0055))
 N = 150001
-if kind in ("batch", "delete", "delete_empty"):
+if kind in ("batch", "delete", "delete_empty", "mixed"):
     sim.add_objs(phys.light.generate_photons_bulk(N, min=phys.light.E_from_wavelength(700e-9),
                                                   max=phys.light.E_from_wavelength(200e-9), seed=21))
 else:
@@ -40,8 +40,14 @@ else:
     sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001), wavelength_dep_scattering=False))
 m1 = phys.light.ScatterMeasureStep(None, True, [[6e5, np.nan, np.nan], [np.nan, 0.0, np.nan]], measure_E=(kind == "objects"))
 m2 = phys.light.ScatterSignMeasureStep(None, True)
-sim.add_step(3, m1)
-sim.add_step(4, m2)
+if kind == "mixed":          # BASELINE configs[4]'s loop with a measure step behind each light step
+    sim.add_step(3, m2)
+    sim.add_step(4, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(5, phys.light.ScatterDeleteStep(np.double(0.0002), np.double(0.001)))
+    sim.add_step(6, m1)
+else:
+    sim.add_step(3, m1)
+    sim.add_step(4, m2)
 sim.run()
 flat = lambda r: [x if isinstance(x, list) else float(x) for x in r]       # measure_E rows carry energy lists
 print(json.dumps({"rank": comm.rank, "m1": [flat(r) for r in m1.data], "m2": [[float(x) for x in r] for r in m2.data],
@@ -88,7 +94,7 @@ def test_two_shards_reproduce_the_single_process_rows(kind):
         assert lists and all(len(set(l)) == len(l) for l in lists)
 
 
-@pytest.mark.parametrize("kind", ["batch", "delete_empty"])
+@pytest.mark.parametrize("kind", ["batch", "delete_empty", "mixed"])
 def test_two_shards_with_several_passes_per_launch_reproduce_the_single_process_rows(kind):
     """Simulation(steps_per_launch=4) on two shards == one pass per launch on one process: the K x counters of a
     launch are all-reduced at once, and the cut at the pass that empties the GLOBAL store is taken by both ranks."""

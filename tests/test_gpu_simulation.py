@@ -517,3 +517,38 @@ def test_trace_path_from_device_arrays_equals_the_per_object_walk(kind, monkeypa
             assert np.array_equal(np.asarray(x, dtype=float), np.asarray(y, dtype=float), equal_nan=True)
     if kind == "delete":
         assert any(np.isscalar(x) and np.isnan(x) for row in tf.data[1:] for x in row[2:])      # NaN padding after removal
+
+
+def test_steps_per_launch_survives_another_thread_looking_at_the_objects():
+    """with steps_per_launch > 1 a pass must re-upload after anything took the objects back to the host.
+    The main thread keeps indexing ``sim.objects`` while the simulation thread runs K passes per launch: rows, times
+    and final state are those of the undisturbed run (looking never changes a run: ids, hence random streams, stay)."""
+    import time
+
+    def build(K):
+        sim = phys.Simulation(cl_on=True, rng="philox", seed=3, steps_per_launch=K, exit=lambda s: len(s.ts) >= 24)
+        sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i)
+                      for i in range(3000)])
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+        sign = phys.light.ScatterSignMeasureStep(None, True)
+        sim.add_step(3, sign)
+        return sim, sign
+    ref, ref_sign = build(1)
+    run(ref)
+    sim, sign = build(4)
+    sim.start()
+    looks = 0
+    while sim.running or not sim.ts:
+        o = sim.objects[looks % 3000]                # brings the state to the host between launches
+        assert o.uid == looks % 3000
+        looks += 1
+        time.sleep(0.001)
+        if not sim.is_alive():
+            break
+    sim.join()
+    assert sim.error is None and looks > 0
+    assert [[float(x) for x in r] for r in sign.data] == [[float(x) for x in r] for r in ref_sign.data] and len(sign.data) == 24
+    for f in ("r", "v", "dv", "id"):
+        assert np.array_equal(sim.download(f), ref.download(f)), f
