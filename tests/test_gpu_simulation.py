@@ -540,13 +540,11 @@ def test_steps_per_launch_survives_another_thread_looking_at_the_objects():
     sim, sign = build(4)
     sim.start()
     looks = 0
-    while sim.running or not sim.ts:
+    while sim.is_alive():
         o = sim.objects[looks % 3000]                # brings the state to the host between launches
         assert o.uid == looks % 3000
         looks += 1
         time.sleep(0.001)
-        if not sim.is_alive():
-            break
     sim.join()
     assert sim.error is None and looks > 0
     assert [[float(x) for x in r] for r in sign.data] == [[float(x) for x in r] for r in ref_sign.data] and len(sign.data) == 24
