@@ -78,3 +78,22 @@ def test_rccl_backend_on_one_device_is_an_error_not_a_silent_fallback():
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode != 0 and p.stdout.strip() == ""
     assert "RCCL process group could not be brought up" in p.stderr or "CollectiveError" in p.stderr, p.stderr[-3000:]
+
+
+def test_two_ranks_started_by_torchrun_the_way_the_driver_documents_it():
+    """``python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus 2 ...``: the ranks find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment and do not spawn again."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                                   "--gpus", "2", "--backend", "gloo", "--device", "0", "--photons", "150000", "--steps", "6",
+                                   "--warmup", "3", "--repeats", "2"], cwd=ROOT, stderr=subprocess.DEVNULL, timeout=900)
+    lines = [ln for ln in out.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["collective"]["backend"] == "gloo" and d["collective"]["ranks_seen"] == 2
+    assert d["counters_last_step"]["N"] == 300000 and d["repeats"] == 2

@@ -321,3 +321,33 @@ def test_simulation_steps_per_launch_covers_the_mixed_loop(order, explicit):
     assert a[:6] == b[:6] and len(a[0]) == 12 and a[5] > 0
     for x, y in zip(a[6:], b[6:]):
         assert np.array_equal(x, y)
+
+
+def test_full_size_mixed_multi_equals_single_launches_at_1e8(make_store, hip):
+    """BASELINE configs[4] size: 1e8 photons filled on the device, [Newton, ScatterIsotropic, Newton, ScatterDelete] x 3 in
+    one pass + one compaction give the rows of 6 single launches, the same survivor ids and the same positions /
+    velocities / implicit dv at both ends and in the middle of the store (64-bit element offsets, 48 828 tiles)."""
+    N, K, seed = 100_000_000, 3, 11
+    sc = lambda k: dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, n_expr=None, rng_mode=hip.RNG_PHILOX, seed=seed, step=k)
+    out = []
+    for multi in (True, False):
+        d = make_store(N)
+        d.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, seed)
+        if multi:
+            rows = d.step_mixed_multi(1e-3, K, ("iso", "delete"), sc(2), (2e-5, 1e-3), (), seed, 2)
+            log = [(o["N"], o["hits"] if o["phase"] == "iso" else o["removed"], list(o["sign"])) for o in rows]
+        else:
+            log = []
+            for k in range(K):
+                o = d.step_fused(1e-3, sc(2 + 2 * k), [], lazy=True)
+                log.append((o["N"], o["hits"], list(o["sign"])))
+                o = d.step_fused_delete(1e-3, 2e-5, 1e-3, hip.RNG_PHILOX, seed, 3 + 2 * k, [], lazy=True)
+                log.append((o["N"], o["removed"], list(o["sign"])))
+        n = d.count
+        ends = [d.download_ids(4096, off) for off in (0, n // 2, n - 4096)] + \
+               [d.download(f, 4096, off) for f in (hip.R0, hip.V1, hip.DV2, hip.DR0, hip.E) for off in (0, n // 2 + 333, n - 4096)]
+        out.append((log, n, ends))
+        d.close()
+    assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
+    assert all(np.array_equal(a, b) for a, b in zip(out[0][2], out[1][2]))
+    assert abs(out[0][1] / N - (1 - 5.9958e-3) ** K) < 2e-4 and abs(out[0][0][0][1] / N - 0.2998) < 1e-3
