@@ -273,6 +273,27 @@ struct pcl_nprof {
     T p0, p1, p2;
 };
 
+// exp() inside a variable_n_fn expression.  Where the argument lies beyond the range in which exp saturates the result
+// is exactly +inf or +0 in any IEEE libm (fp64: x > 709.79 / x < -745.14; fp32: 88.73 / -103.98).  When EVERY active lane
+// of the wave is that far out -- the state of examples/variable_n_scattering.ipynb after its first step: one step moves a
+// photon 1.5e6 m while exp(r0 - 5) saturates 750 m from the origin -- the ~40-instruction polynomial is skipped for the
+// whole wave; one compare and one ballot otherwise.  Same value either way, so every kernel (and both libraries'
+// specialisations) keep agreeing bit for bit.
+__device__ __forceinline__ double pcl_exp_wave(double x) {
+#ifndef PCL_NO_EXP_WAVE
+    if (__ballot(!(__builtin_fabs(x) > 750.0)) == 0ull) return x > 0.0 ? __builtin_inf() : 0.0;
+#endif
+    return exp(x);
+}
+__device__ __forceinline__ float pcl_exp_wave(float x) {
+#ifndef PCL_NO_EXP_WAVE
+    if (__ballot(!(__builtin_fabsf(x) > 105.0f)) == 0ull) return x > 0.0f ? __builtin_inff() : 0.0f;
+#endif
+    return expf(x);
+}
+__device__ __forceinline__ double pcl_exp_wave(int x) { return pcl_exp_wave((double)x); } // exp(2) in user text: C promotes
+
+#define exp(x) pcl_exp_wave(x) /* for the body of pcl_n_expr_val only; undefined again right after it */
 template <typename T>
 __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev) {
     const T r0[1] = {r0v}, r1[1] = {r1v}, r2[1] = {r2v}, d0[1] = {d0v}, d1[1] = {d1v}, d2[1] = {d2v}, E[1] = {Ev};
@@ -292,6 +313,7 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
     return (T)(np.p0 * exp(rA[gid] / np.p1));
 #endif
 }
+#undef exp
 
 // pcoll exactly as the generated kernel text multiplies it            physicl/light.py:299-306
 //   A * n * norm  |  A * (<expr>) * norm  [ * pow((h*c)/E, -4) ]   -- left to right
