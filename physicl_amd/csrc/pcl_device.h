@@ -273,20 +273,21 @@ struct pcl_nprof {
     T p0, p1, p2;
 };
 
-// exp() inside a variable_n_fn expression.  Where the argument lies beyond the range in which exp saturates the result
-// is exactly +inf or +0 in any IEEE libm (fp64: x > 709.79 / x < -745.14; fp32: 88.73 / -103.98).  When EVERY active lane
-// of the wave is that far out -- the state of examples/variable_n_scattering.ipynb after its first step: one step moves a
-// photon 1.5e6 m while exp(r0 - 5) saturates 750 m from the origin -- the ~40-instruction polynomial is skipped for the
-// whole wave; one compare and one ballot otherwise.  Same value either way, so every kernel (and both libraries'
-// specialisations) keep agreeing bit for bit.
+// exp() inside a variable_n_fn expression.  EXPERIMENT, off unless PCL_EXP_WAVE is defined (PCL_RTC_EXTRA=PCL_EXP_WAVE):
+// where the argument lies beyond the range in which exp saturates the result is exactly +inf or +0 in any IEEE libm
+// (fp64: x > 709.79 / x < -745.14; fp32: 88.73 / -103.98), so when EVERY active lane of the wave is that far out -- the
+// state of examples/variable_n_scattering.ipynb after its first step -- the ~40-instruction polynomial can be skipped for
+// the whole wave at the price of a compare, a ballot and a branch.  Same value either way.  Measured on the K-step kernel
+// (DESIGN.md section 4): +9 % on the example's regime (with the kernel pinned to 4 waves / SIMD), -6 % on a regime where
+// exp never saturates -- the branch splits the two photons' dependency chains and costs registers -- so it is not on.
 __device__ __forceinline__ double pcl_exp_wave(double x) {
-#ifndef PCL_NO_EXP_WAVE
+#ifdef PCL_EXP_WAVE
     if (__ballot(!(__builtin_fabs(x) > 750.0)) == 0ull) return x > 0.0 ? __builtin_inf() : 0.0;
 #endif
     return exp(x);
 }
 __device__ __forceinline__ float pcl_exp_wave(float x) {
-#ifndef PCL_NO_EXP_WAVE
+#ifdef PCL_EXP_WAVE
     if (__ballot(!(__builtin_fabsf(x) > 105.0f)) == 0ull) return x > 0.0f ? __builtin_inff() : 0.0f;
 #endif
     return expf(x);
