@@ -37,6 +37,6 @@ work = sum(int(r[1]) for r in sign.data) + sum(int(r[1]) for r in planes.data)
 print("%d passes, %d photons left of %d, last pass: %d scattered, %d absorbed" % (len(sim.ts), len(sim.objects), N, sim.hits,
                                                                                sim.steps[5].removed))
 print("run time %.3f s  ->  %.3g light steps x photons per second" % (sim.run_time, work / sim.run_time))
-print("fraction moving along +x after 64 passes: %.4f (isotropised: 0.25 with theta in [0, 2 pi), phi in [0, pi))"
+print("fraction moving along +x after 64 passes: %.4f (all of them at the start; 1/2 once every photon has scattered)"
       % (sign.data[-1][2] / sign.data[-1][1]))
 sim.close(download=False)
