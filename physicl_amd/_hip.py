@@ -22,9 +22,10 @@ DTYPE_F64, DTYPE_F32 = 0, 1
 _NP_DTYPE = {DTYPE_F64: np.float64, DTYPE_F32: np.float32}
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
-PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED, PROF_MULTI = range(7)
+PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED, PROF_MULTI, PROF_ONEPASS = range(8)
 PROF_NAMES = {PROF_NEWTON: "k_newton", PROF_SCATTER: "k_scatter", PROF_DELETE_MASK: "k_delete_mask",
-              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused", PROF_MULTI: "k_multi"}
+              PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused", PROF_MULTI: "k_multi",
+              PROF_ONEPASS: "k_delete_onepass"}
 ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
              -6: "PCL_ERR_NOMEM"}
 

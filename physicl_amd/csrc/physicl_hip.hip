@@ -842,6 +842,277 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
     }
 }
 
+// ---- the delete loop body in ONE pass: Newton + delete flag + stable compaction with a decoupled look-back ----------
+//   The three-kernel pipeline reads r and v twice (pass 1 moves and flags, pass 3 moves the survivors) and writes r twice.
+//   Here a workgroup takes a UNIT of 1024 consecutive particles (ticket order = particle order), moves them and draws
+//   their flags with r and v in registers, learns where its survivors go from the units before it -- every unit
+//   publishes its survivor count (AGGREGATE), adds up the counts of the predecessors that have not yet published a
+//   running total, and publishes its own (PREFIX): Merrill & Garland's decoupled look-back, one 8-byte status word
+//   per unit carrying flag and count together, relaxed agent-scope atomics (the word IS the payload) -- and writes them,
+//   field by field through LDS in aligned 16-byte groups (as k_compact_lds).  Per particle: 80 B read + 88 B per
+//   survivor written, instead of 72 + 80 + 88 per survivor.  Same arithmetic, same Philox draws, same stable order as
+//   k_newton_mask -> k_tile_scan -> k_compact_*: bit-identical state, masks and counters.
+//   Progress: a unit only ever waits for units with smaller tickets, which are resident or finished.  Every wait is
+//   bounded all the same: a unit that gives up raises ``err`` (all others then stop waiting too) and the host, which has
+//   not lost anything -- the source slab is never written -- runs the three-kernel pipeline instead.
+constexpr int kUnit = 1024; // particles per look-back unit: 8 double rows of 128, two per wave
+constexpr unsigned long long kLbAgg = 1ull << 62, kLbPrefix = 2ull << 62, kLbCount = (1ull << 62) - 1ull;
+constexpr int kLbSpinLimit = 400000;
+
+template <typename T, typename W>
+struct onepass_args {
+    const W *src[10]; // rows of the current slab: r0 r1 r2 v0 v1 v2 x0 x1 x2 (dv, or vprev while dv is implicit) E
+    W *dst[10];       // the same rows of the other slab
+    const T *rand;    // PCL_RNG_INPUT
+    const int64_t *ids_src; // NULL: id = id_base + index
+    int64_t *ids_dst;
+    uint64_t *masks;             // keep-masks, k_newton_mask layout (pcl_store_last_delete_flags)
+    unsigned long long *status;  // [units], zeroed before the launch
+    unsigned int *ticket;        // zeroed before the launch
+    int *err;                    // zeroed before the launch
+    int64_t *total;              // survivors of the whole store
+    uint64_t *cnt;               // [1..3] sign counts, [4..] plane crossings of the survivors
+    int64_t id_base, N, ts;
+    T dt, An;
+    uint64_t seed;
+    uint32_t step;
+    int rng_mode;
+    int n_planes; // -1: no counters
+    T plane_L[PCL_MAX_PLANES];
+    int plane_ax[PCL_MAX_PLANES];
+};
+
+__device__ __forceinline__ uint64_t spread_bits(uint32_t x) { // bit i -> bit 2i
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+template <typename T, typename W>
+__global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a) {
+    typedef pcl_rt<T> R;
+    typedef typename w2_of<W>::type W2;
+    constexpr int VW = 16 / (int)sizeof(W);
+    constexpr int TRIPS = kUnit / 128 / (kBlock / 64); // double rows per wave: 2
+    __shared__ uint64_t s_raw[2][kUnit];
+    __shared__ int s_drc[kUnit / 128 + 1];
+    __shared__ long long s_excl;
+    __shared__ unsigned int s_unit;
+    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_unit = atomicAdd(a.ticket, 1u);
+    if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t u = s_unit;
+    const int64_t n_units = (a.N + kUnit - 1) / kUnit;
+    const pcl_u32 k0s = (pcl_u32)a.seed, k1s = (pcl_u32)(a.seed >> 32);
+    const uint64_t below = (1ull << lane) - 1ull;
+    T Rn[3][TRIPS][2], V[3][TRIPS][2];
+    W2 X[4][TRIPS];
+    int64_t ids[TRIPS][2];
+    bool keep[TRIPS][2];
+    int pre[TRIPS];
+    uint32_t w_s[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+        const int drow = wave * TRIPS + t;
+        const int64_t i0 = u * kUnit + (int64_t)drow * 128 + 2 * lane; // the lane's pair; the slab holds whole tiles, so it exists
+        const int64_t pair = pcl_tix(i0, a.ts) >> 1;
+        W2 rr[3], vv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rr[k] = reinterpret_cast<const W2 *>(a.src[k])[pair];
+            vv[k] = reinterpret_cast<const W2 *>(a.src[3 + k])[pair];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) X[j][t] = reinterpret_cast<const W2 *>(a.src[6 + j])[pair];
+        T d[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            V[k][t][0] = word_as<T, W>(vv[k].x);
+            V[k][t][1] = word_as<T, W>(vv[k].y);
+            d[k][0] = R::mul(V[k][t][0], a.dt);                                  // newton.py:15
+            d[k][1] = R::mul(V[k][t][1], a.dt);
+            Rn[k][t][0] = R::add(word_as<T, W>(rr[k].x), d[k][0]);              // newton.py:16
+            Rn[k][t][1] = R::add(word_as<T, W>(rr[k].y), d[k][1]);
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int64_t i = i0 + e;
+            const bool in = i < a.N;
+            ids[t][e] = in ? (a.ids_src ? a.ids_src[i] : a.id_base + i) : 0;
+            const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0][e], d[1][e], d[2][e]));   // light.py:241-244
+            T rand;
+            if (a.rng_mode == PCL_RNG_PHX)
+                rand = pcl_draw_rand<T>((pcl_u64)ids[t][e], a.step, k0s, k1s);
+            else
+                rand = in ? a.rand[i] : (T)0;
+            keep[t][e] = in && !(pcoll >= rand);
+        }
+        const uint64_t b0 = __ballot(keep[t][0]), b1 = __ballot(keep[t][1]);
+        pre[t] = (int)__popcll(b0 & below) + (int)__popcll(b1 & below);
+        if (lane == 0) {
+            s_drc[drow] = (int)__popcll(b0) + (int)__popcll(b1);
+            const int64_t row = (u * kUnit + (int64_t)drow * 128) >> 6; // two 64-particle rows of the mask array
+            a.masks[row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+            a.masks[row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+        }
+        if (a.n_planes >= 0) { // the counters of the measure steps, on the survivors      light.py:385-399, 414-431
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                w_s[k] += (uint32_t)__popcll(__ballot(keep[t][0] && V[k][t][0] > (T)0)) +
+                          (uint32_t)__popcll(__ballot(keep[t][1] && V[k][t][1] > (T)0));
+            for (int p = 0; p < a.n_planes; ++p) {
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                uint32_t np = 0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const T x = pcl_pick<T>(ax, Rn[0][t][e], Rn[1][t][e], Rn[2][t][e]);
+                    const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
+                    np += (uint32_t)__popcll(__ballot(keep[t][e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                }
+                if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { // exclusive offsets of the unit's double rows
+        int run = 0;
+        for (int k = 0; k < kUnit / 128; ++k) {
+            const int c = s_drc[k];
+            s_drc[k] = run;
+            run += c;
+        }
+        s_drc[kUnit / 128] = run;
+    }
+    __syncthreads();
+    const int kept = s_drc[kUnit / 128];
+    if (wave == 0) { // decoupled look-back: where do this unit's survivors go?
+        long long excl = 0;
+        if (u == 0) {
+            if (lane == 0) __hip_atomic_store(&a.status[0], kLbPrefix | (unsigned long long)kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&a.status[u], kLbAgg | (unsigned long long)kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long base = u - 1; // lane i looks at unit base - i
+            int spins = 0;
+            bool done = false;
+            while (!done) {
+                const long long idx = base - lane;
+                const unsigned long long val = idx >= 0 ? __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                        : kLbPrefix; // before unit 0: running total 0
+                const unsigned flag = (unsigned)(val >> 62);
+                const uint64_t has_prefix = __ballot(flag == 2u), not_ready = __ballot(flag == 0u);
+                const int first = has_prefix ? (int)__ffsll((long long)has_prefix) - 1 : 63;
+                const uint64_t window = first >= 63 ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first: the units that count
+                if (not_ready & window) {
+                    if (++spins > kLbSpinLimit || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        if (lane == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break; // give up: the host discards this launch
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+                long long part = ((window >> lane) & 1ull) ? (long long)(val & kLbCount) : 0ll;
+                for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                excl += part;
+                if (has_prefix)
+                    done = true;
+                else
+                    base -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&a.status[u], kLbPrefix | (unsigned long long)(excl + kept), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (u == n_units - 1) *a.total = excl + kept;
+        }
+    }
+    __syncthreads();
+    const int64_t o0 = s_excl;
+    int pos[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) pos[t] = s_drc[wave * TRIPS + t] + pre[t];
+    auto write_out = [&](W *dst_row, const W *buf) {
+        const int64_t g0 = o0 / VW, g1 = (o0 + kept + VW - 1) / VW;
+        for (int64_t g = g0 + threadIdx.x; g < g1; g += kBlock) {
+            const int64_t first = g * VW;
+            W *d = dst_row + pcl_tix(first, a.ts);
+            const int j = (int)(first - o0);
+            if (j >= 0 && j + VW <= kept) {
+                if constexpr (VW == 2)
+                    *reinterpret_cast<ulonglong2 *>(d) = make_ulonglong2(buf[j], buf[j + 1]);
+                else
+                    *reinterpret_cast<uint4 *>(d) = make_uint4(buf[j], buf[j + 1], buf[j + 2], buf[j + 3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e)
+                    if (j + e >= 0 && j + e < kept) d[e] = buf[j + e];
+            }
+        }
+    };
+    auto as_word = [](T x) -> W {
+        W w;
+        __builtin_memcpy(&w, &x, sizeof(W));
+        return w;
+    };
+#pragma unroll
+    for (int f = 0; f < 10; ++f) {
+        W *buf = reinterpret_cast<W *>(s_raw[f & 1]);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            W x0, x1;
+            if (f < 3) {
+                x0 = as_word(Rn[f][t][0]);
+                x1 = as_word(Rn[f][t][1]);
+            } else if (f < 6) {
+                x0 = as_word(V[f - 3][t][0]);
+                x1 = as_word(V[f - 3][t][1]);
+            } else {
+                x0 = X[f - 6][t].x;
+                x1 = X[f - 6][t].y;
+            }
+            if (keep[t][0]) buf[pos[t]] = x0;
+            if (keep[t][1]) buf[pos[t] + (keep[t][0] ? 1 : 0)] = x1;
+        }
+        __syncthreads();
+        write_out(a.dst[f], buf);
+    }
+    { // ids: always 8 bytes, dense destination
+        uint64_t *buf = s_raw[0]; // field 9 used buffer 1; field 8's write-out (buffer 0) is behind the last barrier
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            if (keep[t][0]) buf[pos[t]] = (uint64_t)ids[t][0];
+            if (keep[t][1]) buf[pos[t] + (keep[t][0] ? 1 : 0)] = (uint64_t)ids[t][1];
+        }
+        __syncthreads();
+        const int64_t g0 = o0 / 2, g1 = (o0 + kept + 1) / 2;
+        for (int64_t g = g0 + threadIdx.x; g < g1; g += kBlock) {
+            const int j = (int)(g * 2 - o0);
+            uint64_t *d = reinterpret_cast<uint64_t *>(a.ids_dst) + g * 2;
+            if (j >= 0 && j + 2 <= kept) {
+                *reinterpret_cast<ulonglong2 *>(d) = make_ulonglong2(buf[j], buf[j + 1]);
+            } else {
+                if (j >= 0 && j < kept) d[0] = buf[j];
+                if (j + 1 >= 0 && j + 1 < kept) d[1] = buf[j + 1];
+            }
+        }
+    }
+    if (a.n_planes >= 0) {
+        if (lane == 0)
+            for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
+        __syncthreads();
+        const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
+        if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+            atomicAdd(&a.cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    }
+}
+
 // expand the keep-masks of the last delete back into the reference's int32 ``res`` array
 __global__ void __launch_bounds__(kBlock) k_masks_to_flags(const uint64_t *__restrict__ masks,
                                                            int32_t *__restrict__ flags, int64_t N) {
@@ -1137,6 +1408,8 @@ struct pcl_ctx {
     int32_t *tile_keep = nullptr;
     int64_t *tile_off = nullptr;
     int64_t last_delete_n = -1;
+    unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
+    int64_t lb_units = 0;
 
     // counters: device slots + pinned host mirror
     uint64_t *d_cnt = nullptr;
@@ -2172,6 +2445,57 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool 
     return launch_compact_count<T>(ctx, !lazy, dv_implicit, cc);
 }
 
+// The delete loop body as ONE kernel (k_delete_onepass).  Returns PCL_OK with *gave_up = true when a look-back timed out:
+// nothing of the store has been modified then and the caller runs the three-kernel pipeline.
+template <typename T>
+int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, bool dv_implicit, int rng_mode, uint64_t seed,
+                           uint32_t step, const double *planes_host, int n_planes) {
+    typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
+    const int64_t N = ctx->count;
+    const int64_t units = div_up(N, kUnit);
+    if (ctx->lb_units < units) {
+        dev_free(ctx->lb_status);
+        ctx->lb_units = 0;
+        PCL_TRY(dev_alloc(&ctx->lb_status, div_up(ctx->capacity, kUnit)));
+        ctx->lb_units = div_up(ctx->capacity, kUnit);
+    }
+    PCL_HIP(hipMemsetAsync(ctx->lb_status, 0, (size_t)units * sizeof(unsigned long long), ctx->stream));
+    PCL_HIP(hipMemsetAsync(ctx->d_cnt + kCounterSlots - 4, 0, 2 * sizeof(uint64_t), ctx->stream)); // ticket, err
+    compact_args ca{};
+    compact_fields(ctx, ca, false, dv_implicit); // r v (dv | vprev) E, and the id arrays
+    onepass_args<T, W> a{};
+    for (int f = 0; f < 10; ++f) {
+        a.src[f] = static_cast<const W *>(ca.src[f]);
+        a.dst[f] = static_cast<W *>(ca.dst[f]);
+    }
+    a.rand = static_cast<const T *>(ctx->rnd[2]);
+    a.ids_src = ca.ids_src;
+    a.ids_dst = ca.ids_dst;
+    a.masks = ctx->masks;
+    a.status = ctx->lb_status;
+    a.ticket = reinterpret_cast<unsigned int *>(ctx->d_cnt + kCounterSlots - 4);
+    a.err = reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 3);
+    a.total = reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1);
+    a.cnt = ctx->d_cnt;
+    a.id_base = ctx->id_base;
+    a.N = N;
+    a.ts = tile_stride(ctx);
+    a.dt = (T)dt;
+    a.An = (T)A * (T)n;
+    a.seed = seed;
+    a.step = step;
+    a.rng_mode = rng_mode;
+    a.n_planes = n_planes;
+    plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
+    const int ps = prof_begin(ctx, PCL_PROF_ONEPASS);
+    hipLaunchKernelGGL((k_delete_onepass<T, W>), dim3((unsigned)units), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
+    PCL_TRY(launch_check("k_delete_onepass"));
+    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 4, ctx->d_cnt + kCounterSlots - 4, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    return PCL_OK;
+}
+
 template <typename T>
 int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool dv_implicit, uint64_t seed,
                          uint32_t step, const double *planes_host, int n_planes) {
@@ -2755,6 +3079,8 @@ int pcl_store_free(pcl_ctx *ctx) {
     dev_free(ctx->masks);
     dev_free(ctx->tile_keep);
     dev_free(ctx->tile_off);
+    dev_free(ctx->lb_status);
+    ctx->lb_units = 0;
     ctx->scratch_cap = 0;
     ctx->capacity = ctx->count = 0;
     ctx->last_delete_n = -1;
@@ -3256,15 +3582,35 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
-    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
-                         fused_delete_t<float>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
     int64_t alive = 0;
-    if (n_planes >= 0 && out_host) {
+    // One kernel for the whole loop body where it applies (dr implicit, all photons); the three-kernel pipeline otherwise --
+    // and as the fallback should a look-back ever give up (the one-pass kernel does not touch the source slab).
+    static const bool no_onepass = getenv("PCL_NO_ONEPASS") != nullptr; // perf-experiment hook
+    bool done = false;
+    if (lazy && !ctx->kind && !no_onepass) {
+        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_onepass_t<double>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
+                             fused_delete_onepass_t<float>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
+        if (n_planes >= 0)
+            PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_cnt[kCounterSlots - 3] == 0) { // no look-back gave up
+            alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+            if (alive < 0 || alive > N)
+                return fail(PCL_ERR_HIP, "one-pass compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
+            done = true;
+        } else {
+            PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
+        }
+    }
+    if (!done)
+        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
+                             fused_delete_t<float>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
+    if (!done && n_planes >= 0 && out_host) {
         // the measure counters come out of pass 3 itself: wait for it
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
     }
-    PCL_TRY(wait_count(ctx, N, &alive)); // the count alone is ready before pass 3 has finished
+    if (!done) PCL_TRY(wait_count(ctx, N, &alive)); // the count alone is ready before pass 3 has finished
     adopt_compacted(ctx, alive, N);      // (lazy: the dr rows of the new slab are stale -- dr is implicit anyway)
     if (lazy) {
         ctx->lazy_dr = true; // dr = v*dt with the (unchanged) velocities of the survivors
