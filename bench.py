@@ -428,8 +428,9 @@ def run_rank(args):
 # (test/test_light.py:52-59; physicl/light.py:231-260, physicl/__init__.py:455-459)
 # ---------------------------------------------------------------------------------------------------------------------
 def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
-    """Delete-until-empty at each size, two formulations: "per_step" = one pipeline (k_newton_mask -> scan ->
-    k_compact_count) per loop body, the HBM-bound form whose kernels get a roofline figure each; "multi" = K loop
+    """Delete-until-empty at each size, two formulations: "per_step" = one launch sequence per loop body (the one-pass
+    kernel k_delete_onepass, or the pipeline k_newton_mask -> scan -> k_compact_* where that does not apply), the
+    HBM-bound form with a roofline figure per kernel; "multi" = K loop
     bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation(steps_per_launch=K) runs.
     A "particle-step" is one photon alive at the start of one loop body.  Algorithmic bytes (DESIGN.md section 4,
     fp64): pass 1 reads r, v (48), writes r (24) + 1 mask bit; pass 3 reads 1 bit per particle and moves
@@ -477,13 +478,22 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
                  "run_ms": [round(x[0] * 1e3, 4) for x in runs],
                  "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
                  "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
-            if mode == "per_step":
+            if mode == "per_step" and kern["k_delete_onepass"]["launches"]:
+                # the whole loop body is one kernel (Newton + flag + decoupled look-back + compaction): it must read r, v of
+                # every particle (48) and dv | vprev, E (32) of the survivors, and write their r, v, dv | vprev, E, id (88)
+                ms = kern["k_delete_onepass"]["total_ms"]
+                b = tot * 48.125 + surv * (32.0 + 88.0)
+                g = b / (ms * 1e-3) / 1e9 if ms else 0.0
+                r["roofline"] = {"bound": "hbm", "kernel": "k_delete_onepass (Newton + delete flag + look-back + stable compaction, one pass)",
+                                 "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS, "traffic": None,
+                                 "algorithmic_bytes": b, "total_ms": ms}
+            elif mode == "per_step":
                 p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
                 b1 = tot * 72.125                              # r, v read; r written; one mask bit
                 b3 = tot * 0.125 + surv * 2.0 * 88.0           # mask bit; survivors' 10 fields + id read and written
                 g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
-                r["roofline"] = {"bound": "hbm", "kernel": "k_compact_count (stable compaction, pass 3)", "achieved": g3,
+                r["roofline"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction, pass 3)", "achieved": g3,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS, "traffic": None,
                                  "algorithmic_bytes": b3, "total_ms": p3_ms}
                 r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_newton_mask (Newton + delete flag -> ballot masks, pass 1)",
