@@ -433,8 +433,8 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
     HBM-bound form with a roofline figure per kernel; "multi" = K loop
     bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation(steps_per_launch=K) runs.
     A "particle-step" is one photon alive at the start of one loop body.  Algorithmic bytes (DESIGN.md section 4,
-    fp64): pass 1 reads r, v (48), writes r (24) + 1 mask bit; pass 3 reads 1 bit per particle and moves
-    r, v, dv, E + the id of every survivor ((80 + 8) x 2 per survivor; dr stays implicit)."""
+    fp64): pass 1 reads v (24) and writes 1 mask bit; pass 3 reads 1 bit per particle, moves r, v, dv, E + the id of
+    every survivor ((80 + 8) x 2 per survivor; dr stays implicit) and applies the Newton move to them on the way."""
     plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]          # test/test_light.py:58
     dt, A, n = 1e-3, 1e-3, 1e-3
     out = {"workload": "BASELINE configs[1](ii): Newton + ScatterDelete(A=n=1e-3) + plane counter until empty, E = 1, "
@@ -489,14 +489,14 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
                                  "algorithmic_bytes": b, "total_ms": ms}
             elif mode == "per_step":
                 p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
-                b1 = tot * 72.125                              # r, v read; r written; one mask bit
+                b1 = tot * 24.125                              # v read (the flag needs |v * dt| only); one mask bit
                 b3 = tot * 0.125 + surv * 2.0 * 88.0           # mask bit; survivors' 10 fields + id read and written
                 g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
                 r["roofline"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction, pass 3)", "achieved": g3,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS, "traffic": None,
                                  "algorithmic_bytes": b3, "total_ms": p3_ms}
-                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_newton_mask (Newton + delete flag -> ballot masks, pass 1)",
+                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_newton_mask, flag only (delete flag -> ballot masks, pass 1; pass 3 moves the survivors)",
                                        "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
                                        "traffic": None, "algorithmic_bytes": b1, "total_ms": p1_ms}
             else:

@@ -457,6 +457,7 @@ struct newtonmask_args {
     uint32_t step;
     int rng_mode;
     int lazy;
+    int flag_only; // 1: do not touch r at all -- the flag needs |v * dt| only; pass 3 moves the survivors (lazy mode)
 };
 
 template <typename T>
@@ -477,8 +478,10 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 d[k] = R::mul(a.v[k][ti], a.dt);
-                a.r[k][ti] = R::add(a.r[k][ti], d[k]);
-                if (!a.lazy) a.dr[k][ti] = d[k];
+                if (!a.flag_only) {
+                    a.r[k][ti] = R::add(a.r[k][ti], d[k]);
+                    if (!a.lazy) a.dr[k][ti] = d[k];
+                }
             }
             const bool photon = a.kind ? (a.kind[i] != 0) : true;
             const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2]));
@@ -624,6 +627,7 @@ struct compact_counter_args {
     int plane_ax[PCL_MAX_PLANES];
     int n_planes;  // -1: no counters
     T dt;          // dr = v*dt when it is implicit
+    int move;      // 1: pass 1 only flagged; the survivors' Newton move r = r + v*dt (newton.py:15-16) happens here
 };
 
 template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
@@ -659,6 +663,13 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
             const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
 #pragma unroll
             for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
+            if (c.move) { // the survivors' Newton move, with the operations of k_newton_mask
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T rn = R::add(word_as<T, W>(val[k]), R::mul(word_as<T, W>(val[3 + k]), c.dt));
+                    __builtin_memcpy(&val[k], &rn, sizeof(W));
+                }
+            }
 #pragma unroll
             for (int f = 0; f < NF; ++f) static_cast<W *>(a.dst[f])[to] = val[f];
             if (a.ids_dst) a.ids_dst[o] = a.ids_src ? a.ids_src[i] : a.id_base + i;
@@ -704,8 +715,10 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
 //   loads, a wave covers a 128-particle double row), the workgroup gathers one field of its whole 2048-particle tile into
 //   LDS in survivor order, and writes it out as aligned 16-byte groups of the destination row (the first / last group of
 //   a tile's output range, which it shares with its neighbours, goes element by element).  Fields go one after the
-//   other through two LDS buffers: one barrier per field.  r rows are kept in registers until the v rows arrive, so the
-//   sign / plane counters see the same values as in k_compact_count (dr = v * dt is recomputed: pass 1 wrote exactly that).
+//   other through two LDS buffers: one barrier per field.  The v rows go first and stay in registers until the r rows
+//   arrive: with ``move`` set pass 1 has only flagged (it needs |v * dt|, not r) and the survivors' Newton move happens
+//   here, r = r + v * dt, the very operations of k_newton_mask; the sign / plane counters see the same values as in
+//   k_compact_count (dr = v * dt is recomputed: it is what pass 1 would have written).
 template <typename W> struct w2_of;
 template <> struct w2_of<uint64_t> { typedef ulonglong2 type; };
 template <> struct w2_of<uint32_t> { typedef uint2 type; };
@@ -754,7 +767,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
         src_pair[t] = pcl_tix(i0, a.ts) >> 1;
     }
     const bool counters = c.n_planes >= 0;
-    T rkeep[3][TRIPS][2];
+    T vkeep[3][TRIPS][2]; // the v rows go first and wait here for the r rows (Newton move of the survivors, plane crossings)
     uint32_t w_s[3] = {0, 0, 0};
     auto write_out = [&](void *dst_row, const W *buf, bool dense) {
         // aligned groups of VW destination elements; group g covers outputs [VW*g, VW*g + VW)
@@ -778,37 +791,45 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
         }
     };
 #pragma unroll
-    for (int f = 0; f < NF; ++f) {
-        W *buf = reinterpret_cast<W *>(s_raw[f & 1]);
+    for (int j = 0; j < NF; ++j) {
+        const int f = j < 3 ? j + 3 : (j < 6 ? j - 3 : j); // processing order: v0 v1 v2, r0 r1 r2, then the rest
+        W *buf = reinterpret_cast<W *>(s_raw[j & 1]);
         const W2 *src = static_cast<const W2 *>(a.src[f]);
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
             W2 x;
             x.x = x.y = 0;
             if (k0[t] || k1[t]) x = src[src_pair[t]]; // nothing is read for a pair that is gone
-            if (k0[t]) buf[pos[t]] = x.x;
-            if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = x.y;
-            if (counters) {
-                if (f < 3) { // r rows: wait for the v rows (plane crossings)
-                    rkeep[f][t][0] = word_as<T, W>(x.x);
-                    rkeep[f][t][1] = word_as<T, W>(x.y);
-                } else if (f < 6) { // v rows: sign counts, and the planes on this axis
-                    const int ax = f - 3;
-                    const T v0 = word_as<T, W>(x.x), v1 = word_as<T, W>(x.y);
-                    w_s[ax] += (uint32_t)__popcll(__ballot(k0[t] && v0 > (T)0)) + (uint32_t)__popcll(__ballot(k1[t] && v1 > (T)0));
-                    for (int p = 0; p < c.n_planes; ++p) {
+            if (j < 3) { // v rows: sign counts                                        light.py:424-426
+                const T v0 = word_as<T, W>(x.x), v1 = word_as<T, W>(x.y);
+                vkeep[j][t][0] = v0;
+                vkeep[j][t][1] = v1;
+                if (counters)
+                    w_s[j] += (uint32_t)__popcll(__ballot(k0[t] && v0 > (T)0)) + (uint32_t)__popcll(__ballot(k1[t] && v1 > (T)0));
+            } else if (j < 6) { // r rows: the survivors' move when pass 1 only flagged, then the planes on this axis
+                const int ax = j - 3;
+                T x0 = word_as<T, W>(x.x), x1 = word_as<T, W>(x.y);
+                const T d0 = R::mul(vkeep[ax][t][0], c.dt), d1 = R::mul(vkeep[ax][t][1], c.dt); // newton.py:15
+                if (c.move) {
+                    x0 = R::add(x0, d0);                                                              // newton.py:16
+                    x1 = R::add(x1, d1);
+                    __builtin_memcpy(&x.x, &x0, sizeof(W));
+                    __builtin_memcpy(&x.y, &x1, sizeof(W));
+                }
+                if (counters)
+                    for (int p = 0; p < c.n_planes; ++p) {                                           // light.py:385-399
                         if (c.plane_ax[p] != ax) continue;
                         const T L = c.plane_L[p];
-                        const T x0 = rkeep[ax][t][0], x1 = rkeep[ax][t][1];
-                        const T p0 = R::sub(x0, R::mul(v0, c.dt)), p1 = R::sub(x1, R::mul(v1, c.dt));
+                        const T p0 = R::sub(x0, d0), p1 = R::sub(x1, d1);
                         const uint32_t np = (uint32_t)__popcll(__ballot(k0[t] && ((p0 <= L && L <= x0) || (p0 >= L && L >= x0)))) +
                                             (uint32_t)__popcll(__ballot(k1[t] && ((p1 <= L && L <= x1) || (p1 >= L && L >= x1))));
                         if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
                     }
-                }
             }
+            if (k0[t]) buf[pos[t]] = x.x;
+            if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = x.y;
         }
-        __syncthreads(); // field f is complete in its buffer (and the write-out of field f - 1 is behind every thread)
+        __syncthreads(); // this field is complete in its buffer (and the write-out of the previous one is behind every thread)
         write_out(a.dst[f], buf, false);
     }
     if (a.ids_dst) { // ids: one more "field", always 8 bytes, dense destination
@@ -2432,6 +2453,10 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool 
     m.step = step;
     m.rng_mode = rng_mode;
     m.lazy = lazy ? 1 : 0;
+    // dr implicit: the flag needs |v * dt| only, so pass 1 reads v (24 B) and leaves r alone; pass 3 moves the survivors
+    // while they go through its registers.  Eager mode writes dr and r for everybody here, as before.
+    static const bool move_in_pass1 = getenv("PCL_MOVE_IN_PASS1") != nullptr; // perf-experiment hook: round 1's split
+    m.flag_only = (lazy && !move_in_pass1) ? 1 : 0;
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     hipLaunchKernelGGL(k_newton_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);
@@ -2441,6 +2466,7 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool 
     cc.cnt = ctx->d_cnt;
     cc.n_planes = n_planes;
     cc.dt = (T)dt;
+    cc.move = m.flag_only;
     plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
     return launch_compact_count<T>(ctx, !lazy, dv_implicit, cc);
 }
@@ -3583,11 +3609,13 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     PCL_TRY(ensure_alt(ctx));
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
     int64_t alive = 0;
-    // One kernel for the whole loop body where it applies (dr implicit, all photons); the three-kernel pipeline otherwise --
-    // and as the fallback should a look-back ever give up (the one-pass kernel does not touch the source slab).
-    static const bool no_onepass = getenv("PCL_NO_ONEPASS") != nullptr; // perf-experiment hook
+    // EXPERIMENT (PCL_ONEPASS=1): one kernel for the whole loop body (k_delete_onepass, decoupled look-back).  Bit-identical,
+    // but measured slower than the pipeline below on this chip (0.20 vs 0.5 of peak at 1e8 photons: with ~1000 units in
+    // flight a unit's look-back walks ~16 windows of 64 predecessors at ~2 us of cross-XCD latency each, as long as the
+    // unit's own memory traffic takes), so it is not the default.  Falls back to the pipeline should a look-back give up.
+    static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
     bool done = false;
-    if (lazy && !ctx->kind && !no_onepass) {
+    if (lazy && !ctx->kind && onepass) {
         PCL_TRY(PCL_DISPATCH(ctx, fused_delete_onepass_t<double>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
                              fused_delete_onepass_t<float>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
         if (n_planes >= 0)
