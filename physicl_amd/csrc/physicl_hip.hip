@@ -224,6 +224,19 @@ __global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
         }                                                                                                         \
     } while (0)
 
+// is any element of three rows anything but +0.0 (bit pattern 0)?  flag |= 1
+template <typename W>
+__global__ void __launch_bounds__(kBlock) k_any_nonzero(const W *__restrict__ a0, const W *__restrict__ a1, const W *__restrict__ a2,
+                                                        int64_t N, int64_t ts, int *__restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const int64_t ti = pcl_tix(i, ts);
+        any = any || a0[ti] != 0 || a1[ti] != 0 || a2[ti] != 0;
+    }
+    if (__ballot(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
 // store caches it; the fast fused path multiplies by the cached value (bit-identical: same device pow)
 template <typename T>
@@ -619,7 +632,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
 }
 
 // ---- pass 3 with the measure counters folded in: the survivors' r, v (and dr) pass through registers anyway ----
-//   field order in compact_args: r0 r1 r2 v0 v1 v2 [dr0 dr1 dr2] dv0 dv1 dv2 E   (dr present iff HAS_DR)
+//   field order in compact_args: r0 r1 r2 v0 v1 v2 [dr0 dr1 dr2] [dv0 dv1 dv2 | vprev0..2] E   (compact_fields)
 template <typename T>
 struct compact_counter_args {
     uint64_t *cnt; // [1..3] sign counts, [4..] plane crossings (slot 0 is the scatter-hit counter)
@@ -634,10 +647,10 @@ template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
 template <> __device__ __forceinline__ double word_as<double, uint64_t>(uint64_t w) { return __longlong_as_double((long long)w); }
 template <> __device__ __forceinline__ float word_as<float, uint32_t>(uint32_t w) { return __uint_as_float(w); }
 
-template <typename T, typename W, bool HAS_DR>
+template <typename T, typename W, int NF> // NF = 13 (dr travels), 10 (dr implicit) or 7 (dr implicit, dv known to be zero)
 __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compact_counter_args<T> c) {
     typedef pcl_rt<T> R;
-    constexpr int NF = HAS_DR ? 13 : 10;
+    constexpr bool HAS_DR = NF == 13;
     if (a.choice && *a.choice != 0) return; // the scan chose k_compact_lds for this launch
     __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1431,6 +1444,11 @@ struct pcl_ctx {
     int64_t last_delete_n = -1;
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
     int64_t lb_units = 0;
+    // Rows that are known to hold nothing but +0.0 need not travel through a compaction: in a run that never scatters
+    // (delete-until-empty, BASELINE configs[1](ii)) that is dv, 24 of the 88 bytes a survivor costs.
+    int dv_zero = 0;              // 0 unknown (checked on the device when it matters), 1 every live dv element is +0.0, 2 not
+    int64_t alt_dv_zero_n = 0;    // leading elements of the OTHER slab's dv rows known to be +0.0
+    bool compact_skipped_dv = false; // set by the compaction launch, consumed by adopt_compacted
 
     // counters: device slots + pinned host mirror
     uint64_t *d_cnt = nullptr;
@@ -1613,6 +1631,7 @@ int materialize_t(pcl_ctx *ctx) {
 int materialize(pcl_ctx *ctx) {
     if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
     PCL_TRY(PCL_DISPATCH(ctx, materialize_t<double>(ctx), materialize_t<float>(ctx)));
+    if (ctx->lazy_dv) ctx->dv_zero = 2; // real dv values were just written
     ctx->lazy_dr = ctx->lazy_dv = ctx->lazy_dr_vprev = false;
     return PCL_OK;
 }
@@ -2060,6 +2079,9 @@ int wait_count(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 
 // the store after a compaction into the other slab
 void adopt_compacted(pcl_ctx *ctx, int64_t alive, int64_t last_delete_n) {
+    // the slab left behind: its dv rows are zero over the old count if this compaction relied on dv being zero
+    ctx->alt_dv_zero_n = ctx->compact_skipped_dv ? ctx->count : 0;
+    ctx->compact_skipped_dv = false;
     std::swap(ctx->slab, ctx->slab_alt);
     refresh_rows(ctx);
     std::swap(ctx->ids, ctx->ids_alt);
@@ -2358,9 +2380,12 @@ int counters_t(pcl_ctx *ctx, const double *planes_host, int n_planes) {
 }
 
 // Fields a compaction has to move.  r, v and E always; dr unless it is implicit after the call (dr = v*dt); dv -- or,
-// while dv is implicit (dv = v - vprev, all-photon stores), the vprev rows in its place.  Order: r v [dr] dv|vprev E
-// (k_compact_count reads r, v and dr at fixed positions for the measure counters).
-int compact_fields(pcl_ctx *ctx, compact_args &ca, bool move_dr, bool dv_implicit) {
+// while dv is implicit (dv = v - vprev, all-photon stores), the vprev rows in its place -- or nothing, when every dv
+// element is known to be +0.0 and the destination's dv rows are too.  Order: r v [dr] [dv | vprev] E
+// (the compaction kernels read r, v and dr at fixed positions for the measure counters).
+enum { kDvMove = 0, kDvVprev = 1, kDvSkip = 2 };
+int compact_fields(pcl_ctx *ctx, compact_args &ca, bool move_dr, int dv_mode) {
+    const bool dv_implicit = dv_mode == kDvVprev;
     int nf = 0;
     for (int f = PCL_R0; f <= PCL_V2; ++f) {
         ca.src[nf] = ctx->field[f];
@@ -2371,7 +2396,7 @@ int compact_fields(pcl_ctx *ctx, compact_args &ca, bool move_dr, bool dv_implici
             ca.src[nf] = ctx->field[f];
             ca.dst[nf++] = ctx->field_alt[f];
         }
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 3 && dv_mode != kDvSkip; ++k) {
         ca.src[nf] = dv_implicit ? ctx->vprev[k] : ctx->field[PCL_DV0 + k];
         ca.dst[nf++] = dv_implicit ? ctx->vprev_alt[k] : ctx->field_alt[PCL_DV0 + k];
     }
@@ -2402,10 +2427,20 @@ void plane_table(const double *planes_host, int n_planes, int *ax_out, T *L_out)
 // pass 3 of a delete pipeline: stable compaction of the store into the other slab (+ the measure counters when
 // cc.n_planes >= 0); has_dr says whether the dr rows travel (13 fields) or stay implicit (10)
 template <typename T>
-int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_counter_args<T> &cc) {
+int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter_args<T> &cc) {
     const int tiles = (int)div_up(ctx->count, kTile);
+    if (has_dr && dv_mode == kDvSkip) dv_mode = kDvMove; // (13-field form: nothing is skipped)
+    if (dv_mode == kDvSkip && ctx->alt_dv_zero_n < ctx->count) {
+        // the survivors' dv is not written: the destination's dv rows have to be zero already.  Once per run -- after
+        // that the slabs swap roles and the one left behind holds zeros over [0, the larger, earlier count)
+        for (int k = 0; k < 3; ++k)
+            PCL_HIP(hipMemset2DAsync(ctx->field_alt[PCL_DV0 + k], (size_t)kRows * kTileT * ctx->esz, 0, (size_t)kTileT * ctx->esz,
+                                     (size_t)tiles, ctx->stream));
+        ctx->alt_dv_zero_n = (int64_t)tiles * kTileT;
+    }
+    ctx->compact_skipped_dv = dv_mode == kDvSkip;
     compact_args ca{};
-    compact_fields(ctx, ca, has_dr, dv_implicit);
+    compact_fields(ctx, ca, has_dr, dv_mode);
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
     const int pc = prof_begin(ctx, PCL_PROF_COMPACT);
     // Two formulations, both enqueued; the scan's verdict (d_cnt[kCounterSlots - 2]) lets exactly one of them work.
@@ -2414,13 +2449,17 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_co
     const bool both = !ctx->kind && !direct_only;
     ca.choice = both ? reinterpret_cast<const int *>(ctx->d_cnt + kCounterSlots - 2) : nullptr;
     if (has_dr)
-        hipLaunchKernelGGL((k_compact_count<T, W, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        hipLaunchKernelGGL((k_compact_count<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+    else if (dv_mode == kDvSkip)
+        hipLaunchKernelGGL((k_compact_count<T, W, 7>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
     else
-        hipLaunchKernelGGL((k_compact_count<T, W, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        hipLaunchKernelGGL((k_compact_count<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
     if (both) {
         PCL_TRY(launch_check("k_compact_count"));
         if (has_dr)
             hipLaunchKernelGGL((k_compact_lds<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        else if (dv_mode == kDvSkip)
+            hipLaunchKernelGGL((k_compact_lds<T, W, 7>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
         else
             hipLaunchKernelGGL((k_compact_lds<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
     }
@@ -2428,8 +2467,42 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, bool dv_implicit, compact_co
     return launch_check("k_compact");
 }
 
+// How the dv rows go through the compaction of a lazy delete step.  A still-implicit dv (lazy scatter step: dv = v - vprev)
+// stays implicit on all-photon stores -- the vprev rows travel in place of the dv rows -- and is made real otherwise; real
+// dv rows that hold nothing but +0.0 (a run that never scatters; checked on the device once, then remembered) do not
+// travel at all.
+int decide_dv_mode(pcl_ctx *ctx, bool lazy, int *mode_out) {
+    *mode_out = kDvMove;
+    if (ctx->lazy_dv) {
+        if (lazy && !ctx->kind)
+            *mode_out = kDvVprev;
+        else
+            PCL_TRY(materialize(ctx));
+        return PCL_OK;
+    }
+    static const bool no_skip = getenv("PCL_NO_DV_SKIP") != nullptr; // perf-experiment hook
+    if (!lazy || ctx->kind || no_skip || ctx->count == 0) return PCL_OK;
+    if (ctx->dv_zero == 0) {
+        int *flag = reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 5);
+        PCL_HIP(hipMemsetAsync(flag, 0, sizeof(uint64_t), ctx->stream));
+        const int grid = grid_for(ctx, ctx->count, kBlock);
+        if (ctx->dtype == PCL_DTYPE_F64)
+            hipLaunchKernelGGL(k_any_nonzero<uint64_t>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const uint64_t *)ctx->field[PCL_DV0],
+                               (const uint64_t *)ctx->field[PCL_DV1], (const uint64_t *)ctx->field[PCL_DV2], ctx->count, tile_stride(ctx), flag);
+        else
+            hipLaunchKernelGGL(k_any_nonzero<uint32_t>, dim3(grid), dim3(kBlock), 0, ctx->stream, (const uint32_t *)ctx->field[PCL_DV0],
+                               (const uint32_t *)ctx->field[PCL_DV1], (const uint32_t *)ctx->field[PCL_DV2], ctx->count, tile_stride(ctx), flag);
+        PCL_TRY(launch_check("k_any_nonzero"));
+        PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 5, flag, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->dv_zero = ctx->h_cnt[kCounterSlots - 5] ? 2 : 1;
+    }
+    if (ctx->dv_zero == 1) *mode_out = kDvSkip;
+    return PCL_OK;
+}
+
 template <typename T>
-int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool dv_implicit, int rng_mode, uint64_t seed,
+int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int dv_mode, int rng_mode, uint64_t seed,
                    uint32_t step, const double *planes_host, int n_planes) {
     const int64_t N = ctx->count;
     const int tiles = (int)div_up(N, kTile);
@@ -2468,13 +2541,13 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, bool 
     cc.dt = (T)dt;
     cc.move = m.flag_only;
     plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
-    return launch_compact_count<T>(ctx, !lazy, dv_implicit, cc);
+    return launch_compact_count<T>(ctx, !lazy, dv_mode, cc);
 }
 
 // The delete loop body as ONE kernel (k_delete_onepass).  Returns PCL_OK with *gave_up = true when a look-back timed out:
 // nothing of the store has been modified then and the caller runs the three-kernel pipeline.
 template <typename T>
-int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, bool dv_implicit, int rng_mode, uint64_t seed,
+int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, int dv_mode, int rng_mode, uint64_t seed,
                            uint32_t step, const double *planes_host, int n_planes) {
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
     const int64_t N = ctx->count;
@@ -2488,7 +2561,7 @@ int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, bool dv_
     PCL_HIP(hipMemsetAsync(ctx->lb_status, 0, (size_t)units * sizeof(unsigned long long), ctx->stream));
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + kCounterSlots - 4, 0, 2 * sizeof(uint64_t), ctx->stream)); // ticket, err
     compact_args ca{};
-    compact_fields(ctx, ca, false, dv_implicit); // r v (dv | vprev) E, and the id arrays
+    compact_fields(ctx, ca, false, dv_mode == kDvSkip ? kDvMove : dv_mode); // r v (dv | vprev) E, and the id arrays
     onepass_args<T, W> a{};
     for (int f = 0; f < 10; ++f) {
         a.src[f] = static_cast<const W *>(ca.src[f]);
@@ -2523,7 +2596,7 @@ int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, bool dv_
 }
 
 template <typename T>
-int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool dv_implicit, uint64_t seed,
+int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int dv_mode, uint64_t seed,
                          uint32_t step, const double *planes_host, int n_planes) {
     const int64_t N = ctx->count;
     const int tiles = (int)div_up(N, kTile);
@@ -2556,7 +2629,7 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     cc.cnt = ctx->d_cnt;
     cc.n_planes = -1; // the counters were taken step by step in pass 1
     cc.dt = (T)dt;
-    return launch_compact_count<T>(ctx, false, dv_implicit, cc);
+    return launch_compact_count<T>(ctx, false, dv_mode, cc);
 }
 
 // K passes of a loop with an isotropic-scatter phase and/or a delete phase (pcl_mixed_body): the pass itself.
@@ -2607,13 +2680,13 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
 
 // scan + stable compaction after a pass that left keep-masks (counters off: the pass tallied them)
 template <typename T>
-int compact_after_pass_t(pcl_ctx *ctx, double dt, bool has_dr, bool dv_implicit) {
+int compact_after_pass_t(pcl_ctx *ctx, double dt, bool has_dr, int dv_mode) {
     PCL_TRY(scan_tiles(ctx, ctx->count));
     compact_counter_args<T> cc{};
     cc.cnt = ctx->d_cnt;
     cc.n_planes = -1;
     cc.dt = (T)dt;
-    return launch_compact_count<T>(ctx, has_dr, dv_implicit, cc);
+    return launch_compact_count<T>(ctx, has_dr, dv_mode, cc);
 }
 
 template <typename T>
@@ -3071,6 +3144,8 @@ int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     ctx->count = 0;
     ctx->id_base = 0;
     ctx->ids_iota = true;
+    ctx->dv_zero = 0;
+    ctx->alt_dv_zero_n = 0;
     return PCL_OK;
 }
 
@@ -3107,6 +3182,8 @@ int pcl_store_free(pcl_ctx *ctx) {
     dev_free(ctx->tile_off);
     dev_free(ctx->lb_status);
     ctx->lb_units = 0;
+    ctx->dv_zero = 0;
+    ctx->alt_dv_zero_n = 0;
     ctx->scratch_cap = 0;
     ctx->capacity = ctx->count = 0;
     ctx->last_delete_n = -1;
@@ -3134,6 +3211,8 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
     ctx->lam4_valid = false;
+    ctx->dv_zero = 0;
+    ctx->alt_dv_zero_n = 0;
     // a new population: every particle is a photon again until pcl_store_upload_kind says otherwise (a kind array left
     // over from an earlier, mixed upload would silently switch the light steps off for whoever sits at those indices)
     if (ctx->kind || ctx->kind_alt) PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -3147,6 +3226,7 @@ int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, 
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
     if (field == PCL_E) ctx->lam4_valid = false;
+    if (field >= PCL_DV0 && field <= PCL_DV2) ctx->dv_zero = 0; // unknown again: looked at on the device when it matters
     return copy_row(ctx, ctx->field[field], const_cast<void *>(host), offset, n, true);
 }
 
@@ -3199,6 +3279,7 @@ int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
     if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
+    if (field >= PCL_DV0 && field <= PCL_DV2) ctx->dv_zero = 0;
     *dev_out = ctx->field[field];
     return PCL_OK;
 }
@@ -3234,6 +3315,7 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
     ctx->id_base = id_base;
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
+    ctx->dv_zero = 1; // the fill wrote +0.0 into every dv element
     return PCL_OK;
 }
 
@@ -3261,6 +3343,7 @@ int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, doubl
     ctx->id_base = id_base;
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
+    ctx->dv_zero = 1;
     return PCL_OK;
 }
 
@@ -3289,6 +3372,7 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
+    ctx->dv_zero = 2; // the step writes dv
     PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv),
                          step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv)));
     if (hits_out) {
@@ -3415,6 +3499,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             ctx, step_fused_t<double>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy),
             step_fused_t<float>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy)));
     }
+    if (!lazy && do_scatter) ctx->dv_zero = 2; // the eager step wrote dv
     if (lazy) {
         if (do_scatter) {
             for (int k = 0; k < 3; ++k) std::swap(ctx->row[PCL_V0 + k], ctx->row[kRowVprev + k]); // V rows = new v
@@ -3592,8 +3677,8 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     // A still-implicit dv (lazy scatter step): an all-photon store keeps it implicit -- the vprev rows travel through the
     // compaction in place of the dv rows -- anything else makes it real before the state is moved.  An implicit dr is
     // simply superseded by this step's Newton move.
-    const bool dv_implicit = lazy && ctx->lazy_dv && !ctx->kind;
-    if (ctx->lazy_dv && !dv_implicit) PCL_TRY(materialize(ctx));
+    int dv_mode = kDvMove;
+    PCL_TRY(decide_dv_mode(ctx, lazy, &dv_mode));
     ctx->lazy_dr = ctx->lazy_dr_vprev = false;
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
@@ -3616,8 +3701,8 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
     bool done = false;
     if (lazy && !ctx->kind && onepass) {
-        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_onepass_t<double>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
-                             fused_delete_onepass_t<float>(ctx, dt, A, n, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
+        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_onepass_t<double>(ctx, dt, A, n, dv_mode, rng_mode, seed, step, planes_host, n_planes),
+                             fused_delete_onepass_t<float>(ctx, dt, A, n, dv_mode, rng_mode, seed, step, planes_host, n_planes)));
         if (n_planes >= 0)
             PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -3631,8 +3716,8 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
         }
     }
     if (!done)
-        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes),
-                             fused_delete_t<float>(ctx, dt, A, n, lazy, dv_implicit, rng_mode, seed, step, planes_host, n_planes)));
+        PCL_TRY(PCL_DISPATCH(ctx, fused_delete_t<double>(ctx, dt, A, n, lazy, dv_mode, rng_mode, seed, step, planes_host, n_planes),
+                             fused_delete_t<float>(ctx, dt, A, n, lazy, dv_mode, rng_mode, seed, step, planes_host, n_planes)));
     if (!done && n_planes >= 0 && out_host) {
         // the measure counters come out of pass 3 itself: wait for it
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -3660,8 +3745,8 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
-    const bool dv_implicit = ctx->lazy_dv && !ctx->kind;    // see pcl_step_fused_delete
-    if (ctx->lazy_dv && !dv_implicit) PCL_TRY(materialize(ctx));
+    int dv_mode = kDvMove;                                   // see pcl_step_fused_delete
+    PCL_TRY(decide_dv_mode(ctx, true, &dv_mode));
     ctx->lazy_dr = ctx->lazy_dr_vprev = false;               // an implicit dr is superseded by these steps' own moves
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;
@@ -3671,8 +3756,8 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)k_steps * nslots * sizeof(uint64_t), ctx->stream));
-    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, dv_implicit, seed, step0, planes_host, n_planes),
-                         fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, dv_implicit, seed, step0, planes_host, n_planes)));
+    PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, dv_mode, seed, step0, planes_host, n_planes),
+                         fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, dv_mode, seed, step0, planes_host, n_planes)));
     // the per-step rows were complete when pass 1 ended: their copy was enqueued behind the compaction only to keep
     // one wait; the count event fires before pass 3
     PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)k_steps * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
@@ -3761,13 +3846,13 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     ctx->lazy_dt = dt;
     if (has_delete) {
         bool has_dr = false;
-        const bool dv_implicit = ctx->lazy_dv && !ctx->kind;
+        int dv_mode = (ctx->lazy_dv && !ctx->kind) ? kDvVprev : kDvMove;
         if (ctx->lazy_dv && ctx->kind) { // plain Objects keep real dv rows: make the photons' real too, move everything
             PCL_TRY(materialize(ctx));
             has_dr = true;
         }
-        PCL_TRY(PCL_DISPATCH(ctx, compact_after_pass_t<double>(ctx, dt, has_dr, dv_implicit),
-                             compact_after_pass_t<float>(ctx, dt, has_dr, dv_implicit)));
+        PCL_TRY(PCL_DISPATCH(ctx, compact_after_pass_t<double>(ctx, dt, has_dr, dv_mode),
+                             compact_after_pass_t<float>(ctx, dt, has_dr, dv_mode)));
     }
     PCL_HIP(hipStreamSynchronize(ctx->stream));
     if (has_delete) {
