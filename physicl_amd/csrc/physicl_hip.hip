@@ -1448,7 +1448,7 @@ struct pcl_ctx {
     // (delete-until-empty, BASELINE configs[1](ii)) that is dv, 24 of the 88 bytes a survivor costs.
     int dv_zero = 0;              // 0 unknown (checked on the device when it matters), 1 every live dv element is +0.0, 2 not
     int64_t alt_dv_zero_n = 0;    // leading elements of the OTHER slab's dv rows known to be +0.0
-    bool compact_skipped_dv = false; // set by the compaction launch, consumed by adopt_compacted
+    int compact_dv_mode = 0;      // how the last compaction launch treated dv (kDvMove / kDvVprev / kDvSkip), for adopt_compacted
 
     // counters: device slots + pinned host mirror
     uint64_t *d_cnt = nullptr;
@@ -2079,9 +2079,12 @@ int wait_count(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 
 // the store after a compaction into the other slab
 void adopt_compacted(pcl_ctx *ctx, int64_t alive, int64_t last_delete_n) {
-    // the slab left behind: its dv rows are zero over the old count if this compaction relied on dv being zero
-    ctx->alt_dv_zero_n = ctx->compact_skipped_dv ? ctx->count : 0;
-    ctx->compact_skipped_dv = false;
+    // dv bookkeeping.  The slab left behind keeps zero dv rows over the old count if the live dv rows were all zero.  The
+    // new slab's dv rows hold what was moved (zero iff it was zero), zeros that were there (skip), or -- vprev travelled in
+    // their place -- whatever the other slab held, in which case "all zero" is no longer known.
+    if (ctx->compact_dv_mode == 1 /* kDvVprev */ && ctx->dv_zero == 1 && ctx->alt_dv_zero_n < alive) ctx->dv_zero = 0;
+    ctx->alt_dv_zero_n = ctx->dv_zero == 1 ? ctx->count : 0;
+    ctx->compact_dv_mode = 0;
     std::swap(ctx->slab, ctx->slab_alt);
     refresh_rows(ctx);
     std::swap(ctx->ids, ctx->ids_alt);
@@ -2430,15 +2433,11 @@ template <typename T>
 int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter_args<T> &cc) {
     const int tiles = (int)div_up(ctx->count, kTile);
     if (has_dr && dv_mode == kDvSkip) dv_mode = kDvMove; // (13-field form: nothing is skipped)
-    if (dv_mode == kDvSkip && ctx->alt_dv_zero_n < ctx->count) {
-        // the survivors' dv is not written: the destination's dv rows have to be zero already.  Once per run -- after
-        // that the slabs swap roles and the one left behind holds zeros over [0, the larger, earlier count)
-        for (int k = 0; k < 3; ++k)
-            PCL_HIP(hipMemset2DAsync(ctx->field_alt[PCL_DV0 + k], (size_t)kRows * kTileT * ctx->esz, 0, (size_t)kTileT * ctx->esz,
-                                     (size_t)tiles, ctx->stream));
-        ctx->alt_dv_zero_n = (int64_t)tiles * kTileT;
-    }
-    ctx->compact_skipped_dv = dv_mode == kDvSkip;
+    // Not writing the survivors' dv needs a destination whose dv rows are zero already.  The first compaction of a run
+    // therefore still moves them (zeros); from then on the slabs swap roles and the one left behind holds zeros over
+    // [0, the larger, earlier count) -- adopt_compacted keeps the book.
+    if (dv_mode == kDvSkip && ctx->alt_dv_zero_n < ctx->count) dv_mode = kDvMove;
+    ctx->compact_dv_mode = dv_mode;
     compact_args ca{};
     compact_fields(ctx, ca, has_dr, dv_mode);
     typedef typename std::conditional<sizeof(T) == 8, uint64_t, uint32_t>::type W;
@@ -2561,7 +2560,9 @@ int fused_delete_onepass_t(pcl_ctx *ctx, double dt, double A, double n, int dv_m
     PCL_HIP(hipMemsetAsync(ctx->lb_status, 0, (size_t)units * sizeof(unsigned long long), ctx->stream));
     PCL_HIP(hipMemsetAsync(ctx->d_cnt + kCounterSlots - 4, 0, 2 * sizeof(uint64_t), ctx->stream)); // ticket, err
     compact_args ca{};
-    compact_fields(ctx, ca, false, dv_mode == kDvSkip ? kDvMove : dv_mode); // r v (dv | vprev) E, and the id arrays
+    if (dv_mode == kDvSkip) dv_mode = kDvMove; // (this kernel always moves ten fields)
+    ctx->compact_dv_mode = dv_mode;
+    compact_fields(ctx, ca, false, dv_mode); // r v (dv | vprev) E, and the id arrays
     onepass_args<T, W> a{};
     for (int f = 0; f < 10; ++f) {
         a.src[f] = static_cast<const W *>(ca.src[f]);
@@ -3656,14 +3657,8 @@ int pcl_step_scatter_delete(pcl_ctx *ctx, double A, double n, int rng_mode, uint
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
     if (alive < 0 || alive > N)
         return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
-    std::swap(ctx->slab, ctx->slab_alt); // every field row was written into the other slab
-    refresh_rows(ctx);
-    std::swap(ctx->ids, ctx->ids_alt);
-    if (ctx->kind) std::swap(ctx->kind, ctx->kind_alt);
-    ctx->ids_iota = false;
-    ctx->count = alive;
-    ctx->last_delete_n = N;
-    ctx->lam4_valid = false;
+    ctx->compact_dv_mode = kDvMove;
+    adopt_compacted(ctx, alive, N); // every field row was written into the other slab
     if (n_alive_out) *n_alive_out = alive;
     if (n_removed_out) *n_removed_out = N - alive;
     return PCL_OK;
