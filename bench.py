@@ -433,8 +433,9 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
     HBM-bound form with a roofline figure per kernel; "multi" = K loop
     bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation(steps_per_launch=K) runs.
     A "particle-step" is one photon alive at the start of one loop body.  Algorithmic bytes (DESIGN.md section 4,
-    fp64): pass 1 reads v (24) and writes 1 mask bit; pass 3 reads 1 bit per particle, moves r, v, dv, E + the id of
-    every survivor ((80 + 8) x 2 per survivor; dr stays implicit) and applies the Newton move to them on the way."""
+    fp64): pass 1 reads v (24) and writes 1 mask bit; pass 3 reads 1 bit per particle, moves r, v, E + the id of every
+    survivor ((56 + 8) x 2 per survivor; dr stays implicit; dv, all +0.0 in a run that never scatters, travels in the first
+    loop body only) and applies the Newton move to them on the way."""
     plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]          # test/test_light.py:58
     dt, A, n = 1e-3, 1e-3, 1e-3
     out = {"workload": "BASELINE configs[1](ii): Newton + ScatterDelete(A=n=1e-3) + plane counter until empty, E = 1, "
@@ -490,7 +491,10 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
             elif mode == "per_step":
                 p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
                 b1 = tot * 24.125                              # v read (the flag needs |v * dt| only); one mask bit
-                b3 = tot * 0.125 + surv * 2.0 * 88.0           # mask bit; survivors' 10 fields + id read and written
+                # mask bit; the survivors' r, v, E + id read and written (64 B each way) -- and dv (24) in the first
+                # loop body only: these photons never scatter, so from then on dv is known to be all +0.0 and stays put
+                first = per_step[0][1] if per_step else 0
+                b3 = tot * 0.125 + surv * 2.0 * 64.0 + first * 2.0 * 24.0
                 g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
                 r["roofline"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction, pass 3)", "achieved": g3,
