@@ -328,7 +328,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
 //   0  k_compact_count (8 bytes per surviving lane, nothing read for the dead): wins when few survive or the store is small
 __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ tile_keep, int64_t n_tiles,
                                                     int64_t *__restrict__ tile_off, int64_t *__restrict__ total,
-                                                    int64_t n_particles, int *__restrict__ choice) {
+                                                    int64_t n_particles, int *__restrict__ choice,
+                                                    int64_t *__restrict__ total_host /* pinned, device-visible */) {
     __shared__ int64_t s_wave[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t per = div_up(n_tiles, 1024);
@@ -359,6 +360,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     }
     if (t == 1023) {
         *total = s_wave[15];
+        *total_host = s_wave[15]; // straight into the host's pinned mirror: no copy to enqueue, the event below publishes it
         *choice = (n_particles >= (int64_t)1 << 22 && s_wave[15] * 20 > n_particles * 7) ? 1 : 0; // > 35 % survive
     }
 }
@@ -471,6 +473,8 @@ struct newtonmask_args {
     int rng_mode;
     int lazy;
     int flag_only; // 1: do not touch r at all -- the flag needs |v * dt| only; pass 3 moves the survivors (lazy mode)
+    uint64_t *zero_cnt; // counter slots pass 3 will add into: cleared here (one stream operation fewer than a memset)
+    int n_zero;
 };
 
 template <typename T>
@@ -479,6 +483,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
     __shared__ int s_cnt[kBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
+    if (tile == 0 && (int)threadIdx.x < a.n_zero) a.zero_cnt[threadIdx.x] = 0;
     int kept = 0;
 #pragma unroll 2
     for (int rr = 0; rr < kTileRows / 4; ++rr) {
@@ -2057,10 +2062,9 @@ int scan_tiles(pcl_ctx *ctx, int64_t n) {
     const int64_t tiles = div_up(n, kTile);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
                        reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1), n,
-                       reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 2));
+                       reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 2),
+                       reinterpret_cast<int64_t *>(ctx->h_cnt + kCounterSlots - 1));
     PCL_TRY(launch_check("k_tile_scan"));
-    PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 1, ctx->d_cnt + kCounterSlots - 1, sizeof(uint64_t),
-                           hipMemcpyDeviceToHost, ctx->stream));
     // the host needs the survivor count (next launch geometry, exit tests), not the end of the compaction that follows:
     // it waits for this event and prepares the next step while pass 3 is still moving the survivors
     PCL_HIP(hipEventRecord(ctx->ev_count, ctx->stream));
@@ -2445,7 +2449,7 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter
     // Two formulations, both enqueued; the scan's verdict (d_cnt[kCounterSlots - 2]) lets exactly one of them work.
     // Stores with kind bytes (plain Objects) always take the direct kernel -- the staged one does not move them.
     static const bool direct_only = getenv("PCL_COMPACT_DIRECT") != nullptr; // perf-experiment hook
-    const bool both = !ctx->kind && !direct_only;
+    const bool both = !ctx->kind && !direct_only && ctx->count >= ((int64_t)1 << 22); // (the scan's rule needs >= 4M particles)
     ca.choice = both ? reinterpret_cast<const int *>(ctx->d_cnt + kCounterSlots - 2) : nullptr;
     if (has_dr)
         hipLaunchKernelGGL((k_compact_count<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
@@ -2529,6 +2533,8 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int d
     // while they go through its registers.  Eager mode writes dr and r for everybody here, as before.
     static const bool move_in_pass1 = getenv("PCL_MOVE_IN_PASS1") != nullptr; // perf-experiment hook: round 1's split
     m.flag_only = (lazy && !move_in_pass1) ? 1 : 0;
+    m.zero_cnt = ctx->d_cnt + 1;
+    m.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     hipLaunchKernelGGL(k_newton_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);
@@ -3687,7 +3693,6 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
         return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=2) for all %lld particles", (long long)N);
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
-    PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
     int64_t alive = 0;
     // EXPERIMENT (PCL_ONEPASS=1): one kernel for the whole loop body (k_delete_onepass, decoupled look-back).  Bit-identical,
     // but measured slower than the pipeline below on this chip (0.20 vs 0.5 of peak at 1e8 photons: with ~1000 units in
@@ -3696,6 +3701,7 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
     bool done = false;
     if (lazy && !ctx->kind && onepass) {
+        PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
         PCL_TRY(PCL_DISPATCH(ctx, fused_delete_onepass_t<double>(ctx, dt, A, n, dv_mode, rng_mode, seed, step, planes_host, n_planes),
                              fused_delete_onepass_t<float>(ctx, dt, A, n, dv_mode, rng_mode, seed, step, planes_host, n_planes)));
         if (n_planes >= 0)
@@ -3706,8 +3712,6 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
             if (alive < 0 || alive > N)
                 return fail(PCL_ERR_HIP, "one-pass compaction produced an impossible count %lld of %lld", (long long)alive, (long long)N);
             done = true;
-        } else {
-            PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
         }
     }
     if (!done)
