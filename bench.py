@@ -490,7 +490,9 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
                                  "algorithmic_bytes": b, "total_ms": ms}
             elif mode == "per_step":
                 p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
-                b1 = tot * 24.125                              # v read (the flag needs |v * dt| only); one mask bit
+                # v read (the flag needs |v * dt| only) and one mask bit; from the second loop body on the store has been
+                # compacted and the Philox key of a photon is its explicit id: +8 B read
+                b1 = tot * 24.125 + (tot - per_step[0][0]) * 8.0 if per_step else 0.0
                 # mask bit; the survivors' r, v, E + id read and written (64 B each way) -- and dv (24) in the first
                 # loop body only: these photons never scatter, so from then on dv is known to be all +0.0 and stays put
                 first = per_step[0][1] if per_step else 0
@@ -500,7 +502,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
                 r["roofline"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction, pass 3)", "achieved": g3,
                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS, "traffic": None,
                                  "algorithmic_bytes": b3, "total_ms": p3_ms}
-                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_newton_mask, flag only (delete flag -> ballot masks, pass 1; pass 3 moves the survivors)",
+                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_flag_mask2 (delete flag -> ballot masks, pass 1; pass 3 moves the survivors)",
                                        "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
                                        "traffic": None, "algorithmic_bytes": b1, "total_ms": p1_ms}
             else:

@@ -521,6 +521,76 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
     if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+__device__ __forceinline__ uint64_t spread_bits(uint32_t x) { // bit i -> bit 2i
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+// ---- pass 1, flag-only form for all-photon stores with the device RNG (the lazy delete pipeline's usual case) --------
+//   Same flag, masks and tile counts as k_newton_mask with flag_only = 1; a lane takes TWO neighbouring particles so
+//   that the three v rows (and the id row after a compaction) come in with 16-B loads: half the load instructions per
+//   byte, twice the bytes in flight per wave.  A wave covers a pair of mask rows per trip; the two ballots (even /
+//   odd particles) are interleaved into the two row words.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_flag_mask2(newtonmask_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    __shared__ int s_cnt[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    if (tile == 0 && (int)threadIdx.x < a.n_zero) a.zero_cnt[threadIdx.x] = 0;
+    int kept = 0;
+#pragma unroll 2
+    for (int pp = 0; pp < kTileRows / 8; ++pp) {
+        const int row = (wave * (kTileRows / 8) + pp) * 2;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane;
+        bool keep0 = false, keep1 = false;
+        if (i < a.N) {
+            const bool two = i + 1 < a.N;
+            const int64_t ti = pcl_tix(i, a.ts);
+            T vx[2], vy[2], vz[2];
+            uint64_t id[2];
+            if (two) {
+                const T2 x = *reinterpret_cast<const T2 *>(a.v[0] + ti), y = *reinterpret_cast<const T2 *>(a.v[1] + ti),
+                         z = *reinterpret_cast<const T2 *>(a.v[2] + ti);
+                vx[0] = x.x, vx[1] = x.y, vy[0] = y.x, vy[1] = y.y, vz[0] = z.x, vz[1] = z.y;
+                if (a.ids) {
+                    const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + i);
+                    id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+                } else {
+                    id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                }
+            } else {
+                vx[0] = vx[1] = a.v[0][ti], vy[0] = vy[1] = a.v[1][ti], vz[0] = vz[1] = a.v[2][ti];
+                id[0] = id[1] = (uint64_t)(a.ids ? a.ids[i] : a.id_base + i);
+            }
+            bool kp[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const T pcoll = R::mul(a.An, pcl_step_norm<T>(R::mul(vx[e], a.dt), R::mul(vy[e], a.dt), R::mul(vz[e], a.dt)));
+                const T rand = pcl_draw_rand<T>(id[e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                kp[e] = !(pcoll >= rand);
+            }
+            keep0 = kp[0];
+            keep1 = two && kp[1];
+        }
+        const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+        if (lane == 0) {
+            a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+            a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+        }
+        kept += __popcll(b0) + __popcll(b1);
+    }
+    if (lane == 0) s_cnt[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
 // ---- K delete loop bodies in one pass: Newton + delete test K times per photon, ONE mask at the end -------
 //   A photon of a delete simulation never changes its velocity, so dr = v*dt, |dr| and pcoll = A*n*|dr| are constants
 //   of the photon: per step only r += dr (3 adds), the decision draw and the compare remain, until the photon is
@@ -921,15 +991,6 @@ struct onepass_args {
     int plane_ax[PCL_MAX_PLANES];
 };
 
-__device__ __forceinline__ uint64_t spread_bits(uint32_t x) { // bit i -> bit 2i
-    uint64_t v = x;
-    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    v = (v | (v << 2)) & 0x3333333333333333ull;
-    v = (v | (v << 1)) & 0x5555555555555555ull;
-    return v;
-}
 
 template <typename T, typename W>
 __global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a) {
@@ -2536,7 +2597,11 @@ int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int d
     m.zero_cnt = ctx->d_cnt + 1;
     m.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
-    hipLaunchKernelGGL(k_newton_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    static const bool no_pair = getenv("PCL_MASK_SINGLE") != nullptr; // perf-experiment hook: the lane == particle kernel
+    if (m.flag_only && !m.kind && rng_mode == PCL_RNG_PHILOX && !no_pair)
+        hipLaunchKernelGGL(k_flag_mask2<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    else
+        hipLaunchKernelGGL(k_newton_mask<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);
     PCL_TRY(launch_check("k_newton_mask"));
     PCL_TRY(scan_tiles(ctx, N));
