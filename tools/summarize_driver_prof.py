@@ -123,7 +123,7 @@ def main():
           "kernels enqueued per compaction the one the scan did not choose returns at once)", "",
           "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
     for k in sorted(disp):
-        if any(t in k for t in ("k_newton_mask", "k_compact_count", "k_compact_lds", "k_tile_scan", "k_mixed", "k_any_nonzero", "k_delete_onepass")):
+        if any(t in k for t in ("k_newton_mask", "k_flag_mask2", "k_compact_count", "k_compact_lds", "k_tile_scan", "k_mixed", "k_any_nonzero", "k_delete_onepass")):
             fb = sum(x.get("FETCH_SIZE", 0) for x in fetch.get(k, [])) * 2 * 1024 / 1e9
             wb = sum(x.get("WRITE_SIZE", 0) for x in write.get(k, [])) * 1024 / 1e9
             L.append("| `%s` | %d | %.3f | %.2f | %.2f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, fb, wb))
@@ -132,7 +132,7 @@ def main():
         p = rec["per_step"]
         L.append("")
         L.append("`delete` %s photons under the profiler, per_step: %.4g particle-steps/s; pass 3 (`k_compact_*`) %.0f GB/s algorithmic = %.3f of "
-                 "peak, pass 1 (`k_newton_mask`, flag only) %.0f GB/s = %.3f; multi (K = %d): %.4g particle-steps/s."
+                 "peak, pass 1 (`k_flag_mask2`) %.0f GB/s = %.3f; multi (K = %d): %.4g particle-steps/s."
                  % (size, p["value"], p["roofline"]["achieved"], p["roofline"]["frac"], p["roofline_pass1"]["achieved"],
                     p["roofline_pass1"]["frac"], rec["multi"]["steps_per_launch"], rec["multi"]["value"]))
     L += ["", "## All kernels of the trace pass (count, total ms)", "", "| kernel | dispatches | total ms | avg ms |", "|---|---|---|---|"]
