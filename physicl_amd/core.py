@@ -23,6 +23,7 @@ ScatterDeleteStepReference.__run_py, light.py:216-223), still executed by the HI
 created when the first device step needs it, and ``cl_ctx`` / ``cl_q`` stay None as in the reference.
 """
 import copy
+import collections
 import threading
 import time
 
@@ -214,6 +215,9 @@ class Simulation(threading.Thread):
                (photons do not interact; state, ``hits`` and every measure row are bit-identical to K=1).  The host
                side of those passes -- the time update and ``exit(sim)`` -- is evaluated ahead of the launch, so
                ``exit`` may depend on ``t``/``ts``/``dt`` and the object count only, not on measured data.
+
+    ``sim.schedule`` (a Counter) tells afterwards how the passes were launched: "fused", "fused_delete" (one launch per
+    light step), "fused_multi", "fused_delete_multi", "mixed_multi" (K passes per launch).
     """
 
     def __init__(self, *args, **kwargs):
@@ -259,6 +263,7 @@ class Simulation(threading.Thread):
         self._uploaded, self._upload_lo = [], 0
         self._all_photons = True
         self.hits = 0                 # photons scattered by the most recent ScatterIsotropicStep
+        self.schedule = collections.Counter()   # diagnostic: device launches by formulation ("fused", "fused_multi", ...)
         self._hip = None
         if self.cl_on:
             self._open_device()                     # raises if there is no GPU / no library: no fallback
@@ -625,12 +630,15 @@ class Simulation(threading.Thread):
         if phases == ["iso"] and dev.is_uniform():
             sc.update(rng_mode=hip.RNG_PHILOX, seed=self.seed, step=step0)
             rows = [dict(o, evt=o["hits"]) for o in dev.step_fused_multi(dt0, k, sc, planes)]
+            self.schedule["fused_multi"] += 1
         elif phases == ["delete"]:
             rows = [dict(o, evt=o["removed"]) for o in
                     dev.step_fused_delete_multi(dt0, k, dl[0], dl[1], self.seed, step0, planes if groups[0][2:] else None)]
+            self.schedule["fused_delete_multi"] += 1
         else:
             rows = [dict(o, evt=o["hits"] if o["phase"] == "iso" else o["removed"]) for o in
                     dev.step_mixed_multi(dt0, k, phases, sc, dl, planes, self.seed, step0)]
+            self.schedule["mixed_multi"] += 1
         npl = len(planes)
         flat = np.array([np.concatenate([[o["N"], o["evt"]], o["sign"], o["planes"] if len(o["planes"]) else np.zeros(npl, np.int64)])
                          for o in rows], dtype=np.int64)
@@ -673,6 +681,7 @@ class Simulation(threading.Thread):
             A_k, n_k = delete._kernel_consts()
             out = dev.step_fused_delete(self._dt_code(), A_k, n_k, mode, self.seed, self._next_launch(),
                                         planes if measures else None, lazy=True)
+            self.schedule["fused_delete"] += 1
             g = self._global(np.concatenate([[out["N"], out["removed"]], out["sign"], out["planes"]]))
             self._alive, delete.removed = int(g[0]), int(g[1])
             k = 5
@@ -690,6 +699,7 @@ class Simulation(threading.Thread):
             self._scattered = True
         # dr/dv stay implicit unless something after this pass looks at them (the store materialises on demand)
         out = dev.step_fused(self._dt_code(), sc, planes if (measures or scatter) else None, sync=True, lazy=True)
+        self.schedule["fused"] += 1
         if out is not None:
             if scatter is not None:
                 self.hits = int(self._global([out["hits"]])[0])

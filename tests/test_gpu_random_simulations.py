@@ -1,0 +1,175 @@
+"""GPU: randomly generated simulations through the plugin API -- the scheduler's choices must not show.
+
+``Simulation`` decides per pass how the step list runs: one launch per Step (``fuse=False``), consecutive native steps
+as one kernel (``fuse=True``), up to K whole passes per launch (``steps_per_launch=K``), with the particles resident on
+the device until a host plugin or a foreign thread looks at ``sim.objects`` (physicl/__init__.py:512-516 is the loop
+being reproduced: every step, in insertion order, every pass).  This file draws step lists at random -- one to three
+[Newton, light step, measure steps] groups, a time step that may change from pass to pass, host plugins that read,
+edit or remove objects at random places, photons with or without plain Objects among them, or a bulk PhotonBatch --
+runs each with three schedules and requires IDENTICAL results: ``ts``, every measure row, ``hits``, what the host
+plugins saw, and the final r, v, dr, dv, E of every object, bit for bit.
+"""
+import numpy as np
+import pytest
+
+import physicl as phys
+import physicl.light
+import physicl.newton
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+
+
+class Reader(phys.Step):
+    """Looks without touching: object count and one photon's position, every pass."""
+    def __init__(self):
+        self.seen = []
+
+    def run(self, s):
+        n = len(s.objects)
+        self.seen.append((n, tuple(np.asarray(s.objects[0].r, dtype=float)) if n else ()))
+
+
+class Kicker(phys.Step):
+    """Edits an object in Python every other pass."""
+    def __init__(self):
+        self.passes = 0
+
+    def run(self, s):
+        self.passes += 1
+        if self.passes % 2 == 0 and len(s.objects) > 3:
+            o = s.objects[3]
+            o.r = o.r + np.array([0.0, 0.25, 0.0])
+
+
+class Remover(phys.Step):
+    """Removes the first object on its third pass (physicl/__init__.py:455-459)."""
+    def __init__(self):
+        self.passes = 0
+
+    def run(self, s):
+        self.passes += 1
+        if self.passes == 3 and len(s.objects) > 1:
+            s.remove_obj(s.objects[0])
+
+
+def draw_config(rs):
+    cfg = {"dt_kind": rs.choice(["const", "vary"]), "passes": int(rs.randint(4, 11)), "groups": [], "seed": int(rs.randint(1 << 30))}
+    for _ in range(rs.randint(1, 4)):
+        light = rs.choice(["iso", "iso_lambda", "delete", "none"], p=[0.35, 0.15, 0.35, 0.15])
+        measures = [m for m in ("sign", "plane") if rs.random_sample() < 0.6]
+        cfg["groups"].append((light, measures))
+    source = rs.choice(["photons", "mixed", "batch"], p=[0.4, 0.3, 0.3])
+    cfg["source"] = source
+    cfg["n"] = int(rs.choice([40, 700, 2600])) if source != "batch" else int(rs.choice([5000, 150_000]))
+    plugins = []
+    if source != "batch":
+        for kind in ("reader", "kicker", "remover"):
+            if rs.random_sample() < 0.3:
+                plugins.append((kind, int(rs.randint(0, 3 * len(cfg["groups"]) + 1))))
+    elif rs.random_sample() < 0.3:
+        plugins.append(("count", int(rs.randint(0, 3 * len(cfg["groups"]) + 1))))
+    cfg["plugins"] = plugins
+    cfg["K"] = int(rs.randint(2, 7))
+    return cfg
+
+
+class Count(phys.Step):
+    def __init__(self):
+        self.seen = []
+
+    def run(self, s):
+        self.seen.append(len(s.objects))
+
+
+def build_and_run(cfg, steps_per_launch, fuse):
+    T = cfg["passes"]
+    sim = phys.Simulation(cl_on=True, rng="philox", seed=cfg["seed"], steps_per_launch=steps_per_launch, fuse=fuse,
+                          exit=lambda s: len(s.ts) >= T or len(s.objects) == 0)
+    rs = np.random.RandomState(cfg["seed"])
+    if cfg["source"] == "batch":
+        sim.add_objs(phys.light.generate_photons_bulk(cfg["n"], min=phys.light.E_from_wavelength(700e-9),
+                                                      max=phys.light.E_from_wavelength(200e-9), seed=cfg["seed"]))
+    else:
+        objs = []
+        for i in range(cfg["n"]):
+            d = np.zeros(3)                                   # PhotonObject insists on |v| == c exactly (light.py:23-24)
+            d[rs.randint(3)] = rs.choice([-1.0, 1.0])
+            if cfg["source"] == "mixed" and i % 5 == 2:
+                objs.append(phys.Object(v=phys.Measurement(rs.normal(size=3), "m**1 s**-1"), uid=i))
+            else:
+                objs.append(phys.light.PhotonObject(v=d * C_LIT, E=np.double(rs.uniform(2.8e-19, 9.9e-19)), uid=i))
+        sim.add_objs(objs)
+    if cfg["dt_kind"] == "const":
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    else:
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001) if len(s.ts) % 3 else np.double(0.0005)))
+    steps, measures = [], []
+    for light, ms in cfg["groups"]:
+        steps.append(phys.newton.NewtonianKinematicsStep())
+        if light == "iso":
+            steps.append(phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+        elif light == "iso_lambda":
+            steps.append(phys.light.ScatterIsotropicStep(A=np.double(1e-19), n=np.double(1e-15), wavelength_dep_scattering=True))
+        elif light == "delete":
+            steps.append(phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.0004)))
+        for m in ms:
+            st = phys.light.ScatterSignMeasureStep(None, True) if m == "sign" else \
+                phys.light.ScatterMeasureStep(None, True, [[100.0, np.nan, np.nan], [np.nan, -50.0, np.nan]])
+            steps.append(st)
+            measures.append(st)
+    plugs = []
+    for kind, pos in sorted(cfg["plugins"], key=lambda p: -p[1]):
+        p = {"reader": Reader, "kicker": Kicker, "remover": Remover, "count": Count}[kind]()
+        steps.insert(min(pos, len(steps)), p)
+        plugs.append(p)
+    for k, st in enumerate(steps):
+        sim.add_step(k + 1, st)
+    sim.start()
+    sim.join()
+    assert sim.error is None, sim.error
+    out = {"ts": [float(t) for t in sim.ts], "hits": int(sim.hits),
+           "rows": [[[float(x) for x in np.ravel(np.asarray(c, dtype=float))] for c in m.data] for m in measures],
+           "seen": [getattr(p, "seen", None) for p in plugs], "n": len(sim.objects), "schedule": dict(sim.schedule)}
+    if cfg["source"] == "batch":
+        out["state"] = {f: sim.download(f) for f in ("r", "v", "dr", "dv", "E")} if out["n"] else {}
+    else:
+        objs = list(sim.objects)
+        out["uids"] = [o.uid for o in objs]
+        out["state"] = {f: np.array([np.asarray(getattr(o, f), dtype=float) for o in objs]) for f in ("r", "v", "dr", "dv")}
+        out["state"]["E"] = np.array([float(o.E) if type(o) is phys.light.PhotonObject else np.nan for o in objs])
+    sim.close()
+    return out
+
+
+def assert_same(a, b, what):
+    for k in ("ts", "hits", "rows", "seen", "n"):
+        assert a[k] == b[k], (what, k)
+    assert a.get("uids") == b.get("uids"), what
+    assert sorted(a["state"]) == sorted(b["state"])
+    for f in a["state"]:
+        assert np.array_equal(a["state"][f], b["state"][f], equal_nan=True), (what, f)
+
+
+SEEN = {}
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_simulation_does_not_depend_on_the_schedule(seed):
+    cfg = draw_config(np.random.RandomState(500 + seed))
+    base = build_and_run(cfg, 1, False)
+    assert len(base["ts"]) >= 1 and not base["schedule"]
+    fused = build_and_run(cfg, 1, True)
+    assert_same(base, fused, ("fuse", cfg))
+    multi = build_and_run(cfg, cfg["K"], True)
+    assert_same(base, multi, ("steps_per_launch", cfg))
+    for k, v in list(fused["schedule"].items()) + list(multi["schedule"].items()):
+        SEEN[k] = SEEN.get(k, 0) + v
+
+
+def test_the_random_simulations_reached_every_schedule():
+    """(runs after the cases above) the draw is only worth its time if all five launch formulations were chosen."""
+    if len(SEEN) == 0:
+        pytest.skip("the parametrised cases did not run in this process")
+    assert {"fused", "fused_delete", "fused_multi", "fused_delete_multi", "mixed_multi"} <= set(SEEN), SEEN
