@@ -1,0 +1,69 @@
+"""GPU: the drop-in boundary is a C ABI -- a host written in plain C binds it with nothing but include/physicl_hip.h.
+
+tests/native/abi_consumer.c is compiled with gcc (-std=c99 -pedantic: the header must be C, not C++), linked against
+libphysicl_hip.so and run; what it prints -- the flags of both delete kernels (physicl/light.py:146-158, 239-249), the
+stable survivor indices (light.py:258-260), r and dr after one Newton step on the resident store (newton.py:15-16), the
+sign counters (light.py:424-426) -- is compared bit for bit with the CPU oracle on the same inputs, generated on both
+sides by the same 64-bit LCG.
+"""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "abi_consumer.c")
+LIBDIR = os.path.join(ROOT, "physicl_amd", "_lib")
+
+
+def build(tmp_path):
+    exe = str(tmp_path / "abi_consumer")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I", os.path.join(ROOT, "include"),
+                           SRC, "-o", exe, "-L", LIBDIR, "-lphysicl_hip", "-Wl,-rpath," + LIBDIR])
+    return exe
+
+
+def lcg_inputs(N):
+    state, mask = 0x9E3779B97F4A7C15, (1 << 64) - 1
+    c, dt = 299792458.0, 1e-3
+    cols = np.empty((4, N))
+    for i in range(N):
+        for k in range(4):
+            state = (state * 6364136223846793005 + 1442695040888963407) & mask
+            u = float(state >> 11) * (1.0 / 9007199254740992.0)
+            cols[k, i] = (2.0 * u - 1.0) * c * dt if k < 3 else u
+    return cols
+
+
+@pytest.mark.skipif(shutil.which("gcc") is None or not os.path.exists(os.path.join(LIBDIR, "libphysicl_hip.so")),
+                    reason="needs gcc and the built library")
+def test_header_is_plain_c_and_the_program_links(tmp_path):
+    """No GPU needed: C99 -pedantic -Werror compile of the header's user and a link against every symbol it uses."""
+    assert os.path.exists(build(tmp_path))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 4099])
+def test_c_host_program_gets_the_oracles_results(tmp_path, N):
+    exe = build(tmp_path)
+    out = subprocess.check_output([exe, str(N)], timeout=300).decode().splitlines()
+    rec = {ln.split(" ", 1)[0]: ln.split(" ", 1)[1] for ln in out}
+    d0, d1, d2, rand = lcg_inputs(N)
+    A, n, dt = 1e-3, 1e-3, 1e-3
+    flags = orc.delete_flags(d0, d1, d2, rand, A, n)
+    want = "".join("1" if f else "0" for f in flags)
+    assert rec["flags"] == want and rec["del"] == want and (N < 100 or 0 < flags.sum() < N)
+    keep = orc.survivors(flags)
+    assert rec["keep"] == "%d %d" % (len(keep), int(keep.sum()))
+    h = [d0, d1, d2]
+    v = [h[k] / dt for k in range(3)]
+    r = [h[(k + 1) % 3] for k in range(3)]
+    rn, dr = orc.newton_euler(r, v, dt)
+    hexes = lambda arrs: " ".join("%016x" % x for a in arrs for x in np.asarray(a, dtype=np.float64).view(np.uint64))
+    assert rec["r"] == hexes(rn)
+    assert rec["dr"] == hexes(dr)
+    assert rec["counters"] == "%d %d %d %d" % ((N,) + orc.sign_counts(v))
