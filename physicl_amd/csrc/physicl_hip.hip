@@ -3375,9 +3375,9 @@ int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n) 
 int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max,
                            uint64_t seed) {
     PCL_TRY(need_store_raw(ctx));
+    if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
     ctx->lazy_dr = ctx->lazy_dv = false; // every array is overwritten
     ctx->lam4_valid = false;
-    if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
     if (n > 0) {
         PCL_TRY(PCL_DISPATCH(ctx, fill_photons_t<double>(ctx, n, id_base, c, e_min, e_max, seed),
                              fill_photons_t<float>(ctx, n, id_base, c, e_min, e_max, seed)));
@@ -3740,12 +3740,7 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     if (flags & ~PCL_FUSED_LAZY) return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool lazy = flags & PCL_FUSED_LAZY;
     PCL_TRY(need_store_raw(ctx));
-    // A still-implicit dv (lazy scatter step): an all-photon store keeps it implicit -- the vprev rows travel through the
-    // compaction in place of the dv rows -- anything else makes it real before the state is moved.  An implicit dr is
-    // simply superseded by this step's Newton move.
-    int dv_mode = kDvMove;
-    PCL_TRY(decide_dv_mode(ctx, lazy, &dv_mode));
-    ctx->lazy_dr = ctx->lazy_dr_vprev = false;
+    // every check comes before the first change of the store's state: a refused call leaves it as it was
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
@@ -3758,6 +3753,12 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
         return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=2) for all %lld particles", (long long)N);
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
+    // A still-implicit dv (lazy scatter step): an all-photon store keeps it implicit -- the vprev rows travel through the
+    // compaction in place of the dv rows -- anything else makes it real before the state is moved.  An implicit dr is
+    // simply superseded by this step's Newton move.
+    int dv_mode = kDvMove;
+    PCL_TRY(decide_dv_mode(ctx, lazy, &dv_mode));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false;
     int64_t alive = 0;
     // EXPERIMENT (PCL_ONEPASS=1): one kernel for the whole loop body (k_delete_onepass, decoupled look-back).  Bit-identical,
     // but measured slower than the pipeline below on this chip (0.20 vs 0.5 of peak at 1e8 photons: with ~1000 units in
@@ -3809,9 +3810,6 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
-    int dv_mode = kDvMove;                                   // see pcl_step_fused_delete
-    PCL_TRY(decide_dv_mode(ctx, true, &dv_mode));
-    ctx->lazy_dr = ctx->lazy_dr_vprev = false;               // an implicit dr is superseded by these steps' own moves
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;
     if (out_host)
@@ -3819,6 +3817,9 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     if (N == 0) return PCL_OK;
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
+    int dv_mode = kDvMove;                                   // see pcl_step_fused_delete
+    PCL_TRY(decide_dv_mode(ctx, true, &dv_mode));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false;               // an implicit dr is superseded by these steps' own moves
     PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)k_steps * nslots * sizeof(uint64_t), ctx->stream));
     PCL_TRY(PCL_DISPATCH(ctx, fused_delete_multi_t<double>(ctx, dt, k_steps, A, n, dv_mode, seed, step0, planes_host, n_planes),
                          fused_delete_multi_t<float>(ctx, dt, k_steps, A, n, dv_mode, seed, step0, planes_host, n_planes)));
@@ -3886,12 +3887,12 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     if (N == 0) return PCL_OK;
     // a pending implicit dv: superseded by the pass's own scatter phase; a pass without one (delete only) carries it
     // through the compaction (all-photon stores) or makes it real first
-    if (!has_iso && ctx->lazy_dv && ctx->kind) PCL_TRY(materialize(ctx));
-    ctx->lazy_dr = ctx->lazy_dr_vprev = false; // superseded by the pass's own moves
     if (has_delete) {
         PCL_TRY(ensure_scratch(ctx, N));
         PCL_TRY(ensure_alt(ctx));
     }
+    if (!has_iso && ctx->lazy_dv && ctx->kind) PCL_TRY(materialize(ctx));
+    ctx->lazy_dr = ctx->lazy_dr_vprev = false; // superseded by the pass's own moves
     PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)n_rows * nslots * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
