@@ -706,6 +706,185 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
         if (s_cnt[j]) atomicAdd(reinterpret_cast<unsigned long long *>(&a.cnt[j]), (unsigned long long)s_cnt[j]);
 }
 
+// ---- the same K loop bodies with the dead photons taken out of the lanes -------------------------------------------
+//   A removed photon still occupies its lane in k_newton_mask_multi: with 30 % removed per step two thirds of the Philox
+//   blocks of an 8-step launch are computed for photons that are gone.  Here a wave runs only the first step pair (one
+//   Philox block: the pair shares it) with lane == photon; survivors go into a wave-private ring in LDS (position,
+//   displacement, pcoll, id, home slot and the three sign bits: 68 B), and whenever 64 are waiting they are taken out and
+//   finish their remaining steps together, all lanes busy at the start.  Per-step tallies are sums, so regrouping cannot
+//   change them; a survivor's r goes back to its home slot and its bit into the row's mask word in LDS.  Same masks,
+//   tile counts, r and counter rows as k_newton_mask_multi, bit for bit (tests/test_gpu_multi.py run both).
+//   The ring never holds more than 63 + 64 entries, so plain Objects (never removed) need no special case.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi_args<T> a) {
+    typedef pcl_rt<T> R;
+    constexpr int kWaves = kBlock / 64, kCap = 128, kRowsPerWave = kTileRows / kWaves;
+    __shared__ T q_f[kWaves][7][kCap];          // r0 r1 r2 d0 d1 d2 pcoll
+    __shared__ uint64_t q_id[kWaves][kCap];
+    __shared__ uint32_t q_meta[kWaves][kCap];   // home slot within the wave's rows (9 bits) | sign bits << 9
+    __shared__ uint32_t s_mask[kWaves][2 * kRowsPerWave];
+    __shared__ uint32_t s_cnt[PCL_MULTI_MAX * (4 + PCL_MAX_PLANES)];
+    __shared__ int s_keep[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = a.n_planes > 0 ? a.n_planes : 0, nslots = 4 + np;
+    for (int j = threadIdx.x; j < a.K * nslots; j += blockDim.x) s_cnt[j] = 0;
+    if (lane < 2 * kRowsPerWave) s_mask[wave][lane] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const int64_t tile = blockIdx.x;
+    const int64_t wave_base = tile * kTile + (int64_t)wave * kRowsPerWave * 64; // first particle of this wave's rows
+    const int first = ((a.step & 1u) ? 1 : 2) < a.K ? ((a.step & 1u) ? 1 : 2) : a.K; // steps run lane == photon: up to the pair boundary
+    uint32_t t_alive = 0, t_sx = 0, t_sy = 0, t_sz = 0; // per-step tallies, lane k holding step k's
+    int qhead = 0, qcount = 0;                           // wave-uniform
+    int kept = 0;
+
+    // steps [k_from, K) of one photon per lane; tallies as in k_newton_mask_multi
+    auto run_steps = [&](int k_from, bool &alive, T (&rv)[3], const T (&d)[3], T pcoll, pcl_u64 id, bool photon, uint64_t sx,
+                         uint64_t sy, uint64_t sz, int k_to) {
+        pcl_u32 wodd0 = 0, wodd1 = 0;
+        for (int k = k_from; k < k_to; ++k) {
+            if (!__ballot(alive)) break;
+            const pcl_u32 st = a.step + (pcl_u32)k;
+            rv[0] = R::add(rv[0], d[0]);                              // newton.py:16
+            rv[1] = R::add(rv[1], d[1]);
+            rv[2] = R::add(rv[2], d[2]);
+            T rand;
+            if ((st & 1u) == 0u || k == k_from) { // decision block of the step pair (pcl_draw_rand)
+                const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, k0, k1);
+                rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                wodd0 = w.z;
+                wodd1 = w.w;
+            } else {
+                rand = R::uniform(wodd0, wodd1);
+            }
+            alive = alive && !(photon && (pcoll >= rand));
+            const uint64_t m = __ballot(alive);
+            const bool mine = lane == k;
+            t_alive += mine ? (uint32_t)__popcll(m) : 0u;
+            t_sx += mine ? (uint32_t)__popcll(m & sx) : 0u;
+            t_sy += mine ? (uint32_t)__popcll(m & sy) : 0u;
+            t_sz += mine ? (uint32_t)__popcll(m & sz) : 0u;
+            for (int p = 0; p < np; ++p) {
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
+                const T prev = R::sub(x, pcl_pick<T>(ax, d[0], d[1], d[2]));
+                const uint32_t nc = (uint32_t)__popcll(__ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                if (lane == 0 && nc) atomicAdd(&s_cnt[k * nslots + 4 + p], nc);
+            }
+        }
+    };
+    // a survivor of all K steps: r to its home slot, its bit into the row's mask word
+    auto settle = [&](bool alive, int slot, const T (&rv)[3]) {
+        if (alive) {
+            const int64_t ti = tile * a.ts + (int64_t)wave * kRowsPerWave * 64 + slot;
+            a.r[0][ti] = rv[0];
+            a.r[1][ti] = rv[1];
+            a.r[2][ti] = rv[2];
+            atomicOr(&s_mask[wave][slot >> 5], 1u << (slot & 31));
+        }
+        kept += __popcll(__ballot(alive));
+    };
+    // take n waiting photons (n <= 64) out of the ring and run their remaining steps
+    auto finish = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // wave-private ring: ordering only, no barrier
+        __builtin_amdgcn_wave_barrier();
+        const bool have = lane < n;
+        const int pos = (qhead + lane) & (kCap - 1);
+        T rv[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rv[k] = q_f[wave][k][pos];
+            d[k] = q_f[wave][3 + k][pos];
+        }
+        const T pcoll = q_f[wave][6][pos];
+        const pcl_u64 id = q_id[wave][pos];
+        const uint32_t meta = q_meta[wave][pos];
+        bool alive = have;
+        run_steps(first, alive, rv, d, pcoll, id, true, __ballot(have && (meta >> 9 & 1u)), __ballot(have && (meta >> 10 & 1u)),
+                  __ballot(have && (meta >> 11 & 1u)), a.K);
+        settle(alive, (int)(meta & 511u), rv);
+        qhead = (qhead + n) & (kCap - 1);
+        qcount -= n;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // the next row's loads are issued before the current row's steps (a row's steps are a long dependent chain)
+    T nv[3], nr[3];
+    pcl_u64 nid = 0;
+    bool nphoton = false;
+    auto fetch = [&](int rr) {
+        const int64_t i = wave_base + (int64_t)rr * 64 + lane;
+        const bool in = i < a.N;
+        const int64_t ti = pcl_tix(in ? i : 0, a.ts);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            nv[k] = a.v[k][ti];
+            nr[k] = a.r[k][ti];
+        }
+        nphoton = in && (a.kind ? (a.kind[in ? i : 0] != 0) : true);
+        nid = (pcl_u64)(a.ids ? a.ids[in ? i : 0] : a.id_base + i);
+    };
+    fetch(0);
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int64_t i = wave_base + (int64_t)rr * 64 + lane;
+        const bool in = i < a.N;
+        T rv[3], d[3];
+        bool sg[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            rv[k] = nr[k];
+            d[k] = R::mul(nv[k], a.dt);                               // newton.py:15
+            sg[k] = in && nv[k] > (T)0;
+        }
+        const bool photon = nphoton;
+        const pcl_u64 id = nid;
+        if (rr + 1 < kRowsPerWave) fetch(rr + 1);
+        const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])); // light.py:241-244
+        bool alive = in;
+        run_steps(0, alive, rv, d, pcoll, id, photon, __ballot(sg[0]), __ballot(sg[1]), __ballot(sg[2]), first);
+        const int slot = rr * 64 + lane;
+        if (first == a.K) { // (K <= 2: nothing left to run densely)
+            settle(alive, slot, rv);
+            continue;
+        }
+        const uint64_t m = __ballot(alive);
+        if (alive) {
+            const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const int pos = (qhead + qcount + pre) & (kCap - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                q_f[wave][k][pos] = rv[k];
+                q_f[wave][3 + k][pos] = d[k];
+            }
+            q_f[wave][6][pos] = photon ? pcoll : (T)-1; // a plain Object: pcoll >= rand never holds (rand >= 0)
+            q_id[wave][pos] = id;
+            q_meta[wave][pos] = (uint32_t)slot | (sg[0] ? 1u << 9 : 0u) | (sg[1] ? 1u << 10 : 0u) | (sg[2] ? 1u << 11 : 0u);
+        }
+        qcount += __popcll(m);
+        while (qcount >= 64) finish(64);
+    }
+    if (qcount > 0) finish(qcount);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kRowsPerWave)
+        a.masks[tile * kTileRows + wave * kRowsPerWave + lane] = (uint64_t)s_mask[wave][2 * lane] | ((uint64_t)s_mask[wave][2 * lane + 1] << 32);
+    if (lane < a.K) {
+        if (t_alive) atomicAdd(&s_cnt[lane * nslots + 0], t_alive);
+        if (a.n_planes >= 0) {
+            if (t_sx) atomicAdd(&s_cnt[lane * nslots + 1], t_sx);
+            if (t_sy) atomicAdd(&s_cnt[lane * nslots + 2], t_sy);
+            if (t_sz) atomicAdd(&s_cnt[lane * nslots + 3], t_sz);
+        }
+    }
+    if (lane == 0) s_keep[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    for (int j = threadIdx.x; j < a.K * nslots; j += blockDim.x)
+        if (s_cnt[j]) atomicAdd(reinterpret_cast<unsigned long long *>(&a.cnt[j]), (unsigned long long)s_cnt[j]);
+}
+
 // ---- pass 3 with the measure counters folded in: the survivors' r, v (and dr) pass through registers anyway ----
 //   field order in compact_args: r0 r1 r2 v0 v1 v2 [dr0 dr1 dr2] [dv0 dv1 dv2 | vprev0..2] E   (compact_fields)
 template <typename T>
@@ -2693,7 +2872,11 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     m.n_planes = n_planes;
     plane_table<T>(planes_host, n_planes, m.plane_ax, m.plane_L);
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
-    hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    static const bool no_queue = getenv("PCL_MULTI_NOQUEUE") != nullptr; // perf-experiment hook: lane == photon throughout
+    if (k_steps > 2 && !no_queue)
+        hipLaunchKernelGGL(k_newton_mask_multi_q<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    else
+        hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);
     PCL_TRY(launch_check("k_newton_mask_multi"));
     PCL_TRY(scan_tiles(ctx, N));

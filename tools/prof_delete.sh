@@ -14,6 +14,6 @@ for d in ("sq", "f", "w"):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
-        if "mask_multi" in k or "compact_count" in k or "tile_scan" in k:
+        if "mask_multi" in k or "flag_mask" in k or "compact_count" in k or "tile_scan" in k:
             print(d, k, {a: b[-1] for a, b in v.items()})
 PY
