@@ -427,7 +427,7 @@ def run_rank(args):
 # BASELINE configs[1](ii): Newton + ScatterDeleteStep(A = n = 1e-3) + plane counter until no photon is left
 # (test/test_light.py:52-59; physicl/light.py:231-260, physicl/__init__.py:455-459)
 # ---------------------------------------------------------------------------------------------------------------------
-def delete_leg(dev, hip, sizes, seed, repeats=3, K=8):
+def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     """Delete-until-empty at each size, two formulations: "per_step" = one launch sequence per loop body (the one-pass
     kernel k_delete_onepass, or the pipeline k_newton_mask -> scan -> k_compact_* where that does not apply), the
     HBM-bound form with a roofline figure per kernel; "multi" = K loop

@@ -706,6 +706,141 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
         if (s_cnt[j]) atomicAdd(reinterpret_cast<unsigned long long *>(&a.cnt[j]), (unsigned long long)s_cnt[j]);
 }
 
+// ---- EXPERIMENT, opt-in (PCL_MULTI_FORM=p): K delete loop bodies with persistent lanes -------------------------------
+//   The lane, not the photon, is the unit of work: a wave owns 512 photons and 64 lanes; whenever a lane's photon has
+//   been removed (or has finished its K steps) the lane takes the next unassigned photon of the wave, at the start of
+//   the next step PAIR -- every lane then needs exactly one Philox decision block per round, whatever step its photon
+//   is at, so rounds stay convergent while every round starts with all lanes busy.  With 30 % removed per step a wave
+//   runs ~17 rounds for K = 8 and ~20 for K = 16 where lane == photon costs 32 and 64 (and the LDS ring of
+//   k_newton_mask_multi_q 20 and 35).
+//   Lanes are at different steps, so the per-step rows cannot be tallied with ballots.  They do not have to be: a photon
+//   removed in its step D was among the survivors of steps 0..D-1 and of no later one, so the workgroup keeps a
+//   histogram over D (D = K: never removed) of the photon count and the three sign counts (v never changes here) and
+//   the rows are its suffix sums; plane crossings are per-step events and go to an LDS counter of their step.  Sums of
+//   the same integers: identical rows, masks, tile counts and r to k_newton_mask_multi (tests/test_gpu_multi.py).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_newton_mask_multi_p(newtonmask_multi_args<T> a) {
+    typedef pcl_rt<T> R;
+    constexpr int kWaves = kBlock / 64, kRowsPerWave = kTileRows / kWaves, kPool = kRowsPerWave * 64;
+    __shared__ uint32_t s_hist[(PCL_MULTI_MAX + 1) * 2]; // [D]: count | (#v_x>0) << 16,  (#v_y>0) | (#v_z>0) << 16   (<= 2048 each)
+    __shared__ uint32_t s_plane[PCL_MULTI_MAX * PCL_MAX_PLANES];
+    __shared__ uint32_t s_mask[kWaves][2 * kRowsPerWave];
+    __shared__ int s_keep[kWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int np = a.n_planes > 0 ? a.n_planes : 0, nslots = 4 + np;
+    for (int j = threadIdx.x; j < (a.K + 1) * 2; j += blockDim.x) s_hist[j] = 0;
+    for (int j = threadIdx.x; j < a.K * np; j += blockDim.x) s_plane[j] = 0;
+    if (lane < 2 * kRowsPerWave) s_mask[wave][lane] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const int64_t tile = blockIdx.x;
+    const int64_t wave_base = tile * kTile + (int64_t)wave * kPool;   // first particle of this wave's pool
+    const int64_t ti_base = tile * a.ts + (int64_t)wave * kPool;
+    const int n_pool = a.N - wave_base >= kPool ? kPool : (a.N > wave_base ? (int)(a.N - wave_base) : 0);
+    int next = 0, kept = 0;                                           // wave-uniform
+    bool has = false;
+    int k = 0, slot = 0;
+    uint32_t sgn = 0; // bit 0..2: v_x, v_y, v_z > 0
+    T rv[3] = {(T)0, (T)0, (T)0}, d[3] = {(T)0, (T)0, (T)0}, pcoll = (T)-1;
+    pcl_u64 id = 0;
+
+    // one loop body for the lane's photon, deciding with ``rand``            newton.py:16, light.py:241-249
+    auto body = [&](T rand) {
+        rv[0] = R::add(rv[0], d[0]);
+        rv[1] = R::add(rv[1], d[1]);
+        rv[2] = R::add(rv[2], d[2]);
+        const bool dies = pcoll >= rand; // plain Objects carry pcoll = -1
+        if (!dies) {
+            for (int p = 0; p < np; ++p) { // the measure step sees the survivors of the step (light.py:385-399)
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
+                const T prev = R::sub(x, pcl_pick<T>(ax, d[0], d[1], d[2]));
+                if ((prev <= L && L <= x) || (prev >= L && L >= x)) atomicAdd(&s_plane[k * np + p], 1u);
+            }
+        }
+        ++k;
+        if (dies || k == a.K) {
+            const int D = dies ? k - 1 : a.K;
+            atomicAdd(&s_hist[2 * D], 1u | ((sgn & 1u) << 16));
+            atomicAdd(&s_hist[2 * D + 1], ((sgn >> 1) & 1u) | ((sgn >> 2) << 16));
+            if (!dies) { // through all K steps: r to its slot, its bit into the row's mask word
+                const int64_t ti = ti_base + slot;
+                a.r[0][ti] = rv[0];
+                a.r[1][ti] = rv[1];
+                a.r[2][ti] = rv[2];
+                atomicOr(&s_mask[wave][slot >> 5], 1u << (slot & 31));
+            }
+            has = false;
+        }
+        return !dies && k == a.K;
+    };
+
+    while (true) {
+        // ---- idle lanes take the next photons of the pool, in order
+        const uint64_t fm = __ballot(!has);
+        const int want = __popcll(fm), left = n_pool - next;
+        const int take = want < left ? want : left;
+        if (take > 0) {
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            if (!has && rank < take) {
+                slot = next + rank;
+                const int64_t i = wave_base + slot, ti = ti_base + slot;
+                sgn = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const T vc = a.v[c][ti];
+                    rv[c] = a.r[c][ti];
+                    d[c] = R::mul(vc, a.dt);                          // newton.py:15
+                    sgn |= vc > (T)0 ? 1u << c : 0u;
+                }
+                const bool photon = a.kind ? (a.kind[i] != 0) : true;
+                pcoll = photon ? R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])) : (T)-1; // light.py:241-244
+                id = (pcl_u64)(a.ids ? a.ids[i] : a.id_base + i);
+                k = 0;
+                has = true;
+            }
+            next += take;
+        }
+        if (!__ballot(has)) break;
+        // ---- one round: the decision block of the lane's current step pair, then its one or two steps
+        const pcl_u32 st = a.step + (pcl_u32)k;
+        const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, k0, k1);
+        bool through = false;
+        if (has) through = body((st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y));
+        if (has && (st & 1u) == 0u) through = body(R::uniform(w.z, w.w)) || through;
+        kept += __popcll(__ballot(through));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < kRowsPerWave)
+        a.masks[tile * kTileRows + wave * kRowsPerWave + lane] = (uint64_t)s_mask[wave][2 * lane] | ((uint64_t)s_mask[wave][2 * lane + 1] << 32);
+    if (lane == 0) s_keep[wave] = kept;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    // rows: survivors of step j = everything removed later or never
+    if ((int)threadIdx.x < a.K) {
+        const int j = threadIdx.x;
+        uint32_t n = 0, sx = 0, sy = 0, sz = 0;
+        for (int D = j + 1; D <= a.K; ++D) {
+            const uint32_t h0 = s_hist[2 * D], h1 = s_hist[2 * D + 1];
+            n += h0 & 0xFFFFu;
+            sx += h0 >> 16;
+            sy += h1 & 0xFFFFu;
+            sz += h1 >> 16;
+        }
+        unsigned long long *c = reinterpret_cast<unsigned long long *>(a.cnt) + (int64_t)j * nslots;
+        if (n) atomicAdd(&c[0], (unsigned long long)n);
+        if (a.n_planes >= 0) {
+            if (sx) atomicAdd(&c[1], (unsigned long long)sx);
+            if (sy) atomicAdd(&c[2], (unsigned long long)sy);
+            if (sz) atomicAdd(&c[3], (unsigned long long)sz);
+        }
+        for (int p = 0; p < np; ++p)
+            if (s_plane[j * np + p]) atomicAdd(&c[4 + p], (unsigned long long)s_plane[j * np + p]);
+    }
+}
+
 // ---- the same K loop bodies with the dead photons taken out of the lanes -------------------------------------------
 //   A removed photon still occupies its lane in k_newton_mask_multi: with 30 % removed per step two thirds of the Philox
 //   blocks of an 8-step launch are computed for photons that are gone.  Here a wave runs only the first step pair (one
@@ -2873,7 +3008,13 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     plane_table<T>(planes_host, n_planes, m.plane_ax, m.plane_L);
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     static const bool no_queue = getenv("PCL_MULTI_NOQUEUE") != nullptr; // perf-experiment hook: lane == photon throughout
-    if (k_steps > 2 && !no_queue)
+    // EXPERIMENT (PCL_MULTI_FORM=p): persistent lanes (k_newton_mask_multi_p).  Bit-identical, 20 % fewer VALU instructions
+    // than the ring at K = 16, but its per-round dependent gathers and LDS atomics leave the VALU 45 % busy: slower at
+    // K = 8 (2.97 vs 2.12 ms at 1e8 photons), equal from K = 16 on -- not the default.
+    static const char *form = getenv("PCL_MULTI_FORM");
+    if (k_steps > 2 && !no_queue && form && !strcmp(form, "p"))
+        hipLaunchKernelGGL(k_newton_mask_multi_p<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    else if (k_steps > 2 && !no_queue)
         hipLaunchKernelGGL(k_newton_mask_multi_q<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     else
         hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
