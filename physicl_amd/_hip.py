@@ -49,6 +49,8 @@ _vp = c_void_p
 _PROTOTYPES = {
     "pcl_abi_version": [],
     "pcl_device_count": [POINTER(c_int)],
+    "pcl_pool_trim": [POINTER(c_int64)],
+    "pcl_pool_bytes": [POINTER(c_int64)],
     "pcl_ctx_create": [c_int, _vp, POINTER(_vp)],
     "pcl_ctx_destroy": [_vp],
     "pcl_ctx_sync": [_vp],
@@ -150,6 +152,20 @@ def device_count():
     n = c_int(0)
     rc = load().pcl_device_count(byref(n))
     return n.value if rc == 0 else 0
+
+
+def pool_bytes():
+    """Bytes of freed device blocks the library keeps for the next store of this process (PCL_POOL_GB bounds it)."""
+    n = c_int64(0)
+    check(load().pcl_pool_bytes(byref(n)))
+    return n.value
+
+
+def pool_trim():
+    """Hand every idle block back to the driver; returns the bytes released."""
+    n = c_int64(0)
+    check(load().pcl_pool_trim(byref(n)))
+    return n.value
 
 
 def validate_expr(expr):

@@ -25,6 +25,7 @@
 //   k_counters<T>         ScatterSignMeasureStep / ScatterMeasureStep physicl/light.py:374-431
 //   k_fill_photons<T>     generate_photons (bulk, on device)          physicl/light.py:112-128
 #include <hip/hip_runtime.h>
+#include <unordered_map>
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
@@ -1937,10 +1938,110 @@ int grid_for(const pcl_ctx *ctx, int64_t items, int per_block) {
 
 // Every particle array is padded to a multiple of 64 elements: the 16-byte-per-lane kernels load and
 // store whole groups, so the elements after N in the last group must exist (their contents are never used).
+// ---- big device blocks are kept for the next store of this process ----------------------------------------------
+//   A simulation script creates and drops stores of the same size over and over (one Simulation per parameter set, the
+//   reference's notebooks).  On this runtime a hipMalloc of tens of GB that follows the hipFree of a block of that size
+//   now and then takes 2-4 s (measured: 13.6 GB slab, about one run in four; the first allocation of a process takes
+//   0.3 ms) -- the driver is still taking the freed pages apart.  Blocks of >= 64 MB therefore go to a small per-process
+//   pool instead of back to the driver and the next request of about that size takes one from there.  PCL_POOL_GB
+//   (default 64; 0 = off) bounds what the pool may hold; an out-of-memory hipMalloc empties it and tries again.
+struct pool_block {
+    void *p;
+    size_t bytes;
+    int device;
+};
+std::mutex g_pool_mu;
+std::vector<pool_block> g_pool;            // idle blocks, oldest first
+std::unordered_map<void *, size_t> g_big;  // live blocks that may go to the pool when freed
+size_t g_pool_bytes = 0;
+constexpr size_t kPoolMinBlock = (size_t)64 << 20;
+
+size_t pool_limit() {
+    static const size_t lim = [] {
+        const char *e = getenv("PCL_POOL_GB");
+        const double gb = e ? atof(e) : 64.0;
+        return gb > 0 ? (size_t)(gb * (double)((size_t)1 << 30)) : (size_t)0;
+    }();
+    return lim;
+}
+
+void pool_flush_locked() {
+    for (const pool_block &b : g_pool) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    g_pool.clear();
+    g_pool_bytes = 0;
+}
+
+hipError_t big_malloc(void **p, size_t bytes) {
+    const bool eligible = bytes >= kPoolMinBlock && pool_limit() > 0;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    if (eligible) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (int k = 0; k < (int)g_pool.size(); ++k) // smallest idle block that holds the request without wasting half of itself
+            if (g_pool[k].device == device && g_pool[k].bytes >= bytes && g_pool[k].bytes <= bytes + bytes / 2 &&
+                (best < 0 || g_pool[k].bytes < g_pool[best].bytes))
+                best = k;
+        if (best >= 0) {
+            *p = g_pool[best].p;
+            g_big[*p] = g_pool[best].bytes;
+            g_pool_bytes -= g_pool[best].bytes;
+            g_pool.erase(g_pool.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(g_pool_mu);
+            pool_flush_locked();
+        }
+        (void)hipSetDevice(device);
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess && eligible) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_big[*p] = bytes;
+    }
+    return e;
+}
+
+void big_free(void *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_big.find(p);
+        if (it != g_big.end()) {
+            const size_t bytes = it->second;
+            g_big.erase(it);
+            if (bytes <= pool_limit()) {
+                (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block
+                int device = 0;
+                (void)hipGetDevice(&device);
+                while (g_pool_bytes + bytes > pool_limit() && !g_pool.empty()) { // make room: the oldest idle block goes
+                    (void)hipSetDevice(g_pool.front().device);
+                    (void)hipFree(g_pool.front().p);
+                    g_pool_bytes -= g_pool.front().bytes;
+                    g_pool.erase(g_pool.begin());
+                }
+                (void)hipSetDevice(device);
+                g_pool.push_back({p, bytes, device});
+                g_pool_bytes += bytes;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
 int dev_alloc_bytes(void **p, int64_t n_elems, size_t esz) {
     void *q = nullptr;
     const int64_t n = ((n_elems > 0 ? n_elems : 1) + 63) & ~int64_t(63);
-    PCL_HIP(hipMalloc(&q, (size_t)n * esz));
+    PCL_HIP(big_malloc(&q, (size_t)n * esz));
     *p = q;
     return PCL_OK;
 }
@@ -1954,7 +2055,7 @@ int dev_alloc(T **p, int64_t n) {
 
 template <typename T>
 void dev_free(T *&p) {
-    if (p) (void)hipFree(p);
+    if (p) big_free(p);
     p = nullptr;
 }
 
@@ -1974,7 +2075,7 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n) {
 
 int ensure_alt(pcl_ctx *ctx) {
     if (!ctx->slab_alt) {
-        PCL_HIP(hipMalloc(&ctx->slab_alt, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
+        PCL_HIP(big_malloc(&ctx->slab_alt, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
         refresh_rows(ctx);
     }
     if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
@@ -3139,6 +3240,23 @@ extern "C" {
 int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 const char *pcl_last_error(void) { return g_err.c_str(); }
 
+int pcl_pool_trim(int64_t *released_out) {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (released_out) *released_out = (int64_t)g_pool_bytes;
+    int device = 0;
+    const bool had = hipGetDevice(&device) == hipSuccess;
+    pool_flush_locked();
+    if (had) (void)hipSetDevice(device);
+    return PCL_OK;
+}
+
+int pcl_pool_bytes(int64_t *idle_out) {
+    if (!idle_out) return fail(PCL_ERR_ARG, "idle_out is NULL");
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    *idle_out = (int64_t)g_pool_bytes;
+    return PCL_OK;
+}
+
 int pcl_device_count(int *n_out) {
     if (!n_out) return fail(PCL_ERR_ARG, "n_out is NULL");
     int n = 0;
@@ -3270,7 +3388,7 @@ int pcl_ctx_device_pci(pcl_ctx *ctx, char *pci, int pci_len) {
 int pcl_dev_alloc(pcl_ctx *ctx, int64_t bytes, void **dev_out) {
     PCL_TRY(bind(ctx));
     if (!dev_out || bytes < 0) return fail(PCL_ERR_ARG, "bad argument");
-    PCL_HIP(hipMalloc(dev_out, (size_t)(bytes > 0 ? bytes : 1)));
+    PCL_HIP(big_malloc(dev_out, (size_t)(bytes > 0 ? bytes : 1)));
     return PCL_OK;
 }
 
@@ -3278,7 +3396,7 @@ int pcl_dev_free(pcl_ctx *ctx, void *dev) {
     PCL_TRY(bind(ctx));
     if (dev) {
         PCL_HIP(hipStreamSynchronize(ctx->stream));
-        PCL_HIP(hipFree(dev));
+        big_free(dev);
     }
     return PCL_OK;
 }
@@ -3534,7 +3652,7 @@ int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     ctx->esz = dtype == PCL_DTYPE_F64 ? 8 : 4;
     ctx->tiles = div_up(capacity, kTileT);
     for (int k = 0; k < kRows; ++k) ctx->row[k] = k;
-    PCL_HIP(hipMalloc(&ctx->slab, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
+    PCL_HIP(big_malloc(&ctx->slab, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
     refresh_rows(ctx);
     ctx->capacity = capacity;
     ctx->count = 0;
