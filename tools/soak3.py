@@ -1,3 +1,5 @@
+"""One scatter simulation at 1e8 photons, then two delete-until-empty simulations in the same process: run times of the
+latter two (the case that showed the allocation stall recorded in DESIGN.md, "Device memory between stores")."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,8 +28,6 @@ for rep in range(2):
     m = light.ScatterMeasureStep(None, True, [[1.0 / (0.001 * 0.001), np.nan, np.nan]])
     sim.add_step(3, m)
     t1 = time.perf_counter()
-    import cProfile, pstats
-    pr = cProfile.Profile(); tt = time.perf_counter(); pr.runcall(sim.run); sim.run_time = time.perf_counter() - tt
-    if rep == 0: pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+    sim.start(); sim.join()
     print("rep %d: build %.3f s, run_time %.3f s, passes %d, schedule %s" % (rep, t1 - t0, sim.run_time, len(sim.ts), dict(sim.schedule)), flush=True)
     t = time.perf_counter(); sim.close(); print("close %.3f s" % (time.perf_counter() - t), flush=True)
