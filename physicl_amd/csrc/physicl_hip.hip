@@ -855,7 +855,7 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi_args<T> a) {
     typedef pcl_rt<T> R;
     constexpr int kWaves = kBlock / 64, kCap = 128, kRowsPerWave = kTileRows / kWaves;
-    __shared__ T q_f[kWaves][7][kCap];          // r0 r1 r2 d0 d1 d2 pcoll
+    __shared__ T q_f[kWaves][4][kCap];          // r0 r1 r2 pcoll (d = v * dt is read again from the v rows: L2)
     __shared__ uint64_t q_id[kWaves][kCap];
     __shared__ uint32_t q_meta[kWaves][kCap];   // home slot within the wave's rows (9 bits) | sign bits << 9
     __shared__ uint32_t s_mask[kWaves][2 * kRowsPerWave];
@@ -927,15 +927,16 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
         __builtin_amdgcn_wave_barrier();
         const bool have = lane < n;
         const int pos = (qhead + lane) & (kCap - 1);
+        const uint32_t meta = have ? q_meta[wave][pos] : 0u;
+        const int64_t hti = tile * a.ts + (int64_t)wave * kRowsPerWave * 64 + (int64_t)(meta & 511u);
         T rv[3], d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
+            d[k] = R::mul(a.v[k][hti], a.dt);                         // newton.py:15, as in the first pass over the row
             rv[k] = q_f[wave][k][pos];
-            d[k] = q_f[wave][3 + k][pos];
         }
-        const T pcoll = q_f[wave][6][pos];
+        const T pcoll = q_f[wave][3][pos];
         const pcl_u64 id = q_id[wave][pos];
-        const uint32_t meta = q_meta[wave][pos];
         bool alive = have;
         run_steps(first, alive, rv, d, pcoll, id, true, __ballot(have && (meta >> 9 & 1u)), __ballot(have && (meta >> 10 & 1u)),
                   __ballot(have && (meta >> 11 & 1u)), a.K);
@@ -990,11 +991,8 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
             const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             const int pos = (qhead + qcount + pre) & (kCap - 1);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                q_f[wave][k][pos] = rv[k];
-                q_f[wave][3 + k][pos] = d[k];
-            }
-            q_f[wave][6][pos] = photon ? pcoll : (T)-1; // a plain Object: pcoll >= rand never holds (rand >= 0)
+            for (int k = 0; k < 3; ++k) q_f[wave][k][pos] = rv[k];
+            q_f[wave][3][pos] = photon ? pcoll : (T)-1; // a plain Object: pcoll >= rand never holds (rand >= 0)
             q_id[wave][pos] = id;
             q_meta[wave][pos] = (uint32_t)slot | (sg[0] ? 1u << 9 : 0u) | (sg[1] ? 1u << 10 : 0u) | (sg[2] ? 1u << 11 : 0u);
         }
