@@ -845,22 +845,27 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_p(newtonmask_multi
 // ---- the same K loop bodies with the dead photons taken out of the lanes -------------------------------------------
 //   A removed photon still occupies its lane in k_newton_mask_multi: with 30 % removed per step two thirds of the Philox
 //   blocks of an 8-step launch are computed for photons that are gone.  Here a wave runs only the first step pair (one
-//   Philox block: the pair shares it) with lane == photon; survivors go into a wave-private ring in LDS (position,
-//   displacement, pcoll, id, home slot and the three sign bits: 68 B), and whenever 64 are waiting they are taken out and
-//   finish their remaining steps together, all lanes busy at the start.  Per-step tallies are sums, so regrouping cannot
-//   change them; a survivor's r goes back to its home slot and its bit into the row's mask word in LDS.  Same masks,
-//   tile counts, r and counter rows as k_newton_mask_multi, bit for bit (tests/test_gpu_multi.py run both).
-//   The ring never holds more than 63 + 64 entries, so plain Objects (never removed) need no special case.
-template <typename T>
+//   Philox block: the pair shares it) with lane == photon; survivors go into a wave-private ring in LDS (position, id,
+//   home slot, the three sign bits and the kind: 36 B -- d = v*dt and pcoll are formed again from the v rows, which are
+//   still in L2), and whenever 64 are waiting they are taken out and run on together, all lanes busy at the start:
+//   to the end of the launch (RINGS = 1), or for one more step pair, after which the survivors are parked in a second
+//   ring and finished from there (RINGS = 2: pays from K = 12 on, same-box A/B in profiles/r02_experiments).  Per-step
+//   tallies are sums, so regrouping cannot change them; a survivor's r goes back to its home slot and its bit into the
+//   row's mask word in LDS.  Same masks, tile counts, r and counter rows as k_newton_mask_multi, bit for bit
+//   (tests/test_gpu_multi.py run both).  A ring never holds more than 63 + 64 entries, so plain Objects (never
+//   removed) need no special case.
+template <typename T, int RINGS>
 __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi_args<T> a) {
     typedef pcl_rt<T> R;
     constexpr int kWaves = kBlock / 64, kCap = 128, kRowsPerWave = kTileRows / kWaves;
-    __shared__ T q_f[kWaves][4][kCap];          // r0 r1 r2 pcoll (d = v * dt is read again from the v rows: L2)
-    __shared__ uint64_t q_id[kWaves][kCap];
-    __shared__ uint32_t q_meta[kWaves][kCap];   // home slot within the wave's rows (9 bits) | sign bits << 9
+    // two rings per wave: [0] survivors of the first step pair, [1] survivors of the second.  An entry is r, id and a
+    // word of bookkeeping (36 B); d = v * dt and pcoll are formed again from the v rows (L2) when the entry is taken out
+    __shared__ T q_f[kWaves][RINGS][3][kCap];
+    __shared__ uint64_t q_id[kWaves][RINGS][kCap];
+    __shared__ uint32_t q_meta[kWaves][RINGS][kCap]; // home slot within the wave's rows (9 bits) | sign bits << 9 | photon << 12
     __shared__ uint32_t s_mask[kWaves][2 * kRowsPerWave];
-    __shared__ uint32_t s_cnt[PCL_MULTI_MAX * (4 + PCL_MAX_PLANES)];
     __shared__ int s_keep[kWaves];
+    extern __shared__ uint32_t s_cnt[];          // [K][4 + n_planes]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int np = a.n_planes > 0 ? a.n_planes : 0, nslots = 4 + np;
     for (int j = threadIdx.x; j < a.K * nslots; j += blockDim.x) s_cnt[j] = 0;
@@ -871,8 +876,10 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
     const int64_t wave_base = tile * kTile + (int64_t)wave * kRowsPerWave * 64; // first particle of this wave's rows
     const int first = ((a.step & 1u) ? 1 : 2) < a.K ? ((a.step & 1u) ? 1 : 2) : a.K; // steps run lane == photon: up to the pair boundary
     uint32_t t_alive = 0, t_sx = 0, t_sy = 0, t_sz = 0; // per-step tallies, lane k holding step k's
-    int qhead = 0, qcount = 0;                           // wave-uniform
+    int qhead[2] = {0, 0}, qcount[2] = {0, 0};           // wave-uniform
     int kept = 0;
+    // ring 0's entries run steps [first, mid), ring 1's [mid, K); short launches do not repay the second parking (measured)
+    const int mid = (RINGS == 2 && first + 2 < a.K) ? first + 2 : a.K;
 
     // steps [k_from, K) of one photon per lane; tallies as in k_newton_mask_multi
     auto run_steps = [&](int k_from, bool &alive, T (&rv)[3], const T (&d)[3], T pcoll, pcl_u64 id, bool photon, uint64_t sx,
@@ -921,28 +928,47 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
         }
         kept += __popcll(__ballot(alive));
     };
-    // take n waiting photons (n <= 64) out of the ring and run their remaining steps
-    auto finish = [&](int n) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // wave-private ring: ordering only, no barrier
+    // park the lanes' surviving photons in ring ``lv``
+    auto park = [&](int lv, bool alive, const T (&rv)[3], pcl_u64 id, uint32_t meta) {
+        const uint64_t m = __ballot(alive);
+        if (alive) {
+            const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            const int pos = (qhead[lv] + qcount[lv] + pre) & (kCap - 1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) q_f[wave][lv][k][pos] = rv[k];
+            q_id[wave][lv][pos] = id;
+            q_meta[wave][lv][pos] = meta;
+        }
+        qcount[lv] += __popcll(m);
+    };
+    // take n waiting photons (n <= 64) out of ring ``lv`` and run their next steps: ring 0's one more step pair (the
+    // survivors move on to ring 1), ring 1's all that are left
+    auto finish = [&](int lv, int n) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // wave-private rings: ordering only, no barrier
         __builtin_amdgcn_wave_barrier();
         const bool have = lane < n;
-        const int pos = (qhead + lane) & (kCap - 1);
-        const uint32_t meta = have ? q_meta[wave][pos] : 0u;
+        const int pos = (qhead[lv] + lane) & (kCap - 1);
+        const uint32_t meta = have ? q_meta[wave][lv][pos] : 0u;
         const int64_t hti = tile * a.ts + (int64_t)wave * kRowsPerWave * 64 + (int64_t)(meta & 511u);
         T rv[3], d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             d[k] = R::mul(a.v[k][hti], a.dt);                         // newton.py:15, as in the first pass over the row
-            rv[k] = q_f[wave][k][pos];
+            rv[k] = q_f[wave][lv][k][pos];
         }
-        const T pcoll = q_f[wave][3][pos];
-        const pcl_u64 id = q_id[wave][pos];
+        // a plain Object: pcoll >= rand never holds (rand >= 0)
+        const T pcoll = (meta >> 12 & 1u) ? R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])) : (T)-1; // light.py:241-244
+        const pcl_u64 id = q_id[wave][lv][pos];
         bool alive = have;
-        run_steps(first, alive, rv, d, pcoll, id, true, __ballot(have && (meta >> 9 & 1u)), __ballot(have && (meta >> 10 & 1u)),
-                  __ballot(have && (meta >> 11 & 1u)), a.K);
-        settle(alive, (int)(meta & 511u), rv);
-        qhead = (qhead + n) & (kCap - 1);
-        qcount -= n;
+        const int k_from = lv == 0 ? first : mid, k_to = lv == 0 ? mid : a.K;
+        run_steps(k_from, alive, rv, d, pcoll, id, true, __ballot(have && (meta >> 9 & 1u)), __ballot(have && (meta >> 10 & 1u)),
+                  __ballot(have && (meta >> 11 & 1u)), k_to);
+        qhead[lv] = (qhead[lv] + n) & (kCap - 1);
+        qcount[lv] -= n;
+        if (RINGS == 1 || k_to == a.K)
+            settle(alive, (int)(meta & 511u), rv);
+        else
+            park(RINGS - 1, alive, rv, id, meta);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
@@ -986,20 +1012,17 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
             settle(alive, slot, rv);
             continue;
         }
-        const uint64_t m = __ballot(alive);
-        if (alive) {
-            const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            const int pos = (qhead + qcount + pre) & (kCap - 1);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) q_f[wave][k][pos] = rv[k];
-            q_f[wave][3][pos] = photon ? pcoll : (T)-1; // a plain Object: pcoll >= rand never holds (rand >= 0)
-            q_id[wave][pos] = id;
-            q_meta[wave][pos] = (uint32_t)slot | (sg[0] ? 1u << 9 : 0u) | (sg[1] ? 1u << 10 : 0u) | (sg[2] ? 1u << 11 : 0u);
+        park(0, alive, rv, id,
+             (uint32_t)slot | (sg[0] ? 1u << 9 : 0u) | (sg[1] ? 1u << 10 : 0u) | (sg[2] ? 1u << 11 : 0u) | (photon ? 1u << 12 : 0u));
+        while (qcount[0] >= 64) {
+            finish(0, 64);
+            if (RINGS == 2)
+                while (qcount[RINGS - 1] >= 64) finish(RINGS - 1, 64);
         }
-        qcount += __popcll(m);
-        while (qcount >= 64) finish(64);
     }
-    if (qcount > 0) finish(qcount);
+    if (qcount[0] > 0) finish(0, qcount[0]);
+    if (RINGS == 2)
+        while (qcount[RINGS - 1] > 0) finish(RINGS - 1, qcount[RINGS - 1] < 64 ? qcount[RINGS - 1] : 64);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (lane < kRowsPerWave)
@@ -3113,8 +3136,14 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     static const char *form = getenv("PCL_MULTI_FORM");
     if (k_steps > 2 && !no_queue && form && !strcmp(form, "p"))
         hipLaunchKernelGGL(k_newton_mask_multi_p<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
-    else if (k_steps > 2 && !no_queue)
-        hipLaunchKernelGGL(k_newton_mask_multi_q<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
+    else if (k_steps > 2 && !no_queue) {
+        const size_t lds = (size_t)k_steps * (4 + (n_planes > 0 ? n_planes : 0)) * sizeof(uint32_t); // the per-step rows
+        const bool two = form && !strncmp(form, "ring", 4) && form[4] ? form[4] == '2' : k_steps >= 12;
+        if (two)
+            hipLaunchKernelGGL((k_newton_mask_multi_q<T, 2>), dim3(tiles), dim3(kBlock), lds, ctx->stream, m);
+        else
+            hipLaunchKernelGGL((k_newton_mask_multi_q<T, 1>), dim3(tiles), dim3(kBlock), lds, ctx->stream, m);
+    }
     else
         hipLaunchKernelGGL(k_newton_mask_multi<T>, dim3(tiles), dim3(kBlock), 0, ctx->stream, m);
     prof_end(ctx, ps);

@@ -167,7 +167,7 @@ def test_multi_state_errors(make_store, hip):
 
 # ============================================================================ K delete loop bodies per pass
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("N,K", [(1, 1), (64, 3), (2049, 2), (100_003, 9), (500_003, 40)])
+@pytest.mark.parametrize("N,K", [(1, 1), (64, 3), (2049, 2), (100_003, 9), (30_011, 12), (70_001, 13), (500_003, 40)])
 def test_delete_multi_is_bit_identical_to_single_fused_delete_steps(make_store, hip, N, K, dtype):
     """pcl_step_fused_delete_multi == K x pcl_step_fused_delete (lazy, Philox): per-step rows (alive, sign counts,
     plane crossings, removed) and the survivors' whole state, ids and kinds included; mixed kinds, a previous
