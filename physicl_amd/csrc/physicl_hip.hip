@@ -16,16 +16,20 @@
 //   k_lam4<T>             cache of pow((h*c)/E, -4)                   physicl/light.py:301
 //   k_materialize<T>      dr, dv after lazy fused steps               physicl/newton.py:15, light.py:329-331
 //   k_delete_mask<T>      delete-flag kernel -> wave64 ballot masks   physicl/light.py:239-249
-//   k_newton_mask<T>      Newton + delete flag -> masks (fused delete pipeline, pass 1)
-//   k_newton_mask_multi<T> K delete loop bodies per pass -> one mask + per-step measure rows
-//   k_compact_count<T,W>  compaction with the measure counters folded in (pass 3)
+//   k_newton_mask<T>      Newton + delete flag -> masks (fused delete pipeline, pass 1; any store, any RNG mode)
+//   k_flag_mask2<T>       the same flag for all-photon stores with the device RNG: two photons per lane, 16-B loads
+//   k_newton_mask_multi<T> K delete loop bodies per pass -> one mask + per-step measure rows (K <= 2)
+//   k_newton_mask_multi_q<T,RINGS> the same with the removed photons taken out of the lanes (LDS rings; K > 2)
+//   k_mixed<T,E>          K passes of [Newton, ScatterIsotropic] and/or [Newton, ScatterDelete] on any store (pcl_device.h)
+//   k_compact_count<T,W>  compaction with the measure counters folded in (pass 3, 8 B per surviving lane)
+//   k_compact_lds<T,W>    the same through LDS: aligned 16-B groups (chosen on the device when > 35 % survive)
+//   (opt-in experiments, measured and not adopted: k_delete_onepass, k_newton_mask_multi_p, pcl_multi_body_nq)
 //   k_tile_scan           exclusive scan of per-tile survivor counts
 //   k_compact<W,NF>       stable compaction of the SoA state          physicl/light.py:258-260,
 //                                                                      physicl/__init__.py:455-459
 //   k_counters<T>         ScatterSignMeasureStep / ScatterMeasureStep physicl/light.py:374-431
 //   k_fill_photons<T>     generate_photons (bulk, on device)          physicl/light.py:112-128
 #include <hip/hip_runtime.h>
-#include <unordered_map>
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
@@ -42,6 +46,7 @@
 #include <new>
 #include <string>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/physicl_hip.h"
