@@ -738,7 +738,16 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const pcl_i64 nq = (a.N + VEC - 1) / VEC; // VEC-wide groups
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
+#if defined(PCL_XCD_MAP) // EXPERIMENT: blocks of one XCD (b % 8) walk neighbouring chunks
+    const unsigned xb = (gridDim.x % 8u == 0u) ? (blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u : blockIdx.x;
+    pcl_i64 base = (pcl_i64)xb * blockDim.x;
+#elif defined(PCL_TILE_MAP) // EXPERIMENT: the four blocks of a tile are b, b+8, b+16, b+24: one XCD per tile
+    const unsigned g32 = blockIdx.x / 32u, r32 = blockIdx.x % 32u;
+    const unsigned xb = (gridDim.x % 32u == 0u) ? g32 * 32u + (r32 % 8u) * 4u + r32 / 8u : blockIdx.x;
+    pcl_i64 base = (pcl_i64)xb * blockDim.x;
+#else
     pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x;
+#endif
     // register double buffer: the next trip's loads are in flight while this trip computes
     pcl_fast_tile<T, VEC> cur;
     if (base < nq) {

@@ -36,6 +36,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1891,11 +1892,22 @@ namespace {
 
 template <typename T> T *F(pcl_ctx *c, int f) { return static_cast<T *>(c->field[f]); }
 
-inline int64_t tile_stride(const pcl_ctx *c) { return (int64_t)kRows * kTileT; } // elements from tile to tile
+// bytes between the rows of a tile beyond the row's own kTileT elements (EXPERIMENT hook PCL_ROW_PAD, multiple of 16)
+inline size_t row_pad_bytes() {
+    static const size_t pad = [] {
+        const char *e = getenv("PCL_ROW_PAD");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)(v / 16 * 16) : (size_t)0;
+    }();
+    return pad;
+}
+inline size_t row_pitch_bytes(const pcl_ctx *c) { return (size_t)kTileT * c->esz + row_pad_bytes(); }
+inline size_t slab_bytes(const pcl_ctx *c) { return (size_t)c->tiles * kRows * row_pitch_bytes(c); }
+inline int64_t tile_stride(const pcl_ctx *c) { return (int64_t)(kRows * row_pitch_bytes(c) / c->esz); } // elements from tile to tile
 
 // recompute the tile-0 row addresses after the slab pointers or the row roles changed
 void refresh_rows(pcl_ctx *c) {
-    const size_t rowb = (size_t)kTileT * c->esz;
+    const size_t rowb = row_pitch_bytes(c);
     for (int f = 0; f < PCL_NFIELDS; ++f) {
         c->field[f] = c->slab ? static_cast<char *>(c->slab) + rowb * c->row[f] : nullptr;
         c->field_alt[f] = c->slab_alt ? static_cast<char *>(c->slab_alt) + rowb * c->row[f] : nullptr;
@@ -1908,7 +1920,9 @@ void refresh_rows(pcl_ctx *c) {
 }
 
 // element i of a row lives at (i / T) * tile_stride + i % T
-inline int64_t tix_host(int64_t i) { return (i / kTileT) * ((int64_t)kRows * kTileT) + (i % kTileT); }
+inline int64_t tix_host(const pcl_ctx *c, int64_t i) { return (i / kTileT) * tile_stride(c) + (i % kTileT); }
+
+int64_t rows_in_handle(const void *d, size_t pitch, size_t rowbytes, int64_t k); // below, with the allocator
 
 // copy n elements [offset, offset+n) of one row between a dense host array and the tiled slab
 int copy_row(pcl_ctx *ctx, void *row0, void *host, int64_t offset, int64_t n, bool to_device) {
@@ -1917,11 +1931,12 @@ int copy_row(pcl_ctx *ctx, void *row0, void *host, int64_t offset, int64_t n, bo
     int64_t i = offset;
     while (n > 0) {
         const int64_t lo = i % kTileT;
-        char *d = static_cast<char *>(row0) + (size_t)tix_host(i) * esz;
-        if (lo == 0 && n >= kTileT) {
-            const int64_t k = n / kTileT; // whole tiles: one strided copy
-            PCL_HIP(hipMemcpy2DAsync(to_device ? (void *)d : (void *)h, to_device ? (size_t)kRows * kTileT * esz : (size_t)kTileT * esz,
-                                     to_device ? (const void *)h : (const void *)d, to_device ? (size_t)kTileT * esz : (size_t)kRows * kTileT * esz,
+        char *d = static_cast<char *>(row0) + (size_t)tix_host(ctx, i) * esz;
+        const size_t tile_pitch = (size_t)tile_stride(ctx) * esz;
+        const int64_t k = (lo == 0 && n >= kTileT) ? rows_in_handle(d, tile_pitch, (size_t)kTileT * esz, n / kTileT) : 0;
+        if (k > 0) { // whole tiles: one strided copy (per physical handle of the slab)
+            PCL_HIP(hipMemcpy2DAsync(to_device ? (void *)d : (void *)h, to_device ? tile_pitch : (size_t)kTileT * esz,
+                                     to_device ? (const void *)h : (const void *)d, to_device ? (size_t)kTileT * esz : tile_pitch,
                                      (size_t)kTileT * esz, (size_t)k, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
                                      ctx->stream));
             i += k * kTileT;
@@ -1982,6 +1997,179 @@ std::unordered_map<void *, size_t> g_big;  // live blocks that may go to the poo
 size_t g_pool_bytes = 0;
 constexpr size_t kPoolMinBlock = (size_t)64 << 20;
 
+// ---- where big blocks come from: the virtual-memory API, not hipMalloc ----------------------------------------------
+//   The store's passes run 13 to 20 streams side by side inside every 272 KB tile.  How fast that goes depends on the
+//   physical memory behind the slab, not on the kernel: the same kernel at the same virtual address takes 1.87 or
+//   2.07 ms per step (0.695 or 0.63 of the HBM peak) from one hipMalloc to the next, fixed for the life of the
+//   allocation, about half of the allocations each way (tools/alloc_variance.py, tools/alloc_candidates.py);
+//   hipExtMallocWithFlags(hipDeviceMallocContiguous) always gives the slow kind; row padding does not change it
+//   (tools/pad_sweep.py), nor does the order the tiles are visited in (tools/spread_probe.hip); ranges mapped from
+//   ~1 GB hipMemCreate handles came out at least as fast as the best hipMalloc blocks (tools/vmm_probe.hip) and are
+//   what alloc_slab's candidates are made of.  Blocks of >= 64 MB are built that way; PCL_VMM=0 goes back to hipMalloc
+//   and so does any failure of the virtual-memory calls.  hipMemcpy2DAsync refuses rows that reach from one handle into
+//   the next (tools/vmm_copy_test2.hip): handles hold whole tiles and copy_row cuts its strided copies at their ends.
+struct vmm_block {
+    size_t bytes;
+    size_t chunk; // bytes per physical handle (the last one may be shorter)
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::unordered_map<void *, vmm_block> g_vmm; // guarded by g_vmm_mu
+std::mutex g_vmm_mu;
+std::unordered_map<void *, double> g_rate; // whole-block sweep rate (GB/s) of live and idle blocks (alloc_slab); guarded by g_vmm_mu
+
+bool vmm_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCL_VMM");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// the store's own access pattern, as a probe: every workgroup writes the 13 field rows of a [17][2048] fp64 tile
+__global__ void __launch_bounds__(256) k_slab_sweep(double2 *slab, int64_t tiles, int64_t tile_pitch16, int64_t row_pitch16) {
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        double2 *tile = slab + t * tile_pitch16;
+#pragma unroll
+        for (int row = 0; row < PCL_NFIELDS; ++row)
+            for (int q = threadIdx.x; q < (int)(kTileT * 8 / 16); q += 256) tile[row * row_pitch16 + q] = make_double2(0.0, 0.0);
+    }
+}
+
+// GB/s of that sweep over ``tiles`` tiles at p (default stream, synchronous; 0 on failure)
+double sweep_rate_raw(void *p, int64_t tiles) {
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.0;
+    const int grid = (int)(tiles < 2048 ? tiles : 2048);
+    const int64_t tile_pitch16 = (int64_t)kRows * kTileT * 8 / 16, row_pitch16 = kTileT * 8 / 16;
+    double rate = 0.0;
+    hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, nullptr, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16); // first touch
+    (void)hipEventRecord(a, nullptr);
+    for (int k = 0; k < 2; ++k)
+        hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, nullptr, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16);
+    (void)hipEventRecord(b, nullptr);
+    float ms = 0.f;
+    if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f)
+        rate = 2.0 * (double)tiles * PCL_NFIELDS * (double)(kTileT * 8) / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipGetLastError();
+    return rate;
+}
+
+// physical handles of 3855 fp64 tiles (1.07 GB; PCL_VMM_CHUNK_TILES): whole tiles, so no row of a slab ever straddles two
+constexpr int64_t kChunkTilesDefault = 3855;
+size_t vmm_chunk_bytes() {
+    static const size_t c = [] {
+        const char *e = getenv("PCL_VMM_CHUNK_TILES");
+        const long t = e ? atol(e) : kChunkTilesDefault;
+        return (size_t)(t > 0 ? t : kChunkTilesDefault) * kRows * kTileT * 8;
+    }();
+    return c;
+}
+
+hipError_t vmm_malloc(void **p, size_t bytes, int device) {
+    const size_t chunk = vmm_chunk_bytes();
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    const size_t need = (bytes + chunk - 1) / chunk;
+    // the last handle is cut to what is needed (a multiple of 2 MB)
+    const size_t tail = bytes - (need - 1) * chunk, tail_len = (tail + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+    const size_t total = (need - 1) * chunk + (tail_len < chunk ? tail_len : chunk);
+    void *va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, total, (size_t)2 << 20, nullptr, 0);
+    if (e != hipSuccess) return e;
+    vmm_block blk;
+    blk.bytes = total;
+    blk.chunk = chunk;
+    size_t mapped = 0;
+    while (e == hipSuccess && mapped < total) {
+        const size_t len = total - mapped < chunk ? total - mapped : chunk;
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, len, &prop, 0);
+        if (e != hipSuccess) break;
+        e = hipMemMap(static_cast<char *>(va) + mapped, len, 0, h, 0);
+        if (e != hipSuccess) {
+            (void)hipMemRelease(h);
+            break;
+        }
+        blk.handles.push_back(h);
+        mapped += len;
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, total, &acc, 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(va, mapped);
+        for (auto h : blk.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, total);
+        return e;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_vmm[va] = std::move(blk);
+    }
+    *p = va;
+    return hipSuccess;
+}
+
+hipError_t raw_malloc(void **p, size_t bytes, int device) {
+    if (bytes >= kPoolMinBlock && vmm_enabled()) {
+        const hipError_t e = vmm_malloc(p, bytes, device);
+        if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+    }
+    return hipMalloc(p, bytes);
+}
+
+void raw_free(void *p) {
+    if (!p) return;
+    vmm_block blk;
+    bool mine = false;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_rate.erase(p);
+        auto it = g_vmm.find(p);
+        if (it != g_vmm.end()) {
+            blk = std::move(it->second);
+            g_vmm.erase(it);
+            mine = true;
+        }
+    }
+    if (!mine) {
+        (void)hipFree(p);
+        return;
+    }
+    (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block
+    (void)hipMemUnmap(p, blk.bytes);
+    for (auto h : blk.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(p, blk.bytes);
+}
+
+// hipMemcpy2DAsync refuses a copy that reaches from one physical handle of a mapped range into the next (measured:
+// "invalid argument" as soon as the rows span a handle boundary; 1-D copies and kernels do not care).  Largest number
+// of rows, ``pitch`` bytes apart and ``rowbytes`` long, starting at device address d, that stay inside d's handle
+// (<= k; 0: the first row itself straddles a boundary -- copy it 1-D).
+int64_t rows_in_handle(const void *d, size_t pitch, size_t rowbytes, int64_t k) {
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    for (const auto &kv : g_vmm) {
+        const char *base = static_cast<const char *>(kv.first);
+        const char *p = static_cast<const char *>(d);
+        if (p < base || p >= base + kv.second.bytes) continue;
+        const size_t chunk = kv.second.chunk;
+        if (chunk >= kv.second.bytes) return k;
+        const size_t off = (size_t)(p - base), room = (off / chunk + 1) * chunk - off;
+        if (room < rowbytes) return 0;
+        const int64_t fit = (int64_t)((room - rowbytes) / pitch) + 1;
+        return fit < k ? fit : k;
+    }
+    return k;
+}
+
 size_t pool_limit() {
     static const size_t lim = [] {
         const char *e = getenv("PCL_POOL_GB");
@@ -1994,7 +2182,7 @@ size_t pool_limit() {
 void pool_flush_locked() {
     for (const pool_block &b : g_pool) {
         (void)hipSetDevice(b.device);
-        (void)hipFree(b.p);
+        raw_free(b.p);
     }
     g_pool.clear();
     g_pool_bytes = 0;
@@ -2019,7 +2207,7 @@ hipError_t big_malloc(void **p, size_t bytes) {
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = raw_malloc(p, bytes, device);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
         {
@@ -2027,7 +2215,7 @@ hipError_t big_malloc(void **p, size_t bytes) {
             pool_flush_locked();
         }
         (void)hipSetDevice(device);
-        e = hipMalloc(p, bytes);
+        e = raw_malloc(p, bytes, device);
     }
     if (e == hipSuccess && eligible) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -2050,7 +2238,7 @@ void big_free(void *p) {
                 (void)hipGetDevice(&device);
                 while (g_pool_bytes + bytes > pool_limit() && !g_pool.empty()) { // make room: the oldest idle block goes
                     (void)hipSetDevice(g_pool.front().device);
-                    (void)hipFree(g_pool.front().p);
+                    raw_free(g_pool.front().p);
                     g_pool_bytes -= g_pool.front().bytes;
                     g_pool.erase(g_pool.begin());
                 }
@@ -2061,7 +2249,7 @@ void big_free(void *p) {
             }
         }
     }
-    (void)hipFree(p);
+    raw_free(p);
 }
 
 int dev_alloc_bytes(void **p, int64_t n_elems, size_t esz) {
@@ -2099,9 +2287,82 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n) {
     return PCL_OK;
 }
 
+// ---- choosing the slab among a few candidates ----------------------------------------------------------------------
+//   (see "where big blocks come from": how fast the many-stream passes run is a property of the memory behind a slab,
+//   fixed when it is allocated, 10-15 % apart from one allocation to the next.)  A store of >= 512 MB takes the fastest
+//   of up to PCL_ALLOC_TRIES (default 4; 1 = take the first) candidate blocks -- idle pool blocks first, then fresh
+//   ones -- each measured with the 13-row write sweep over the WHOLE block (a block's speed is not the sum of its
+//   handles' speeds measured one at a time: tools/vmm_chunk_probe.hip); the others go (back) to the pool with their
+//   rate remembered, where the compaction's second slab finds them.  ~10 ms per candidate at 1e8 photons, once per store.
+int tries_wanted() {
+    static const int n = [] {
+        const char *e = getenv("PCL_ALLOC_TRIES");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 8 ? 8 : v);
+    }();
+    return n;
+}
+
+double block_rate(void *blk, int64_t tiles64) {
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        auto it = g_rate.find(blk);
+        if (it != g_rate.end()) return it->second;
+    }
+    const double r = sweep_rate_raw(blk, tiles64);
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    g_rate[blk] = r;
+    return r;
+}
+
+int alloc_slab(pcl_ctx *ctx, void **out) {
+    const size_t bytes = slab_bytes(ctx);
+    const int tries = (bytes >= ((size_t)512 << 20) && row_pad_bytes() == 0) ? tries_wanted() : 1;
+    if (tries == 1) {
+        PCL_HIP(big_malloc(out, bytes));
+        return PCL_OK;
+    }
+    const int64_t tiles64 = (int64_t)(bytes / ((size_t)kRows * kTileT * 8)); // the sweep's tiles are fp64-sized whatever the dtype
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    void *best = nullptr;
+    double best_rate = -1.0;
+    std::vector<void *> losers;
+    std::vector<double> seen;
+    for (int k = 0; k < tries; ++k) {
+        if (k > 0) { // another candidate only while twice its size is still free
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < 2 * bytes) break;
+        }
+        void *cand = nullptr;
+        if (big_malloc(&cand, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        const double r = block_rate(cand, tiles64);
+        seen.push_back(r);
+        if (r > best_rate) {
+            if (best) losers.push_back(best);
+            best = cand;
+            best_rate = r;
+        } else {
+            losers.push_back(cand);
+        }
+    }
+    static const bool debug = getenv("PCL_ALLOC_DEBUG") != nullptr;
+    if (debug) {
+        fprintf(stderr, "physicl_hip: slab of %.2f GB: chose %.0f GB/s among", bytes / 1e9, best_rate);
+        for (double r : seen) fprintf(stderr, " %.0f", r);
+        fprintf(stderr, "\n");
+    }
+    for (void *l : losers) big_free(l); // only now: a freed candidate must not come back as the next one
+    if (!best) PCL_HIP(big_malloc(&best, bytes)); // reports the allocation error
+    *out = best;
+    return PCL_OK;
+}
+
 int ensure_alt(pcl_ctx *ctx) {
     if (!ctx->slab_alt) {
-        PCL_HIP(big_malloc(&ctx->slab_alt, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
+        PCL_TRY(alloc_slab(ctx, &ctx->slab_alt));
         refresh_rows(ctx);
     }
     if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
@@ -3684,7 +3945,7 @@ int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     ctx->esz = dtype == PCL_DTYPE_F64 ? 8 : 4;
     ctx->tiles = div_up(capacity, kTileT);
     for (int k = 0; k < kRows; ++k) ctx->row[k] = k;
-    PCL_HIP(big_malloc(&ctx->slab, (size_t)ctx->tiles * kRows * kTileT * ctx->esz));
+    PCL_TRY(alloc_slab(ctx, &ctx->slab));
     refresh_rows(ctx);
     ctx->capacity = capacity;
     ctx->count = 0;

@@ -43,3 +43,23 @@ def test_pool_can_be_switched_off():
             "d.fill_photons(700000, 0, 299792458.0, 1.0, 1.0, 3); assert d.step_counters([])[0] == 700000; d.close(); print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_POOL_GB="0"), timeout=300)
     assert out.decode().strip().endswith("ok")
+
+
+def test_copies_over_a_slab_made_of_several_physical_handles():
+    """Big blocks are hipMemMap'ed ranges of several physical handles (1.07 GB each; 240 tiles = 67 MB here), and hipMemcpy2DAsync refuses
+    rows that reach from one handle into the next: uploads and downloads are cut at the handle boundaries."""
+    code = ("import numpy as np\n"
+            "from physicl_amd import _hip as hip\n"
+            "N = 2_000_003\n"
+            "rs = np.random.RandomState(1)\n"
+            "d = hip.Device(0); d.store_alloc(N); d.set_count(N, 0)\n"
+            "cols = {f: rs.normal(size=N) for f in (hip.R0, hip.R2, hip.V1, hip.E)}\n"
+            "for f, a in cols.items(): d.upload(f, a)\n"
+            "for f, a in cols.items(): assert np.array_equal(d.download(f, N), a), f\n"
+            "assert np.array_equal(d.download(hip.R2, 70001, 1_234_567), cols[hip.R2][1_234_567:1_234_567 + 70001])\n"
+            "d.upload(hip.V1, cols[hip.E][:500_000], 777_777); cols[hip.V1][777_777:1_277_777] = cols[hip.E][:500_000]\n"
+            "assert np.array_equal(d.download(hip.V1, N), cols[hip.V1])\n"
+            "d.step_newton(0.5)\n"
+            "d.close(); print('ok')\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_VMM_CHUNK_TILES="240", PCL_POOL_GB="0"), timeout=300)
+    assert out.decode().strip().endswith("ok")
