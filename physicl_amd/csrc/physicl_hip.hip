@@ -2317,7 +2317,8 @@ double block_rate(void *blk, int64_t tiles64) {
 
 int alloc_slab(pcl_ctx *ctx, void **out) {
     const size_t bytes = slab_bytes(ctx);
-    const int tries = (bytes >= ((size_t)512 << 20) && row_pad_bytes() == 0) ? tries_wanted() : 1;
+    // (candidates that lose must fit the pool: handing tens of GB back to the driver is what stalls the next allocation)
+    const int tries = (bytes >= ((size_t)512 << 20) && 2 * bytes <= pool_limit() && row_pad_bytes() == 0) ? tries_wanted() : 1;
     if (tries == 1) {
         PCL_HIP(big_malloc(out, bytes));
         return PCL_OK;
