@@ -1813,7 +1813,7 @@ struct pcl_ctx {
     hipDeviceProp_t prop;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_count = nullptr; // recorded behind the D2H copy of a compaction's survivor count (scan_tiles)
-    int grid_cap = 2048; // workgroups for grid-stride kernels: 8 per CU
+    int grid_cap = 16384; // workgroups for grid-stride kernels: 64 per CU
 
     // particle store.  Every array holds elements of the store's dtype (8 or 4 bytes).
     int dtype = PCL_DTYPE_F64;
@@ -3584,7 +3584,9 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
         return fail(PCL_ERR_HIP, "libphysicl_hip is built for gfx950 (MI355X) only; device %d is %s", device,
                     arch.c_str());
     }
-    c->grid_cap = c->prop.multiProcessorCount * 8;
+    // 64 per CU (round 2, measured with chosen slabs: K-step pass 1.62e11 at 8 per CU, 1.71e11 at 16, 1.75e11 at 32, 1.77e11 at
+    // 64; one-step kernel 0.707 / 0.723 / 0.725 / 0.733 of peak; one chunk per workgroup loses the prefetch across trips: 0.48)
+    c->grid_cap = c->prop.multiProcessorCount * 64;
     if (const char *g = getenv("PCL_GRID_PER_CU")) // perf-experiment hook
         if (atoi(g) > 0) c->grid_cap = c->prop.multiProcessorCount * atoi(g);
     if (stream) {
