@@ -1220,16 +1220,27 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
             }
         }
     };
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int f = j < 3 ? j + 3 : (j < 6 ? j - 3 : j); // processing order: v0 v1 v2, r0 r1 r2, then the rest
-        W *buf = reinterpret_cast<W *>(s_raw[j & 1]);
-        const W2 *src = static_cast<const W2 *>(a.src[f]);
+    // the loads of field j+1 are issued before field j goes through LDS, and the barrier between the fields waits for the
+    // LDS traffic only (a __syncthreads would drain the loads in flight as well: loads and stores share vmcnt on gfx9)
+    auto field_of = [](int j) { return j < 3 ? j + 3 : (j < 6 ? j - 3 : j); }; // processing order: v0 v1 v2, r0 r1 r2, then the rest
+    auto fetch = [&](int j, W2 (&o)[TRIPS]) {
+        const W2 *src = static_cast<const W2 *>(a.src[field_of(j)]);
 #pragma unroll
         for (int t = 0; t < TRIPS; ++t) {
-            W2 x;
-            x.x = x.y = 0;
-            if (k0[t] || k1[t]) x = src[src_pair[t]]; // nothing is read for a pair that is gone
+            o[t].x = o[t].y = 0;
+            if (k0[t] || k1[t]) o[t] = src[src_pair[t]]; // nothing is read for a pair that is gone
+        }
+    };
+    W2 cur[TRIPS], nxt[TRIPS];
+    fetch(0, cur);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int f = field_of(j);
+        W *buf = reinterpret_cast<W *>(s_raw[j & 1]);
+        if (j + 1 < NF) fetch(j + 1, nxt);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) {
+            W2 x = cur[t];
             if (j < 3) { // v rows: sign counts                                        light.py:424-426
                 const T v0 = word_as<T, W>(x.x), v1 = word_as<T, W>(x.y);
                 vkeep[j][t][0] = v0;
@@ -1259,8 +1270,11 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
             if (k0[t]) buf[pos[t]] = x.x;
             if (k1[t]) buf[pos[t] + (k0[t] ? 1 : 0)] = x.y;
         }
-        __syncthreads(); // this field is complete in its buffer (and the write-out of the previous one is behind every thread)
+        // this field is complete in its buffer (and the write-out of the previous one is behind every thread)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         write_out(a.dst[f], buf, false);
+#pragma unroll
+        for (int t = 0; t < TRIPS; ++t) cur[t] = nxt[t];
     }
     if (a.ids_dst) { // ids: one more "field", always 8 bytes, dense destination
         uint64_t *buf = s_raw[NF & 1];
