@@ -1226,10 +1226,8 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
     auto fetch = [&](int j, W2 (&o)[TRIPS]) {
         const W2 *src = static_cast<const W2 *>(a.src[field_of(j)]);
 #pragma unroll
-        for (int t = 0; t < TRIPS; ++t) {
-            o[t].x = o[t].y = 0;
-            if (k0[t] || k1[t]) o[t] = src[src_pair[t]]; // nothing is read for a pair that is gone
-        }
+        for (int t = 0; t < TRIPS; ++t) o[t] = src[src_pair[t]]; // unconditional: a 64-B sector almost always holds a survivor
+                                                                  // anyway, and straight-line loads let the waits be counted
     };
     W2 cur[TRIPS], nxt[TRIPS];
     fetch(0, cur);
