@@ -19,6 +19,8 @@ BIT-identical between the two runs, fp64 and fp32, uniform / explicit-id / mixed
 stores the plain run is also compared with the numpy oracle stepping the same program: rows equal, survivor ids
 identical, v within 4 ulp(c), r within (moves) * dt * 4 ulp(c).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -245,7 +247,8 @@ def assert_logs_identical(a, b):
             assert x == y, (k, x, y)
 
 
-PROGRAMS = [(seed, dtype, store) for seed in range(30) for dtype, store in
+N_SEEDS = int(os.environ.get("PCL_RANDOM_SEEDS", "30"))      # a soak run sets this to hundreds
+PROGRAMS = [(seed, dtype, store) for seed in range(N_SEEDS) for dtype, store in
             ((("f64", "uniform"), ("f32", "ids"), ("f64", "both")) if seed % 2 else (("f64", "uniform"), ("f32", "uniform"), ("f64", "kinds")))]
 
 
@@ -276,7 +279,7 @@ def test_random_program_every_formulation_equals_one_launch_per_step(hip, seed, 
         if dtype == "f64" and store == "uniform" and N <= 20_011:
             ref, st, moves = run_oracle(prog, init, tag, 77 + seed, planes)
             dt = CASES[tag][4]
-            rtol = 2 * max(moves, 1) * dt * V_ABS_TOL + 4 * np.spacing(8.0 + moves * dt * C_LIT)
+            rtol = 2 * max(moves, 1) * dt * V_ABS_TOL + (moves + 4) * np.spacing(8.0 + moves * dt * C_LIT)   # one rounding per move on top
             assert len(ref) == len(plain)
             for k, (x, y) in enumerate(zip(ref, plain)):
                 if x[0] == "download":

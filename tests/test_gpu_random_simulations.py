@@ -9,6 +9,8 @@ edit or remove objects at random places, photons with or without plain Objects a
 runs each with three schedules and requires IDENTICAL results: ``ts``, every measure row, ``hits``, what the host
 plugins saw, and the final r, v, dr, dv, E of every object, bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -155,7 +157,7 @@ def assert_same(a, b, what):
 SEEN = {}
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PCL_RANDOM_SEEDS", "60"))))
 def test_random_simulation_does_not_depend_on_the_schedule(seed):
     cfg = draw_config(np.random.RandomState(500 + seed))
     base = build_and_run(cfg, 1, False)
