@@ -49,6 +49,8 @@ _vp = c_void_p
 _PROTOTYPES = {
     "pcl_abi_version": [],
     "pcl_device_count": [POINTER(c_int)],
+    "pcl_ctx_set_rtc_background": [_vp, c_int],
+    "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
     "pcl_pool_trim": [POINTER(c_int64)],
     "pcl_pool_bytes": [POINTER(c_int64)],
     "pcl_ctx_create": [c_int, _vp, POINTER(_vp)],
@@ -267,6 +269,16 @@ class Device:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_rtc_background(self, on=True):
+        """Built-in variable_n_fn shapes start on the ahead-of-time kernels while hipRTC compiles (pcl_ctx_set_rtc_background)."""
+        check(self.lib.pcl_ctx_set_rtc_background(self.ctx, 1 if on else 0))
+
+    def rtc_wait(self):
+        """Block until every specialisation still compiling in the background is in place; returns how many were pending."""
+        n = c_int(0)
+        check(self.lib.pcl_ctx_rtc_wait(self.ctx, byref(n)))
+        return n.value
 
     def sync(self):
         check(self.lib.pcl_ctx_sync(self.ctx))

@@ -37,6 +37,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <thread>
+#include <memory>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1800,6 +1803,18 @@ int validate_expr(const char *e, std::string *f32_out = nullptr) {
 // =================================================================================================
 // context
 // =================================================================================================
+// A hipRTC compile running beside the simulation: the expression is one of the built-in shapes, so the ahead-of-time
+// kernels (same bits, ~10 % slower in the VALU-bound K-step pass) carry the first ~2 s of steps.
+struct rtc_job {
+    std::thread th;
+    std::atomic<int> state{0}; // 0 compiling, 1 code ready, 2 failed
+    std::vector<char> code;
+    std::string err;
+    ~rtc_job() {
+        if (th.joinable()) th.join();
+    }
+};
+
 struct rtc_entry {
     // module == nullptr: hipRTC was not available; the expression matched one of the built-in shapes and runs on the
     // ahead-of-time VAR_N kernels with these parameters (double and float spellings of the user's literals)
@@ -1814,6 +1829,7 @@ struct rtc_entry {
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t multi2[2] = {nullptr, nullptr}; // experiment (PCL_RTC_EXTRA=PCL_MULTI_NQ2): two groups per lane, fp64
+    std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
 
 } // namespace
@@ -1889,6 +1905,7 @@ struct pcl_ctx {
     uint64_t *cnt_target = nullptr;      // where the running step's kernels accumulate
 
     std::map<std::string, rtc_entry> rtc;
+    bool rtc_background = false; // built-in expression shapes start on the ahead-of-time kernels while hipRTC compiles
 
     // per-kernel HIP-event timing (pcl_prof_*): pairs recorded immediately around each launch
     struct prof_slot {
@@ -2674,11 +2691,33 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc
 // The implementation of a variable_n_fn expression for this context: its hipRTC specialisation, or -- when hipRTC is
 // not available on this machine (or the compile fails) and the text is one of the three built-in shapes -- the
 // ahead-of-time VAR_N kernels with the text's literals as parameters (entry with module == nullptr).
+int load_rtc_into(const std::vector<char> &code, rtc_entry &ent); // below
+
+// a background compile that has finished is taken over: from here on the entry runs the specialised kernels
+void poll_job(rtc_entry &ent, bool wait) {
+    if (!ent.job) return;
+    if (!wait && ent.job->state.load() == 0) return;
+    if (ent.job->th.joinable()) ent.job->th.join();
+    if (ent.job->state.load() == 1) {
+        rtc_entry up;
+        if (load_rtc_into(ent.job->code, up) == PCL_OK) {
+            up.np64 = ent.np64;
+            up.np32 = ent.np32;
+            ent = up; // (job dropped with the old value)
+            return;
+        }
+        if (up.module) (void)hipModuleUnload(up.module);
+        (void)hipGetLastError();
+    }
+    ent.job.reset(); // compile or load failed: the ahead-of-time kernels stay
+}
+
 int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     std::string expr_f32;
     PCL_TRY(validate_expr(expr, &expr_f32));
     auto it = ctx->rtc.find(expr);
     if (it != ctx->rtc.end()) {
+        poll_job(it->second, false);
         *out = &it->second;
         return PCL_OK;
     }
@@ -2745,35 +2784,65 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc
             ctx->rtc.erase(expr); // unreadable / stale file: compile again and overwrite it
         }
     }
-    hiprtcProgram prog;
-    hiprtcResult r = rtc_api().CreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
-    if (r != HIPRTC_SUCCESS) return fail(PCL_ERR_RTC, "hiprtcCreateProgram: %s", rtc_api().GetErrorString(r));
-    const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra};
-    r = rtc_api().CompileProgram(prog, (extra && *extra) ? 5 : 4, opts);
-    if (r != HIPRTC_SUCCESS) {
-        size_t n = 0;
-        rtc_api().GetProgramLogSize(prog, &n);
-        std::string log(n, '\0');
-        if (n) rtc_api().GetProgramLog(prog, &log[0]);
+    // the compile itself: hipRTC only, no device call -- it may run on another thread
+    auto compile = [](const std::string src, const std::string arch, const std::string extra, const std::string expr,
+                      const std::string code_key, const std::string disk, std::vector<char> *code, std::string *err) {
+        hiprtcProgram prog;
+        hiprtcResult r = rtc_api().CreateProgram(&prog, src.c_str(), "pcl_variable_n.hip", 0, nullptr, nullptr);
+        if (r != HIPRTC_SUCCESS) {
+            *err = std::string("hiprtcCreateProgram: ") + rtc_api().GetErrorString(r);
+            return false;
+        }
+        const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra.c_str()};
+        r = rtc_api().CompileProgram(prog, extra.empty() ? 4 : 5, opts);
+        if (r != HIPRTC_SUCCESS) {
+            size_t n = 0;
+            rtc_api().GetProgramLogSize(prog, &n);
+            std::string log(n, '\0');
+            if (n) rtc_api().GetProgramLog(prog, &log[0]);
+            rtc_api().DestroyProgram(&prog);
+            *err = "hipRTC could not compile variable_n_fn \"" + expr + "\": " + rtc_api().GetErrorString(r) + "\n" + log;
+            return false;
+        }
+        size_t code_n = 0;
+        rtc_api().GetCodeSize(prog, &code_n);
+        code->resize(code_n);
+        rtc_api().GetCode(prog, code->data());
         rtc_api().DestroyProgram(&prog);
-        return fail(PCL_ERR_RTC, "hipRTC could not compile variable_n_fn \"%s\": %s\n%s", expr,
-                    rtc_api().GetErrorString(r), log.c_str());
+        {
+            std::lock_guard<std::mutex> lock(g_code_mutex);
+            g_code_cache[code_key] = *code;
+        }
+        if (!disk.empty()) write_cached_code(disk, *code);
+        return true;
+    };
+    const std::string extra_s = (extra && *extra) ? extra : "";
+    // One of the built-in shapes, nothing cached: the ahead-of-time kernels start at once and the specialisation is
+    // compiled beside them (~2 s); get_rtc takes it over when it is ready, pcl_ctx_rtc_wait waits for it.  Same bits
+    // either way (tests/test_gpu_aot_fallback.py).  Asked for per context (pcl_ctx_set_rtc_background: Simulation does,
+    // a bare context compiles first, so that a measurement never times the stand-in kernels); PCL_RTC_SYNC overrides.
+    static const bool sync_env = getenv("PCL_RTC_SYNC") != nullptr;
+    rtc_entry aot;
+    if (ctx->rtc_background && !sync_env && match_nprof(expr, &aot)) {
+        aot.job = std::make_shared<rtc_job>();
+        rtc_job *job = aot.job.get();
+        const std::string expr_s = expr;
+        job->th = std::thread([=]() {
+            const bool ok = compile(src, arch, extra_s, expr_s, code_key, disk, &job->code, &job->err);
+            job->state.store(ok ? 1 : 2);
+        });
+        auto ins = ctx->rtc.emplace(std::string(expr), aot);
+        *out = &ins.first->second;
+        return PCL_OK;
     }
-    size_t code_n = 0;
-    rtc_api().GetCodeSize(prog, &code_n);
-    std::vector<char> code(code_n);
-    rtc_api().GetCode(prog, code.data());
-    rtc_api().DestroyProgram(&prog);
-    {
-        std::lock_guard<std::mutex> lock(g_code_mutex);
-        g_code_cache[code_key] = code;
-    }
-    if (!disk.empty()) write_cached_code(disk, code);
+    std::vector<char> code;
+    std::string err;
+    if (!compile(src, arch, extra_s, expr, code_key, disk, &code, &err)) return fail(PCL_ERR_RTC, "%s", err.c_str());
     return load_rtc_module(ctx, expr, code, out);
 }
 
-int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &code, rtc_entry **out) {
-    rtc_entry ent;
+// module + kernel handles of a compiled specialisation into ``ent``
+int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
     PCL_HIP(hipModuleLoadData(&ent.module, code.data()));
     PCL_HIP(hipModuleGetFunction(&ent.sphere[0], ent.module, "pcl_rtc_sphere_e0"));
     PCL_HIP(hipModuleGetFunction(&ent.sphere[1], ent.module, "pcl_rtc_sphere_e1"));
@@ -2800,6 +2869,12 @@ int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &cod
         if (hipModuleGetFunction(&ent.multi2[e], ent.module, nm) != hipSuccess) ent.multi2[e] = nullptr;
     }
     (void)hipGetLastError();
+    return PCL_OK;
+}
+
+int load_rtc_module(pcl_ctx *ctx, const char *expr, const std::vector<char> &code, rtc_entry **out) {
+    rtc_entry ent;
+    PCL_TRY(load_rtc_into(code, ent));
     auto ins = ctx->rtc.emplace(std::string(expr), ent);
     *out = &ins.first->second;
     return PCL_OK;
@@ -3545,6 +3620,24 @@ extern "C" {
 
 int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 const char *pcl_last_error(void) { return g_err.c_str(); }
+
+int pcl_ctx_set_rtc_background(pcl_ctx *ctx, int on) {
+    if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
+    ctx->rtc_background = on != 0;
+    return PCL_OK;
+}
+
+int pcl_ctx_rtc_wait(pcl_ctx *ctx, int *pending_out) {
+    PCL_TRY(bind(ctx));
+    int n = 0;
+    for (auto &kv : ctx->rtc)
+        if (kv.second.job) {
+            ++n;
+            poll_job(kv.second, true);
+        }
+    if (pending_out) *pending_out = n;
+    return PCL_OK;
+}
 
 int pcl_pool_trim(int64_t *released_out) {
     std::lock_guard<std::mutex> lk(g_pool_mu);
