@@ -2826,6 +2826,21 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc
     if (ctx->rtc_background && !sync_env && match_nprof(expr, &aot)) {
         aot.job = std::make_shared<rtc_job>();
         rtc_job *job = aot.job.get();
+        {   // a process that ends while a compile is running waits for it (contexts that were never destroyed)
+            static std::mutex mu;
+            static std::vector<std::weak_ptr<rtc_job>> *all = nullptr;
+            std::lock_guard<std::mutex> lk(mu);
+            if (!all) {
+                all = new std::vector<std::weak_ptr<rtc_job>>();
+                std::atexit([] {
+                    std::lock_guard<std::mutex> lk2(mu);
+                    for (auto &w : *all)
+                        if (auto j = w.lock())
+                            if (j->th.joinable()) j->th.join();
+                });
+            }
+            all->push_back(aot.job);
+        }
         const std::string expr_s = expr;
         job->th = std::thread([=]() {
             const bool ok = compile(src, arch, extra_s, expr_s, code_key, disk, &job->code, &job->err);

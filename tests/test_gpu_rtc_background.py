@@ -65,3 +65,17 @@ def test_simulation_switches_it_on_and_can_switch_it_off():
     finally:
         a.close()
         b.close()
+
+
+def test_a_process_that_ends_while_the_compile_runs_exits_cleanly(tmp_path):
+    code = ("import sys, os\n"
+            "sys.path.insert(0, %r)\n"
+            "from physicl_amd import _hip as hip\n"
+            "d = hip.Device(0); d.set_rtc_background(True); d.store_alloc(1000)\n"
+            "d.fill_photons(1000, 0, 299792458.0, 2.8e-19, 9.9e-19, 1)\n"
+            "sc = dict(A=1e-15, n=1e-19, flags=3, c=299792458.0, h=6.62607015e-34, n_expr='2.5 * exp(r1[gid] / %d.0)', rng_mode=hip.RNG_PHILOX, seed=1, step=0)\n"
+            "print(d.step_fused(1e-9, sc, [], lazy=True)['N'])\n"
+            "os._exit  # (not called: a normal interpreter exit, the context never closed explicitly)\n" % (ROOT, 7000 + os.getpid() % 1000))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCL_RTC_CACHE=str(tmp_path)), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0 and p.stdout.decode().strip() == "1000", p.stderr.decode()[-2000:]
