@@ -2148,6 +2148,8 @@ hipError_t vmm_malloc(void **p, size_t bytes, int device) {
 }
 
 hipError_t raw_malloc(void **p, size_t bytes, int device) {
+    static const bool contig = getenv("PCL_SLAB_CONTIG") != nullptr; // EXPERIMENT (tools/pad_sweep.py): physically contiguous blocks
+    if (contig && bytes >= kPoolMinBlock && hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
     if (bytes >= kPoolMinBlock && vmm_enabled()) {
         const hipError_t e = vmm_malloc(p, bytes, device);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
