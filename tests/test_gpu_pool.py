@@ -63,3 +63,25 @@ def test_copies_over_a_slab_made_of_several_physical_handles():
             "d.close(); print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_VMM_CHUNK_TILES="240", PCL_POOL_GB="0"), timeout=300)
     assert out.decode().strip().endswith("ok")
+
+
+def test_a_big_store_takes_the_fastest_of_a_few_candidate_slabs():
+    """Stores of >= 512 MB are measured (13-row write sweep) against up to PCL_ALLOC_TRIES - 1 other candidates; the ones that
+    lose wait in the pool, where the compaction's second slab takes the best of them; PCL_ALLOC_TRIES=1 takes the first block."""
+    code = ("import os, sys, numpy as np\n"
+            "from physicl_amd import _hip as hip\n"
+            "N = 4_200_000\n"                                   # 17 rows x 8 B x N = 571 MB
+            "d = hip.Device(0); d.store_alloc(N)\n"
+            "slab = -(-N // 2048) * 2048 * 17 * 8\n"
+            "held = hip.pool_bytes()\n"
+            "d.fill_photons(N, 0, 299792458.0, 1.0, 1.0, 3)\n"
+            "o = d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 3, 0, [], lazy=True)\n"   # needs the second slab
+            "held2 = hip.pool_bytes()\n"
+            "assert 0 < o['N'] < N\n"
+            "d.close(); print('RESULT', held // slab, held2 // slab)\n")
+    def run(tries):
+        out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_ALLOC_TRIES=str(tries)), timeout=300)
+        return [int(x) for x in out.decode().split()[-2:]]
+    assert run(1) == [0, 0]
+    held, held2 = run(4)
+    assert held == 3 and held2 == 3          # three losers parked; the second slab took one of them and parked a fresh loser
