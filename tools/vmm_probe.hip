@@ -45,6 +45,7 @@ static int vmm_alloc(vmm_block &blk, size_t bytes, size_t chunk, bool shuffle) {
     size_t gran = 0;
     CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (chunk < gran) chunk = gran;
+    if (chunk > bytes) chunk = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t n = (bytes + chunk - 1) / chunk;
     blk.bytes = n * chunk;
@@ -92,9 +93,25 @@ int main(int argc, char **argv) {
             if (measure("hipExtMalloc contiguous", c, tiles)) return 1;
             CK(hipFree(c));
         } else { (void)hipGetLastError(); printf("  contiguous refused\n"); }
+        {
+            void *a = nullptr;
+            hipStream_t st; CK(hipStreamCreate(&st));
+            if (hipMallocAsync(&a, bytes, st) == hipSuccess) {
+                CK(hipStreamSynchronize(st));
+                if (measure("hipMallocAsync", a, tiles)) return 1;
+                CK(hipFreeAsync(a, st)); CK(hipStreamSynchronize(st));
+            } else { (void)hipGetLastError(); printf("  hipMallocAsync refused\n"); }
+            void *u = nullptr;
+            if (hipExtMallocWithFlags(&u, bytes, hipDeviceMallocUncached) == hipSuccess) {
+                if (measure("hipExtMalloc uncached", u, tiles)) return 1;
+                CK(hipFree(u));
+            } else { (void)hipGetLastError(); printf("  uncached refused\n"); }
+        }
         struct { const char *name; size_t chunk; bool shuffle; } v[] = {
             {"VMM 2 MB chunks, in order", (size_t)2 << 20, false}, {"VMM 2 MB chunks, shuffled", (size_t)2 << 20, true},
-            {"VMM 64 MB chunks, shuffled", (size_t)64 << 20, true}, {"VMM 1 GB chunks, in order", (size_t)1 << 30, false}};
+            {"VMM 64 MB chunks, shuffled", (size_t)64 << 20, true}, {"VMM 64 MB chunks, in order", (size_t)64 << 20, false},
+            {"VMM 256 MB chunks, in order", (size_t)256 << 20, false}, {"VMM 1 GB chunks, in order", (size_t)1 << 30, false},
+            {"VMM one 13.6 GB handle", (size_t)1 << 40, false}};
         for (auto &x : v) {
             vmm_block blk;
             if (vmm_alloc(blk, bytes, x.chunk, x.shuffle)) return 1;
