@@ -79,3 +79,40 @@ def test_a_process_that_ends_while_the_compile_runs_exits_cleanly(tmp_path):
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCL_RTC_CACHE=str(tmp_path)), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0 and p.stdout.decode().strip() == "1000", p.stderr.decode()[-2000:]
+
+
+def test_two_background_compiles_at_once(tmp_path):
+    """Two contexts, two texts, both compiling on their own threads at the same time (hipRTC must cope), against the same
+    two runs compiled up front."""
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from physicl_amd import _hip as hip\n"
+            "C, H = 299792458.0, 6.62607015e-34\n"
+            "exprs = ['0.000000002 * exp(r2[gid] - %s)', '3.5 * exp(r0[gid] / %d.0)']\n"
+            "def run(background):\n"
+            "    devs, outs = [], []\n"
+            "    for e in exprs:\n"
+            "        d = hip.Device(0); d.set_rtc_background(background); d.store_alloc(50_000)\n"
+            "        d.fill_photons(50_000, 0, C, H * C / 700e-9, H * C / 200e-9, 2)\n"
+            "        devs.append(d)\n"
+            "    rows = []\n"
+            "    for d, e in zip(devs, exprs):\n"          # both compiles are started before either is waited for
+            "        sc = dict(A=1e-15, n=1e-19, flags=3, c=C, h=H, n_expr=e, rng_mode=hip.RNG_PHILOX, seed=2, step=0)\n"
+            "        rows.append(d.step_fused_multi(1e-9, 6, sc))\n"
+            "    pend = [d.rtc_wait() for d in devs]\n"
+            "    for d, e, r in zip(devs, exprs, rows):\n"
+            "        sc = dict(A=1e-15, n=1e-19, flags=3, c=C, h=H, n_expr=e, rng_mode=hip.RNG_PHILOX, seed=2, step=6)\n"
+            "        r += d.step_fused_multi(1e-9, 6, sc)\n"
+            "        outs.append(([(o['N'], o['hits'], list(map(int, o['sign']))) for o in r], d.download_state()))\n"
+            "        d.close()\n"
+            "    return pend, outs\n"
+            "pa, a = run(True)\n"
+            "pb, b = run(False)\n"
+            "assert pa == [1, 1] and pb == [0, 0], (pa, pb)\n"
+            "for (ra, sa), (rb, sb) in zip(a, b):\n"
+            "    assert ra == rb\n"
+            "    for g in ('r', 'v', 'dr', 'dv'):\n"
+            "        for k in range(3): assert np.array_equal(sa[g][k], sb[g][k])\n"
+            "print('ok')\n" % (ROOT, repr(4 + (os.getpid() % 997) * 1e-3), 6000 + os.getpid() % 997))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, PCL_RTC_CACHE=str(tmp_path)), timeout=600)
+    assert out.decode().strip().endswith("ok")
