@@ -299,6 +299,7 @@ def run_rank(args):
     f32 = args.dtype == "f32"
     bscale = 0.5 if f32 else 1.0
     b.fill()
+    slab_info = dev.alloc_info()
 
     # every rank reports which physical device it drives: N ranks on N distinct devices is what RCCL needs
     devices = comm.allgather_object({"rank": rank, "device": b.dev_index, "pci": dev.info().get("pci_bus_id")})
@@ -366,7 +367,10 @@ def run_rank(args):
                                    % ("/[3] weak-scaled" if world > 1 else "", N, coll_txt),
                        "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "steps_per_launch": S,
                        "variable_n_fn": prof["expr"], "dt": prof["dt"],
-                       "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world},
+                       "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world,
+                       # which memory the store's slab got (outside the timed region): the library measures a few candidate
+                       # blocks with a write sweep when a big store is created and keeps the fastest ("Placement")
+                       "slab_selection": slab_info},
             "collective": dict(comm.info(), devices=devices) if world > 1 else None,
             "roofline": {"bound": "hbm",
                          "kernel": (("k_multi (pcl_rtc_multi_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "

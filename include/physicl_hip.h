@@ -233,6 +233,10 @@ int pcl_store_download_kind(pcl_ctx *ctx, uint8_t *host, int64_t offset, int64_t
  * step); element i is at row0[(i / tile_len) * tile_stride + i % tile_len], see pcl_store_layout */
 int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out);
 int pcl_store_layout(pcl_ctx *ctx, int64_t *tile_len_out, int64_t *tile_stride_out);
+/* How the store's slab was chosen (stores of >= 512 MB; INTEGRATION.md, "Device memory"): the sweep rates in GB/s of the
+ * candidate blocks in the order they were tried (up to ``cap`` <= 8 values), their number (0: no selection took place) and
+ * the rate of the block that was kept.  Any pointer may be NULL.                                                        */
+int pcl_store_alloc_info(pcl_ctx *ctx, int *n_candidates_out, double *rates_gbps_out, int cap, double *chosen_gbps_out);
 
 /* Random inputs for PCL_RNG_INPUT: which = 0 rtheta, 1 rphi, 2 rand; n values for particles
  * [0, n) in store order (entries of non-photon particles are ignored). */

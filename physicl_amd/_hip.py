@@ -49,6 +49,7 @@ _vp = c_void_p
 _PROTOTYPES = {
     "pcl_abi_version": [],
     "pcl_device_count": [POINTER(c_int)],
+    "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
     "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
     "pcl_pool_trim": [POINTER(c_int64)],
@@ -405,6 +406,13 @@ class Device:
         p = c_void_p()
         check(self.lib.pcl_store_field_ptr(self.ctx, field, byref(p)))
         return p.value
+
+    def alloc_info(self):
+        """How the store's slab was chosen: {'candidates_GBps': [...], 'chosen_GBps': x} (empty list: no selection)."""
+        n, chosen = c_int(0), c_double(0.0)
+        rates = (c_double * 8)()
+        check(self.lib.pcl_store_alloc_info(self.ctx, byref(n), rates, 8, byref(chosen)))
+        return {"candidates_GBps": [round(rates[k], 1) for k in range(n.value)], "chosen_GBps": round(chosen.value, 1)}
 
     def layout(self):
         """(tile_len, tile_stride) in elements: element i of a row is at row0[(i // T) * stride + i % T]."""

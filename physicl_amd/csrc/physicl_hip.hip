@@ -1906,6 +1906,9 @@ struct pcl_ctx {
 
     std::map<std::string, rtc_entry> rtc;
     bool rtc_background = false; // built-in expression shapes start on the ahead-of-time kernels while hipRTC compiles
+    double slab_rates[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // alloc_slab: sweep rates (GB/s) of the candidates of the store's slab
+    int slab_tries = 0;
+    double slab_chosen = 0.0;
 
     // per-kernel HIP-event timing (pcl_prof_*): pairs recorded immediately around each launch
     struct prof_slot {
@@ -2351,6 +2354,7 @@ int alloc_slab(pcl_ctx *ctx, void **out) {
     // (candidates that lose must fit the pool: handing tens of GB back to the driver is what stalls the next allocation)
     const int tries = (bytes >= ((size_t)512 << 20) && 2 * bytes <= pool_limit() && row_pad_bytes() == 0) ? tries_wanted() : 1;
     if (tries == 1) {
+        if (out == &ctx->slab) ctx->slab_tries = 0, ctx->slab_chosen = 0.0;
         PCL_HIP(big_malloc(out, bytes));
         return PCL_OK;
     }
@@ -2379,6 +2383,11 @@ int alloc_slab(pcl_ctx *ctx, void **out) {
         } else {
             losers.push_back(cand);
         }
+    }
+    if (out == &ctx->slab) { // what pcl_store_alloc_info reports
+        ctx->slab_tries = (int)seen.size();
+        for (int k = 0; k < 8; ++k) ctx->slab_rates[k] = k < (int)seen.size() ? seen[k] : 0.0;
+        ctx->slab_chosen = best_rate;
     }
     static const bool debug = getenv("PCL_ALLOC_DEBUG") != nullptr;
     if (debug) {
@@ -4213,6 +4222,15 @@ int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out) {
     if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
     if (field >= PCL_DV0 && field <= PCL_DV2) ctx->dv_zero = 0;
     *dev_out = ctx->field[field];
+    return PCL_OK;
+}
+
+int pcl_store_alloc_info(pcl_ctx *ctx, int *n_candidates_out, double *rates_gbps_out, int cap, double *chosen_gbps_out) {
+    PCL_TRY(need_store_raw(ctx));
+    if (n_candidates_out) *n_candidates_out = ctx->slab_tries;
+    if (chosen_gbps_out) *chosen_gbps_out = ctx->slab_chosen;
+    if (rates_gbps_out)
+        for (int k = 0; k < cap && k < 8; ++k) rates_gbps_out[k] = ctx->slab_rates[k];
     return PCL_OK;
 }
 

@@ -31,6 +31,7 @@ def test_bench_line_has_the_contract_keys(extra):
     assert d["repeats"] == 3 and len(d["repeat_ms_per_step"]) == 3
     assert min(d["repeat_ms_per_step"]) <= d["ms_per_step"] + 1e-4 <= max(d["repeat_ms_per_step"]) + 2e-4       # the median block
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["slab_selection"]["candidates_GBps"] == []        # a 300000-photon store is too small to be chosen among candidates
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
