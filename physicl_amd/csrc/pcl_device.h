@@ -1456,39 +1456,101 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
 // hipRTC translation unit: one expression; both wavelength variants of every kernel, fp64 and fp32.
 #define PCL_RTC_KERNEL(name, argtype, call) \
     extern "C" __global__ void __launch_bounds__(256) name(argtype a) { call(a); }
+// PCL_RTC_DT (0 fp64, 1 fp32) and PCL_RTC_E (wavelength term) select the quarter of the kernels a (store, step) pair can
+// launch; without them every kernel is emitted
+#ifndef PCL_RTC_DT
+#define PCL_RTC_ALL 1
+#define PCL_RTC_DT 0
+#define PCL_RTC_E 0
+#else
+#define PCL_RTC_ALL 0
+#endif
+#define PCL_RTC_WANT(d, e) (PCL_RTC_ALL || (PCL_RTC_DT == (d) && PCL_RTC_E == (e)))
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_sphere_e0, pcl_sphere_args, (pcl_sphere_body<false, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_sphere_e1, pcl_sphere_args, (pcl_sphere_body<true, true>))
+#endif
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_scatter_e0, pcl_scatter_args<double>, (pcl_scatter_body<double, false, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_scatter_e1, pcl_scatter_args<double>, (pcl_scatter_body<double, true, true>))
+#endif
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_fused_e0, pcl_fused_args<double>, (pcl_fused_body<double, false, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_fused_e1, pcl_fused_args<double>, (pcl_fused_body<double, true, true>))
+#endif
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_fast_e0, pcl_fast_args<double>, (pcl_fast_body<double, false, true, 2>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_fast_e1, pcl_fast_args<double>, (pcl_fast_body<double, true, true, 2>))
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_scatter_f_e0, pcl_scatter_args<float>, (pcl_scatter_body<float, false, true>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_scatter_f_e1, pcl_scatter_args<float>, (pcl_scatter_body<float, true, true>))
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_fused_f_e0, pcl_fused_args<float>, (pcl_fused_body<float, false, true>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_fused_f_e1, pcl_fused_args<float>, (pcl_fused_body<float, true, true>))
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e0, pcl_fast_args<float>, (pcl_fast_body<float, false, true, 4>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_fast_f_e1, pcl_fast_args<float>, (pcl_fast_body<float, true, true, 4>))
+#endif
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_fastg_e0, pcl_fast_args<double>, (pcl_fast_body<double, false, true, 2, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_fastg_e1, pcl_fast_args<double>, (pcl_fast_body<double, true, true, 2, true>))
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_fastg_f_e0, pcl_fast_args<float>, (pcl_fast_body<float, false, true, 4, true>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_fastg_f_e1, pcl_fast_args<float>, (pcl_fast_body<float, true, true, 4, true>))
+#endif
+#if PCL_RTC_WANT(0, 0)
 PCL_RTC_KERNEL(pcl_rtc_mixed_e0, pcl_mixed_args<double>, (pcl_mixed_body<double, false, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_mixed_e1, pcl_mixed_args<double>, (pcl_mixed_body<double, true, true>))
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_mixed_f_e0, pcl_mixed_args<float>, (pcl_mixed_body<float, false, true>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_mixed_f_e1, pcl_mixed_args<float>, (pcl_mixed_body<float, true, true>))
+#endif
 #ifndef PCL_MULTI_ATTR /* timing experiments: e.g. -DPCL_MULTI_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) */
 #define PCL_MULTI_ATTR
 #endif
+#if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e0(pcl_multi_args<double> a) {
     pcl_multi_body<double, false, true, 2>(a);
 }
+#endif
+#if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e1(pcl_multi_args<double> a) {
     pcl_multi_body<double, true, true, 2>(a);
 }
+#endif
+#if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float, false, true, 4>))
+#endif
+#if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
+#endif
 #ifdef PCL_MULTI_NQ2 /* experiment: two groups per lane and trip */
 #ifndef PCL_MULTI2_ATTR
 #define PCL_MULTI2_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))

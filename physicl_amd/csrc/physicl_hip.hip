@@ -2697,7 +2697,7 @@ void write_cached_code(const std::string &path, const std::vector<char> &code) {
     write_file_atomic(path, raw);
 }
 
-int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc_entry **out);
+int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, int dt, bool use_e, const std::string &key, rtc_entry **out);
 
 // The implementation of a variable_n_fn expression for this context: its hipRTC specialisation, or -- when hipRTC is
 // not available on this machine (or the compile fails) and the text is one of the three built-in shapes -- the
@@ -2723,10 +2723,13 @@ void poll_job(rtc_entry &ent, bool wait) {
     ent.job.reset(); // compile or load failed: the ahead-of-time kernels stay
 }
 
-int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
+// One entry per (text, element type, wavelength term): a store has one element type and a step one setting of the
+// wavelength term, so only that quarter of the kernels is compiled (1.7 s instead of 2.5 s for the first use of a text).
+int get_rtc(pcl_ctx *ctx, const char *expr, int dt, bool use_e, rtc_entry **out) {
     std::string expr_f32;
     PCL_TRY(validate_expr(expr, &expr_f32));
-    auto it = ctx->rtc.find(expr);
+    const std::string key = std::string(expr) + (dt ? "\x01" "f32" : "\x01" "f64") + (use_e ? "e1" : "e0");
+    auto it = ctx->rtc.find(key);
     if (it != ctx->rtc.end()) {
         poll_job(it->second, false);
         *out = &it->second;
@@ -2734,30 +2737,32 @@ int get_rtc(pcl_ctx *ctx, const char *expr, rtc_entry **out) {
     }
     std::string why = rtc_api().why;
     if (rtc_api().ok) {
-        if (compile_rtc(ctx, expr, expr_f32, out) == PCL_OK) return PCL_OK;
+        if (compile_rtc(ctx, expr, expr_f32, dt, use_e, key, out) == PCL_OK) return PCL_OK;
         why = g_err;
-        ctx->rtc.erase(expr);
+        ctx->rtc.erase(key);
     }
     rtc_entry ent;
     if (!match_nprof(expr, &ent))
         return fail(PCL_ERR_RTC, "variable_n_fn \"%s\" needs hipRTC (%s) -- without it only the built-in shapes "
                     "\"K * exp(rA[gid] - X)\", \"K * exp(rA[gid] / X)\" and the radial exponential of the examples run", expr,
                     why.c_str());
-    auto ins = ctx->rtc.emplace(std::string(expr), ent);
+    auto ins = ctx->rtc.emplace(key, ent);
     *out = &ins.first->second;
     return PCL_OK;
 }
 
-int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc_entry **out) {
+int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, int dt, bool use_e, const std::string &key, rtc_entry **out) {
     const char *extra_env = getenv("PCL_RTC_EXTRA"), *define_env = getenv("PCL_RTC_DEFINE");
     const std::string code_key = std::string(ctx->prop.gcnArchName) + "|" + (extra_env ? extra_env : "") + "|" +
-                                 (define_env ? define_env : "") + "|" + expr;
+                                 (define_env ? define_env : "") + "|" + key;
     {
         std::lock_guard<std::mutex> lock(g_code_mutex);
         auto ci = g_code_cache.find(code_key);
-        if (ci != g_code_cache.end()) return load_rtc_module(ctx, expr, ci->second, out);
+        if (ci != g_code_cache.end()) return load_rtc_module(ctx, key.c_str(), ci->second, out);
     }
     std::string src = "#define PCL_RTC 1\n";
+    src += dt ? "#define PCL_RTC_DT 1\n" : "#define PCL_RTC_DT 0\n";
+    src += use_e ? "#define PCL_RTC_E 1\n" : "#define PCL_RTC_E 0\n";
     // perf-experiment hook (never set in production): PCL_RTC_EXTRA="NAME1,NAME2" -> "#define NAME 1" lines
     if (const char *extra = getenv("PCL_RTC_EXTRA")) {
         std::string tok;
@@ -2786,13 +2791,13 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc
         std::vector<char> cached;
         if (read_cached_code(disk, &cached)) {
             rtc_entry *e = nullptr;
-            if (load_rtc_module(ctx, expr, cached, &e) == PCL_OK) {
+            if (load_rtc_module(ctx, key.c_str(), cached, &e) == PCL_OK) {
                 std::lock_guard<std::mutex> lock(g_code_mutex);
                 g_code_cache[code_key] = cached;
                 *out = e;
                 return PCL_OK;
             }
-            ctx->rtc.erase(expr); // unreadable / stale file: compile again and overwrite it
+            ctx->rtc.erase(key); // unreadable / stale file: compile again and overwrite it
         }
     }
     // the compile itself: hipRTC only, no device call -- it may run on another thread
@@ -2857,37 +2862,41 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, rtc
             const bool ok = compile(src, arch, extra_s, expr_s, code_key, disk, &job->code, &job->err);
             job->state.store(ok ? 1 : 2);
         });
-        auto ins = ctx->rtc.emplace(std::string(expr), aot);
+        auto ins = ctx->rtc.emplace(key, aot);
         *out = &ins.first->second;
         return PCL_OK;
     }
     std::vector<char> code;
     std::string err;
     if (!compile(src, arch, extra_s, expr, code_key, disk, &code, &err)) return fail(PCL_ERR_RTC, "%s", err.c_str());
-    return load_rtc_module(ctx, expr, code, out);
+    return load_rtc_module(ctx, key.c_str(), code, out);
 }
 
 // module + kernel handles of a compiled specialisation into ``ent``
 int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
     PCL_HIP(hipModuleLoadData(&ent.module, code.data()));
-    PCL_HIP(hipModuleGetFunction(&ent.sphere[0], ent.module, "pcl_rtc_sphere_e0"));
-    PCL_HIP(hipModuleGetFunction(&ent.sphere[1], ent.module, "pcl_rtc_sphere_e1"));
+    // a module holds the kernels of ONE element type and wavelength setting (PCL_RTC_DT / PCL_RTC_E): the rest stay NULL
+    auto get = [&](hipFunction_t *f, const char *name) {
+        if (hipModuleGetFunction(f, ent.module, name) != hipSuccess) *f = nullptr;
+    };
+    get(&ent.sphere[0], "pcl_rtc_sphere_e0");
+    get(&ent.sphere[1], "pcl_rtc_sphere_e1");
     const char *dt_tag[2] = {"", "f_"};
     for (int d = 0; d < 2; ++d)
         for (int e = 0; e < 2; ++e) {
             char nm[64];
             snprintf(nm, sizeof nm, "pcl_rtc_scatter_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.scatter[d][e], ent.module, nm));
+            get(&ent.scatter[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_fused_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.fused[d][e], ent.module, nm));
+            get(&ent.fused[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_fast_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.fast[d][e], ent.module, nm));
+            get(&ent.fast[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_multi_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.multi[d][e], ent.module, nm));
+            get(&ent.multi[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_fastg_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.fastg[d][e], ent.module, nm));
+            get(&ent.fastg[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_mixed_%se%d", dt_tag[d], e);
-            PCL_HIP(hipModuleGetFunction(&ent.mixed[d][e], ent.module, nm));
+            get(&ent.mixed[d][e], nm);
         }
     for (int e = 0; e < 2; ++e) { // optional kernels: absent unless the experiment define was given
         char nm[64];
@@ -3928,7 +3937,7 @@ int pcl_k_light_scatter_step_sphere(pcl_ctx *ctx, const double *d0, const double
     if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
     rtc_entry *ent = nullptr;
-    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent)); // compile even for N == 0 so a bad expression fails early
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, 0, use_e, &ent)); // (fp64: the reference's ABI) compile even for N == 0 so a bad expression fails early
     if (N == 0) return PCL_OK;
     if (!d0 || !d1 || !d2 || !rtheta || !rphi || !rand || !res0 || !res1 || !res2)
         return fail(PCL_ERR_ARG, "NULL array argument");
@@ -4310,7 +4319,7 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N, py_dv = flags & PCL_SCATTER_PY_DV;
     rtc_entry *ent = nullptr;
-    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
     const int64_t N = ctx->count;
     if (hits_out) *hits_out = 0;
     if (N == 0) return PCL_OK;
@@ -4411,7 +4420,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     if (out_host && n_planes < 0) return fail(PCL_ERR_ARG, "out_host given but counters are off (n_planes = -1)");
     const bool use_e = do_scatter && (flags & PCL_SCATTER_WAVELENGTH), var_n = do_scatter && (flags & PCL_SCATTER_VARIABLE_N);
     rtc_entry *ent = nullptr;
-    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0;
     if (out_host) {
@@ -4500,7 +4509,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
     const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
     rtc_entry *ent = nullptr;
-    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
     const int64_t N = ctx->count;
     if (out_host)
         for (int k = 0; k < k_steps; ++k) {
@@ -4757,7 +4766,7 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     const bool has_iso = n_iso > 0, has_delete = n_delete > 0;
     const bool use_e = has_iso && (flags & PCL_SCATTER_WAVELENGTH), var_n = has_iso && (flags & PCL_SCATTER_VARIABLE_N);
     rtc_entry *ent = nullptr;
-    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, &ent));
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
     const int np = n_planes, n_rows = k_passes * n_phases, nslots = 5 + np;
     const int64_t N = ctx->count;
     if (out_host)
