@@ -1484,11 +1484,14 @@ PCL_RTC_KERNEL(pcl_rtc_fused_e0, pcl_fused_args<double>, (pcl_fused_body<double,
 #if PCL_RTC_WANT(0, 1)
 PCL_RTC_KERNEL(pcl_rtc_fused_e1, pcl_fused_args<double>, (pcl_fused_body<double, true, true>))
 #endif
+#ifndef PCL_FAST_ATTR /* timing experiments: e.g. -DPCL_FAST_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) */
+#define PCL_FAST_ATTR
+#endif
 #if PCL_RTC_WANT(0, 0)
-PCL_RTC_KERNEL(pcl_rtc_fast_e0, pcl_fast_args<double>, (pcl_fast_body<double, false, true, 2>))
+extern "C" __global__ void __launch_bounds__(256) PCL_FAST_ATTR pcl_rtc_fast_e0(pcl_fast_args<double> a) { pcl_fast_body<double, false, true, 2>(a); }
 #endif
 #if PCL_RTC_WANT(0, 1)
-PCL_RTC_KERNEL(pcl_rtc_fast_e1, pcl_fast_args<double>, (pcl_fast_body<double, true, true, 2>))
+extern "C" __global__ void __launch_bounds__(256) PCL_FAST_ATTR pcl_rtc_fast_e1(pcl_fast_args<double> a) { pcl_fast_body<double, true, true, 2>(a); }
 #endif
 #if PCL_RTC_WANT(1, 0)
 PCL_RTC_KERNEL(pcl_rtc_scatter_f_e0, pcl_scatter_args<float>, (pcl_scatter_body<float, false, true>))
