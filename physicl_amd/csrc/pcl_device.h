@@ -295,7 +295,12 @@ __device__ __forceinline__ float pcl_exp_wave(float x) {
 __device__ __forceinline__ double pcl_exp_wave(int x) { return pcl_exp_wave((double)x); } // exp(2) in user text: C promotes
 
 #define exp(x) pcl_exp_wave(x) /* for the body of pcl_n_expr_val only; undefined again right after it */
-template <typename T>
+// VAR_N (template parameter of every kernel body): 0 = constant n, 1 = variable n -- the spliced text under hipRTC, or
+// whatever pcl_nprof says in the ahead-of-time kernels --, 2 .. 7 = ahead-of-time only: the two one-component shapes
+// (the reference's examples) on a literal axis, so that their loops carry one expression instead of three and a select:
+// 2 + 3 * (0: K * exp(rA - X), 1: K * exp(rA / X)) + axis
+#define PCL_VARN_SHAPED(scale, axis) (2 + 3 * (scale) + (axis))
+template <typename T, int VAR_N = 1>
 __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev) {
     const T r0[1] = {r0v}, r1[1] = {r1v}, r2[1] = {r2v}, d0[1] = {d0v}, d1[1] = {d1v}, d2[1] = {d2v}, E[1] = {Ev};
     const int gid = 0;
@@ -307,6 +312,12 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
         return (T)(PCL_N_EXPR_F);
     }
 #else
+    if constexpr (VAR_N >= 2) {
+        constexpr int ax = (VAR_N - 2) % 3;
+        const T rL[1] = {ax == 0 ? r0v : (ax == 1 ? r1v : r2v)}; // (constant-folded)
+        if constexpr ((VAR_N - 2) / 3 == 0) return (T)(np.p0 * exp(rL[gid] - np.p1));
+        return (T)(np.p0 * exp(rL[gid] / np.p1));
+    }
     const T rA[1] = {np.axis == 0 ? r0v : (np.axis == 1 ? r1v : r2v)};
     if (np.shape == PCL_NPROF_EXP_OFFSET) return (T)(np.p0 * exp(rA[gid] - np.p1));
     if (np.shape == PCL_NPROF_EXP_RADIAL)
@@ -319,20 +330,20 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
 // pcoll exactly as the generated kernel text multiplies it            physicl/light.py:299-306
 //   A * n * norm  |  A * (<expr>) * norm  [ * pow((h*c)/E, -4) ]   -- left to right
 // (the norm is passed in: a K-step pass keeps it in a register between the photon's hits)
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ T pcl_pcoll_norm(const pcl_nprof<T> &np, T A, T n, T h, T c, T norm, T d0, T d1, T d2, T r0, T r1, T r2,
                                             T E) {
     typedef pcl_rt<T> R;
     T p;
     if constexpr (VAR_N) {
-        p = R::mul(R::mul(A, pcl_n_expr_val<T>(np, r0, r1, r2, d0, d1, d2, E)), norm);
+        p = R::mul(R::mul(A, pcl_n_expr_val<T, VAR_N>(np, r0, r1, r2, d0, d1, d2, E)), norm);
     } else {
         p = R::mul(R::mul(A, n), norm);
     }
     if constexpr (USE_E) p = R::mul(p, pcl_wavelength_term<T>(h, c, E));
     return p;
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ T pcl_pcoll(const pcl_nprof<T> &np, T A, T n, T h, T c, T d0, T d1, T d2, T r0, T r1, T r2, T E) {
     return pcl_pcoll_norm<T, USE_E, VAR_N>(np, A, n, h, c, pcl_step_norm<T>(d0, d1, d2), d0, d1, d2, r0, r1, r2, E);
 }
@@ -350,7 +361,7 @@ struct pcl_sphere_args {
     pcl_nprof<double> np; // ahead-of-time VAR_N kernels only
 };
 
-template <bool USE_E, bool VAR_N>
+template <bool USE_E, int VAR_N>
 __device__ __forceinline__ void pcl_sphere_body(const pcl_sphere_args &a) {
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
     for (pcl_i64 gid = (pcl_i64)blockIdx.x * blockDim.x + threadIdx.x; gid < a.N; gid += stride) {
@@ -396,7 +407,7 @@ struct pcl_scatter_args {
 
 #define PCL_SCATTER_ROWS 4 /* particles per thread per grid-stride trip (memory-level parallelism) */
 
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ void pcl_scatter_body(const pcl_scatter_args<T> &a) {
     typedef pcl_rt<T> R;
     const pcl_i64 tile = (pcl_i64)blockDim.x * PCL_SCATTER_ROWS;
@@ -503,7 +514,7 @@ __device__ __forceinline__ T pcl_pick(int ax, T a0, T a1, T a2) { // by value: n
     return ax == 0 ? a0 : (ax == 1 ? a1 : a2);
 }
 
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
     typedef pcl_rt<T> R;
     constexpr int VEC = R::VEC;
@@ -727,7 +738,7 @@ __device__ __forceinline__ void pcl_fast_load(const pcl_fast_args<T> &a, pcl_i64
     }
 }
 
-template <typename T, bool USE_E, bool VAR_N, int VEC, bool GEN = false>
+template <typename T, bool USE_E, int VAR_N, int VEC, bool GEN = false>
 __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
@@ -858,7 +869,7 @@ struct pcl_hit_queue {
     T out[4][256 * VEC];      // the new velocity and its step length |v' * dt|
 };
 
-template <typename T, bool USE_E, bool VAR_N, int VEC>
+template <typename T, bool USE_E, int VAR_N, int VEC>
 __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
@@ -1013,7 +1024,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
 // of its lanes carry a hit, so the more photons a wave queues per step the fuller its passes: with NQ = 2 a wave owns
 // 128 * NQ photons per trip and, while their hits fit the queue (<= 64 * VEC), handles them in ONE round of
 // ceil(hits / 64) passes; a busier step falls back to one round per group.  Same operations per photon either way.
-template <typename T, bool USE_E, bool VAR_N, int VEC, int NQ>
+template <typename T, bool USE_E, int VAR_N, int VEC, int NQ>
 __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
@@ -1268,7 +1279,7 @@ struct pcl_mixed_queue {
     T out[4][256 * 2];   // the new velocity and its step length |v' * dt|
 };
 
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
     typedef pcl_rt<T> R;
     constexpr int NE = 2; // rows (particles per lane) per trip

@@ -193,34 +193,61 @@ __global__ void __launch_bounds__(kBlock) k_delete_flags(const double *__restric
 
 // ---- ahead-of-time variants of the kernels whose bodies live in pcl_device.h: constant n (VAR_N = false) and the three
 // parametrised variable-n shapes of the examples (VAR_N = true, pcl_nprof) for machines without hipRTC ---------------
-template <bool USE_E, bool VAR_N>
+template <bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_sphere(pcl_sphere_args a) {
     pcl_sphere_body<USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_scatter(pcl_scatter_args<T> a) {
     pcl_scatter_body<T, USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fused(pcl_fused_args<T> a) {
     pcl_fused_body<T, USE_E, VAR_N>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
     pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
     pcl_multi_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
     pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC, true>(a);
 }
-template <typename T, bool USE_E, bool VAR_N>
+template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
     pcl_mixed_body<T, USE_E, VAR_N>(a);
 }
+
+// The variable-n shape is an argument of the ahead-of-time kernels, so a body compiled once carries all three expressions and
+// the axis select through its loops: the K-step pass ran 11 % slower than its hipRTC specialisation for that alone (1.60e11
+// against 1.78e11; with one literal shape: 1.78e11).  The arithmetic-heavy kernels therefore exist once more for each of the
+// two one-component shapes on each axis, what the reference's examples use (VAR_N = 2 .. 7: pcl_device.h); the host picks.
+#define PCL_AOT_LAUNCH_SHAPED_E(K, T, E, vn, grid, args)                                                            \
+    do {                                                                                                          \
+        switch (vn) {                                                                                             \
+        case 0: hipLaunchKernelGGL((K<T, E, 0>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 2: hipLaunchKernelGGL((K<T, E, 2>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 3: hipLaunchKernelGGL((K<T, E, 3>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 4: hipLaunchKernelGGL((K<T, E, 4>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 5: hipLaunchKernelGGL((K<T, E, 5>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 6: hipLaunchKernelGGL((K<T, E, 6>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 7: hipLaunchKernelGGL((K<T, E, 7>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        default: hipLaunchKernelGGL((K<T, E, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;          \
+        }                                                                                                         \
+    } while (0)
+#define PCL_AOT_LAUNCH_SHAPED(K, T, use_e, var_n, grid, args)                                                       \
+    do {                                                                                                          \
+        const int sh_ = (args).np.shape, ax_ = (args).np.axis;                                                     \
+        const int vn_ = !(var_n) ? 0                                                                              \
+                        : ((sh_ == PCL_NPROF_EXP_OFFSET || sh_ == PCL_NPROF_EXP_SCALE) && ax_ >= 0 && ax_ <= 2)    \
+                            ? PCL_VARN_SHAPED(sh_ == PCL_NPROF_EXP_SCALE ? 1 : 0, ax_) : 1;                         \
+        if (use_e) PCL_AOT_LAUNCH_SHAPED_E(K, T, true, vn_, grid, args);                                           \
+        else PCL_AOT_LAUNCH_SHAPED_E(K, T, false, vn_, grid, args);                                                \
+    } while (0)
 
 // launch K<[T,] USE_E, VAR_N> for run-time use_e / var_n
 #define PCL_AOT_LAUNCH(K, T, use_e, var_n, grid, args)                                                              \
@@ -1804,7 +1831,8 @@ int validate_expr(const char *e, std::string *f32_out = nullptr) {
 // context
 // =================================================================================================
 // A hipRTC compile running beside the simulation: the expression is one of the built-in shapes, so the ahead-of-time
-// kernels (same bits, ~10 % slower in the VALU-bound K-step pass) carry the first ~2 s of steps.
+// kernels (same bits; as fast for the one-component shapes, ~10 % slower in the K-step pass for the radial one) carry the
+// first ~2 s of steps.
 struct rtc_job {
     std::thread th;
     std::atomic<int> state{0}; // 0 compiling, 1 code ready, 2 failed
@@ -3117,9 +3145,9 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
         PCL_TRY(launch_module(ctx, (gen ? ent->fastg : ent->fast)[d][use_e ? 1 : 0], grid, f, "step_fused fast path (hipRTC)"));
     } else {
         if (gen)
-            PCL_AOT_LAUNCH(k_fastg, T, use_e, var_n, grid, f);
+            PCL_AOT_LAUNCH_SHAPED(k_fastg, T, use_e, var_n, grid, f);
         else
-            PCL_AOT_LAUNCH(k_fast, T, use_e, var_n, grid, f);
+            PCL_AOT_LAUNCH_SHAPED(k_fast, T, use_e, var_n, grid, f);
         PCL_TRY(launch_check("k_fast"));
     }
     prof_end(ctx, ps);
@@ -3163,7 +3191,7 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     } else if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
     } else {
-        PCL_AOT_LAUNCH(k_multi, T, use_e, var_n, grid, f);
+        PCL_AOT_LAUNCH_SHAPED(k_multi, T, use_e, var_n, grid, f);
         PCL_TRY(launch_check("k_multi"));
     }
     prof_end(ctx, ps);
@@ -3584,7 +3612,7 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
     if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
     } else {
-        PCL_AOT_LAUNCH(k_mixed, T, use_e, var_n, tiles, f);
+        PCL_AOT_LAUNCH_SHAPED(k_mixed, T, use_e, var_n, tiles, f);
         PCL_TRY(launch_check("k_mixed"));
     }
     prof_end(ctx, ps);
