@@ -118,8 +118,8 @@ int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_byt
 int pcl_ctx_device_pci(pcl_ctx *ctx, char *pci, int pci_len);
 /* variable_n_fn texts of the three built-in shapes (the reference's examples) can start on the
  * ahead-of-time kernels at once while hipRTC compiles their specialisation on another thread (~2 s), which is taken over
- * at the first step call after it is ready -- same bits either way (the one-component shapes' ahead-of-time kernels are as
- * fast as the specialisation, the radial shape's ~10 % slower in the K-step pass).
+ * at the first step call after it is ready -- same bits either way, and about the same speed (the ahead-of-time kernels
+ * of the hot passes are compiled per shape and axis).
  * Off by default for a bare context (a measurement must not time the stand-in); physicl_amd.Simulation switches it on.
  * pcl_ctx_rtc_wait blocks until every pending specialisation of the context is in place (*pending_out: how many were).   */
 int pcl_ctx_set_rtc_background(pcl_ctx *ctx, int on);

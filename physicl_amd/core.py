@@ -332,7 +332,7 @@ class Simulation(threading.Thread):
         dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
         self._dev = _hip.Device(dev_index)
         # a variable_n_fn of one of the reference's example shapes starts at once on the ahead-of-time kernels while
-        # hipRTC compiles its specialisation beside the run (~2 s; same bits, and for the one-component shapes the same speed)
+        # hipRTC compiles its specialisation beside the run (~2 s; same bits, about the same speed)
         self._dev.set_rtc_background(bool(getattr(self, "rtc_background", True)))
 
     def _py_semantics(self):

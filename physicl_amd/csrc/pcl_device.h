@@ -298,7 +298,7 @@ __device__ __forceinline__ double pcl_exp_wave(int x) { return pcl_exp_wave((dou
 // VAR_N (template parameter of every kernel body): 0 = constant n, 1 = variable n -- the spliced text under hipRTC, or
 // whatever pcl_nprof says in the ahead-of-time kernels --, 2 .. 7 = ahead-of-time only: the two one-component shapes
 // (the reference's examples) on a literal axis, so that their loops carry one expression instead of three and a select:
-// 2 + 3 * (0: K * exp(rA - X), 1: K * exp(rA / X)) + axis
+// 2 + 3 * (0: K * exp(rA - X), 1: K * exp(rA / X)) + axis; 8 = the radial exponential
 #define PCL_VARN_SHAPED(scale, axis) (2 + 3 * (scale) + (axis))
 template <typename T, int VAR_N = 1>
 __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev) {
@@ -312,6 +312,8 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
         return (T)(PCL_N_EXPR_F);
     }
 #else
+    if constexpr (VAR_N == 8) // the radial exponential, literal shape
+        return (T)(np.p0 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - np.p1)/(np.p2)));
     if constexpr (VAR_N >= 2) {
         constexpr int ax = (VAR_N - 2) % 3;
         const T rL[1] = {ax == 0 ? r0v : (ax == 1 ? r1v : r2v)}; // (constant-folded)

@@ -236,6 +236,7 @@ __global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
         case 5: hipLaunchKernelGGL((K<T, E, 5>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
         case 6: hipLaunchKernelGGL((K<T, E, 6>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
         case 7: hipLaunchKernelGGL((K<T, E, 7>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
+        case 8: hipLaunchKernelGGL((K<T, E, 8>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;           \
         default: hipLaunchKernelGGL((K<T, E, 1>), dim3(grid), dim3(kBlock), 0, ctx->stream, args); break;          \
         }                                                                                                         \
     } while (0)
@@ -244,7 +245,8 @@ __global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
         const int sh_ = (args).np.shape, ax_ = (args).np.axis;                                                     \
         const int vn_ = !(var_n) ? 0                                                                              \
                         : ((sh_ == PCL_NPROF_EXP_OFFSET || sh_ == PCL_NPROF_EXP_SCALE) && ax_ >= 0 && ax_ <= 2)    \
-                            ? PCL_VARN_SHAPED(sh_ == PCL_NPROF_EXP_SCALE ? 1 : 0, ax_) : 1;                         \
+                            ? PCL_VARN_SHAPED(sh_ == PCL_NPROF_EXP_SCALE ? 1 : 0, ax_)                             \
+                            : (sh_ == PCL_NPROF_EXP_RADIAL ? 8 : 1);                                               \
         if (use_e) PCL_AOT_LAUNCH_SHAPED_E(K, T, true, vn_, grid, args);                                           \
         else PCL_AOT_LAUNCH_SHAPED_E(K, T, false, vn_, grid, args);                                                \
     } while (0)
@@ -1831,8 +1833,7 @@ int validate_expr(const char *e, std::string *f32_out = nullptr) {
 // context
 // =================================================================================================
 // A hipRTC compile running beside the simulation: the expression is one of the built-in shapes, so the ahead-of-time
-// kernels (same bits; as fast for the one-component shapes, ~10 % slower in the K-step pass for the radial one) carry the
-// first ~2 s of steps.
+// kernels (same bits, compiled per shape and axis: about as fast) carry the first ~2 s of steps.
 struct rtc_job {
     std::thread th;
     std::atomic<int> state{0}; // 0 compiling, 1 code ready, 2 failed
