@@ -96,7 +96,7 @@ int         pcl_abi_version(void);
 const char *pcl_last_error(void);                 /* thread-local, never NULL */
 int         pcl_device_count(int *n_out);         /* host pointer */
 /* Device blocks of >= 64 MB (stores, scratch, pcl_dev_alloc buffers) are not handed back to the driver when freed: the
- * process keeps up to PCL_POOL_GB (environment, default 64, 0 = off) of them for its next store of about that size --
+ * process keeps up to PCL_POOL_GB (environment; default a third of the device's memory, 0 = off) of them for its next store of about that size --
  * a hipMalloc of tens of GB right after a hipFree of that size was measured to stall for seconds on this runtime.
  * pcl_pool_trim() releases everything the pool holds (bytes released in *released_out, may be NULL);
  * pcl_pool_bytes() tells how much it holds.                                                                          */

@@ -2046,7 +2046,7 @@ int grid_for(const pcl_ctx *ctx, int64_t items, int per_block) {
 //   now and then takes 2-4 s (measured: 13.6 GB slab, about one run in four; the first allocation of a process takes
 //   0.3 ms) -- the driver is still taking the freed pages apart.  Blocks of >= 64 MB therefore go to a small per-process
 //   pool instead of back to the driver and the next request of about that size takes one from there.  PCL_POOL_GB
-//   (default 64; 0 = off) bounds what the pool may hold; an out-of-memory hipMalloc empties it and tries again.
+//   (default: a third of the device's memory; 0 = off) bounds what the pool may hold; an out-of-memory hipMalloc empties it and tries again.
 struct pool_block {
     void *p;
     size_t bytes;
@@ -2236,8 +2236,16 @@ int64_t rows_in_handle(const void *d, size_t pitch, size_t rowbytes, int64_t k) 
 size_t pool_limit() {
     static const size_t lim = [] {
         const char *e = getenv("PCL_POOL_GB");
-        const double gb = e ? atof(e) : 64.0;
-        return gb > 0 ? (size_t)(gb * (double)((size_t)1 << 30)) : (size_t)0;
+        if (e) {
+            const double gb = atof(e);
+            return gb > 0 ? (size_t)(gb * (double)((size_t)1 << 30)) : (size_t)0;
+        }
+        size_t free_b = 0, total_b = 0; // default: a third of the device's memory (96 GB on an MI355X)
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+            (void)hipGetLastError();
+            total_b = (size_t)192 << 30;
+        }
+        return total_b / 3;
     }();
     return lim;
 }
@@ -2381,7 +2389,9 @@ double block_rate(void *blk, int64_t tiles64) {
 int alloc_slab(pcl_ctx *ctx, void **out) {
     const size_t bytes = slab_bytes(ctx);
     // (candidates that lose must fit the pool: handing tens of GB back to the driver is what stalls the next allocation)
-    const int tries = (bytes >= ((size_t)512 << 20) && 2 * bytes <= pool_limit() && row_pad_bytes() == 0) ? tries_wanted() : 1;
+    // slab, second slab and every candidate that lost end up in the pool when the store goes: they must all fit
+    const int fit = (int)(pool_limit() / bytes) - 1;
+    const int tries = (bytes >= ((size_t)512 << 20) && row_pad_bytes() == 0 && fit > 1) ? (tries_wanted() < fit ? tries_wanted() : fit) : 1;
     if (tries == 1) {
         if (out == &ctx->slab) ctx->slab_tries = 0, ctx->slab_chosen = 0.0;
         PCL_HIP(big_malloc(out, bytes));
