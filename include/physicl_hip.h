@@ -96,7 +96,8 @@ int         pcl_abi_version(void);
 const char *pcl_last_error(void);                 /* thread-local, never NULL */
 int         pcl_device_count(int *n_out);         /* host pointer */
 /* Device blocks of >= 64 MB (stores, scratch, pcl_dev_alloc buffers) are not handed back to the driver when freed: the
- * process keeps up to PCL_POOL_GB (environment; default a third of the device's memory, 0 = off) of them for its next store of about that size --
+ * process keeps up to PCL_POOL_GB (environment; default a third of the device's memory, 0 = off; without PCL_POOL_GB a freed
+ * block is only kept while at least a quarter of the device stays free) of them for its next store of about that size --
  * a hipMalloc of tens of GB right after a hipFree of that size was measured to stall for seconds on this runtime.
  * pcl_pool_trim() releases everything the pool holds (bytes released in *released_out, may be NULL);
  * pcl_pool_bytes() tells how much it holds.                                                                          */
@@ -113,6 +114,9 @@ int pcl_ctx_stream(pcl_ctx *ctx, void **stream_out);
 /* name: host buffer of name_len bytes.  Replaces Simulation.get_device_info (__init__.py:470-499). */
 int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_bytes, int *n_cu,
                         int *wavefront);
+/* Free and total bytes of the context's device as the driver reports them (hipMemGetInfo; blocks idle in the library's
+ * pool count as used -- add pcl_pool_bytes() for what the process could still get).  Either pointer may be NULL.        */
+int pcl_ctx_mem_info(pcl_ctx *ctx, int64_t *free_out, int64_t *total_out);
 /* PCI bus id of the context's device ("0000:05:00.0"; host buffer of >= 16 bytes): lets N ranks show that they
  * drive N different GPUs (bench.py "collective"). */
 int pcl_ctx_device_pci(pcl_ctx *ctx, char *pci, int pci_len);

@@ -60,6 +60,7 @@ _PROTOTYPES = {
     "pcl_ctx_stream": [_vp, POINTER(_vp)],
     "pcl_ctx_device_info": [_vp, c_char_p, c_int, POINTER(c_int64), POINTER(c_int), POINTER(c_int)],
     "pcl_ctx_device_pci": [_vp, c_char_p, c_int],
+    "pcl_ctx_mem_info": [_vp, POINTER(c_int64), POINTER(c_int64)],
     "pcl_dev_alloc": [_vp, c_int64, POINTER(_vp)],
     "pcl_dev_free": [_vp, _vp],
     "pcl_h2d": [_vp, _vp, _vp, c_int64],
@@ -292,6 +293,12 @@ class Device:
         check(self.lib.pcl_ctx_device_pci(self.ctx, pci, 64))
         return {"name": name.value.decode(), "hbm_bytes": hbm.value, "compute_units": cu.value,
                 "wavefront": wf.value, "device": self.device, "pci_bus_id": pci.value.decode()}
+
+    def mem_info(self):
+        """(free, total) bytes of the device as the driver reports them (idle pool blocks count as used)."""
+        f, t = c_int64(), c_int64()
+        check(self.lib.pcl_ctx_mem_info(self.ctx, byref(f), byref(t)))
+        return f.value, t.value
 
     def timer_start(self):
         check(self.lib.pcl_timer_start(self.ctx))

@@ -30,8 +30,10 @@ import time
 import numpy as np
 
 from .units import Measurement
+from .ahead import AheadView as _AheadView, NotAhead as _NotAhead, clock_only as _clock_only
 
 HOST, DEVICE, BOTH = "host", "device", "both"   # where the authoritative particle state is
+_MAX_PLANES = 12        # == _hip.MAX_PLANES == PCL_MAX_PLANES (include/physicl_hip.h); tests/test_host_api.py checks it
 
 
 class Step:
@@ -209,12 +211,18 @@ class Simulation(threading.Thread):
       comm     a physicl_amd.dist.CounterComm: this process owns one index shard of the particles;
                counters (alive, hits, measure rows) are all-reduced
       steps_per_launch
-               K > 1 (opt-in, default 1): when every pass of the loop is exactly
-               [UpdateTimeStep][NewtonianKinematicsStep][ScatterIsotropicStep | ScatterDeleteStep][counting measures], rng is
-               "philox" and all objects are photons, up to K passes run as ONE pass over the device store
-               (photons do not interact; state, ``hits`` and every measure row are bit-identical to K=1).  The host
-               side of those passes -- the time update and ``exit(sim)`` -- is evaluated ahead of the launch, so
-               ``exit`` may depend on ``t``/``ts``/``dt`` and the object count only, not on measured data.
+               How many passes of the loop one launch may carry.  Default (None): automatic -- when every pass is exactly
+               [UpdateTimeStep] followed by one or two groups [NewtonianKinematicsStep][ScatterIsotropicStep |
+               ScatterDeleteStep][counting measures], rng is "philox", and ``exit`` / the time-step function look at
+               nothing but the clock (``t``, ``dt``, ``ts``) and the object count, up to 32 passes run as ONE pass over the
+               device store (photons do not interact; state, ``hits`` and every measure row are bit-identical to one
+               launch per step).  The host side of those passes -- the time update and ``exit(sim)`` -- is evaluated
+               ahead of the launch on a view of the simulation that exposes exactly those things; a function that
+               touches anything else (measured rows, the objects, ``hits``), or whose verdict depends on HOW MANY
+               objects are left rather than on whether any are, silently gets one launch per light step instead
+               (``sim.launch_note`` says why).  K > 1: the same with up to K passes.  1: always one launch per light step.
+               For loops without a ScatterDeleteStep ``exit`` is evaluated ahead of the launch only; with one it is also
+               replayed on the returned rows and the run is cut at the pass that emptied the store.
 
       rtc_background
                True (default): a ``variable_n_fn`` of one of the reference's example shapes does not wait for hipRTC
@@ -243,7 +251,7 @@ class Simulation(threading.Thread):
         self.seed = 0
         self.fuse = True
         self.comm = None
-        self.steps_per_launch = 1
+        self.steps_per_launch = None          # automatic (see the class docstring)
         for attr, val in kwargs.items():
             setattr(self, attr, val)
         self.dt = Measurement(np.double(0), "s**1")
@@ -263,6 +271,9 @@ class Simulation(threading.Thread):
         self._launch = 0              # Philox "step" word: one per light-step launch
         self._plan_key, self._plan = None, None
         self._upload_gen, self._multi_key, self._multi_ok = 0, None, False   # steps_per_launch eligibility cache
+        self._ahead_ok = True         # exit / the time-step function can be evaluated ahead of a launch (until one cannot)
+        self.launch_note = None       # why the run fell back to one launch per light step, if it did
+        self._ahead_key = None
         self._readonly_scope = False  # inside a host step that promises not to modify objects
         self._dev_lock = threading.RLock()   # one device call in flight per context (include/physicl_hip.h)
         self._uploaded, self._upload_lo = [], 0
@@ -525,7 +536,7 @@ class Simulation(threading.Thread):
                     j += 1
                 n_planes = 0
                 while j < len(steps) and getattr(steps[j], "_fuse_role", None) == "measure" and \
-                        n_planes + steps[j]._n_planes() <= 12:
+                        n_planes + steps[j]._n_planes() <= _MAX_PLANES:
                     n_planes += steps[j]._n_planes()
                     group.append(steps[j])
                     j += 1
@@ -545,9 +556,10 @@ class Simulation(threading.Thread):
         key = tuple(id(s) for s in self.steps.values()) + (self.fuse,)
         if key != self._plan_key:
             self._plan_key, self._plan = key, self._build_plan()
-        if self.steps_per_launch > 1 and not self._py_semantics() and self._multi_agreed():
-            self._run_multi(self._plan[0][1], [item for _, item in self._plan[1:]])
-            return
+        if self._k_wanted() > 1 and self._ahead_ok and not self._py_semantics() and self._multi_agreed() and \
+                self._ahead_agreed(self._plan[0][1]):
+            if self._run_multi(self._plan[0][1], [item for _, item in self._plan[1:]]):
+                return
         for kind, item in self._plan:
             if kind == "fused":
                 self._run_fused(item)
@@ -589,17 +601,54 @@ class Simulation(threading.Thread):
                     any(r != "measure" for r in roles[2:]) or roles[1] in seen:
                 return False
             seen.append(roles[1])
-        if sum(m._n_planes() for _, group in plan[1:] for m in group[2:]) > 12:
+        if sum(m._n_planes() for _, group in plan[1:] for m in group[2:]) > self._hip.MAX_PLANES:
             return False
         return self._rng_mode() == self._hip.RNG_PHILOX
 
-    def _plan_passes(self, upd, k_max):
-        """Host part of up to ``k_max`` passes, ahead of the launch: the time update of each pass, then
-        the exit test the outer loop would make before the next one.  Returns [(t, dt)] per pass and the code dt."""
+    def _k_wanted(self):
+        k = self.steps_per_launch
+        return 32 if k is None else max(1, int(k))
+
+    def _ahead_agreed(self, upd):
+        """Before the first K-pass launch (and again when the functions or the steps change): ``exit`` and the time-step
+        function must be plain functions that reach the run only through their argument (physicl_amd/ahead.py)."""
+        key = (id(self.exit), id(upd.fn), self._plan_key)
+        if key != self._ahead_key:
+            self._ahead_key = key
+            self._ahead_ok, self.launch_note = True, None
+            steps = list(self.steps.values())
+            for what, fn in (("exit", self.exit), ("the time-step function", upd.fn)):
+                ok, why = _clock_only(fn, steps)
+                if not ok:
+                    self._ahead_ok = False
+                    self.launch_note = "one launch per light step: %s %s" % (what, why)
+                    break
+        return self._ahead_ok
+
+    def _ahead_off(self, what, name):
+        self._ahead_ok = False
+        self.launch_note = "one launch per light step: %s %s, which is not known ahead of a launch" % (what, name)
+
+    def _plan_passes(self, upd, k_max, count_matters):
+        """Host part of up to ``k_max`` passes, ahead of the launch: the time update of each pass, then the exit test
+        the outer loop would make before the next one -- both on an _AheadView of the simulation.  Returns [(t, dt)]
+        per pass and the code dt.  Planning stops early (and for good: ``_ahead_ok``) as soon as one of the two
+        functions looks at something the view does not have; the passes planned so far still run as one launch, and the
+        outer loop makes its next exit test on the real simulation.  ``count_matters`` (a ScatterDeleteStep is in the
+        loop): the object count a later pass will see is not known yet, so an exit whose verdict for a NON-EMPTY store
+        depends on the count cannot be evaluated ahead either."""
         times, dt0 = [], None
+        view = _AheadView(self, self._alive)
         while len(times) < k_max:
             before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
-            upd.run(self)
+            try:
+                dt = upd.fn(view)
+            except _NotAhead as e:
+                self._ahead_off("the time-step function reads", "sim." + str(e.args[0]))
+                break
+            self.dt = dt                              # UpdateTimeStep.run (physicl/__init__.py:337-343)
+            self.t += self.dt
+            self.ts.append(copy.deepcopy(self.t))
             if dt0 is None:
                 dt0 = self._dt_code()
             elif self._dt_code() != dt0:              # the time step changed: that pass belongs to the next launch
@@ -607,8 +656,17 @@ class Simulation(threading.Thread):
                 self.ts.pop()
                 break
             times.append((copy.deepcopy(self.t), self.dt))
-            if len(times) < k_max and self.exit(self):
-                break
+            if len(times) < k_max:
+                try:
+                    stop = self.exit(view)
+                    if not stop and count_matters and self._alive > 1 and self.exit(_AheadView(self, 1)):
+                        self._ahead_off("exit(sim) depends on", "how many objects are left")
+                        break
+                except _NotAhead as e:
+                    self._ahead_off("exit(sim) reads", "sim." + str(e.args[0]))
+                    break
+                if stop:
+                    break
         return times, dt0
 
     def _run_multi(self, upd, groups):
@@ -625,8 +683,10 @@ class Simulation(threading.Thread):
         phases = ["iso" if s._fuse_role == "scatter_iso" else "delete" for s in lights]
         has_delete = "delete" in phases
         n_ts = len(self.ts)
-        times, dt0 = self._plan_passes(upd, max(1, min(int(self.steps_per_launch), 64 // P)))     # PCL_MULTI_MAX rows
+        times, dt0 = self._plan_passes(upd, max(1, min(self._k_wanted(), 64 // P)), has_delete)   # PCL_MULTI_MAX rows
         k = len(times)
+        if k == 0:
+            return False                              # nothing could be planned ahead: this pass runs the plain way
         planes, span = [], []
         for g in groups:
             pl = [p for m in g[2:] for p in m._plane_rows()]
@@ -679,6 +739,7 @@ class Simulation(threading.Thread):
                                        "the store being empty only" % (i + 1, k, self._alive))
                 break                                 # the later passes ran on an empty store: their times are dropped
             self.ts.extend(later)
+        return True
 
     def _run_fused(self, group):
         self._to_device()

@@ -2052,11 +2052,25 @@ struct pool_block {
     size_t bytes;
     int device;
 };
+struct big_block {
+    size_t bytes;
+    int device; // the device the block was allocated on (the caller's current device may differ when it is freed)
+};
 std::mutex g_pool_mu;
-std::vector<pool_block> g_pool;            // idle blocks, oldest first
-std::unordered_map<void *, size_t> g_big;  // live blocks that may go to the pool when freed
+std::vector<pool_block> g_pool;               // idle blocks, oldest first
+std::unordered_map<void *, big_block> g_big;  // live blocks that may go to the pool when freed
 size_t g_pool_bytes = 0;
-constexpr size_t kPoolMinBlock = (size_t)64 << 20;
+// blocks of at least this size are built with the virtual-memory API and pooled (64 MB; PCL_BIG_MIN_MB lowers it so that
+// tests reach those paths with small stores)
+size_t big_min_bytes() {
+    static const size_t b = [] {
+        const char *e = getenv("PCL_BIG_MIN_MB");
+        const double mb = e ? atof(e) : 64.0;
+        return (size_t)((mb > 0 ? mb : 64.0) * (double)((size_t)1 << 20));
+    }();
+    return b;
+}
+#define kPoolMinBlock big_min_bytes()
 
 // ---- where big blocks come from: the virtual-memory API, not hipMalloc ----------------------------------------------
 //   The store's passes run 13 to 20 streams side by side inside every 272 KB tile.  How fast that goes depends on the
@@ -2096,18 +2110,19 @@ __global__ void __launch_bounds__(256) k_slab_sweep(double2 *slab, int64_t tiles
     }
 }
 
-// GB/s of that sweep over ``tiles`` tiles at p (default stream, synchronous; 0 on failure)
-double sweep_rate_raw(void *p, int64_t tiles) {
+// GB/s of that sweep over ``tiles`` tiles at p, on ``stream`` (the context's own: the NULL stream would order the sweep
+// against every blocking stream of the host application); synchronous; 0 on failure
+double sweep_rate_raw(void *p, int64_t tiles, hipStream_t stream) {
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.0;
     const int grid = (int)(tiles < 2048 ? tiles : 2048);
     const int64_t tile_pitch16 = (int64_t)kRows * kTileT * 8 / 16, row_pitch16 = kTileT * 8 / 16;
     double rate = 0.0;
-    hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, nullptr, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16); // first touch
-    (void)hipEventRecord(a, nullptr);
+    hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, stream, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16); // first touch
+    (void)hipEventRecord(a, stream);
     for (int k = 0; k < 2; ++k)
-        hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, nullptr, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16);
-    (void)hipEventRecord(b, nullptr);
+        hipLaunchKernelGGL(k_slab_sweep, dim3(grid), dim3(256), 0, stream, static_cast<double2 *>(p), tiles, tile_pitch16, row_pitch16);
+    (void)hipEventRecord(b, stream);
     float ms = 0.f;
     if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess && ms > 0.f)
         rate = 2.0 * (double)tiles * PCL_NFIELDS * (double)(kTileT * 8) / (ms * 1e-3) / 1e9;
@@ -2272,7 +2287,7 @@ hipError_t big_malloc(void **p, size_t bytes) {
                 best = k;
         if (best >= 0) {
             *p = g_pool[best].p;
-            g_big[*p] = g_pool[best].bytes;
+            g_big[*p] = {g_pool[best].bytes, device};
             g_pool_bytes -= g_pool[best].bytes;
             g_pool.erase(g_pool.begin() + best);
             return hipSuccess;
@@ -2290,37 +2305,68 @@ hipError_t big_malloc(void **p, size_t bytes) {
     }
     if (e == hipSuccess && eligible) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        g_big[*p] = bytes;
+        g_big[*p] = {bytes, device};
     }
     return e;
 }
 
+// A freed block is kept for the next store unless the device is short of memory: other allocators of the process (torch,
+// RCCL) and other processes on the device cannot take memory out of this pool, so it only holds what leaves at least a
+// quarter of the device free (PCL_POOL_GB, when set, is the only bound).
+bool pool_may_keep(size_t bytes) {
+    static const bool fixed = getenv("PCL_POOL_GB") != nullptr;
+    if (fixed) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return free_b >= total_b / 4;
+}
+
 void big_free(void *p) {
     if (!p) return;
+    big_block blk{0, -1};
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         auto it = g_big.find(p);
         if (it != g_big.end()) {
-            const size_t bytes = it->second;
+            blk = it->second;
             g_big.erase(it);
-            if (bytes <= pool_limit()) {
-                (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block
-                int device = 0;
-                (void)hipGetDevice(&device);
-                while (g_pool_bytes + bytes > pool_limit() && !g_pool.empty()) { // make room: the oldest idle block goes
-                    (void)hipSetDevice(g_pool.front().device);
-                    raw_free(g_pool.front().p);
-                    g_pool_bytes -= g_pool.front().bytes;
-                    g_pool.erase(g_pool.begin());
-                }
-                (void)hipSetDevice(device);
-                g_pool.push_back({p, bytes, device});
-                g_pool_bytes += bytes;
-                return;
-            }
         }
     }
-    raw_free(p);
+    if (blk.device < 0 || blk.bytes > pool_limit()) {
+        raw_free(p);
+        return;
+    }
+    int device = 0;
+    (void)hipGetDevice(&device);
+    (void)hipSetDevice(blk.device);
+    (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block (no lock held here)
+    const bool keep = pool_may_keep(blk.bytes);
+    std::vector<pool_block> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        while ((!keep || g_pool_bytes + blk.bytes > pool_limit()) && !g_pool.empty()) { // make room: the oldest idle block goes
+            drop.push_back(g_pool.front());
+            g_pool_bytes -= g_pool.front().bytes;
+            g_pool.erase(g_pool.begin());
+            if (!keep) break; // short of memory: this block and one old one go back to the driver
+        }
+        if (keep) {
+            g_pool.push_back({p, blk.bytes, blk.device});
+            g_pool_bytes += blk.bytes;
+        }
+    }
+    for (const pool_block &d : drop) {
+        (void)hipSetDevice(d.device);
+        raw_free(d.p);
+    }
+    if (!keep) {
+        (void)hipSetDevice(blk.device);
+        raw_free(p);
+    }
+    (void)hipSetDevice(device);
 }
 
 int dev_alloc_bytes(void **p, int64_t n_elems, size_t esz) {
@@ -2374,13 +2420,13 @@ int tries_wanted() {
     return n;
 }
 
-double block_rate(void *blk, int64_t tiles64) {
+double block_rate(void *blk, int64_t tiles64, hipStream_t stream) {
     {
         std::lock_guard<std::mutex> lk(g_vmm_mu);
         auto it = g_rate.find(blk);
         if (it != g_rate.end()) return it->second;
     }
-    const double r = sweep_rate_raw(blk, tiles64);
+    const double r = sweep_rate_raw(blk, tiles64, stream);
     std::lock_guard<std::mutex> lk(g_vmm_mu);
     g_rate[blk] = r;
     return r;
@@ -2391,7 +2437,13 @@ int alloc_slab(pcl_ctx *ctx, void **out) {
     // (candidates that lose must fit the pool: handing tens of GB back to the driver is what stalls the next allocation)
     // slab, second slab and every candidate that lost end up in the pool when the store goes: they must all fit
     const int fit = (int)(pool_limit() / bytes) - 1;
-    const int tries = (bytes >= ((size_t)512 << 20) && row_pad_bytes() == 0 && fit > 1) ? (tries_wanted() < fit ? tries_wanted() : fit) : 1;
+    int tries = (bytes >= ((size_t)512 << 20) && row_pad_bytes() == 0 && fit > 1) ? (tries_wanted() < fit ? tries_wanted() : fit) : 1;
+    {   // a store above 1/8 of the device's memory compares two candidates at most: the transient footprint of the
+        // selection (candidates + the slab in use) stays below half of the device whatever PCL_ALLOC_TRIES says
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) (void)hipGetLastError();
+        else if (bytes > total_b / 8 && tries > 2) tries = 2;
+    }
     if (tries == 1) {
         if (out == &ctx->slab) ctx->slab_tries = 0, ctx->slab_chosen = 0.0;
         PCL_HIP(big_malloc(out, bytes));
@@ -2413,7 +2465,7 @@ int alloc_slab(pcl_ctx *ctx, void **out) {
             (void)hipGetLastError();
             break;
         }
-        const double r = block_rate(cand, tiles64);
+        const double r = block_rate(cand, tiles64, ctx->stream);
         seen.push_back(r);
         if (r > best_rate) {
             if (best) losers.push_back(best);
@@ -3845,6 +3897,15 @@ int pcl_ctx_stream(pcl_ctx *ctx, void **stream_out) {
     return PCL_OK;
 }
 
+int pcl_ctx_mem_info(pcl_ctx *ctx, int64_t *free_out, int64_t *total_out) {
+    PCL_TRY(bind(ctx));
+    size_t free_b = 0, total_b = 0;
+    PCL_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (free_out) *free_out = (int64_t)free_b;
+    if (total_out) *total_out = (int64_t)total_b;
+    return PCL_OK;
+}
+
 int pcl_ctx_device_info(pcl_ctx *ctx, char *name, int name_len, int64_t *hbm_bytes, int *n_cu, int *wavefront) {
     if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
     if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
@@ -4333,7 +4394,7 @@ int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, doubl
             rc = PCL_DISPATCH(ctx, fill_table_t<double>(ctx, n, id_base, c, tab, tab + nbins, nbins, seed),
                               fill_table_t<float>(ctx, n, id_base, c, tab, tab + nbins, nbins, seed));
         if (rc == PCL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PCL_ERR_HIP, "sync failed");
-        (void)hipFree(tab);
+        dev_free(tab);
         PCL_TRY(rc);
         if (ctx->kind) PCL_HIP(hipMemsetAsync(ctx->kind, PCL_KIND_PHOTON, (size_t)n, ctx->stream));
     }
@@ -4393,7 +4454,7 @@ int pcl_step_scatter_pcoll(pcl_ctx *ctx, double A, double n, int flags, double c
     int rc = PCL_DISPATCH(ctx, scatter_pcoll_t<double>(ctx, A, n, flags & PCL_SCATTER_WAVELENGTH, c, h, tmp),
                           scatter_pcoll_t<float>(ctx, A, n, flags & PCL_SCATTER_WAVELENGTH, c, h, tmp));
     if (rc == PCL_OK) rc = pcl_d2h(ctx, pcoll_out_host, tmp, N * (int64_t)ctx->esz);
-    (void)hipFree(tmp);
+    dev_free(tmp);
     return rc;
 }
 
@@ -4430,7 +4491,7 @@ int pcl_step_delete_flags(pcl_ctx *ctx, const int32_t *flags_host, int64_t *n_al
         rc = launch_check("k_compact");
     }
     if (rc == PCL_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(PCL_ERR_HIP, "sync failed");
-    (void)hipFree(d_flags);
+    dev_free(d_flags);
     PCL_TRY(rc);
     int64_t alive = 0;
     PCL_TRY(wait_count(ctx, N, &alive));
@@ -4877,7 +4938,7 @@ int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n) {
     hipLaunchKernelGGL(k_masks_to_flags, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->masks, d, n);
     int rc = launch_check("k_masks_to_flags");
     if (rc == PCL_OK) rc = pcl_d2h(ctx, flags_host, d, n * (int64_t)sizeof(int32_t));
-    (void)hipFree(d);
+    dev_free(d);
     return rc;
 }
 

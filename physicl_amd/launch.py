@@ -6,6 +6,7 @@ program nor safely fork workers that use the device.  So this module imports not
 children are fresh interpreters started with ``subprocess`` (never a re-exec of the caller), and ``bench.py`` calls
 ``spawn_ranks`` before it imports ``physicl_amd._hip`` or torch.
 """
+import ctypes
 import os
 import signal
 import socket
@@ -44,14 +45,26 @@ def spawn_ranks(world, cmd, env=None, poll_s=0.05, grace_s=10.0):
     base = dict(os.environ if env is None else env)
     port = free_port()
     procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(list(cmd), env=rank_env(base, r, world, port),
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    captured = []
-    reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
-    reader.start()
-    rc = 0
+    # a SIGTERM / SIGHUP / SIGINT to this process (a driver's timeout, Ctrl-C of a wrapper) must take the ranks down
+    # with it: they would otherwise sit in a collective, holding their GPUs, until its timeout.  The handlers turn the
+    # signal into an exception so that the ``finally`` below runs; should this process die without running it (SIGKILL),
+    # the kernel sends every rank SIGTERM (PR_SET_PDEATHSIG, set in the child between fork and exec).
     try:
+        _libc()                                  # loaded here, not between fork and exec
+    except OSError:
+        pass
+    old_handlers = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
+            old_handlers[sig] = signal.signal(sig, _raise_interrupted)
+    rc = 0
+    captured, reader = [], None
+    try:
+        for r in range(world):
+            procs.append(subprocess.Popen(list(cmd), env=rank_env(base, r, world, port), preexec_fn=_die_with_parent,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+        reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
         while True:
             states = [p.poll() for p in procs]
             bad = [s for s in states if s not in (None, 0)]
@@ -61,11 +74,41 @@ def spawn_ranks(world, cmd, env=None, poll_s=0.05, grace_s=10.0):
             if all(s == 0 for s in states):
                 break
             time.sleep(poll_s)
+    except _Interrupted as e:
+        rc = 128 + e.args[0]
     finally:
         _stop(procs, grace_s)
-    reader.join(timeout=grace_s)
+        for sig, h in old_handlers.items():
+            signal.signal(sig, h)
+    if reader is not None:
+        reader.join(timeout=grace_s)
     out = captured[0] if captured else b""
     return rc, out.decode("utf-8", "replace")
+
+
+class _Interrupted(Exception):
+    """A terminating signal arrived while the ranks were running (args[0] = signal number)."""
+
+
+def _raise_interrupted(signum, frame):
+    raise _Interrupted(signum)
+
+
+def _die_with_parent():
+    """In the child, before exec: ask the kernel for SIGTERM when the launching process dies (Linux prctl)."""
+    try:
+        _libc().prctl(1, int(signal.SIGTERM), 0, 0, 0)     # PR_SET_PDEATHSIG = 1
+    except Exception:                            # noqa: BLE001 -- not Linux / no prctl: the handlers above still apply
+        pass
+
+
+_LIBC = []
+
+
+def _libc():
+    if not _LIBC:
+        _LIBC.append(ctypes.CDLL(None, use_errno=True))
+    return _LIBC[0]
 
 
 def _stop(procs, grace_s):

@@ -85,3 +85,37 @@ def test_a_big_store_takes_the_fastest_of_a_few_candidate_slabs():
     assert run(1) == [0, 0]
     held, held2 = run(4)
     assert held == 3 and held2 == 3          # three losers parked; the second slab took one of them and parked a fresh loser
+
+
+def test_temporaries_of_big_stores_go_back_where_they_came_from():
+    """The staging buffers of last_delete_flags / step_delete_flags / scatter_pcoll / fill_photons_table come from the
+    same allocator as the store (big blocks: mapped virtual-memory ranges, pooled): freeing them any other way leaks the
+    physical handles.  PCL_BIG_MIN_MB=1 takes a 300k-photon store through the big-block paths; free device memory plus
+    what idles in the pool must be back where it started after every call."""
+    code = ("import numpy as np\n"
+            "from physicl_amd import _hip as hip\n"
+            "N = 300_000\n"
+            "d = hip.Device(0); d.store_alloc(N)\n"
+            "grid = np.linspace(1.0, 2.0, 200_000); cdf = np.linspace(0.0, 1.0, 200_000)\n"
+            "def avail():\n"
+            "    d.sync(); f, t = d.mem_info(); return f + hip.pool_bytes()\n"
+            "d.fill_photons_table(N, 0, 299792458.0, cdf, grid, 3)\n"      # 2 x 1.6 MB table: a big block under the knob
+            "t0 = avail()\n"
+            "for k in range(6): d.fill_photons_table(N, 0, 299792458.0, cdf, grid, 3)\n"
+            "assert abs(avail() - t0) <= (2 << 20), (t0, avail())\n"
+            "d.step_newton(1e-3)\n"
+            "o = d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 3, 0, [], lazy=True)\n"   # second slab, scratch
+            "n = o['N']; d.sync()\n"
+            "d.last_delete_flags(N); d.scatter_pcoll(1e-3, 1e-3, 0, 299792458.0, 6.6e-34)\n"   # warm: first-use module loads
+            "a0 = avail()\n"
+            "for k in range(6):\n"
+            "    fl = d.last_delete_flags(N); assert fl.sum() == N - n\n"
+            "    assert d.scatter_pcoll(1e-3, 1e-3, 0, 299792458.0, 6.6e-34).shape == (d.count,)\n"
+            "for k in range(3):\n"
+            "    m = d.count; flags = np.zeros(m, np.int32); flags[::3] = 1\n"
+            "    alive, removed = d.step_delete_flags(flags); assert alive + removed == m\n"
+            "a1 = avail()\n"
+            "assert abs(a1 - a0) <= (2 << 20), (a0, a1)\n"
+            "d.close(); print('ok')\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_BIG_MIN_MB="1"), timeout=300)
+    assert out.decode().strip().endswith("ok")

@@ -6,7 +6,8 @@ the device until a host plugin or a foreign thread looks at ``sim.objects`` (phy
 being reproduced: every step, in insertion order, every pass).  This file draws step lists at random -- one to three
 [Newton, light step, measure steps] groups, a time step that may change from pass to pass, host plugins that read,
 edit or remove objects at random places, photons with or without plain Objects among them, or a bulk PhotonBatch --
-runs each with three schedules and requires IDENTICAL results: ``ts``, every measure row, ``hits``, what the host
+runs each with four schedules (the fourth: the constructor's default, which decides by itself whether the exit test can be
+evaluated ahead of a K-pass launch) and requires IDENTICAL results: ``ts``, every measure row, ``hits``, what the host
 plugins saw, and the final r, v, dr, dv, E of every object, bit for bit.
 """
 import os
@@ -77,6 +78,11 @@ def draw_config(rs):
     # host-drawn randoms in the reference's order (np.random, 3 per photon per scatter step, 1 per delete step) for some of
     # the explicit-object runs: every schedule must consume the global stream identically
     cfg["rng"] = "numpy" if source != "batch" and rs.random_sample() < 0.35 else "philox"
+    # (drawn last, so that the configurations of earlier rounds stay what they were) what ``exit`` looks at: the clock and
+    # emptiness -- plannable ahead of a K-pass launch -- or the run's own data, in three ways that must all fall back to
+    # one launch per light step without showing: a measure step's rows through a closure, ``sim.hits`` through the
+    # argument, a threshold on the object count
+    cfg["exit_kind"] = str(rs.choice(["clock", "closure_rows", "sim_hits", "count"], p=[0.55, 0.15, 0.15, 0.15]))
     return cfg
 
 
@@ -91,8 +97,18 @@ class Count(phys.Step):
 def build_and_run(cfg, steps_per_launch, fuse):
     T = cfg["passes"]
     np.random.seed(cfg["seed"] % (1 << 31))
-    sim = phys.Simulation(cl_on=True, rng=cfg["rng"], seed=cfg["seed"], steps_per_launch=steps_per_launch, fuse=fuse,
-                          exit=lambda s: len(s.ts) >= T or len(s.objects) == 0)
+    measures = []
+    kind = cfg.get("exit_kind", "clock")
+    if kind == "closure_rows":             # stops one pass after the first measure step has T - 2 rows
+        exit_fn = lambda s: len(s.ts) >= T or len(s.objects) == 0 or (len(measures) > 0 and len(measures[0].data) >= T - 2)   # noqa: E731
+    elif kind == "sim_hits":               # stops after a scatter step with fewer than 5 hits
+        exit_fn = lambda s: len(s.ts) >= T or len(s.objects) == 0 or (len(s.ts) > 2 and s.hits < 5)   # noqa: E731
+    elif kind == "count":                  # stops when fewer than 45 % of the objects are left
+        exit_fn = lambda s: len(s.ts) >= T or len(s.objects) * 100 < cfg["n"] * 45   # noqa: E731
+    else:
+        exit_fn = lambda s: len(s.ts) >= T or len(s.objects) == 0   # noqa: E731
+    kw = {} if steps_per_launch == "default" else {"steps_per_launch": steps_per_launch}     # "default": the constructor's own
+    sim = phys.Simulation(cl_on=True, rng=cfg["rng"], seed=cfg["seed"], fuse=fuse, exit=exit_fn, **kw)
     rs = np.random.RandomState(cfg["seed"])
     if cfg["source"] == "batch":
         sim.add_objs(phys.light.generate_photons_bulk(cfg["n"], min=phys.light.E_from_wavelength(700e-9),
@@ -111,7 +127,7 @@ def build_and_run(cfg, steps_per_launch, fuse):
         sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
     else:
         sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001) if len(s.ts) % 3 else np.double(0.0005)))
-    steps, measures = [], []
+    steps = []
     for light, ms in cfg["groups"]:
         steps.append(phys.newton.NewtonianKinematicsStep())
         if light == "iso":
@@ -138,6 +154,7 @@ def build_and_run(cfg, steps_per_launch, fuse):
     out = {"ts": [float(t) for t in sim.ts], "hits": int(sim.hits),
            "rows": [[[float(x) for x in np.ravel(np.asarray(c, dtype=float))] for c in m.data] for m in measures],
            "seen": [getattr(p, "seen", None) for p in plugs], "n": len(sim.objects), "schedule": dict(sim.schedule),
+           "note": sim.launch_note,
            "next_random": float(np.random.random_sample())}        # where the run left the global stream
     if cfg["source"] == "batch":
         out["state"] = {f: sim.download(f) for f in ("r", "v", "dr", "dv", "E")} if out["n"] else {}
@@ -160,6 +177,7 @@ def assert_same(a, b, what):
 
 
 SEEN = {}
+AUTO = {}
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PCL_RANDOM_SEEDS", "60"))))
@@ -171,8 +189,21 @@ def test_random_simulation_does_not_depend_on_the_schedule(seed):
     assert_same(base, fused, ("fuse", cfg))
     multi = build_and_run(cfg, cfg["K"], True)
     assert_same(base, multi, ("steps_per_launch", cfg))
-    for k, v in list(fused["schedule"].items()) + list(multi["schedule"].items()):
+    # the constructor's own default (what a script written against the reference gets): automatic, up to 32 passes per launch
+    auto = build_and_run(cfg, "default", True)
+    assert_same(base, auto, ("default constructor", cfg))
+    has_measures = any(ms for _, ms in cfg["groups"])
+    plannable = cfg["exit_kind"] == "clock" or (cfg["exit_kind"] == "count" and not any(g[0] == "delete" for g in cfg["groups"])) \
+        or (cfg["exit_kind"] == "closure_rows" and not has_measures)
+    went_multi = any(k.endswith("_multi") for k in auto["schedule"])
+    if went_multi and not plannable and len(base["ts"]) > 3:
+        # a launch may carry the passes planned before the guard tripped; after that, one launch per light step -- and a note
+        assert auto["note"] and "one launch per light step" in auto["note"], (cfg, auto["schedule"], auto["note"])
+    if cfg["exit_kind"] == "closure_rows" and has_measures:
+        assert not went_multi and (auto["note"] is None or "closes over" in auto["note"]), (cfg, auto["schedule"], auto["note"])
+    for k, v in list(fused["schedule"].items()) + list(multi["schedule"].items()) + list(auto["schedule"].items()):
         SEEN[k] = SEEN.get(k, 0) + v
+    AUTO[cfg["exit_kind"]] = AUTO.get(cfg["exit_kind"], 0) + int(went_multi)
 
 
 def test_the_random_simulations_reached_every_schedule():
@@ -180,3 +211,5 @@ def test_the_random_simulations_reached_every_schedule():
     if len(SEEN) == 0:
         pytest.skip("the parametrised cases did not run in this process")
     assert {"fused", "fused_delete", "fused_multi", "fused_delete_multi", "mixed_multi"} <= set(SEEN), SEEN
+    # the default constructor took the K-pass path where the exit test allows it, and every kind of exit was drawn
+    assert AUTO.get("clock", 0) > 0 and {"clock", "closure_rows", "sim_hits", "count"} <= set(AUTO), AUTO

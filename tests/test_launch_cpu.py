@@ -69,3 +69,34 @@ def test_bench_parent_starts_ranks_without_loading_torch_or_the_hip_library():
     assert p.returncode != 0
     assert p.stdout.strip() == ""
     assert "PARENT_MODULES_BAD=[]" in p.stderr, p.stderr[-3000:]
+
+
+def test_a_signal_to_the_launcher_takes_the_ranks_down():
+    """SIGTERM to the process that called spawn_ranks (a driver's timeout): its ranks are stopped, not left waiting in
+    a collective.  The children write their PIDs; after the parent has gone none of them may be alive."""
+    import signal
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        child = ("import os, time\n"
+                 "open(os.path.join(%r, 'pid%%s' %% os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                 "time.sleep(600)\n") % tmp
+        parent = ("import sys\n"
+                  "from physicl_amd.launch import spawn_ranks\n"
+                  "rc, out = spawn_ranks(2, [sys.executable, '-c', %r], grace_s=5.0)\n"
+                  "sys.exit(rc)\n") % child
+        p = subprocess.Popen([sys.executable, "-c", parent], cwd=ROOT)
+        t_end = time.time() + 60
+        while time.time() < t_end and len(os.listdir(tmp)) < 2:
+            time.sleep(0.05)
+        pids = [int(open(os.path.join(tmp, f)).read()) for f in sorted(os.listdir(tmp))]
+        assert len(pids) == 2
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=60) == 128 + signal.SIGTERM
+        time.sleep(0.2)
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                alive = open("/proc/%d/stat" % pid).read().split()[2] != "Z"
+            except (OSError, IOError):
+                alive = False
+            assert not alive, "rank process %d outlived its launcher" % pid
