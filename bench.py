@@ -106,6 +106,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-photons", type=float, default=1e8)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of the OpenMP CPU baseline")
     ap.add_argument("--delete-photons", type=str, default="1e7,1e8", help="sizes of the delete leg (comma separated)")
+    ap.add_argument("--api-steps", type=int, default=0,
+                    help="passes of the api leg's simulations (0: 500 -- BASELINE configs[2]'s run length -- at >= 1e7 photons, "
+                         "else --steps)")
+    ap.add_argument("--iso-photons", type=float, default=1e7, help="size of the iso_1e7 leg (BASELINE configs[1](i))")
+    ap.add_argument("--mixed-photons", type=float, default=1e8, help="size of the mixed leg (BASELINE configs[4], 1-GPU form)")
     return ap.parse_args(argv)
 
 
@@ -317,8 +322,10 @@ def run_rank(args):
     ks = kernel_summary(kern, dominant)
     h_blocks = [h / float(N * args.steps) for h in hits]
     bpp = algorithmic_bytes_per_particle(args.profile, h_blocks[mi], args.mode, S > 1) * bscale
-    achieved = N * bpp / (ks["avg_ms"] * 1e-3) / 1e9 if ks["launches"] else 0.0
-    steps_per_timed_launch = args.steps * R / max(1, ks["launches"]) if S > 1 else 1.0
+    # the roofline record refers to the SAME block as ``value`` (the median one): its launches, its hit fraction
+    kb = kern[mi][dominant]
+    achieved = N * bpp / (kb["avg_ms"] * 1e-3) / 1e9 if kb["launches"] else 0.0
+    steps_per_timed_launch = args.steps / max(1, kb["launches"]) if S > 1 else 1.0
 
     single = delete = api = None
     extra = world == 1 and not args.no_extra
@@ -329,20 +336,25 @@ def run_rank(args):
         m1 = median_index(el1)
         k1 = kernel_summary(kern1, "k_fused")
         b1 = 104.0 * bscale
-        a1 = N * b1 / (k1["avg_ms"] * 1e-3) / 1e9 if k1["launches"] else 0.0
+        k1b = kern1[m1]["k_fused"]                  # the median block's launches, as for ``value``
+        a1 = N * b1 / (k1b["avg_ms"] * 1e-3) / 1e9 if k1b["launches"] else 0.0
         single = {"value": N * args.steps / el1[m1], "unit": "particle-steps/s", "ms_per_step": el1[m1] / args.steps * 1e3,
                   "steps": args.steps, "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el1],
                   "roofline": {"bound": "hbm", "kernel": "k_fast (pcl_rtc_fast_e1): one launch per step, dr/dv implicit",
                                "achieved": a1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBPS,
-                               "traffic": None, "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1["avg_ms"],
-                               "min_launch_ms": k1["min_ms"], "max_launch_ms": k1["max_ms"], "launches": k1["launches"],
+                               "traffic": None, "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1b["avg_ms"],
+                               "min_launch_ms": k1b["min_ms"], "max_launch_ms": k1b["max_ms"], "launches": k1b["launches"],
+                               "all_blocks_avg_launch_ms": k1["avg_ms"], "per_block_avg_launch_ms": k1["per_block_avg_ms"],
                                "hit_fraction": hits1[m1] / float(N * args.steps)}}
         b.totals = totals_main
 
     info = dev.info()
     dev.store_free()
+    iso = mixed = None
     if extra and not f32:
         delete = delete_leg(dev, hip, [int(float(x)) for x in args.delete_photons.split(",") if x.strip()], args.seed)
+        iso = iso_leg(dev, hip, int(args.iso_photons), args.seed)
+        mixed = mixed_leg(dev, int(args.mixed_photons))
     dev.close()
     if extra and not f32:
         api = api_leg(args, prof)
@@ -365,7 +377,10 @@ def run_rank(args):
                                    "scatter (variable_n_scattering example); step = UpdateTime + Newton + "
                                    "ScatterIsotropic (Philox) + sign counters%s"
                                    % ("/[3] weak-scaled" if world > 1 else "", N, coll_txt),
-                       "photons_per_gpu": N, "profile": args.profile, "mode": args.mode, "steps_per_launch": S,
+                       "photons_per_gpu": N, "profile": args.profile, "mode": args.mode,
+                       # S = the most loop bodies one launch may carry; a timed block of --steps steps is ceil(steps / S)
+                       # launches, so the launches that were timed carried steps_per_timed_launch each
+                       "steps_per_launch_max": S, "steps_per_timed_launch": steps_per_timed_launch,
                        "variable_n_fn": prof["expr"], "dt": prof["dt"],
                        "rng": "philox4x32-10 keyed by global photon id", "parallelism": "index-sharded x%d" % world,
                        # which memory the store's slab got (outside the timed region): the library measures a few candidate
@@ -385,16 +400,17 @@ def run_rank(args):
                          "traffic": None, "algorithmic_bytes_per_particle": bpp,
                          "algorithmic_bytes_note": "per LAUNCH of the K-step pass (r, v, lam4 read; r, v, vprev written)" if S > 1
                                                    else "per particle-step",
-                         "hit_fraction": h_blocks[mi], "avg_launch_ms": ks["avg_ms"], "min_launch_ms": ks["min_ms"],
-                         "max_launch_ms": ks["max_ms"], "launches": ks["launches"],
-                         "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch": S,
+                         "hit_fraction": h_blocks[mi], "avg_launch_ms": kb["avg_ms"], "min_launch_ms": kb["min_ms"],
+                         "max_launch_ms": kb["max_ms"], "launches": kb["launches"], "block": "median block (index %d), as value" % mi,
+                         "all_blocks_avg_launch_ms": ks["avg_ms"], "all_blocks_launches": ks["launches"],
+                         "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch_max": S,
                          "steps_per_timed_launch": steps_per_timed_launch,
                          # SURVEY 8(d)'s per-step form: what the same particle-steps would have had to move one launch per
                          # step (104 B each).  > peak is possible precisely because the pass does not move those bytes.
                          "per_step_form": ({"bytes_per_particle_step": 104.0 * bscale,
-                                            "GBps": N * 104.0 * bscale * steps_per_timed_launch / (ks["avg_ms"] * 1e-3) / 1e9,
-                                            "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (ks["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-                                           if (S > 1 and ks["launches"]) else None),
+                                            "GBps": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9,
+                                            "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+                                           if (S > 1 and kb["launches"]) else None),
                          "warmup_launches": warm[dominant]["launches"], "warmup_avg_launch_ms": warm[dominant]["avg_ms"]},
             "static_profile": static_profile(args.profile, args.mode, args.dtype, N, S, args.steps),
             # north_star target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons): carried by the
@@ -410,6 +426,10 @@ def run_rank(args):
             out["single_step"] = single
         if delete is not None:
             out["delete"] = delete
+        if iso is not None:
+            out["iso_1e7"] = iso
+        if mixed is not None:
+            out["mixed"] = mixed
         if api is not None:
             out["api"] = api
         if world == 1 and not args.no_cpu_baseline and not f32:
@@ -517,21 +537,102 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     return out
 
 
+def iso_leg(dev, hip, N, seed, steps=100, repeats=3):
+    """BASELINE configs[1](i): ``N`` photons (1e7), r = 0, v = (c,0,0), E = 1, dt = 1e-3, 100 passes of
+    [UpdateTime, Newton, ScatterIsotropicStep(A = n = 1e-3), sign rows] (test/test_light.py:27-45; pcoll = A n |v dt| =
+    0.2998).  Two formulations on the same photons: one launch per step (k_fast: r, v read and written, 96 B per
+    particle-step -- the HBM-bound form, with its roofline record) and up to 32 steps per launch (k_multi)."""
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=seed)
+    out = {"workload": "BASELINE configs[1](i): %.0e photons, E = 1, v = (c,0,0), dt = 1e-3, 100 x [UpdateTime, Newton, "
+                       "ScatterIsotropic(A=n=1e-3), sign counters], Philox" % N, "steps": steps, "repeats": repeats}
+    dev.store_alloc(N)
+    for mode in ("per_step", "multi"):
+        runs = []
+        for rep in range(repeats + 1):                        # rep 0 = warm-up
+            dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
+            dev.prof_enable(True)
+            dev.sync()
+            t0 = time.perf_counter()
+            hits, k = 0, 0
+            if mode == "multi":
+                while k < steps:
+                    ks = min(32, steps - k)
+                    hits += sum(o["hits"] for o in dev.step_fused_multi(1e-3, ks, dict(sc, step=k)))
+                    k += ks
+            else:                                             # software-pipelined like Bench.run_steps: counters one step behind
+                dev.step_fused(1e-3, dict(sc, step=0), planes=(), sync=False, lazy=True)
+                for k in range(1, steps):
+                    dev.step_fused(1e-3, dict(sc, step=k), planes=(), sync=False, lazy=True)
+                    hits += dev.step_fused_read(0)["hits"]
+                hits += dev.step_fused_read(0)["hits"]
+            dev.sync()
+            el = time.perf_counter() - t0
+            kern = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
+            dev.prof_enable(False)
+            if rep:
+                runs.append((el, hits, kern))
+        runs.sort(key=lambda r: r[0])
+        el, hits, kern = runs[(len(runs) - 1) // 2]
+        r = {"value": N * steps / el, "unit": "particle-steps/s", "ms_per_step": el / steps * 1e3, "hit_fraction": hits / float(N * steps),
+             "run_ms": [round(x[0] * 1e3, 4) for x in runs],
+             "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
+             "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
+        if mode == "per_step":
+            kf = kern["k_fused"]
+            g = N * 96.0 / (kf["avg_ms"] * 1e-3) / 1e9 if kf["launches"] else 0.0
+            r["roofline"] = {"bound": "hbm", "kernel": "k_fast<double, no wavelength term, constant n>: one launch per step, dr/dv implicit",
+                             "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS, "traffic": None,
+                             "algorithmic_bytes_per_particle": 96.0, "avg_launch_ms": kf["avg_ms"], "launches": kf["launches"]}
+        else:
+            r["steps_per_launch_max"] = 32
+        out[mode] = r
+    dev.store_free()
+    return out
+
+
+def mixed_leg(dev, N, iterations=100, sample=2_000_000):
+    """BASELINE configs[4], 1-GPU form: [Newton, ScatterIsotropic(A=n=1e-3), Newton, ScatterDelete] x 100 on ``N`` photons
+    (1e8) in fp64 and in fp32, same Philox stream (tools/sweep_fp32.py): seconds per precision (16 iterations per launch,
+    k_mixed, and one launch per light step) and the error figures of the fp32 run against the fp64 run."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sweep_fp32
+    rep = sweep_fp32.sweep(dev, N, iterations, sample, 16)
+    one = sweep_fp32.sweep(dev, N, iterations, 0, 1, timing_only=True)
+    last = rep["checkpoints"][max(rep["checkpoints"])]
+    work = rep["particle_steps_f64"]
+    return {"workload": rep["workload"], "iterations": iterations, "iterations_per_launch": 16,
+            "seconds_f64": last["seconds_f64"], "seconds_f32": last["seconds_f32"],
+            "particle_steps": work, "value_f64": work / last["seconds_f64"], "value_f32": rep["particle_steps_f32"] / last["seconds_f32"],
+            "unit": "particle-steps/s (a particle-step = one photon alive at the start of one Newton + light step)",
+            "one_launch_per_light_step": {"seconds_f64": one["seconds_f64"], "seconds_f32": one["seconds_f32"]},
+            "fp32_vs_fp64": {str(k): {key: v[key] for key in ("decision_mismatch_rate", "identical_history_fraction", "median_rel_err_r",
+                                                                "p99_rel_err_r", "p9999_rel_err_r", "max_rel_err_r", "fraction_above_1e-4",
+                                                                "compared")}
+                             for k, v in rep["checkpoints"].items()}}
+
+
 def api_leg(args, prof):
     """The same workload through the public API (physicl_amd.Simulation + the reference's step classes), so that the
     Simulation / ObjectList / UpdateTimeStep / measure-step overhead is part of a measured number: particle-steps/s
-    over sim.run_time (start() .. join()), with steps_per_launch 32 and 1."""
+    over sim.run_time (start() .. join()).  "default" = the constructor exactly as a script written against the
+    reference calls it (physicl/__init__.py:405-418: no steps_per_launch keyword) -- the simulation decides by itself
+    that ``exit`` can be evaluated ahead of a launch; then steps_per_launch 32 and 1 spelled out.  The runs are
+    BASELINE configs[2]'s 500 passes (examples/variable_n_scattering.ipynb) unless --api-steps says otherwise.
+    "delete_default" = BASELINE configs[1](ii) (test/test_light.py:52-59) at the delete leg's first size, default constructor."""
     import physicl_amd as phys
     import physicl_amd.light as light
     import physicl_amd.newton as newton
-    N, steps = int(args.photons), args.steps
-    out = {"what": "Simulation(steps_per_launch=S) with [UpdateTimeStep, NewtonianKinematicsStep, ScatterIsotropicStep, "
-                   "ScatterSignMeasureStep], exit at t >= %d * dt; whole run incl. upload/fill, hipRTC lookup, terminate" % steps}
-    for S in (32, 1):
-        sim = phys.Simulation(exit=lambda s: len(s.ts) >= steps, steps_per_launch=S, seed=args.seed)
+    N = int(args.photons)
+    steps = args.api_steps if args.api_steps > 0 else (500 if N >= 10_000_000 else args.steps)
+    out = {"what": "Simulation(...) with [UpdateTimeStep, NewtonianKinematicsStep, ScatterIsotropicStep, ScatterSignMeasureStep], "
+                   "exit after %d passes; whole run incl. hipRTC lookup and terminate (creation of the photons is set-up)" % steps,
+           "steps": steps}
+    dt = np.double(prof["dt"])
+    for name, kw in (("default", {}), ("steps_per_launch_32", {"steps_per_launch": 32}), ("steps_per_launch_1", {"steps_per_launch": 1})):
+        sim = phys.Simulation(exit=lambda s: len(s.ts) >= steps, seed=args.seed, **kw)
         sim.add_objs(light.generate_photons_bulk(N, min=light.E_from_wavelength(700e-9), max=light.E_from_wavelength(200e-9),
                                                  seed=args.seed))
-        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(prof["dt"])))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: dt))
         sim.add_step(1, newton.NewtonianKinematicsStep())
         sim.add_step(2, light.ScatterIsotropicStep(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True,
                                                    variable_n=True, variable_n_fn=prof["expr"]))
@@ -543,9 +644,28 @@ def api_leg(args, prof):
         sim.join()
         if sim.error is not None:
             raise sim.error
-        out["steps_per_launch_%d" % S] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s",
-                                          "steps": len(sim.ts), "run_time_s": sim.run_time, "rows": len(m.data)}
+        out[name] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s", "steps": len(sim.ts),
+                     "run_time_s": sim.run_time, "rows": len(m.data), "schedule": dict(sim.schedule), "note": sim.launch_note}
         sim.close(download=False)
+    # the delete loop of test/test_light.py:52-59 with the constructor's defaults (exit: no objects left)
+    Nd = int(float(args.delete_photons.split(",")[0]))
+    sim = phys.Simulation(seed=args.seed)
+    sim.add_objs(light.generate_photons_bulk(Nd, min=1.0, max=1.0, seed=args.seed))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, newton.NewtonianKinematicsStep())
+    sim.add_step(2, light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+    m = light.ScatterMeasureStep(None, True, [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])
+    sim.add_step(3, m)
+    sim._to_device()
+    sim._dev.sync()
+    sim.start()
+    sim.join()
+    if sim.error is not None:
+        raise sim.error
+    work = int(sum(int(np.asarray(row)[1]) for row in m.data)) + Nd - (int(np.asarray(m.data[-1])[1]) if m.data else 0)
+    out["delete_default"] = {"photons": Nd, "value": work / sim.run_time, "unit": "particle-steps/s", "particle_steps": work,
+                             "passes": len(sim.ts), "run_time_s": sim.run_time, "schedule": dict(sim.schedule), "note": sim.launch_note}
+    sim.close(download=False)
     return out
 
 

@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run_bench(*extra, photons="300000"):
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--photons", photons, "--steps", "6",
                                    "--warmup", "3", "--repeats", "3", "--cpu-photons", "20000", "--cpu-seconds", "0.5",
-                                   "--delete-photons", "30000", *extra], cwd=ROOT)
+                                   "--delete-photons", "30000", "--iso-photons", "30000",
+                                   "--mixed-photons", "30000", *extra], cwd=ROOT)
     lines = [ln for ln in out.decode().splitlines() if ln.strip()]
     assert len(lines) == 1, lines
     return json.loads(lines[0])
@@ -37,7 +38,7 @@ def test_bench_line_has_the_contract_keys(extra):
         assert k in r, k
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None and "valu" not in r          # nothing from a committed profile inside the measured record
-    assert r["launches"] == (3 if "--mode" not in extra else 18) or "--steps-per-launch" in extra
+    assert r["launches"] == (1 if "--mode" not in extra else 6) or "--steps-per-launch" in extra        # of the median block
     assert d["counters_last_step"]["N"] == 300000 and d["collective"] is None
     if "--dtype" not in extra:
         c = d["cpu_baseline"]
@@ -48,8 +49,19 @@ def test_bench_line_has_the_contract_keys(extra):
             assert rec["per_step"]["particle_steps"] == rec["multi"]["particle_steps"]       # same photons removed at the same steps
             assert rec["per_step"]["roofline"]["bound"] == "hbm" and rec["per_step"]["roofline"]["achieved"] > 0
         assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
+        # the constructor as a reference script calls it takes the K-pass launches by itself
+        assert d["api"]["default"]["steps"] == 6 and d["api"]["default"]["schedule"] == {"fused_multi": 1} and d["api"]["default"]["note"] is None
+        assert d["api"]["steps_per_launch_1"]["schedule"] == {"fused": 6}
+        assert d["api"]["delete_default"]["schedule"].get("fused_delete_multi", 0) >= 1 and d["api"]["delete_default"]["particle_steps"] >= 30000
+        iso = d["iso_1e7"]
+        assert iso["per_step"]["roofline"]["algorithmic_bytes_per_particle"] == 96.0 and iso["multi"]["value"] > 0
+        assert abs(iso["per_step"]["hit_fraction"] - iso["multi"]["hit_fraction"]) < 1e-12        # same photons, same decisions
+        mx = d["mixed"]
+        assert mx["iterations"] == 100 and mx["seconds_f64"] > 0 and mx["seconds_f32"] > 0 and set(mx["fp32_vs_fp64"]) == {"1", "10", "100"}
+        assert mx["fp32_vs_fp64"]["1"]["decision_mismatch_rate"] < 1e-3
     if not extra:
-        assert d["config"]["steps_per_launch"] == 32 and d["single_step"]["roofline"]["bound"] == "hbm"
+        assert d["config"]["steps_per_launch_max"] == 32 and d["config"]["steps_per_timed_launch"] == 6
+        assert d["single_step"]["roofline"]["bound"] == "hbm" and d["roofline"]["launches"] == 1      # the median block's one launch
         assert d["hbm_target"]["target"] == 0.6 and d["single_step"]["repeats"] == 3
 
 
