@@ -224,6 +224,14 @@ int pcl_store_dtype(pcl_ctx *ctx, int *dtype_out);
 int pcl_store_free(pcl_ctx *ctx);
 int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out);
 int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, no sync */
+/* The one-launch-per-body delete path (pcl_step_fused_delete with PCL_FUSED_LAZY, all photons, PCL_RNG_PHILOX) keeps
+ * removed photons' slots until fewer than half of the slots are alive: a bit per slot says who is there, a loop body is
+ * one kernel that moves nothing, and the stable compaction the reference's removal loop amounts to
+ * (physicl/light.py:258-260) is run for several bodies at once.  *slots_out = slots the store currently spans (== the
+ * count when it is dense); *pending_moves_out (may be NULL) = Newton moves r has not been given yet.  Every other entry
+ * point sees the dense store: it is compacted first, survivors in order, r up to date.                               */
+int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
+
 /* Set the particle count (<= capacity) and declare a new population: ids = id_base + index (no id array is read) and
  * every particle a photon (a kind array of an earlier upload is dropped) until pcl_store_upload_ids / _kind. */
 int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base);

@@ -86,6 +86,7 @@ _PROTOTYPES = {
     "pcl_store_capacity": [_vp, POINTER(c_int64)],
     "pcl_store_count": [_vp, POINTER(c_int64)],
     "pcl_store_set_count": [_vp, c_int64, c_int64],
+    "pcl_store_slots": [_vp, POINTER(c_int64), POINTER(c_int)],
     "pcl_store_upload": [_vp, c_int, _vp, c_int64, c_int64],
     "pcl_store_download": [_vp, c_int, _vp, c_int64, c_int64],
     "pcl_store_upload_ids": [_vp, _vp, c_int64, c_int64],
@@ -373,6 +374,14 @@ class Device:
     def count(self):
         v = c_int64()
         check(self.lib.pcl_store_count(self.ctx, byref(v)))
+        return v.value
+
+    @property
+    def slots(self):
+        """Slots the store spans: the count when it is dense, more while the delete path keeps removed photons' slots
+        behind its alive mask (pcl_store_slots)."""
+        v = c_int64()
+        check(self.lib.pcl_store_slots(self.ctx, byref(v), None))
         return v.value
 
     def set_count(self, count, id_base=0):

@@ -95,6 +95,7 @@ constexpr int kBlock = 256;           // 4 wave64 per workgroup
 constexpr int kTileRows = 32;         // compaction tile = 32 rows of 64 particles
 constexpr int kTile = kTileRows * 64; // 2048 particles: one workgroup, 8 rows per wave
 constexpr int kCounterSlots = 32;
+constexpr int kAccSlots = 32;          // accumulators of k_delete_alive, behind the counter slots in d_cnt
 constexpr int kMultiSlots = PCL_MULTI_MAX * (5 + PCL_MAX_PLANES); // per-step counter rows of a K-step pass
 static_assert(PCL_MAXPL == PCL_MAX_PLANES, "device header and C ABI disagree on the number of measure planes");
 static_assert(PCL_MULTI_MAX <= 64, "per-step tallies are kept one per lane of a wave64");
@@ -630,6 +631,202 @@ __global__ void __launch_bounds__(kBlock) k_flag_mask2(newtonmask_args<T> a) {
     if (threadIdx.x == 0) a.tile_keep[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
+// ---- the delete loop body behind an ALIVE MASK: one kernel, nothing moves ----------------------------------------------
+//   physicl/newton.py:15-16 + physicl/light.py:239-249 + the removal loop light.py:258-260 (which only needs the
+//   survivors to keep their order) + the counting measure steps behind it (light.py:385-399, 414-431).
+//   The store keeps every slot it had at its last compaction; a bit per slot says whether the photon is still there
+//   (the ballot masks of the delete passes ARE that mask: bit set = alive).  A loop body then is ONE kernel: per
+//   64-slot row pair read the alive words, for the alive photons read v (16-B loads, a lane takes two neighbouring
+//   slots as in k_flag_mask2), draw the flag, write the new alive words and the tile's alive count; the alive count of
+//   the whole store and the measure counters of the survivors are added up over the grid and the LAST workgroup to
+//   finish writes them straight into the host's pinned counter block -- no scan, no second kernel, no copy to enqueue.
+//   Dead slots cost their share of a 64-B sector and nothing else; the host compacts (k_tile_scan + k_compact_*, fed
+//   with these very masks and tile counts) only when fewer than half of the slots are alive (pcl_step_fused_delete).
+//   r is not touched either: a photon of a delete run keeps its velocity, so the moves of the bodies since r was last
+//   written (at most kPendMax, their dt in pend_dt[]) are applied in registers, in order, with the operations of
+//   newton.py:15-16 -- to whoever needs r: the plane counters here (NEED_R), the compaction, k_apply_pending.
+constexpr int kPendMax = 8;
+template <typename T>
+struct alive_args {
+    const T *v[3];
+    const T *r[3];              // NEED_R only
+    const int64_t *ids;         // NULL: id = id_base + slot
+    uint64_t *masks;            // alive bits, read (unless fresh) and written in place
+    uint64_t *masks_prev;       // the alive bits as they were before this body (pcl_store_last_delete_flags)
+    int32_t *tile_keep;         // alive photons per tile after this body (input of k_tile_scan)
+    unsigned long long *acc;    // device accumulators: [0] ticket, [1] alive, [2..4] sign counts, [5..] plane crossings
+    uint64_t *host;             // pinned host block: [kCounterSlots - 1] alive, [1..3] sign, [4..] planes
+    int64_t id_base, slots;     // slots: extent of the store (alive + dead)
+    int64_t ts;
+    T dt, An;
+    T pend_dt[kPendMax];
+    int n_pend;
+    uint64_t seed;
+    uint32_t step;
+    uint64_t *zero_cnt;         // count == 0: counter slots the compaction behind this launch adds into, cleared here
+    int n_zero;
+    int fresh;                  // 1: the store is dense -- every slot below ``slots`` is alive, masks are not read
+    int count;                  // 1: measure counters + totals to the host (a body without compaction); 0: flags only
+    int n_planes;
+    int plane_ax[PCL_MAX_PLANES];
+    T plane_L[PCL_MAX_PLANES];
+};
+
+template <typename T, bool NEED_R>
+__global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES]; // [0] alive, [1..3] sign, [4..] planes
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
+    if (!a.count && tile == 0 && (int)threadIdx.x < a.n_zero) a.zero_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t kept = 0, w_s[3] = {0, 0, 0};
+    const bool hi = lane >= 32;
+    const int bit = 2 * (lane & 31);
+#pragma unroll 2
+    for (int pp = 0; pp < kTileRows / 8; ++pp) {
+        const int row = (wave * (kTileRows / 8) + pp) * 2;
+        const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
+        uint64_t m_lo, m_hi;
+        if (a.fresh) {
+            const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64); // slots from the row pair's start
+            m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+            m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
+        } else {
+            m_lo = a.masks[tile * kTileRows + row];
+            m_hi = a.masks[tile * kTileRows + row + 1];
+        }
+        if (lane == 0) {
+            a.masks_prev[tile * kTileRows + row] = m_lo;
+            a.masks_prev[tile * kTileRows + row + 1] = m_hi;
+        }
+        if ((m_lo | m_hi) == 0ull) { // nobody left in these 128 slots (wave-uniform)
+            if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
+            continue;
+        }
+        const uint64_t mm = hi ? m_hi : m_lo;
+        const bool al0 = (mm >> bit) & 1ull, al1 = (mm >> (bit + 1)) & 1ull;
+        bool keep0 = false, keep1 = false;
+        T vv[3][2], xx[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vv[k][0] = vv[k][1] = xx[k][0] = xx[k][1] = (T)0;
+        if (al0 || al1) {
+            const int64_t ti = pcl_tix(i, a.ts); // whole tiles exist in the slab: the pair is readable whatever the extent
+            uint64_t id[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+                vv[k][0] = q.x, vv[k][1] = q.y;
+            }
+            if (a.ids) { // dense array padded to whole 64-element groups; i is even and below the extent
+                const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + i);
+                id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+            } else {
+                id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+            }
+            if constexpr (NEED_R) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+                    xx[k][0] = q.x, xx[k][1] = q.y;
+                }
+            }
+            bool kp[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const T d0 = R::mul(vv[0][e], a.dt), d1 = R::mul(vv[1][e], a.dt), d2 = R::mul(vv[2][e], a.dt); // newton.py:15
+                const T pcoll = R::mul(a.An, pcl_step_norm<T>(d0, d1, d2));                                        // light.py:241-247
+                const T rand = pcl_draw_rand<T>(id[e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                kp[e] = !(pcoll >= rand);
+                if constexpr (NEED_R) { // r as the reference holds it after this body's move: earlier bodies' moves first
+                    for (int q = 0; q < a.n_pend; ++q) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                    }
+                    xx[0][e] = R::add(xx[0][e], d0);                                                              // newton.py:16
+                    xx[1][e] = R::add(xx[1][e], d1);
+                    xx[2][e] = R::add(xx[2][e], d2);
+                }
+            }
+            keep0 = al0 && kp[0];
+            keep1 = al1 && kp[1];
+        }
+        const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+        if (lane == 0) {
+            a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+            a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+        }
+        kept += (uint32_t)(__popcll(b0) + __popcll(b1));
+        if (a.count && a.n_planes >= 0) { // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 3; ++k)                                                                          // light.py:424-426
+                w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[k][1] > (T)0));
+            if constexpr (NEED_R) {
+                for (int p = 0; p < a.n_planes; ++p) {                                                           // light.py:385-399
+                    const int ax = a.plane_ax[p];
+                    const T L = a.plane_L[p];
+                    uint32_t np = 0;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
+                        const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[0][e], vv[1][e], vv[2][e]), a.dt));
+                        np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    }
+                    if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+                }
+            }
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&s_cnt[0], kept);
+        if (a.count && a.n_planes >= 0)
+            for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_keep[tile] = (int32_t)s_cnt[0];
+    if (!a.count) return;
+    // grid totals: every workgroup adds its sums, the last one to arrive hands them to the host and leaves the
+    // accumulators zero for the next launch (device-scope atomics: the XCDs' L2s do not see each other's plain stores)
+    const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
+    if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x]) atomicAdd(&a.acc[1 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&a.acc[0], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if ((int)threadIdx.x < nslots) {
+        const unsigned long long v = atomicExch(&a.acc[1 + threadIdx.x], 0ull);
+        if (threadIdx.x == 0) a.host[kCounterSlots - 1] = v;
+        else a.host[threadIdx.x] = v;
+    }
+    if (threadIdx.x == 0) atomicExch(&a.acc[0], 0ull);
+}
+
+// the pending moves of an alive-mask store made real: r = (...((r + v*dt_1) + v*dt_2)...) for every slot of the extent
+// (dead slots included -- nobody reads them again), when the list is full and no compaction is due
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; 2 * p < a.slots; p += (int64_t)gridDim.x * kBlock) {
+        const int64_t ti = pcl_tix(2 * p, a.ts);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T2 v = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+            T2 x = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+            for (int q = 0; q < a.n_pend; ++q) {
+                x.x = R::add(x.x, R::mul(v.x, a.pend_dt[q]));
+                x.y = R::add(x.y, R::mul(v.y, a.pend_dt[q]));
+            }
+            *reinterpret_cast<T2 *>(const_cast<T *>(a.r[k]) + ti) = x;
+        }
+    }
+}
+
 // ---- K delete loop bodies in one pass: Newton + delete test K times per photon, ONE mask at the end -------
 //   A photon of a delete simulation never changes its velocity, so dr = v*dt, |dr| and pcoll = A*n*|dr| are constants
 //   of the photon: per step only r += dr (3 adds), the decision draw and the compare remain, until the photon is
@@ -1090,6 +1287,8 @@ struct compact_counter_args {
     int n_planes;  // -1: no counters
     T dt;          // dr = v*dt when it is implicit
     int move;      // 1: pass 1 only flagged; the survivors' Newton move r = r + v*dt (newton.py:15-16) happens here
+    int n_pend;    // alive-mask stores: moves of earlier loop bodies that r has not seen yet, applied first, in order
+    T pend_dt[kPendMax];
 };
 
 template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
@@ -1125,10 +1324,13 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
             const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
 #pragma unroll
             for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
-            if (c.move) { // the survivors' Newton move, with the operations of k_newton_mask
+            if (c.move || c.n_pend) { // the survivors' Newton move(s), with the operations of k_newton_mask
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const T rn = R::add(word_as<T, W>(val[k]), R::mul(word_as<T, W>(val[3 + k]), c.dt));
+                    T rn = word_as<T, W>(val[k]);
+                    const T vk = word_as<T, W>(val[3 + k]);
+                    for (int q = 0; q < c.n_pend; ++q) rn = R::add(rn, R::mul(vk, c.pend_dt[q]));
+                    if (c.move) rn = R::add(rn, R::mul(vk, c.dt));
                     __builtin_memcpy(&val[k], &rn, sizeof(W));
                 }
             }
@@ -1281,9 +1483,15 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
                 const int ax = j - 3;
                 T x0 = word_as<T, W>(x.x), x1 = word_as<T, W>(x.y);
                 const T d0 = R::mul(vkeep[ax][t][0], c.dt), d1 = R::mul(vkeep[ax][t][1], c.dt); // newton.py:15
+                for (int q = 0; q < c.n_pend; ++q) { // moves of earlier loop bodies r has not seen yet (alive-mask stores)
+                    x0 = R::add(x0, R::mul(vkeep[ax][t][0], c.pend_dt[q]));
+                    x1 = R::add(x1, R::mul(vkeep[ax][t][1], c.pend_dt[q]));
+                }
                 if (c.move) {
                     x0 = R::add(x0, d0);                                                              // newton.py:16
                     x1 = R::add(x1, d1);
+                }
+                if (c.move || c.n_pend) {
                     __builtin_memcpy(&x.x, &x0, sizeof(W));
                     __builtin_memcpy(&x.y, &x1, sizeof(W));
                 }
@@ -1907,6 +2115,17 @@ struct pcl_ctx {
     int32_t *tile_keep = nullptr;
     int64_t *tile_off = nullptr;
     int64_t last_delete_n = -1;
+    // alive-mask state of the one-launch-per-body delete path (k_delete_alive): while ``holes`` the store's extent is
+    // ``slots`` (alive + dead), ``count`` is the alive count, ``masks`` holds the alive bits and ``tile_keep`` the alive
+    // count per tile; r lags pend_n moves behind.  Every entry point but pcl_step_fused_delete makes the store dense
+    // again first (densify, through need_store / ensure_scratch).
+    bool holes = false;
+    int64_t slots = 0;
+    int pend_n = 0;
+    double pend_dt[kPendMax] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t *masks_prev = nullptr;  // alive bits before the last body of the alive path (last_delete_flags)
+    bool last_delete_masked = false; // the last delete was such a body: flags come from masks_prev / masks
+    int64_t last_delete_slots = 0;
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
     int64_t lb_units = 0;
     // Rows that are known to hold nothing but +0.0 need not travel through a compaction: in a run that never scatters
@@ -2390,14 +2609,21 @@ void dev_free(T *&p) {
     p = nullptr;
 }
 
-int ensure_scratch(pcl_ctx *ctx, int64_t n) {
+int densify(pcl_ctx *ctx);
+
+// scratch of the delete / gather pipelines.  The masks of a store in the alive-mask state are not scratch but state: any
+// other user makes the store dense first (``for_alive``: the alive path itself asking)
+int ensure_scratch(pcl_ctx *ctx, int64_t n, bool for_alive = false) {
+    if (ctx->holes && !for_alive) PCL_TRY(densify(ctx));
     if (n <= ctx->scratch_cap) return PCL_OK;
     dev_free(ctx->masks);
+    dev_free(ctx->masks_prev);
     dev_free(ctx->tile_keep);
     dev_free(ctx->tile_off);
     ctx->scratch_cap = 0;
     const int64_t tiles = div_up(n, kTile);
     PCL_TRY(dev_alloc(&ctx->masks, tiles * kTileRows));
+    PCL_TRY(dev_alloc(&ctx->masks_prev, tiles * kTileRows));
     PCL_TRY(dev_alloc(&ctx->tile_keep, tiles));
     PCL_TRY(dev_alloc(&ctx->tile_off, tiles));
     ctx->scratch_cap = tiles * kTile;
@@ -2545,6 +2771,7 @@ int need_store_raw(pcl_ctx *ctx) {
 // every entry point that reads or writes store arrays goes through here: implicit dr/dv become real first
 int need_store(pcl_ctx *ctx) {
     PCL_TRY(need_store_raw(ctx));
+    PCL_TRY(densify(ctx)); // a store behind an alive mask becomes dense (stable) first
     return materialize(ctx);
 }
 
@@ -3073,6 +3300,7 @@ void adopt_compacted(pcl_ctx *ctx, int64_t alive, int64_t last_delete_n) {
     ctx->ids_iota = false;
     ctx->count = alive;
     ctx->last_delete_n = last_delete_n;
+    ctx->last_delete_masked = false; // (the alive path sets it again behind this call)
     ctx->lam4_valid = false;
 }
 
@@ -3481,6 +3709,201 @@ int decide_dv_mode(pcl_ctx *ctx, bool lazy, int *mode_out) {
     return PCL_OK;
 }
 
+// ---- the alive-mask delete path (k_delete_alive) ---------------------------------------------------------------------
+// fewer than 1/kAliveRatio of the slots alive -> the next body compacts; stores below kAliveMinSlots never do (their
+// kernels are latency, not bytes).  PCL_ALIVE=0 switches the path off (every body compacts, as in round 2).
+bool alive_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("PCL_ALIVE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+double alive_ratio() {
+    static const double r = [] {
+        const char *e = getenv("PCL_ALIVE_RATIO");
+        const double v = e ? atof(e) : 0.5;
+        return v > 0.0 && v <= 1.0 ? v : 0.5;
+    }();
+    return r;
+}
+int64_t alive_min_slots() {
+    static const int64_t n = [] {
+        const char *e = getenv("PCL_ALIVE_MIN_SLOTS");
+        const long long v = e ? atoll(e) : 65536;
+        return (int64_t)(v >= 0 ? v : 65536);
+    }();
+    return n;
+}
+
+template <typename T>
+void fill_alive_args(pcl_ctx *ctx, alive_args<T> &a, int64_t slots) {
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = F<T>(ctx, PCL_V0 + k);
+        a.r[k] = F<T>(ctx, PCL_R0 + k);
+    }
+    a.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    a.masks = ctx->masks;
+    a.masks_prev = ctx->masks_prev;
+    a.tile_keep = ctx->tile_keep;
+    a.acc = reinterpret_cast<unsigned long long *>(ctx->d_cnt + kCounterSlots);
+    a.host = ctx->h_cnt;
+    a.id_base = ctx->id_base;
+    a.slots = slots;
+    a.ts = tile_stride(ctx);
+    a.n_pend = ctx->pend_n;
+    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q];
+}
+
+// r catches up with the moves it has not seen (the list is full and no compaction is due)
+template <typename T>
+int apply_pending_t(pcl_ctx *ctx) {
+    alive_args<T> a{};
+    fill_alive_args<T>(ctx, a, ctx->slots);
+    hipLaunchKernelGGL(k_apply_pending<T>, dim3(grid_for(ctx, div_up(ctx->slots, 2), kBlock)), dim3(kBlock), 0, ctx->stream, a);
+    PCL_TRY(launch_check("k_apply_pending"));
+    ctx->pend_n = 0;
+    return PCL_OK;
+}
+
+// one loop body on the alive mask.  count: totals and measure counters go to the host (a body without compaction);
+// otherwise only the new masks and tile counts are produced (the compaction behind it counts)
+template <typename T>
+int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double dt, double A, double n, uint64_t seed, uint32_t step,
+                   const double *planes_host, int n_planes) {
+    alive_args<T> a{};
+    fill_alive_args<T>(ctx, a, slots);
+    a.dt = (T)dt;
+    a.An = (T)A * (T)n;
+    a.seed = seed;
+    a.step = step;
+    a.fresh = fresh ? 1 : 0;
+    a.count = count ? 1 : 0;
+    a.n_planes = n_planes;
+    a.zero_cnt = ctx->d_cnt + 1;
+    a.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
+    plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
+    const int tiles = (int)div_up(slots, kTile);
+    const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
+    if (count && n_planes > 0)
+        hipLaunchKernelGGL((k_delete_alive<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_delete_alive<T, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
+    return launch_check("k_delete_alive");
+}
+
+// scan + stable compaction of a store in the alive-mask state into the other slab: the survivors' r catches up with the
+// pending moves (and, ``move``, with this body's) on the way.  The caller adopts the result.
+template <typename T>
+int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const double *planes_host, int n_planes) {
+    PCL_TRY(scan_tiles(ctx, ctx->count));
+    compact_counter_args<T> cc{};
+    cc.cnt = ctx->d_cnt;
+    cc.n_planes = n_planes;
+    cc.dt = (T)dt;
+    cc.move = move ? 1 : 0;
+    cc.n_pend = ctx->pend_n;
+    for (int q = 0; q < ctx->pend_n; ++q) cc.pend_dt[q] = (T)ctx->pend_dt[q];
+    plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
+    return launch_compact_count<T>(ctx, false, dv_mode, cc);
+}
+
+void drop_holes(pcl_ctx *ctx) {
+    ctx->holes = false;
+    ctx->slots = 0;
+    ctx->pend_n = 0;
+    ctx->last_delete_masked = false;
+}
+
+// Make a store in the alive-mask state dense again (stable: the survivors keep their order), r up to date.  What every
+// entry point other than the alive path sees.  dr stays implicit (= v * lazy_dt) as the last body left it.
+int densify(pcl_ctx *ctx) {
+    if (!ctx->holes) return PCL_OK;
+    const int64_t alive = ctx->count, slots = ctx->slots;
+    const int64_t last_n = ctx->last_delete_n;
+    const bool last_masked = ctx->last_delete_masked;
+    ctx->holes = false; // (ensure_alt and the helpers below must not come back here)
+    ctx->count = slots; // the pipeline's launch geometry is the extent
+    int rc = ensure_alt(ctx);
+    int dv_mode = kDvMove;
+    if (rc == PCL_OK) rc = decide_dv_mode(ctx, true, &dv_mode);
+    if (rc == PCL_OK)
+        rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, false, 0.0, nullptr, -1),
+                          compact_alive_t<float>(ctx, dv_mode, false, 0.0, nullptr, -1));
+    int64_t got = 0;
+    if (rc == PCL_OK) rc = wait_count(ctx, slots, &got);
+    if (rc == PCL_OK && got != alive)
+        rc = fail(PCL_ERR_HIP, "compaction of the alive mask found %lld photons, the store holds %lld", (long long)got, (long long)alive);
+    if (rc != PCL_OK) {
+        ctx->holes = true;
+        ctx->count = alive;
+        return rc;
+    }
+    adopt_compacted(ctx, alive, last_n);
+    ctx->last_delete_masked = last_masked; // the two mask arrays still describe the last delete
+    ctx->slots = 0;
+    ctx->pend_n = 0;
+    return PCL_OK;
+}
+
+// pcl_step_fused_delete on the alive mask (lazy, all photons, device RNG).  Returns the alive count in *alive_out; the
+// measure counters are in h_cnt[1..] when n_planes >= 0.
+int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t seed, uint32_t step, const double *planes_host,
+                       int n_planes, int64_t *alive_out) {
+    const int64_t before = ctx->count;
+    const bool fresh = !ctx->holes;
+    const int64_t slots = fresh ? ctx->count : ctx->slots;
+    const int np = n_planes > 0 ? n_planes : 0;
+    PCL_TRY(ensure_scratch(ctx, slots, true));
+    const bool compact_now = slots > alive_min_slots() && (double)before < alive_ratio() * (double)slots;
+    int64_t alive = 0;
+    if (!compact_now) {
+        if (ctx->pend_n == kPendMax) PCL_TRY(PCL_DISPATCH(ctx, apply_pending_t<double>(ctx), apply_pending_t<float>(ctx)));
+        ctx->slots = slots; // (apply_pending above ran on the old extent, which is this one)
+        PCL_TRY(PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes),
+                             delete_alive_t<float>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes)));
+        PCL_HIP(hipEventRecord(ctx->ev_count, ctx->stream));
+        PCL_TRY(wait_count(ctx, before, &alive)); // the last workgroup wrote the totals into the pinned block
+        ctx->holes = true;
+        ctx->slots = slots;
+        ctx->pend_dt[ctx->pend_n++] = dt;
+        ctx->count = alive;
+        ctx->last_delete_n = before;
+    } else {
+        // flags on the mask, then the usual scan + compaction of the survivors (whose r catches up on the way)
+        PCL_TRY(ensure_alt(ctx));
+        ctx->holes = false;
+        ctx->count = slots; // launch geometry of the pipeline = the extent
+        int dv_mode = kDvMove;
+        int rc = decide_dv_mode(ctx, true, &dv_mode);
+        if (rc == PCL_OK)
+            rc = PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, false, dt, A, n, seed, step, planes_host, n_planes),
+                              delete_alive_t<float>(ctx, slots, fresh, false, dt, A, n, seed, step, planes_host, n_planes));
+        if (rc == PCL_OK)
+            rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, true, dt, planes_host, n_planes),
+                              compact_alive_t<float>(ctx, dv_mode, true, dt, planes_host, n_planes));
+        if (rc == PCL_OK && n_planes >= 0) {
+            rc = hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                         hipStreamSynchronize(ctx->stream) == hipSuccess
+                     ? PCL_OK : fail(PCL_ERR_HIP, "reading the counters failed");
+        }
+        if (rc == PCL_OK) rc = wait_count(ctx, before, &alive);
+        if (rc != PCL_OK) {
+            ctx->holes = !fresh;
+            ctx->count = before;
+            return rc;
+        }
+        adopt_compacted(ctx, alive, before);
+        ctx->slots = 0;
+        ctx->pend_n = 0;
+    }
+    ctx->last_delete_masked = true;
+    ctx->last_delete_slots = slots;
+    *alive_out = alive;
+    return PCL_OK;
+}
+
 template <typename T>
 int fused_delete_t(pcl_ctx *ctx, double dt, double A, double n, bool lazy, int dv_mode, int rng_mode, uint64_t seed,
                    uint32_t step, const double *planes_host, int n_planes) {
@@ -3832,13 +4255,13 @@ int pcl_ctx_create(int device, void *stream, pcl_ctx **ctx_out) {
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_count, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&c->d_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&c->d_cnt), (kCounterSlots + kAccSlots) * sizeof(uint64_t)) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&c->h_cnt), kCounterSlots * sizeof(uint64_t)) != hipSuccess) {
         pcl_ctx_destroy(c);
         return fail(PCL_ERR_HIP, "context resource allocation failed");
     }
     memset(c->h_cnt, 0, kCounterSlots * sizeof(uint64_t));
-    (void)hipMemset(c->d_cnt, 0, kCounterSlots * sizeof(uint64_t));
+    (void)hipMemset(c->d_cnt, 0, (kCounterSlots + kAccSlots) * sizeof(uint64_t));
     for (int b = 0; b < 2; ++b) {
         if (hipMalloc(reinterpret_cast<void **>(&c->d_bank[b]), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void **>(&c->h_bank[b]), kCounterSlots * sizeof(uint64_t)) != hipSuccess ||
@@ -4228,9 +4651,11 @@ int pcl_store_free(pcl_ctx *ctx) {
         ctx->rnd_n[k] = 0;
     }
     dev_free(ctx->masks);
+    dev_free(ctx->masks_prev);
     dev_free(ctx->tile_keep);
     dev_free(ctx->tile_off);
     dev_free(ctx->lb_status);
+    drop_holes(ctx);
     ctx->lb_units = 0;
     ctx->dv_zero = 0;
     ctx->alt_dv_zero_n = 0;
@@ -4250,6 +4675,13 @@ int pcl_store_capacity(pcl_ctx *ctx, int64_t *capacity_out) {
 int pcl_store_count(pcl_ctx *ctx, int64_t *count_out) {
     if (!ctx || !count_out) return fail(PCL_ERR_ARG, "NULL argument");
     *count_out = ctx->count;
+    return PCL_OK;
+}
+
+int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out) {
+    if (!ctx || !slots_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *slots_out = ctx->holes ? ctx->slots : ctx->count;
+    if (pending_moves_out) *pending_moves_out = ctx->holes ? ctx->pend_n : 0;
     return PCL_OK;
 }
 
@@ -4363,6 +4795,7 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
                            uint64_t seed) {
     PCL_TRY(need_store_raw(ctx));
     if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
+    drop_holes(ctx);
     ctx->lazy_dr = ctx->lazy_dv = false; // every array is overwritten
     ctx->lam4_valid = false;
     if (n > 0) {
@@ -4383,6 +4816,7 @@ int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, doubl
     PCL_TRY(need_store_raw(ctx));
     if (n < 0 || n > ctx->capacity) return fail(PCL_ERR_ARG, "n outside [0, capacity]");
     if (nbins < 1 || !cdf_host || !grid_host) return fail(PCL_ERR_ARG, "bad table");
+    drop_holes(ctx);
     ctx->lazy_dr = ctx->lazy_dv = false;
     ctx->lam4_valid = false;
     if (n > 0) {
@@ -4511,6 +4945,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
         // a Newton-only pass keeps the dv of a still-implicit scatter step implicit (dv = v - vprev): only the source of
         // dr changes, to the current v rows
         PCL_TRY(need_store_raw(ctx));
+        PCL_TRY(densify(ctx)); // (a store behind an alive mask: dense first; dr / dv stay implicit)
     } else {
         PCL_TRY(need_store(ctx));
     }
@@ -4591,7 +5026,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
 int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out) {
     PCL_TRY(need_store_raw(ctx));
     if (!uniform_out) return fail(PCL_ERR_ARG, "uniform_out is NULL");
-    *uniform_out = (!ctx->kind && ctx->ids_iota) ? 1 : 0;
+    *uniform_out = (!ctx->kind && ctx->ids_iota && !ctx->holes) ? 1 : 0; // (behind an alive mask the ids are about to become explicit)
     return PCL_OK;
 }
 
@@ -4604,7 +5039,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     const int np = n_planes, nslots = 4 + np;
-    if (ctx->kind || !ctx->ids_iota)
+    if (ctx->kind || !ctx->ids_iota || ctx->holes)
         return fail(PCL_ERR_STATE, "pcl_step_fused_multi needs an all-photon store with implicit ids (use pcl_step_fused)");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
     const bool use_e = flags & PCL_SCATTER_WAVELENGTH, var_n = flags & PCL_SCATTER_VARIABLE_N;
@@ -4738,6 +5173,24 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     if (N == 0) return PCL_OK;
     if (rng_mode == PCL_RNG_INPUT && (!ctx->rnd[2] || ctx->rnd_n[2] < N))
         return fail(PCL_ERR_STATE, "PCL_RNG_INPUT needs pcl_store_upload_rand(which=2) for all %lld particles", (long long)N);
+    static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
+    if (lazy && !ctx->kind && rng_mode == PCL_RNG_PHILOX && !onepass && alive_enabled()) {
+        // the usual case of a delete run: the body runs on the alive mask -- one kernel, nothing moves -- and the
+        // store is compacted only when fewer than half of its slots are alive (k_delete_alive)
+        ctx->lazy_dr = ctx->lazy_dr_vprev = false; // an implicit dr is superseded by this body's move
+        int64_t alive = 0;
+        PCL_TRY(fused_delete_alive(ctx, dt, A, n, seed, step, planes_host, n_planes, &alive));
+        ctx->lazy_dr = true; // dr = v*dt with the (unchanged) velocities of the survivors
+        ctx->lazy_dt = dt;
+        if (out_host) {
+            out_host[0] = alive;
+            if (n_planes >= 0)
+                for (int k = 0; k < 3 + np; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
+            out_host[4 + np] = N - alive;
+        }
+        return PCL_OK;
+    }
+    PCL_TRY(densify(ctx));
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));
     // A still-implicit dv (lazy scatter step): an all-photon store keeps it implicit -- the vprev rows travel through the
@@ -4751,7 +5204,6 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
     // but measured slower than the pipeline below on this chip (0.20 vs 0.5 of peak at 1e8 photons: with ~1000 units in
     // flight a unit's look-back walks ~16 windows of 64 predecessors at ~2 us of cross-XCD latency each, as long as the
     // unit's own memory traffic takes), so it is not the default.  Falls back to the pipeline should a look-back give up.
-    static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
     bool done = false;
     if (lazy && !ctx->kind && onepass) {
         PCL_HIP(hipMemsetAsync(ctx->d_cnt + 1, 0, (size_t)(3 + np) * sizeof(uint64_t), ctx->stream));
@@ -4797,6 +5249,7 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    PCL_TRY(densify(ctx));
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;
     if (out_host)
@@ -4849,6 +5302,7 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    PCL_TRY(densify(ctx));
     int phase_del[PCL_MIXED_MAXPH] = {0, 0};
     int n_iso = 0, n_delete = 0, last_iso_in_pass = -1;
     for (int j = 0; j < n_phases; ++j) {
@@ -4929,10 +5383,32 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
 }
 
 int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n) {
-    PCL_TRY(need_store(ctx));
+    PCL_TRY(need_store_raw(ctx));
     if (ctx->last_delete_n < 0) return fail(PCL_ERR_STATE, "no delete step has run since the store last changed");
     if (n != ctx->last_delete_n || !flags_host)
         return fail(PCL_ERR_ARG, "flags_host must hold exactly the pre-delete count %lld", (long long)ctx->last_delete_n);
+    if (ctx->last_delete_masked) {
+        // the last delete ran on the alive mask: the photons it saw are the set bits of masks_prev, in slot order, and it
+        // removed those whose bit in masks is clear.  Two small arrays (a bit per slot) expanded on the host; the store
+        // is not touched (no compaction is forced by looking).
+        const int64_t words = div_up(ctx->last_delete_slots, kTile) * kTileRows;
+        std::vector<uint64_t> prev((size_t)words), cur((size_t)words);
+        PCL_TRY(pcl_d2h(ctx, prev.data(), ctx->masks_prev, words * (int64_t)sizeof(uint64_t)));
+        PCL_TRY(pcl_d2h(ctx, cur.data(), ctx->masks, words * (int64_t)sizeof(uint64_t)));
+        int64_t k = 0;
+        for (int64_t w = 0; w < words; ++w) {
+            uint64_t m = prev[(size_t)w];
+            while (m) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1;
+                if (k < n) flags_host[k] = ((cur[(size_t)w] >> b) & 1ull) ? 0 : 1;
+                ++k;
+            }
+        }
+        if (k != n) return fail(PCL_ERR_HIP, "the alive masks describe %lld photons, expected %lld", (long long)k, (long long)n);
+        return PCL_OK;
+    }
+    PCL_TRY(need_store(ctx));
     int32_t *d = nullptr;
     PCL_TRY(dev_alloc(&d, n));
     hipLaunchKernelGGL(k_masks_to_flags, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->masks, d, n);

@@ -106,10 +106,14 @@ def test_temporaries_of_big_stores_go_back_where_they_came_from():
             "d.step_newton(1e-3)\n"
             "o = d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 3, 0, [], lazy=True)\n"   # second slab, scratch
             "n = o['N']; d.sync()\n"
+            "fl0 = d.last_delete_flags(N); assert fl0.sum() == N - n\n"            # from the alive masks, store untouched
+            "assert d.slots == N and d.count == n\n"
+            "d.download_ids(1)\n"                                                    # any other access compacts: second slab, ids
+            "assert d.slots == n\n"
             "d.last_delete_flags(N); d.scatter_pcoll(1e-3, 1e-3, 0, 299792458.0, 6.6e-34)\n"   # warm: first-use module loads
             "a0 = avail()\n"
             "for k in range(6):\n"
-            "    fl = d.last_delete_flags(N); assert fl.sum() == N - n\n"
+            "    fl = d.last_delete_flags(N); assert np.array_equal(fl, fl0)\n"
             "    assert d.scatter_pcoll(1e-3, 1e-3, 0, 299792458.0, 6.6e-34).shape == (d.count,)\n"
             "for k in range(3):\n"
             "    m = d.count; flags = np.zeros(m, np.int32); flags[::3] = 1\n"
