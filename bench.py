@@ -452,14 +452,15 @@ def run_rank(args):
 # (test/test_light.py:52-59; physicl/light.py:231-260, physicl/__init__.py:455-459)
 # ---------------------------------------------------------------------------------------------------------------------
 def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
-    """Delete-until-empty at each size, two formulations: "per_step" = one launch sequence per loop body (the one-pass
-    kernel k_delete_onepass, or the pipeline k_newton_mask -> scan -> k_compact_* where that does not apply), the
-    HBM-bound form with a roofline figure per kernel; "multi" = K loop
-    bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation(steps_per_launch=K) runs.
-    A "particle-step" is one photon alive at the start of one loop body.  Algorithmic bytes (DESIGN.md section 4,
-    fp64): pass 1 reads v (24) and writes 1 mask bit; pass 3 reads 1 bit per particle, moves r, v, E + the id of every
-    survivor ((56 + 8) x 2 per survivor; dr stays implicit; dv, all +0.0 in a run that never scatters, travels in the first
-    loop body only) and applies the Newton move to them on the way."""
+    """Delete-until-empty at each size, two formulations: "per_step" = one call per loop body (pcl_step_fused_delete: the
+    body runs on the store's alive mask -- ONE kernel, k_delete_alive, nothing moves -- and the store is compacted, flag
+    kernel -> scan -> k_compact_*, only in the bodies that start with fewer than half of the slots alive); "multi" = K
+    loop bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation runs by itself when the exit
+    test allows it.  A "particle-step" is one photon alive at the start of one loop body.  The roofline records count the
+    bytes of the SLOTS a kernel sweeps, dead ones included (fp64): k_delete_alive reads v (24) and, for the plane
+    counter, r (24) of every slot, the id (8) once ids are explicit, and reads + writes the alive bit; the compaction
+    reads a bit per slot and moves r, v, E, id of the survivors (64 B each way; dv, all +0.0 in a run that never
+    scatters, travels in the first compaction only)."""
     plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]          # test/test_light.py:58
     dt, A, n = 1e-3, 1e-3, 1e-3
     out = {"workload": "BASELINE configs[1](ii): Newton + ScatterDelete(A=n=1e-3) + plane counter until empty, E = 1, "
@@ -480,13 +481,14 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                     if mode == "multi":
                         for o in dev.step_fused_delete_multi(dt, K, A, n, seed, k, plane):
                             work += nb
-                            per_step.append((nb, o["N"]))
+                            per_step.append((nb, o["N"], nb, o["N"]))
                             nb = o["N"]
                         k += K
                     else:
+                        sb = dev.slots
                         o = dev.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, k, plane, lazy=True)
                         work += nb
-                        per_step.append((nb, o["N"]))
+                        per_step.append((nb, o["N"], sb, dev.slots))      # alive before / after, slots before / after
                         k += 1
                 dev.sync()
                 el = time.perf_counter() - t0
@@ -496,39 +498,40 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                     runs.append((el, work, per_step, kern))
             runs.sort(key=lambda r: r[0])
             el, work, per_step, kern = runs[(len(runs) - 1) // 2]
-            tot = sum(nb for nb, _ in per_step if nb)
-            surv = sum(al for nb, al in per_step if nb)
-            r = {"value": work / el, "unit": "particle-steps/s", "ms_total": el * 1e3, "loop_bodies": len([1 for nb, _ in per_step if nb]),
+            tot = sum(b[0] for b in per_step if b[0])
+            surv = sum(b[1] for b in per_step if b[0])
+            r = {"value": work / el, "unit": "particle-steps/s", "ms_total": el * 1e3, "loop_bodies": len([1 for b in per_step if b[0]]),
                  "particle_steps": work, "survivor_fraction": surv / float(tot) if tot else 0.0,
                  "run_ms": [round(x[0] * 1e3, 4) for x in runs],
                  "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
                  "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
-            if mode == "per_step" and kern["k_delete_onepass"]["launches"]:
-                # the whole loop body is one kernel (Newton + flag + decoupled look-back + compaction): it must read r, v of
-                # every particle (48) and dv | vprev, E (32) of the survivors, and write their r, v, dv | vprev, E, id (88)
-                ms = kern["k_delete_onepass"]["total_ms"]
-                b = tot * 48.125 + surv * (32.0 + 88.0)
-                g = b / (ms * 1e-3) / 1e9 if ms else 0.0
-                r["roofline"] = {"bound": "hbm", "kernel": "k_delete_onepass (Newton + delete flag + look-back + stable compaction, one pass)",
-                                 "achieved": g, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g / HBM_PEAK_GBPS, "traffic": None,
-                                 "algorithmic_bytes": b, "total_ms": ms}
-            elif mode == "per_step":
+            if mode == "per_step":
+                b1 = b3 = 0.0
+                slots_swept = compactions = 0
+                explicit_ids = False
+                for nb, na, sb, sa in per_step:
+                    if not nb:
+                        continue
+                    compacting = sa < sb                           # the body ended on a smaller extent: it compacted
+                    slots_swept += sb
+                    # k_delete_alive: alive bit read + written, v, the id once explicit; r only when it counts the plane
+                    # crossings itself (a compacting body leaves the counters to the compaction)
+                    b1 += sb * (0.25 + 24.0 + (8.0 if explicit_ids else 0.0) + (0.0 if compacting else 24.0))
+                    if compacting:
+                        compactions += 1
+                        b3 += sb * 0.125 + na * 2.0 * 64.0 + (0.0 if explicit_ids else na * 2.0 * 24.0)
+                        explicit_ids = True
                 p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
-                # v read (the flag needs |v * dt| only) and one mask bit; from the second loop body on the store has been
-                # compacted and the Philox key of a photon is its explicit id: +8 B read
-                b1 = tot * 24.125 + (tot - per_step[0][0]) * 8.0 if per_step else 0.0
-                # mask bit; the survivors' r, v, E + id read and written (64 B each way) -- and dv (24) in the first
-                # loop body only: these photons never scatter, so from then on dv is known to be all +0.0 and stays put
-                first = per_step[0][1] if per_step else 0
-                b3 = tot * 0.125 + surv * 2.0 * 64.0 + first * 2.0 * 24.0
                 g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
-                r["roofline"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction, pass 3)", "achieved": g3,
-                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS, "traffic": None,
-                                 "algorithmic_bytes": b3, "total_ms": p3_ms}
-                r["roofline_pass1"] = {"bound": "hbm", "kernel": "k_flag_mask2 (delete flag -> ballot masks, pass 1; pass 3 moves the survivors)",
-                                       "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
-                                       "traffic": None, "algorithmic_bytes": b1, "total_ms": p1_ms}
+                r["roofline"] = {"bound": "hbm", "kernel": "k_delete_alive (one loop body on the alive mask: Newton + delete flag + counters, nothing moves)",
+                                 "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS, "traffic": None,
+                                 "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
+                                 "bytes_per_alive_particle_step": (b1 + b3) / tot if tot else 0.0}
+                r["roofline_compaction"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction of the survivors, %d of %d bodies)"
+                                                                      % (compactions, r["loop_bodies"]),
+                                            "achieved": g3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS,
+                                            "traffic": None, "algorithmic_bytes": b3, "total_ms": p3_ms, "compactions": compactions}
             else:
                 r["steps_per_launch"] = K
             rec[mode] = r
