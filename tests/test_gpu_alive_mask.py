@@ -1,0 +1,178 @@
+"""GPU: the delete loop body behind an alive mask (k_delete_alive, pcl_step_fused_delete) against the oracle.
+
+The reference removes the flagged photons from ``sim.objects`` every pass (physicl/light.py:258-260); all that is
+observable is that the survivors keep their order.  The device keeps the removed photons' slots, one kernel per body,
+until fewer than half of the slots are alive, and lets r lag behind by up to 8 moves.  Everything observable must be
+what the oracle's step-by-step chain gives: survivor ids (bit-exact), positions and velocities (bit-exact: IEEE mul / add
+only), every measure row, the flags of each body -- whenever and however the store is looked at in between.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+C_LIT = 299792458.0
+
+
+def cols(a):
+    return [np.ascontiguousarray(a[:, k]) for k in range(3)]
+
+
+def oracle_body(st, dt, A, n, seed, step, planes, dtype=np.float64):
+    """One loop body on the oracle state: Newton, ScatterDelete, then the counters of the measure steps."""
+    orc.step_newton(st, dt, dtype=dtype)
+    before = len(st["id"])
+    flags, keep = orc.step_scatter_delete(st, orc.philox_draws(seed, step, st["id"], dtype=dtype)[2], A, n, dtype=dtype)
+    row = [len(keep), before - len(keep)] + [int(x) for x in orc.sign_counts(st["v"])]
+    for loc in planes:                               # light.py:385-399 in the store's precision: prev = r - dr, rounded
+        ax = [k for k in range(3) if not np.isnan(loc[k])][0]
+        L, x = dtype(loc[ax]), np.asarray(st["r"][ax], dtype=dtype)
+        prev = (x - np.asarray(st["dr"][ax], dtype=dtype)).astype(dtype)
+        row.append(int(np.count_nonzero(((prev <= L) & (L <= x)) | ((prev >= L) & (L >= x)))))
+    return flags, row
+
+
+def device_row(o):
+    return [o["N"], o["removed"]] + [int(x) for x in o["sign"]] + [int(x) for x in o["planes"]]
+
+
+def assert_state(d, st, hip, what):
+    s = d.download_state()
+    assert np.array_equal(s["id"], st["id"]), what
+    for f in ("r", "v", "dr"):
+        for k in range(3):
+            assert np.array_equal(s[f][k], st[f][k]), (what, f, k)
+    assert np.array_equal(s["E"], st["E"]), what
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("N,pdel", [(300_000, 0.3), (200_001, 0.04), (70_000, 0.55)])
+def test_delete_bodies_on_the_alive_mask_vs_oracle(N, pdel, dtype):
+    """Chains of bodies at three removal rates: 0.3 compacts every third body, 0.04 lets more than 8 moves pile up
+    (k_apply_pending) before the first compaction, 0.55 compacts every second body.  Rows and flags are compared after
+    every body (looking at the flags does not disturb the store), the whole state at a few points and at the end."""
+    from physicl_amd import _hip as hip
+    np_t = np.float64 if dtype == "f64" else np.float32
+    rs = np.random.RandomState(N)
+    direction = rs.normal(size=(N, 3))
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    init = {"r": (rs.normal(size=(N, 3)) * 1e5).astype(np_t), "v": (direction * C_LIT).astype(np_t), "E": rs.uniform(1, 2, N).astype(np_t)}
+    dt, n_k, seed = 1e-3, 1e-3, 17
+    A_k = pdel / (n_k * C_LIT * dt)
+    planes = [[2e5, np.nan, np.nan], [np.nan, -1e5, np.nan], [np.nan, np.nan, 0.0]]
+    st = {"r": cols(init["r"]), "v": cols(init["v"]), "dr": [np.zeros(N, np_t)] * 3, "dv": [np.zeros(N, np_t)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64) + 5}
+    bodies = 14 if pdel < 0.1 else 9
+    with hip.Device(0) as d:
+        d.store_alloc(N, dtype)
+        d.upload_state(dict(init, id_base=5))
+        extents = []
+        for step in range(bodies):
+            before = d.count
+            flags, row = oracle_body(st, dt, A_k, n_k, seed, step, planes, dtype=np_t)
+            o = d.step_fused_delete(dt, A_k, n_k, hip.RNG_PHILOX, seed, step, planes, lazy=True)
+            assert device_row(o) == row, (step, device_row(o), row)
+            extents.append(d.slots)
+            assert d.count == row[0] and d.slots >= d.count
+            assert np.array_equal(d.last_delete_flags(before), flags), step
+            assert d.slots == extents[-1]                                     # looking at the flags moved nothing
+            if step in (3, bodies - 1):
+                assert_state(d, st, hip, (step, "download"))
+                assert d.slots == d.count                                     # ... a download compacts
+        if pdel < 0.1:      # nothing was compacted by the path itself for more than 8 bodies: the pending moves were flushed
+            assert extents[4:13] == [extents[4]] * 9 and extents[4] > d.count
+        elif pdel < 0.5:
+            assert extents[0] == N and extents[1] == N and extents[2] < N    # the third body starts below 50 % and compacts
+        else:
+            assert extents[0] == N and extents[1] < N                         # the second body already does
+
+
+def test_alive_mask_chain_without_looking_equals_chain_with_looking():
+    """Same bodies on two stores: one is downloaded after every body (dense every time), the other never until the end.
+    Rows and final state must agree bit for bit; so must a third store on the round-2 pipeline (PCL_ALIVE=0)."""
+    code = r"""
+import json, os, sys
+import numpy as np
+from physicl_amd import _hip as hip
+N, look = 400_000, sys.argv[1] == "look"
+d = hip.Device(0); d.store_alloc(N); d.fill_photons(N, 1000, 299792458.0, 1.0, 2.0, 9)
+rows = []
+for step in range(12):
+    o = d.step_fused_delete(1e-3, 1e-3, 0.8e-3, hip.RNG_PHILOX, 9, step, [[1.0e6, np.nan, np.nan]], lazy=True)
+    rows.append([o["N"], o["removed"]] + [int(x) for x in o["sign"]] + [int(x) for x in o["planes"]])
+    if look:
+        d.download(hip.R0, 3)
+s = d.download_state()
+import hashlib
+h = hashlib.sha256()
+for f in ("r", "v", "dr", "dv"):
+    for k in range(3):
+        h.update(np.ascontiguousarray(s[f][k]).tobytes())
+h.update(s["E"].tobytes()); h.update(s["id"].tobytes())
+print("RESULT", json.dumps({"rows": rows, "sha": h.hexdigest(), "n": int(len(s["id"]))}))
+"""
+    outs = []
+    for arg, env in (("look", {}), ("blind", {}), ("blind", {"PCL_ALIVE": "0"}), ("blind", {"PCL_ALIVE_RATIO": "0.9", "PCL_ALIVE_MIN_SLOTS": "0"})):
+        out = subprocess.check_output([sys.executable, "-c", code, arg], cwd=ROOT, env=dict(os.environ, **env), timeout=600).decode()
+        outs.append(out[out.index("RESULT") + 7:].strip())
+    assert outs[0] == outs[1] == outs[2] == outs[3]
+    assert '"n": 0' not in outs[0]
+
+
+def test_alive_mask_interleaved_with_scatter_steps_and_multi_launches():
+    """A delete body leaves the store behind its mask; a scatter step, a K-step launch or a K-body delete launch that
+    follows must see the dense store (ids explicit from then on), and a delete body after THEM starts fresh."""
+    from physicl_amd import _hip as hip
+    N = 150_000
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=6.62607015e-34, rng_mode=hip.RNG_PHILOX, seed=4)
+    results = []
+    for env_alive in ("1", "0"):
+        code_rows = []
+        # (same process for both: PCL_ALIVE is read once, so the comparison run uses explicit downloads to force density)
+        with hip.Device(0) as d:
+            d.store_alloc(N)
+            d.fill_photons(N, 0, C_LIT, 1.0, 1.0, 4)
+            for step in range(0, 12, 4):
+                o = d.step_fused_delete(1e-3, 1e-3, 0.5e-3, hip.RNG_PHILOX, 4, step, [], lazy=True)
+                if env_alive == "0":
+                    d.download(hip.R0, 1)
+                code_rows.append((o["N"], o["removed"], tuple(o["sign"])))
+                assert not d.is_uniform()
+                o = d.step_fused(1e-3, dict(sc, step=step + 1), (), lazy=True)
+                code_rows.append((o["N"], o["hits"], tuple(o["sign"])))
+                o = d.step_fused_delete(1e-3, 1e-3, 0.5e-3, hip.RNG_PHILOX, 4, step + 2, [], lazy=True)
+                if env_alive == "0":
+                    d.download(hip.R0, 1)
+                code_rows.append((o["N"], o["removed"], tuple(o["sign"])))
+                for o in d.step_fused_delete_multi(1e-3, 2, 1e-3, 0.3e-3, 4, step + 3, []):
+                    code_rows.append((o["N"], o["removed"], tuple(o["sign"])))
+            s = d.download_state()
+        results.append((code_rows, s))
+    (ra, sa), (rb, sb) = results
+    assert ra == rb and len(sa["id"]) == len(sb["id"]) > 0
+    assert np.array_equal(sa["id"], sb["id"])
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(sa[f][k], sb[f][k]), (f, k)
+
+
+@pytest.mark.parametrize("env", [{"PCL_ALIVE_MIN_SLOTS": "0"}, {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}, {"PCL_ALIVE": "0"}])
+def test_the_delete_tests_of_the_suite_under_other_compaction_rules(env):
+    """The suite's stores are mostly below 65536 slots, where the alive path never compacts by itself.  Run the tests
+    that delete again with compaction allowed at any size (ratio 0.5 and 0.95: nearly every body compacts), and with
+    the alive path off (the round-2 pipeline must still be right)."""
+    if os.environ.get("PCL_ALIVE_RERUN"):
+        pytest.skip("already inside the re-run")
+    files = ["tests/test_gpu_parity.py", "tests/test_gpu_multi.py", "tests/test_gpu_mixed.py", "tests/test_gpu_simulation.py",
+             "tests/test_gpu_random_programs.py", "tests/test_gpu_fp32.py"]
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "delete or random or mixed or program", *files],
+                       cwd=ROOT, env=dict(os.environ, PCL_ALIVE_RERUN="1", **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert " passed" in p.stdout
