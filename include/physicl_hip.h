@@ -231,6 +231,10 @@ int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, n
  * count when it is dense); *pending_moves_out (may be NULL) = Newton moves r has not been given yet.  Every other entry
  * point sees the dense store: it is compacted first, survivors in order, r up to date.                               */
 int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
+/* Allocate now what the first compaction of the store would allocate on demand (the second slab -- chosen among a few
+ * candidates like the first, tens of ms for a big store --, the id arrays, the mask scratch), so that a run whose step
+ * list holds a delete step pays for it at set-up and not inside its third loop body.  Optional.                        */
+int pcl_store_reserve_compaction(pcl_ctx *ctx);
 
 /* Set the particle count (<= capacity) and declare a new population: ids = id_base + index (no id array is read) and
  * every particle a photon (a kind array of an earlier upload is dropped) until pcl_store_upload_ids / _kind. */

@@ -87,6 +87,7 @@ _PROTOTYPES = {
     "pcl_store_count": [_vp, POINTER(c_int64)],
     "pcl_store_set_count": [_vp, c_int64, c_int64],
     "pcl_store_slots": [_vp, POINTER(c_int64), POINTER(c_int)],
+    "pcl_store_reserve_compaction": [_vp],
     "pcl_store_upload": [_vp, c_int, _vp, c_int64, c_int64],
     "pcl_store_download": [_vp, c_int, _vp, c_int64, c_int64],
     "pcl_store_upload_ids": [_vp, _vp, c_int64, c_int64],
@@ -383,6 +384,10 @@ class Device:
         v = c_int64()
         check(self.lib.pcl_store_slots(self.ctx, byref(v), None))
         return v.value
+
+    def reserve_compaction(self):
+        """Allocate the second slab, id arrays and mask scratch of the delete path now (pcl_store_reserve_compaction)."""
+        check(self.lib.pcl_store_reserve_compaction(self.ctx))
 
     def set_count(self, count, id_base=0):
         check(self.lib.pcl_store_set_count(self.ctx, int(count), int(id_base)))

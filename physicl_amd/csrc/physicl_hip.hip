@@ -4678,6 +4678,13 @@ int pcl_store_count(pcl_ctx *ctx, int64_t *count_out) {
     return PCL_OK;
 }
 
+int pcl_store_reserve_compaction(pcl_ctx *ctx) {
+    PCL_TRY(need_store_raw(ctx));
+    if (ctx->holes) return PCL_OK; // (only a store that has already deleted is behind a mask: everything exists)
+    PCL_TRY(ensure_scratch(ctx, ctx->capacity));
+    return ensure_alt(ctx);
+}
+
 int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out) {
     if (!ctx || !slots_out) return fail(PCL_ERR_ARG, "NULL argument");
     *slots_out = ctx->holes ? ctx->slots : ctx->count;
