@@ -676,134 +676,146 @@ template <typename T, bool NEED_R>
 __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
     typedef pcl_rt<T> R;
     typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
-    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES]; // [0] alive, [1..3] sign, [4..] planes
+    __shared__ uint32_t s_cnt[4 + PCL_MAX_PLANES]; // [0] alive, [1..3] sign, [4..] planes: sums over the workgroup's tiles
+    __shared__ uint32_t s_keep[2][kBlock / 64];    // alive per wave of the current tile (two buffers: one barrier per tile)
     __shared__ int s_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t tile = blockIdx.x;
     if (threadIdx.x < 4 + PCL_MAX_PLANES) s_cnt[threadIdx.x] = 0;
-    if (!a.count && tile == 0 && (int)threadIdx.x < a.n_zero) a.zero_cnt[threadIdx.x] = 0;
+    if (!a.count && blockIdx.x == 0 && (int)threadIdx.x < a.n_zero) a.zero_cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t kept = 0, w_s[3] = {0, 0, 0};
+    uint32_t kept_all = 0, w_s[3] = {0, 0, 0};
     const bool hi = lane >= 32;
     const int bit = 2 * (lane & 31);
+    const int64_t n_tiles = (a.slots + kTile - 1) / kTile;
+    int par = 0;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+        uint32_t kept = 0;
 #pragma unroll 2
-    for (int pp = 0; pp < kTileRows / 8; ++pp) {
-        const int row = (wave * (kTileRows / 8) + pp) * 2;
-        const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
-        uint64_t m_lo, m_hi;
-        if (a.fresh) {
-            const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64); // slots from the row pair's start
-            m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
-            m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
-        } else {
-            m_lo = a.masks[tile * kTileRows + row];
-            m_hi = a.masks[tile * kTileRows + row + 1];
-        }
-        if (lane == 0) {
-            a.masks_prev[tile * kTileRows + row] = m_lo;
-            a.masks_prev[tile * kTileRows + row + 1] = m_hi;
-        }
-        if ((m_lo | m_hi) == 0ull) { // nobody left in these 128 slots (wave-uniform)
-            if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
-            continue;
-        }
-        const uint64_t mm = hi ? m_hi : m_lo;
-        const bool al0 = (mm >> bit) & 1ull, al1 = (mm >> (bit + 1)) & 1ull;
-        bool keep0 = false, keep1 = false;
-        T vv[3][2], xx[3][2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) vv[k][0] = vv[k][1] = xx[k][0] = xx[k][1] = (T)0;
-        if (al0 || al1) {
-            const int64_t ti = pcl_tix(i, a.ts); // whole tiles exist in the slab: the pair is readable whatever the extent
-            uint64_t id[2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
-                vv[k][0] = q.x, vv[k][1] = q.y;
-            }
-            if (a.ids) { // dense array padded to whole 64-element groups; i is even and below the extent
-                const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + i);
-                id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+        for (int pp = 0; pp < kTileRows / 8; ++pp) {
+            const int row = (wave * (kTileRows / 8) + pp) * 2;
+            const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
+            uint64_t m_lo, m_hi;
+            if (a.fresh) {
+                const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64); // slots from the row pair's start
+                m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+                m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
             } else {
-                id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                m_lo = a.masks[tile * kTileRows + row];
+                m_hi = a.masks[tile * kTileRows + row + 1];
             }
-            if constexpr (NEED_R) {
+            if (lane == 0) {
+                a.masks_prev[tile * kTileRows + row] = m_lo;
+                a.masks_prev[tile * kTileRows + row + 1] = m_hi;
+            }
+            if ((m_lo | m_hi) == 0ull) { // nobody left in these 128 slots (wave-uniform)
+                if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
+                continue;
+            }
+            const uint64_t mm = hi ? m_hi : m_lo;
+            const bool al0 = (mm >> bit) & 1ull, al1 = (mm >> (bit + 1)) & 1ull;
+            bool keep0 = false, keep1 = false;
+            T vv[3][2], xx[3][2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vv[k][0] = vv[k][1] = xx[k][0] = xx[k][1] = (T)0;
+            if (al0 || al1) {
+                const int64_t ti = pcl_tix(i, a.ts); // whole tiles exist in the slab: the pair is readable whatever the extent
+                uint64_t id[2];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
-                    xx[k][0] = q.x, xx[k][1] = q.y;
+                    const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+                    vv[k][0] = q.x, vv[k][1] = q.y;
                 }
-            }
-            bool kp[2];
+                if (a.ids) { // dense array padded to whole 64-element groups; i is even and below the extent
+                    const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + i);
+                    id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+                } else {
+                    id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                }
+                if constexpr (NEED_R) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const T d0 = R::mul(vv[0][e], a.dt), d1 = R::mul(vv[1][e], a.dt), d2 = R::mul(vv[2][e], a.dt); // newton.py:15
-                const T pcoll = R::mul(a.An, pcl_step_norm<T>(d0, d1, d2));                                        // light.py:241-247
-                const T rand = pcl_draw_rand<T>(id[e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                kp[e] = !(pcoll >= rand);
-                if constexpr (NEED_R) { // r as the reference holds it after this body's move: earlier bodies' moves first
-                    for (int q = 0; q < a.n_pend; ++q) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                    for (int k = 0; k < 3; ++k) {
+                        const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+                        xx[k][0] = q.x, xx[k][1] = q.y;
                     }
-                    xx[0][e] = R::add(xx[0][e], d0);                                                              // newton.py:16
-                    xx[1][e] = R::add(xx[1][e], d1);
-                    xx[2][e] = R::add(xx[2][e], d2);
                 }
-            }
-            keep0 = al0 && kp[0];
-            keep1 = al1 && kp[1];
-        }
-        const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
-        if (lane == 0) {
-            a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
-            a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
-        }
-        kept += (uint32_t)(__popcll(b0) + __popcll(b1));
-        if (a.count && a.n_planes >= 0) { // wave-uniform
+                bool kp[2];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)                                                                          // light.py:424-426
-                w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[k][1] > (T)0));
-            if constexpr (NEED_R) {
-                for (int p = 0; p < a.n_planes; ++p) {                                                           // light.py:385-399
-                    const int ax = a.plane_ax[p];
-                    const T L = a.plane_L[p];
-                    uint32_t np = 0;
+                for (int e = 0; e < 2; ++e) {
+                    const T d0 = R::mul(vv[0][e], a.dt), d1 = R::mul(vv[1][e], a.dt), d2 = R::mul(vv[2][e], a.dt); // newton.py:15
+                    const T pcoll = R::mul(a.An, pcl_step_norm<T>(d0, d1, d2));                                        // light.py:241-247
+                    const T rand = pcl_draw_rand<T>(id[e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                    kp[e] = !(pcoll >= rand);
+                    if constexpr (NEED_R) { // r as the reference holds it after this body's move: earlier bodies' moves first
+                        for (int q = 0; q < a.n_pend; ++q) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
-                        const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[0][e], vv[1][e], vv[2][e]), a.dt));
-                        np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                            for (int k = 0; k < 3; ++k) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                        }
+                        xx[0][e] = R::add(xx[0][e], d0);                                                              // newton.py:16
+                        xx[1][e] = R::add(xx[1][e], d1);
+                        xx[2][e] = R::add(xx[2][e], d2);
                     }
-                    if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+                }
+                keep0 = al0 && kp[0];
+                keep1 = al1 && kp[1];
+            }
+            const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+            if (lane == 0) {
+                a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+                a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+            }
+            kept += (uint32_t)(__popcll(b0) + __popcll(b1));
+            if (a.count && a.n_planes >= 0) { // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 3; ++k)                                                                          // light.py:424-426
+                    w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[k][1] > (T)0));
+                if constexpr (NEED_R) {
+                    for (int p = 0; p < a.n_planes; ++p) {                                                           // light.py:385-399
+                        const int ax = a.plane_ax[p];
+                        const T L = a.plane_L[p];
+                        uint32_t np = 0;
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
+                            const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[0][e], vv[1][e], vv[2][e]), a.dt));
+                            np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                        }
+                        if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
+                    }
                 }
             }
         }
+        kept_all += kept;
+        if (lane == 0) s_keep[par][wave] = kept;
+        __syncthreads();
+        if (threadIdx.x == 0) a.tile_keep[tile] = (int32_t)(s_keep[par][0] + s_keep[par][1] + s_keep[par][2] + s_keep[par][3]);
     }
+    if (!a.count) return;
     if (lane == 0) {
-        atomicAdd(&s_cnt[0], kept);
-        if (a.count && a.n_planes >= 0)
+        atomicAdd(&s_cnt[0], kept_all);
+        if (a.n_planes >= 0)
             for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) a.tile_keep[tile] = (int32_t)s_cnt[0];
-    if (!a.count) return;
     // grid totals: every workgroup adds its sums, the last one to arrive hands them to the host and leaves the
-    // accumulators zero for the next launch (device-scope atomics: the XCDs' L2s do not see each other's plain stores)
+    // accumulators zero for the next launch.  Agent-scope atomics only (they are coherent across the XCDs' L2s by
+    // themselves); NO fence: an agent-scope release would write the L2's dirty lines back once per workgroup.  The sums
+    // are in place before the ticket is drawn because the adds return (their data comes back before the barrier).
     const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
-    if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x]) atomicAdd(&a.acc[1 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    __threadfence();
+    unsigned long long seen = 0;
+    if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+        seen = __hip_atomic_fetch_add(&a.acc[1 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(seen) : "memory"); // the returned value is consumed: the add has been performed
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&a.acc[0], 1ull) == (unsigned long long)gridDim.x - 1ull;
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&a.acc[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if ((int)threadIdx.x < nslots) {
-        const unsigned long long v = atomicExch(&a.acc[1 + threadIdx.x], 0ull);
+        const unsigned long long v = __hip_atomic_exchange(&a.acc[1 + threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) a.host[kCounterSlots - 1] = v;
         else a.host[threadIdx.x] = v;
     }
-    if (threadIdx.x == 0) atomicExch(&a.acc[0], 0ull);
+    if (threadIdx.x == 0) __hip_atomic_exchange(&a.acc[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // the pending moves of an alive-mask store made real: r = (...((r + v*dt_1) + v*dt_2)...) for every slot of the extent
@@ -3783,12 +3795,21 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double d
     a.zero_cnt = ctx->d_cnt + 1;
     a.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
-    const int tiles = (int)div_up(slots, kTile);
+    // workgroups walk the tiles with the grid's stride: a workgroup's sums reach the grid totals with one atomic per
+    // counter, so the grid is kept at 16 workgroups per CU (PCL_ALIVE_WG_PER_CU), not one per tile
+    static const int wg_per_cu = [] {
+        const char *e = getenv("PCL_ALIVE_WG_PER_CU");
+        const int v = e ? atoi(e) : 16;
+        return v > 0 ? v : 16;
+    }();
+    int64_t grid = div_up(slots, kTile);
+    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * wg_per_cu;
+    if (grid > cap) grid = cap;
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     if (count && n_planes > 0)
-        hipLaunchKernelGGL((k_delete_alive<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_delete_alive<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_delete_alive<T, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_delete_alive<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     prof_end(ctx, ps);
     return launch_check("k_delete_alive");
 }
