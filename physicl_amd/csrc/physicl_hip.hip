@@ -665,6 +665,7 @@ struct alive_args {
     uint32_t step;
     uint64_t *zero_cnt;         // count == 0: counter slots the compaction behind this launch adds into, cleared here
     int n_zero;
+    uint64_t seq;               // count == 1: written to host[kCounterSlots - 6] after the totals -- the host polls for it
     int fresh;                  // 1: the store is dense -- every slot below ``slots`` is alive, masks are not read
     int count;                  // 1: measure counters + totals to the host (a body without compaction); 0: flags only
     int n_planes;
@@ -690,7 +691,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
     int par = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
         uint32_t kept = 0;
-#pragma unroll 2
+#pragma unroll
         for (int pp = 0; pp < kTileRows / 8; ++pp) {
             const int row = (wave * (kTileRows / 8) + pp) * 2;
             const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
@@ -812,10 +813,18 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
     if (!s_last) return;
     if ((int)threadIdx.x < nslots) {
         const unsigned long long v = __hip_atomic_exchange(&a.acc[1 + threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (threadIdx.x == 0) a.host[kCounterSlots - 1] = v;
-        else a.host[threadIdx.x] = v;
+        volatile uint64_t *h = a.host;
+        if (threadIdx.x == 0) h[kCounterSlots - 1] = v;
+        else h[threadIdx.x] = v;
+        __threadfence_system(); // (once per launch, by the last workgroup's first wave: the totals are in host memory ...
     }
-    if (threadIdx.x == 0) __hip_atomic_exchange(&a.acc[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_exchange(&a.acc[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ... before the launch's sequence number, which the host is polling for: it learns the count a few microseconds
+        // after the last workgroup is done instead of waiting for the kernel's completion signal to travel)
+        __hip_atomic_store(&a.host[kCounterSlots - 6], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // the pending moves of an alive-mask store made real: r = (...((r + v*dt_1) + v*dt_2)...) for every slot of the extent
@@ -2132,6 +2141,7 @@ struct pcl_ctx {
     // count per tile; r lags pend_n moves behind.  Every entry point but pcl_step_fused_delete makes the store dense
     // again first (densify, through need_store / ensure_scratch).
     bool holes = false;
+    uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
     int64_t slots = 0;
     int pend_n = 0;
     double pend_dt[kPendMax] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2730,10 +2740,31 @@ int alloc_slab(pcl_ctx *ctx, void **out) {
     return PCL_OK;
 }
 
+// zero three rows (dv0..2) of every tile of a slab
+__global__ void __launch_bounds__(256) k_zero_rows3(double2 *r0, double2 *r1, double2 *r2, int64_t tiles, int64_t tile_pitch16, int row_len16) {
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x)
+        for (int q = threadIdx.x; q < row_len16; q += 256) {
+            r0[t * tile_pitch16 + q] = make_double2(0.0, 0.0);
+            r1[t * tile_pitch16 + q] = make_double2(0.0, 0.0);
+            r2[t * tile_pitch16 + q] = make_double2(0.0, 0.0);
+        }
+}
+
 int ensure_alt(pcl_ctx *ctx) {
     if (!ctx->slab_alt) {
         PCL_TRY(alloc_slab(ctx, &ctx->slab_alt));
         refresh_rows(ctx);
+        // The new slab's dv rows are zeroed once, here: a delete run never scatters, its dv is all +0.0, and a
+        // compaction whose destination is known to hold zeros does not move the dv rows at all (launch_compact_count:
+        // 24 of the 88 bytes a survivor costs, and 24 bytes per SLOT of reads) -- from the FIRST compaction on.
+        const int64_t tile_pitch16 = (int64_t)(kRows * row_pitch_bytes(ctx) / 16);
+        const int row_len16 = (int)(kTileT * ctx->esz / 16);
+        const int grid = (int)(ctx->tiles < 4096 ? ctx->tiles : 4096);
+        hipLaunchKernelGGL(k_zero_rows3, dim3(grid), dim3(256), 0, ctx->stream, static_cast<double2 *>(ctx->field_alt[PCL_DV0]),
+                           static_cast<double2 *>(ctx->field_alt[PCL_DV1]), static_cast<double2 *>(ctx->field_alt[PCL_DV2]), ctx->tiles,
+                           tile_pitch16, row_len16);
+        PCL_TRY(launch_check("k_zero_rows3"));
+        ctx->alt_dv_zero_n = ctx->tiles * kTileT;
     }
     if (!ctx->ids) PCL_TRY(dev_alloc(&ctx->ids, ctx->capacity));
     if (!ctx->ids_alt) PCL_TRY(dev_alloc(&ctx->ids_alt, ctx->capacity));
@@ -3792,15 +3823,16 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double d
     a.fresh = fresh ? 1 : 0;
     a.count = count ? 1 : 0;
     a.n_planes = n_planes;
+    a.seq = count ? ++ctx->alive_seq : 0;
     a.zero_cnt = ctx->d_cnt + 1;
     a.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
     // workgroups walk the tiles with the grid's stride: a workgroup's sums reach the grid totals with one atomic per
-    // counter, so the grid is kept at 16 workgroups per CU (PCL_ALIVE_WG_PER_CU), not one per tile
+    // counter, so the grid is capped at 64 workgroups per CU (PCL_ALIVE_WG_PER_CU; measured: 8, 16, 64 within 3 %), not one per tile
     static const int wg_per_cu = [] {
         const char *e = getenv("PCL_ALIVE_WG_PER_CU");
-        const int v = e ? atoi(e) : 16;
-        return v > 0 ? v : 16;
+        const int v = e ? atoi(e) : 64;
+        return v > 0 ? v : 64;
     }();
     int64_t grid = div_up(slots, kTile);
     const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * wg_per_cu;
@@ -3828,6 +3860,38 @@ int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const doubl
     for (int q = 0; q < ctx->pend_n; ++q) cc.pend_dt[q] = (T)ctx->pend_dt[q];
     plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
     return launch_compact_count<T>(ctx, false, dv_mode, cc);
+}
+
+// The host side of k_delete_alive's report: poll the pinned block for the launch's sequence number (written after the
+// totals, system-scope release) instead of waiting for the stream -- a loop body of a small store is a 5 us kernel, and
+// the completion signal's way to a blocked host thread takes longer than that.  The stream is asked now and then, so a
+// failed launch ends the wait with its error (PCL_ALIVE_POLL=0: hipStreamSynchronize).
+int wait_alive(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
+    static const bool poll = [] {
+        const char *e = getenv("PCL_ALIVE_POLL");
+        return !(e && e[0] == '0');
+    }();
+    volatile uint64_t *seq = ctx->h_cnt + kCounterSlots - 6;
+    if (!poll) {
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        if (*seq != ctx->alive_seq) return fail(PCL_ERR_HIP, "k_delete_alive did not report");
+    } else {
+        for (uint64_t spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != ctx->alive_seq; ++spins) {
+            if ((spins & 0x3FFF) == 0) {
+                const hipError_t e = hipStreamQuery(ctx->stream);
+                if (e == hipSuccess) { // the kernel is over: its report must be there
+                    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != ctx->alive_seq) return fail(PCL_ERR_HIP, "k_delete_alive did not report");
+                    break;
+                }
+                if (e != hipErrorNotReady) return fail(PCL_ERR_HIP, "k_delete_alive failed: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
+    if (alive < 0 || alive > before)
+        return fail(PCL_ERR_HIP, "the alive mask holds an impossible count %lld of %lld", (long long)alive, (long long)before);
+    *alive_out = alive;
+    return PCL_OK;
 }
 
 void drop_holes(pcl_ctx *ctx) {
@@ -3884,8 +3948,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         ctx->slots = slots; // (apply_pending above ran on the old extent, which is this one)
         PCL_TRY(PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes),
                              delete_alive_t<float>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes)));
-        PCL_HIP(hipEventRecord(ctx->ev_count, ctx->stream));
-        PCL_TRY(wait_count(ctx, before, &alive)); // the last workgroup wrote the totals into the pinned block
+        PCL_TRY(wait_alive(ctx, before, &alive)); // the last workgroup wrote the totals into the pinned block
         ctx->holes = true;
         ctx->slots = slots;
         ctx->pend_dt[ctx->pend_n++] = dt;
