@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
 __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ tile_keep, int64_t n_tiles,
                                                     int64_t *__restrict__ tile_off, int64_t *__restrict__ total,
                                                     int64_t n_particles, int *__restrict__ choice,
-                                                    int64_t *__restrict__ total_host /* pinned, device-visible */) {
+                                                    int64_t *__restrict__ total_host /* pinned, device-visible */, int lds_min_pct) {
     __shared__ int64_t s_wave[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int64_t per = div_up(n_tiles, 1024);
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     if (t == 1023) {
         *total = s_wave[15];
         *total_host = s_wave[15]; // straight into the host's pinned mirror: no copy to enqueue, the event below publishes it
-        *choice = (n_particles >= (int64_t)1 << 22 && s_wave[15] * 20 > n_particles * 7) ? 1 : 0; // > 35 % survive
+        *choice = (n_particles >= (int64_t)1 << 22 && s_wave[15] * 100 > n_particles * lds_min_pct) ? 1 : 0; // > 35 % survive
     }
 }
 
@@ -691,96 +691,103 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
     int par = 0;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
         uint32_t kept = 0;
+        // two row pairs (256 slots) per trip: their loads are issued together, unconditionally -- whole tiles exist in
+        // the slab whatever the extent, and a dead lane's share of a sector is fetched anyway -- so that a wave has
+        // 2 x (3 [+ 3] + 1) 16-byte loads in flight instead of one row pair's
+#pragma unroll 1
+        for (int pp = 0; pp < kTileRows / 8; pp += 2) {
+            uint64_t m_lo[2], m_hi[2];
+            T vv[2][3][2], xx[2][3][2];
+            uint64_t id[2][2];
 #pragma unroll
-        for (int pp = 0; pp < kTileRows / 8; ++pp) {
-            const int row = (wave * (kTileRows / 8) + pp) * 2;
-            const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
-            uint64_t m_lo, m_hi;
-            if (a.fresh) {
-                const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64); // slots from the row pair's start
-                m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
-                m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
-            } else {
-                m_lo = a.masks[tile * kTileRows + row];
-                m_hi = a.masks[tile * kTileRows + row + 1];
-            }
-            if (lane == 0) {
-                a.masks_prev[tile * kTileRows + row] = m_lo;
-                a.masks_prev[tile * kTileRows + row + 1] = m_hi;
-            }
-            if ((m_lo | m_hi) == 0ull) { // nobody left in these 128 slots (wave-uniform)
-                if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
-                continue;
-            }
-            const uint64_t mm = hi ? m_hi : m_lo;
-            const bool al0 = (mm >> bit) & 1ull, al1 = (mm >> (bit + 1)) & 1ull;
-            bool keep0 = false, keep1 = false;
-            T vv[3][2], xx[3][2];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) vv[k][0] = vv[k][1] = xx[k][0] = xx[k][1] = (T)0;
-            if (al0 || al1) {
-                const int64_t ti = pcl_tix(i, a.ts); // whole tiles exist in the slab: the pair is readable whatever the extent
-                uint64_t id[2];
+            for (int u = 0; u < 2; ++u) {
+                const int row = (wave * (kTileRows / 8) + pp + u) * 2;
+                const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
+                if (a.fresh) {
+                    const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64); // slots from the row pair's start
+                    m_lo[u] = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+                    m_hi[u] = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
+                } else {
+                    m_lo[u] = a.masks[tile * kTileRows + row];
+                    m_hi[u] = a.masks[tile * kTileRows + row + 1];
+                }
+                const int64_t ti = pcl_tix(i, a.ts);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
-                    vv[k][0] = q.x, vv[k][1] = q.y;
-                }
-                if (a.ids) { // dense array padded to whole 64-element groups; i is even and below the extent
-                    const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + i);
-                    id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
-                } else {
-                    id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                    vv[u][k][0] = q.x, vv[u][k][1] = q.y;
                 }
                 if constexpr (NEED_R) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
-                        xx[k][0] = q.x, xx[k][1] = q.y;
+                        xx[u][k][0] = q.x, xx[u][k][1] = q.y;
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) xx[u][k][0] = xx[u][k][1] = (T)0;
                 }
+                if (a.ids) { // dense array of ``capacity`` ids padded to whole 64-element groups: pairs beyond the extent read pair 0
+                    const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + (i < a.slots ? i : 0));
+                    id[u][0] = (uint64_t)q.x, id[u][1] = (uint64_t)q.y;
+                } else {
+                    id[u][0] = (uint64_t)(a.id_base + i), id[u][1] = id[u][0] + 1;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int row = (wave * (kTileRows / 8) + pp + u) * 2;
+                if (lane == 0) {
+                    a.masks_prev[tile * kTileRows + row] = m_lo[u];
+                    a.masks_prev[tile * kTileRows + row + 1] = m_hi[u];
+                }
+                if ((m_lo[u] | m_hi[u]) == 0ull) { // nobody left in these 128 slots (wave-uniform)
+                    if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
+                    continue;
+                }
+                const uint64_t mm = hi ? m_hi[u] : m_lo[u];
+                const bool al0 = (mm >> bit) & 1ull, al1 = (mm >> (bit + 1)) & 1ull;
                 bool kp[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const T d0 = R::mul(vv[0][e], a.dt), d1 = R::mul(vv[1][e], a.dt), d2 = R::mul(vv[2][e], a.dt); // newton.py:15
-                    const T pcoll = R::mul(a.An, pcl_step_norm<T>(d0, d1, d2));                                        // light.py:241-247
-                    const T rand = pcl_draw_rand<T>(id[e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                    const T d0 = R::mul(vv[u][0][e], a.dt), d1 = R::mul(vv[u][1][e], a.dt), d2 = R::mul(vv[u][2][e], a.dt); // newton.py:15
+                    const T pcoll = R::mul(a.An, pcl_step_norm<T>(d0, d1, d2));                                                // light.py:241-247
+                    const T rand = pcl_draw_rand<T>(id[u][e], a.step, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
                     kp[e] = !(pcoll >= rand);
                     if constexpr (NEED_R) { // r as the reference holds it after this body's move: earlier bodies' moves first
                         for (int q = 0; q < a.n_pend; ++q) {
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                            for (int k = 0; k < 3; ++k) xx[u][k][e] = R::add(xx[u][k][e], R::mul(vv[u][k][e], a.pend_dt[q]));
                         }
-                        xx[0][e] = R::add(xx[0][e], d0);                                                              // newton.py:16
-                        xx[1][e] = R::add(xx[1][e], d1);
-                        xx[2][e] = R::add(xx[2][e], d2);
+                        xx[u][0][e] = R::add(xx[u][0][e], d0);                                                                // newton.py:16
+                        xx[u][1][e] = R::add(xx[u][1][e], d1);
+                        xx[u][2][e] = R::add(xx[u][2][e], d2);
                     }
                 }
-                keep0 = al0 && kp[0];
-                keep1 = al1 && kp[1];
-            }
-            const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
-            if (lane == 0) {
-                a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
-                a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
-            }
-            kept += (uint32_t)(__popcll(b0) + __popcll(b1));
-            if (a.count && a.n_planes >= 0) { // wave-uniform
+                const bool keep0 = al0 && kp[0], keep1 = al1 && kp[1];
+                const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+                if (lane == 0) {
+                    a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+                    a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+                }
+                kept += (uint32_t)(__popcll(b0) + __popcll(b1));
+                if (a.count && a.n_planes >= 0) { // wave-uniform
 #pragma unroll
-                for (int k = 0; k < 3; ++k)                                                                          // light.py:424-426
-                    w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[k][1] > (T)0));
-                if constexpr (NEED_R) {
-                    for (int p = 0; p < a.n_planes; ++p) {                                                           // light.py:385-399
-                        const int ax = a.plane_ax[p];
-                        const T L = a.plane_L[p];
-                        uint32_t np = 0;
+                    for (int k = 0; k < 3; ++k)                                                                              // light.py:424-426
+                        w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[u][k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[u][k][1] > (T)0));
+                    if constexpr (NEED_R) {
+                        for (int p = 0; p < a.n_planes; ++p) {                                                               // light.py:385-399
+                            const int ax = a.plane_ax[p];
+                            const T L = a.plane_L[p];
+                            uint32_t np = 0;
 #pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
-                            const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[0][e], vv[1][e], vv[2][e]), a.dt));
-                            np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                            for (int e = 0; e < 2; ++e) {
+                                const T x = pcl_pick<T>(ax, xx[u][0][e], xx[u][1][e], xx[u][2][e]);
+                                const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[u][0][e], vv[u][1][e], vv[u][2][e]), a.dt));
+                                np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                            }
+                            if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
                         }
-                        if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
                     }
                 }
             }
@@ -3307,10 +3314,14 @@ int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const ch
 // run pass 2 of the compaction pipeline on tile_keep already produced for n particles
 int scan_tiles(pcl_ctx *ctx, int64_t n) {
     const int64_t tiles = div_up(n, kTile);
+    static const int lds_min_pct = [] { // perf-experiment hook: survivor percentage above which pass 3 is k_compact_lds
+        const char *e = getenv("PCL_COMPACT_LDS_MIN_PCT");
+        return e ? atoi(e) : 15; // (round 2: 35; re-measured with the alive path, whose compactions start at 34 % survivors)
+    }();
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
                        reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1), n,
                        reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 2),
-                       reinterpret_cast<int64_t *>(ctx->h_cnt + kCounterSlots - 1));
+                       reinterpret_cast<int64_t *>(ctx->h_cnt + kCounterSlots - 1), lds_min_pct);
     PCL_TRY(launch_check("k_tile_scan"));
     // the host needs the survivor count (next launch geometry, exit tests), not the end of the compaction that follows:
     // it waits for this event and prepares the next step while pass 3 is still moving the survivors
@@ -3827,16 +3838,17 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double d
     a.zero_cnt = ctx->d_cnt + 1;
     a.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
-    // workgroups walk the tiles with the grid's stride: a workgroup's sums reach the grid totals with one atomic per
-    // counter, so the grid is capped at 64 workgroups per CU (PCL_ALIVE_WG_PER_CU; measured: 8, 16, 64 within 3 %), not one per tile
+    // A workgroup's sums reach the grid totals with one atomic per counter, so the grid is capped (64 workgroups per
+    // CU, PCL_ALIVE_WG_PER_CU) and workgroups walk the tiles with the grid's stride -- every one of them the SAME number
+    // of tiles (k = ceil(tiles / cap), grid = ceil(tiles / k)): a grid just below the tile count leaves a second, nearly
+    // empty round (measured at 16761 tiles: 500 us with 16384 workgroups, 390 us with 4096).
     static const int wg_per_cu = [] {
         const char *e = getenv("PCL_ALIVE_WG_PER_CU");
         const int v = e ? atoi(e) : 64;
         return v > 0 ? v : 64;
     }();
-    int64_t grid = div_up(slots, kTile);
-    const int64_t cap = (int64_t)ctx->prop.multiProcessorCount * wg_per_cu;
-    if (grid > cap) grid = cap;
+    const int64_t n_tiles = div_up(slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * wg_per_cu;
+    const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
     if (count && n_planes > 0)
         hipLaunchKernelGGL((k_delete_alive<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
