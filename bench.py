@@ -461,7 +461,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     counter, r (24) of every slot, the id (8) once ids are explicit, and reads + writes the alive bit; the compaction
     reads a bit per slot and moves r, v, E, id of the survivors (64 B each way; dv, all +0.0 in a run that never
     scatters, travels in the first compaction only)."""
-    plane = [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]          # test/test_light.py:58
+    plane = np.array([[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])          # test/test_light.py:58
     dt, A, n = 1e-3, 1e-3, 1e-3
     out = {"workload": "BASELINE configs[1](ii): Newton + ScatterDelete(A=n=1e-3) + plane counter until empty, E = 1, "
                        "v = (c,0,0), dt = 1e-3, Philox", "repeats": repeats, "sizes": {}}

@@ -602,14 +602,17 @@ class Device:
         if planes is None:
             npl, pp = -1, None
         else:
-            pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+            # (a loop calls this once per body with the same planes: a ready float64 array is taken as it is)
+            pl = planes if (type(planes) is np.ndarray and planes.dtype == np.float64 and planes.ndim == 2 and
+                            planes.flags.c_contiguous) else np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
             npl = len(pl)
-            pp = pl.ctypes.data_as(c_void_p) if npl else None
+            pp = pl.ctypes.data if npl else None
         k = max(npl, 0)
         out = np.zeros(5 + k, dtype=np.int64)
-        check(self.lib.pcl_step_fused_delete(self.ctx, float(dt), float(A), float(n), FUSED_LAZY if lazy else 0,
-                                             int(rng_mode), int(seed), int(step) & 0xFFFFFFFF, pp, npl,
-                                             out.ctypes.data_as(c_void_p)))
+        rc = self.lib.pcl_step_fused_delete(self.ctx, float(dt), float(A), float(n), FUSED_LAZY if lazy else 0,
+                                            int(rng_mode), int(seed), int(step) & 0xFFFFFFFF, pp, npl, out.ctypes.data)
+        if rc != 0:
+            check(rc)
         return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + k].copy(), "removed": int(out[4 + k])}
 
     def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None):

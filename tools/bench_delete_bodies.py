@@ -26,7 +26,7 @@ def main():
     N = int(a.photons)
     dev = _hip.Device(0)
     dev.store_alloc(N)
-    plane = [] if a.no_plane else [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]]
+    plane = np.zeros((0, 3)) if a.no_plane else np.array([[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])
     for rep in range(a.reps + 1):
         dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, 1234)
         dev.prof_enable(True)
