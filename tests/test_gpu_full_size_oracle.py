@@ -1,0 +1,137 @@
+"""GPU: BASELINE.json's FULL sizes against the ORACLE -- not against another device kernel.
+
+Photons do not interact and the device RNG is keyed by the photon's id, so what happens to the photons of any id window
+can be computed by the CPU oracle alone, whatever the store's size.  Each test runs a BASELINE configuration at its
+full size on the device, then downloads WINDOWS of the store -- at offset 0, across a tile boundary in the middle
+(tiles are 2048 photons; the slab's physical handles end on tile boundaries) and at the very end, where 64-bit element
+offsets, the ragged last tile and the last workgroups of the 64-per-CU grid are -- and compares them with the oracle's
+step-by-step chain on exactly those ids:
+
+* configs[2] (1e8 photons, variable-n + wavelength scatter, examples/variable_n_scattering.ipynb:30,52-56): 32 steps as
+  ONE k_multi pass and as 32 k_fast launches; hit decisions per photon exact, v within 4 ulp of c, r within the bound of
+  tests/test_gpu_bench_regime.py;
+* configs[1](ii) (Newton + ScatterDeleteStep until empty, test/test_light.py:52-59) at 1e7 and 1e8: one call per loop
+  body (the alive-mask path: bodies with and without compaction) and K bodies per launch; survivor ids and positions
+  bit-exact (IEEE mul / add only), measure rows equal between the two formulations.
+"""
+import numpy as np
+import pytest
+
+from oracle import physicl_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+C_LIT = 299792458.0
+H_LIT = 6.62607015e-34
+W = 4096
+
+
+def windows(N):
+    mid = (N // 2 // 2048) * 2048 - W // 2           # straddles a tile boundary
+    return [(0, W), (mid, W), (N - W, W)]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from physicl_amd import _hip
+    return _hip
+
+
+def test_config3_at_1e8_windows_vs_oracle(hip):
+    N, K, SEED, DT = 100_000_000, 32, 1234, 5e-3
+    EXPR, A_K, N_K = "0.000000001 * exp(r0[gid] - 5)", 1e-15, 1e-19          # bench.py PROFILES["example"]
+    e_lo, e_hi = H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9
+    sc = lambda k: dict(A=A_K, n=N_K, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=C_LIT, h=H_LIT,
+                        n_expr=EXPR, rng_mode=hip.RNG_PHILOX, seed=SEED, step=k)
+    wins = windows(N)
+    got = {}
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        for how in ("multi", "single"):
+            d.fill_photons(N, 0, C_LIT, e_lo, e_hi, SEED)
+            E = [d.download(hip.E, n, off) for off, n in wins]
+            if how == "multi":
+                rows = d.step_fused_multi(DT, K, sc(0))
+            else:
+                rows = [d.step_fused(DT, sc(k), [], lazy=True) for k in range(K)]
+            state = [{f: [d.download(fid, n, off) for fid in hip.FIELD_GROUPS[f]] for f in ("r", "v", "dr", "dv")} for off, n in wins]
+            got[how] = ([(o["hits"], tuple(int(x) for x in o["sign"])) for o in rows], state, E)
+    assert got["multi"][0] == got["single"][0]                               # the whole store's rows agree
+    ulp_c = float(np.spacing(C_LIT))
+    for w, (off, n) in enumerate(wins):
+        ids = np.arange(off, off + n, dtype=np.int64)
+        E = got["multi"][2][w]
+        want_E = orc.philox_energy(SEED, ids, e_lo, e_hi)
+        assert np.max(np.abs(E - want_E) / want_E) <= 4e-16
+        z = lambda: np.zeros(n)
+        st = {"r": [z(), z(), z()], "v": [np.full(n, C_LIT), z(), z()], "dr": [z(), z(), z()], "dv": [z(), z(), z()], "E": E.copy(), "id": ids}
+        hits_ref = np.zeros(n, dtype=np.int64)
+        for k in range(K):
+            orc.step_newton(st, DT)
+            hits_ref += orc.step_scatter_isotropic(st, orc.philox_draws(SEED, k, ids), A_K, N_K, C_LIT, h=H_LIT, use_E=True, n_expr=EXPR)
+        for how in ("multi", "single"):
+            s = got[how][1][w]
+            v, r = np.stack(s["v"], 1), np.stack(s["r"], 1)
+            v_ref, r_ref = np.stack(st["v"], 1), np.stack(st["r"], 1)
+            assert np.max(np.abs(v - v_ref)) <= 4 * ulp_c, (how, off)
+            slack = K * float(np.spacing(np.max(np.abs(r_ref))))
+            assert np.max(np.abs(r - r_ref)) <= K * DT * 4 * ulp_c + slack + 1e-12, (how, off)
+            # dr / dv of the last step, made real by the download: dr = v_before * dt, dv = v_after - v_before
+            assert np.max(np.abs(np.stack(s["dr"], 1) - np.stack(st["dr"], 1))) <= DT * 4 * ulp_c + 1e-12, (how, off)
+            assert np.max(np.abs(np.stack(s["dv"], 1) - np.stack(st["dv"], 1))) <= 8 * ulp_c, (how, off)
+        assert hits_ref.sum() > n                                             # the window did scatter (regime check)
+        for f in ("r", "v", "dr", "dv"):
+            for k in range(3):
+                assert np.array_equal(got["multi"][1][w][f][k], got["single"][1][w][f][k]), (off, f, k)
+
+
+def oracle_delete_windows(N, wins, bodies, dt, A, n, seed):
+    """The oracle's chain on the ids of the windows only: {window: (ids, r_x, r_y, r_z)} after ``bodies`` bodies."""
+    out = []
+    for off, cnt in wins:
+        ids = np.arange(off, off + cnt, dtype=np.int64)
+        z = lambda: np.zeros(cnt)
+        st = {"r": [z(), z(), z()], "v": [np.full(cnt, C_LIT), z(), z()], "dr": [z(), z(), z()], "dv": [z(), z(), z()], "E": np.ones(cnt), "id": ids}
+        for step in range(bodies):
+            orc.step_newton(st, dt)
+            orc.step_scatter_delete(st, orc.philox_draws(seed, step, st["id"])[2], A, n)
+        out.append(st)
+    return out
+
+
+@pytest.mark.parametrize("N", [10_000_000, 100_000_000])
+def test_config2_delete_at_full_size_windows_vs_oracle(hip, N):
+    dt, A, n, seed, bodies = 1e-3, 1e-3, 1e-3, 1234, 7            # 7 bodies: two compactions on the alive-mask path
+    plane = np.array([[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])      # test/test_light.py:58
+    wins = windows(N)
+    ref = oracle_delete_windows(N, wins, bodies, dt, A, n, seed)
+    rows = {}
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        for how in ("per_body", "multi"):
+            d.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
+            if how == "per_body":
+                extents = []
+                rows[how] = []
+                for step in range(bodies):
+                    o = d.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, step, plane, lazy=True)
+                    rows[how].append((o["N"], o["removed"], tuple(int(x) for x in o["sign"]), tuple(int(x) for x in o["planes"])))
+                    extents.append(d.slots)
+                assert extents[0] == N and extents[2] < N and extents[5] < extents[2] and d.slots > d.count    # holes, two compactions
+            else:
+                rows[how] = [(o["N"], o["removed"], tuple(int(x) for x in o["sign"]), tuple(int(x) for x in o["planes"]))
+                             for o in d.step_fused_delete_multi(dt, bodies, A, n, seed, 0, plane)]
+            ids = d.download_ids()
+            assert len(ids) == rows[how][-1][0] and np.all(np.diff(ids) > 0)       # stable: ascending ids
+            for (off, cnt), st in zip(wins, ref):
+                lo, hi = np.searchsorted(ids, off), np.searchsorted(ids, off + cnt)
+                assert np.array_equal(ids[lo:hi], st["id"]), (how, off)           # the very photons the oracle keeps
+                for k in range(3):
+                    assert np.array_equal(d.download(hip.R0 + k, hi - lo, lo), st["r"][k]), (how, off, k)
+                    assert np.array_equal(d.download(hip.V0 + k, hi - lo, lo), st["v"][k]), (how, off, k)
+                    assert np.array_equal(d.download(hip.DR0 + k, hi - lo, lo), st["dr"][k]), (how, off, k)
+                assert np.all(d.download(hip.E, hi - lo, lo) == 1.0)
+    assert rows["per_body"] == rows["multi"]
+    p = 1e-3 * 1e-3 * C_LIT * dt
+    assert abs(rows["multi"][0][1] - N * p) < 5 * np.sqrt(N * p * (1 - p))           # the expected removal rate
+    assert any(r[3][0] > 0 for r in rows["multi"])                                    # the plane was crossed (x = 1e6 after 4 moves)
