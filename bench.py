@@ -476,8 +476,8 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 dev.sync()
                 t0 = time.perf_counter()
                 work, per_step, k = 0, [], 0
-                while dev.count > 0 and k < 4096:
-                    nb = dev.count
+                nb = sb = N                                   # alive photons / slots of the store (dense after the fill)
+                while nb > 0 and k < 4096:
                     if mode == "multi":
                         for o in dev.step_fused_delete_multi(dt, K, A, n, seed, k, plane):
                             work += nb
@@ -485,10 +485,11 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                             nb = o["N"]
                         k += K
                     else:
-                        sb = dev.slots
                         o = dev.step_fused_delete(dt, A, n, hip.RNG_PHILOX, seed, k, plane, lazy=True)
                         work += nb
-                        per_step.append((nb, o["N"], sb, dev.slots))      # alive before / after, slots before / after
+                        sa = dev.slots
+                        per_step.append((nb, o["N"], sb, sa))             # alive before / after, slots before / after
+                        nb, sb = o["N"], sa
                         k += 1
                 dev.sync()
                 el = time.perf_counter() - t0

@@ -33,12 +33,16 @@ def main():
         dev.sync()
         t0 = time.perf_counter()
         bodies, work, k = [], 0, 0
-        while dev.count > 0:
-            nb, sb = dev.count, dev.slots
-            t1 = time.perf_counter()
+        nb = sb = N
+        t1 = time.perf_counter()
+        while nb > 0:
             o = dev.step_fused_delete(1e-3, 1e-3, 1e-3, _hip.RNG_PHILOX, 1234, k, plane, lazy=True)
-            bodies.append((nb, sb, o["N"], (time.perf_counter() - t1) * 1e6))
+            sa = dev.slots
+            t2 = time.perf_counter()
+            bodies.append((nb, sb, o["N"], (t2 - t1) * 1e6))
+            t1 = t2
             work += nb
+            nb, sb = o["N"], sa
             k += 1
         dev.sync()
         el = time.perf_counter() - t0
