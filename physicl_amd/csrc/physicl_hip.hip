@@ -649,7 +649,7 @@ constexpr int kPendMax = 8;
 template <typename T>
 struct alive_args {
     const T *v[3];
-    const T *r[3];              // NEED_R only
+    T *r[3];                    // NEED_R only; written back when write_r
     const int64_t *ids;         // NULL: id = id_base + slot
     uint64_t *masks;            // alive bits, read (unless fresh) and written in place
     uint64_t *masks_prev;       // the alive bits as they were before this body (pcl_store_last_delete_flags)
@@ -666,6 +666,8 @@ struct alive_args {
     uint64_t *zero_cnt;         // count == 0: counter slots the compaction behind this launch adds into, cleared here
     int n_zero;
     uint64_t seq;               // count == 1: written to host[kCounterSlots - 6] after the totals -- the host polls for it
+    int write_r;                // NEED_R: store r with every move up to and including this body's applied (the list of
+                                // pending moves was full): the caller starts a new, empty list
     int fresh;                  // 1: the store is dense -- every slot below ``slots`` is alive, masks are not read
     int count;                  // 1: measure counters + totals to the host (a body without compaction); 0: flags only
     int n_planes;
@@ -741,7 +743,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                     a.masks_prev[tile * kTileRows + row] = m_lo[u];
                     a.masks_prev[tile * kTileRows + row + 1] = m_hi[u];
                 }
-                if ((m_lo[u] | m_hi[u]) == 0ull) { // nobody left in these 128 slots (wave-uniform)
+                if ((m_lo[u] | m_hi[u]) == 0ull) { // nobody left in these 128 slots (wave-uniform; their r may stay stale)
                     if (lane == 0 && a.fresh) a.masks[tile * kTileRows + row] = 0ull, a.masks[tile * kTileRows + row + 1] = 0ull;
                     continue;
                 }
@@ -762,6 +764,17 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                         xx[u][0][e] = R::add(xx[u][0][e], d0);                                                                // newton.py:16
                         xx[u][1][e] = R::add(xx[u][1][e], d1);
                         xx[u][2][e] = R::add(xx[u][2][e], d2);
+                    }
+                }
+                if constexpr (NEED_R) {
+                    if (a.write_r) { // (wave-uniform; dead slots get a value too -- nobody reads them again)
+                        const int64_t ti = pcl_tix(tile * kTile + (int64_t)row * 64 + 2 * lane, a.ts);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            T2 q;
+                            q.x = xx[u][k][0], q.y = xx[u][k][1];
+                            *reinterpret_cast<T2 *>(a.r[k] + ti) = q;
+                        }
                     }
                 }
                 const bool keep0 = al0 && kp[0], keep1 = al1 && kp[1];
@@ -850,7 +863,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
                 x.x = R::add(x.x, R::mul(v.x, a.pend_dt[q]));
                 x.y = R::add(x.y, R::mul(v.y, a.pend_dt[q]));
             }
-            *reinterpret_cast<T2 *>(const_cast<T *>(a.r[k]) + ti) = x;
+            *reinterpret_cast<T2 *>(a.r[k] + ti) = x;
         }
     }
 }
@@ -3823,8 +3836,8 @@ int apply_pending_t(pcl_ctx *ctx) {
 // one loop body on the alive mask.  count: totals and measure counters go to the host (a body without compaction);
 // otherwise only the new masks and tile counts are produced (the compaction behind it counts)
 template <typename T>
-int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double dt, double A, double n, uint64_t seed, uint32_t step,
-                   const double *planes_host, int n_planes) {
+int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, bool write_r, double dt, double A, double n, uint64_t seed,
+                   uint32_t step, const double *planes_host, int n_planes) {
     alive_args<T> a{};
     fill_alive_args<T>(ctx, a, slots);
     a.dt = (T)dt;
@@ -3832,6 +3845,7 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double d
     a.seed = seed;
     a.step = step;
     a.fresh = fresh ? 1 : 0;
+    a.write_r = write_r ? 1 : 0;
     a.count = count ? 1 : 0;
     a.n_planes = n_planes;
     a.seq = count ? ++ctx->alive_seq : 0;
@@ -3850,7 +3864,7 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, double d
     const int64_t n_tiles = div_up(slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * wg_per_cu;
     const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_MASK);
-    if (count && n_planes > 0)
+    if ((count && n_planes > 0) || write_r)
         hipLaunchKernelGGL((k_delete_alive<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((k_delete_alive<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
@@ -3956,14 +3970,24 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     const bool compact_now = slots > alive_min_slots() && (double)before < alive_ratio() * (double)slots;
     int64_t alive = 0;
     if (!compact_now) {
-        if (ctx->pend_n == kPendMax) PCL_TRY(PCL_DISPATCH(ctx, apply_pending_t<double>(ctx), apply_pending_t<float>(ctx)));
-        ctx->slots = slots; // (apply_pending above ran on the old extent, which is this one)
-        PCL_TRY(PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes),
-                             delete_alive_t<float>(ctx, slots, fresh, true, dt, A, n, seed, step, planes_host, n_planes)));
+        // the list of moves r has not seen is full: this body's kernel writes r back, this body's move included
+        // (PCL_ALIVE_FLUSH_KERNEL: a separate k_apply_pending launch first, for A/B)
+        static const bool flush_kernel = getenv("PCL_ALIVE_FLUSH_KERNEL") != nullptr;
+        bool write_r = ctx->pend_n == kPendMax;
+        if (write_r && flush_kernel) {
+            ctx->slots = slots;
+            PCL_TRY(PCL_DISPATCH(ctx, apply_pending_t<double>(ctx), apply_pending_t<float>(ctx)));
+            write_r = false;
+        }
+        PCL_TRY(PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, true, write_r, dt, A, n, seed, step, planes_host, n_planes),
+                             delete_alive_t<float>(ctx, slots, fresh, true, write_r, dt, A, n, seed, step, planes_host, n_planes)));
         PCL_TRY(wait_alive(ctx, before, &alive)); // the last workgroup wrote the totals into the pinned block
         ctx->holes = true;
         ctx->slots = slots;
-        ctx->pend_dt[ctx->pend_n++] = dt;
+        if (write_r)
+            ctx->pend_n = 0;
+        else
+            ctx->pend_dt[ctx->pend_n++] = dt;
         ctx->count = alive;
         ctx->last_delete_n = before;
     } else {
@@ -3974,8 +3998,8 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         int dv_mode = kDvMove;
         int rc = decide_dv_mode(ctx, true, &dv_mode);
         if (rc == PCL_OK)
-            rc = PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, false, dt, A, n, seed, step, planes_host, n_planes),
-                              delete_alive_t<float>(ctx, slots, fresh, false, dt, A, n, seed, step, planes_host, n_planes));
+            rc = PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, false, false, dt, A, n, seed, step, planes_host, n_planes),
+                              delete_alive_t<float>(ctx, slots, fresh, false, false, dt, A, n, seed, step, planes_host, n_planes));
         if (rc == PCL_OK)
             rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, true, dt, planes_host, n_planes),
                               compact_alive_t<float>(ctx, dv_mode, true, dt, planes_host, n_planes));

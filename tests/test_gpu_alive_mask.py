@@ -162,7 +162,7 @@ def test_alive_mask_interleaved_with_scatter_steps_and_multi_launches():
             assert np.array_equal(sa[f][k], sb[f][k]), (f, k)
 
 
-@pytest.mark.parametrize("env", [{"PCL_ALIVE_MIN_SLOTS": "0"}, {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}, {"PCL_ALIVE": "0"}])
+@pytest.mark.parametrize("env", [{"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_FLUSH_KERNEL": "1", "PCL_ALIVE_POLL": "0"}, {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}, {"PCL_ALIVE": "0"}])
 def test_the_delete_tests_of_the_suite_under_other_compaction_rules(env):
     """The suite's stores are mostly below 65536 slots, where the alive path never compacts by itself.  Run the tests
     that delete again with compaction allowed at any size (ratio 0.5 and 0.95: nearly every body compacts), and with
