@@ -534,7 +534,7 @@ class Device:
         check(self.lib.pcl_store_is_uniform(self.ctx, byref(u)))
         return bool(u.value)
 
-    def step_fused_multi(self, dt, k_steps, scatter, planes=(), sync=True):
+    def step_fused_multi(self, dt, k_steps, scatter, planes=(), sync=True, raw=False):
         """``k_steps`` consecutive lazy fused steps (Newton + ScatterIsotropic + sign / plane counters, device RNG,
         launch indices scatter['step'] .. +k_steps-1) in one pass over the store.  Returns a list of k_steps dicts like
         step_fused's (or None if not sync)."""
@@ -550,9 +550,11 @@ class Device:
             out.ctypes.data_as(c_void_p) if sync else None))
         if out is None:
             return None
+        if raw:                   # (k_steps, 5 + n_planes) int64: [N, sign x 3, planes ..., hits] per step
+            return out
         return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + npl].copy(), "hits": int(o[4 + npl])} for o in out]
 
-    def step_mixed_multi(self, dt, k_passes, phases, scatter=None, delete=None, planes=(), seed=0, step=0):
+    def step_mixed_multi(self, dt, k_passes, phases, scatter=None, delete=None, planes=(), seed=0, step=0, raw=False):
         """``k_passes`` passes of a loop whose body holds the phases ``phases`` -- a sequence of "iso" / "delete", at
         most one of each -- every phase being Newton + the light step + the counters of the measure steps behind it;
         one pass over the store and (with a delete phase) one compaction.  ``scatter``: dict A, n, flags, c, h, n_expr
@@ -571,6 +573,8 @@ class Device:
             float(sc.get("n", 0.0)), int(sc.get("flags", 0)), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
             expr.encode() if expr is not None else None, float(A_d), float(n_d), int(seed), int(step) & 0xFFFFFFFF,
             pl.ctypes.data_as(c_void_p) if npl else None, npl, out.ctypes.data_as(c_void_p)))
+        if raw:                   # (k_passes * len(phases), 5 + n_planes) int64: [N, sign x 3, planes ..., hits | removed]
+            return out
         rows = []
         for k, o in enumerate(out):
             ph = phases[k % len(kinds)]
@@ -615,7 +619,7 @@ class Device:
             check(rc)
         return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + k].copy(), "removed": int(out[4 + k])}
 
-    def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None):
+    def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None, raw=False):
         """``k_steps`` delete loop bodies (Newton + ScatterDelete + counters on the survivors) in one pass and one
         compaction.  Returns a list of k_steps dicts {'N','removed','sign','planes'}."""
         if planes is None:
@@ -628,6 +632,8 @@ class Device:
         out = np.zeros((k_steps, 5 + k), dtype=np.int64)
         check(self.lib.pcl_step_fused_delete_multi(self.ctx, float(dt), int(k_steps), float(A), float(n), int(seed),
                                                    int(step) & 0xFFFFFFFF, pp, npl, out.ctypes.data_as(c_void_p)))
+        if raw:                   # (k_steps, 5 + n_planes) int64: [N, sign x 3, planes ..., removed] per body
+            return out
         return [{"N": int(o[0]), "sign": o[1:4].copy(), "planes": o[4:4 + k].copy(), "removed": int(o[4 + k])} for o in out]
 
     def last_delete_flags(self, n):

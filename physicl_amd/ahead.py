@@ -50,18 +50,27 @@ class _CountOnly:
 
 
 class AheadView:
-    """The simulation as the two functions may see it ahead of a launch."""
-    __slots__ = ("_sim", "_count")
-    READABLE = frozenset(("t", "dt", "ts", "bounds", "cl_on", "seed", "rng", "device", "start_time", "running",
-                          "steps_per_launch", "fuse", "state_need_lock"))
+    """The simulation as the two functions may see it ahead of a launch.  The clock and the count are plain attributes
+    (``refresh()`` copies them from the simulation: they are read once per planned pass), everything else goes through
+    ``__getattr__``."""
+    __slots__ = ("_sim", "_count", "t", "dt", "ts", "objects")
+    READABLE = frozenset(("bounds", "cl_on", "seed", "rng", "device", "start_time", "running", "steps_per_launch", "fuse",
+                          "state_need_lock"))
 
     def __init__(self, sim, count):
-        object.__setattr__(self, "_sim", sim)
-        object.__setattr__(self, "_count", int(count))
+        set_ = object.__setattr__
+        set_(self, "_sim", sim)
+        set_(self, "_count", int(count))
+        set_(self, "objects", _CountOnly(int(count)))
+        self.refresh()
+
+    def refresh(self):
+        set_, sim = object.__setattr__, self._sim
+        set_(self, "t", sim.t)
+        set_(self, "dt", sim.dt)
+        set_(self, "ts", sim.ts)
 
     def __getattr__(self, name):
-        if name == "objects":
-            return _CountOnly(self._count)
         if name in AheadView.READABLE:
             return getattr(self._sim, name)
         raise NotAhead(name)

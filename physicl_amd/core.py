@@ -33,6 +33,15 @@ from .units import Measurement
 from .ahead import AheadView as _AheadView, NotAhead as _NotAhead, clock_only as _clock_only
 
 HOST, DEVICE, BOTH = "host", "device", "both"   # where the authoritative particle state is
+_IMMUTABLE = (int, float, complex, np.generic)  # values later in-place arithmetic cannot change: no copy needed to keep them
+_PLAIN_FLOATS = (float, np.float64, np.float32)
+
+
+def _snap(x):
+    """``x`` as it is now, safe from a later ``x += ...`` (physicl/__init__.py:343 deep-copies t into ts)."""
+    return x if isinstance(x, _IMMUTABLE) else copy.deepcopy(x)
+
+
 _MAX_PLANES = 12        # == _hip.MAX_PLANES == PCL_MAX_PLANES (include/physicl_hip.h); tests/test_host_api.py checks it
 
 
@@ -647,29 +656,36 @@ class Simulation(threading.Thread):
         depends on the count cannot be evaluated ahead either."""
         times, dt0 = [], None
         view = _AheadView(self, self._alive)
+        view1 = _AheadView(self, 1) if count_matters and self._alive > 1 else None
+        fn, exit_fn, ts = upd.fn, self.exit, self.ts
         while len(times) < k_max:
-            before = (copy.deepcopy(self.t), self.dt)   # ``t += dt`` is in place on an ndarray
+            t_before, dt_before = _snap(self.t), self.dt   # ``t += dt`` is in place on an ndarray
             try:
-                dt = upd.fn(view)
+                dt = fn(view)
             except _NotAhead as e:
                 self._ahead_off("the time-step function reads", "sim." + str(e.args[0]))
                 break
             self.dt = dt                              # UpdateTimeStep.run (physicl/__init__.py:337-343)
-            self.t += self.dt
-            self.ts.append(copy.deepcopy(self.t))
+            self.t += dt
+            t_now = _snap(self.t)
+            ts.append(t_now)
+            code = float(dt) if type(dt) in _PLAIN_FLOATS else self._dt_code()
             if dt0 is None:
-                dt0 = self._dt_code()
-            elif self._dt_code() != dt0:              # the time step changed: that pass belongs to the next launch
-                self.t, self.dt = before
-                self.ts.pop()
+                dt0 = code
+            elif code != dt0:                         # the time step changed: that pass belongs to the next launch
+                self.t, self.dt = t_before, dt_before
+                ts.pop()
                 break
-            times.append((copy.deepcopy(self.t), self.dt))
+            times.append((t_now, dt))
             if len(times) < k_max:
                 try:
-                    stop = self.exit(view)
-                    if not stop and count_matters and self._alive > 1 and self.exit(_AheadView(self, 1)):
-                        self._ahead_off("exit(sim) depends on", "how many objects are left")
-                        break
+                    view.refresh()
+                    stop = exit_fn(view)
+                    if not stop and view1 is not None:
+                        view1.refresh()
+                        if exit_fn(view1):
+                            self._ahead_off("exit(sim) depends on", "how many objects are left")
+                            break
                 except _NotAhead as e:
                     self._ahead_off("exit(sim) reads", "sim." + str(e.args[0]))
                     break
@@ -708,45 +724,51 @@ class Simulation(threading.Thread):
                 dl = s._kernel_consts()
         step0 = self._launch + 1
         self._launch += k * P
+        # raw rows from the library: one per light step per pass, columns [N, sign x 3, planes ..., hits | removed]
         if phases == ["iso"] and dev.is_uniform():
             sc.update(rng_mode=hip.RNG_PHILOX, seed=self.seed, step=step0)
-            rows = [dict(o, evt=o["hits"]) for o in dev.step_fused_multi(dt0, k, sc, planes)]
+            raw = dev.step_fused_multi(dt0, k, sc, planes, raw=True)
             self.schedule["fused_multi"] += 1
         elif phases == ["delete"]:
-            rows = [dict(o, evt=o["removed"]) for o in
-                    dev.step_fused_delete_multi(dt0, k, dl[0], dl[1], self.seed, step0, planes if groups[0][2:] else None)]
+            raw = dev.step_fused_delete_multi(dt0, k, dl[0], dl[1], self.seed, step0, planes if groups[0][2:] else None, raw=True)
             self.schedule["fused_delete_multi"] += 1
         else:
-            rows = [dict(o, evt=o["hits"] if o["phase"] == "iso" else o["removed"]) for o in
-                    dev.step_mixed_multi(dt0, k, phases, sc, dl, planes, self.seed, step0)]
+            raw = dev.step_mixed_multi(dt0, k, phases, sc, dl, planes, self.seed, step0, raw=True)
             self.schedule["mixed_multi"] += 1
         npl = len(planes)
-        flat = np.array([np.concatenate([[o["N"], o["evt"]], o["sign"], o["planes"] if len(o["planes"]) else np.zeros(npl, np.int64)])
-                         for o in rows], dtype=np.int64)
-        glob = self._global(flat.reshape(-1)).reshape(k * P, flat.shape[1])
+        have = raw.shape[1] - 5                       # plane columns the library returned (0 when no measure step asked)
+        flat = np.zeros((k * P, 5 + npl), dtype=np.int64)     # [N, event count, sign x 3, planes ...]: what is all-reduced
+        flat[:, 0] = raw[:, 0]
+        flat[:, 1] = raw[:, 4 + have]
+        flat[:, 2:5] = raw[:, 1:4]
+        flat[:, 5:5 + have] = raw[:, 4:4 + have]
+        glob = self._global(flat.reshape(-1)).reshape(k * P, 5 + npl) if self.comm is not None else flat
+        rows = glob.tolist()                          # Python ints: the replay below touches every element
+        ts = self.ts
         for i, (t, dt) in enumerate(times):
             self.t, self.dt = t, dt                   # each row carries its own pass's time ...
-            later = self.ts[n_ts + i + 1:]            # ... and sees ``ts`` as it stood after that pass
-            del self.ts[n_ts + i + 1:]
             for j, g in enumerate(groups):
-                row = glob[i * P + j]
+                row = rows[i * P + j]
                 if phases[j] == "iso":
-                    self.hits = int(row[1])
+                    self.hits = row[1]
                     self._scattered = True
                 else:
-                    self._alive, lights[j].removed = int(row[0]), int(row[1])
+                    self._alive, lights[j].removed = row[0], row[1]
                 at = 5 + span[j][0]
                 for m in g[2:]:
                     n_m = m._n_planes()
-                    m._record(self, int(row[0]), row[2:5], row[at:at + n_m])
+                    m._record(self, row[0], row[2:5], row[at:at + n_m])
                     at += n_m
-            if has_delete and i + 1 < k and self.exit(self):         # the outer loop would have stopped here
-                if self._alive != 0:
-                    raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
-                                       "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
-                                       "the store being empty only" % (i + 1, k, self._alive))
-                break                                 # the later passes ran on an empty store: their times are dropped
-            self.ts.extend(later)
+            if has_delete and i + 1 < k:
+                later = ts[n_ts + i + 1:]             # ... and exit sees ``ts`` as it stood after that pass
+                del ts[n_ts + i + 1:]
+                if self.exit(self):                   # the outer loop would have stopped here
+                    if self._alive != 0:
+                        raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
+                                           "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
+                                           "the store being empty only" % (i + 1, k, self._alive))
+                    break                             # the later passes ran on an empty store: their times are dropped
+                ts.extend(later)
         return True
 
     def _run_fused(self, group):

@@ -6,8 +6,8 @@ import physicl as phys
 import physicl.light as light
 import physicl.newton as newton
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
-K = int(sys.argv[2]) if len(sys.argv) > 2 else 16
-for rep in range(2):
+K = (None if sys.argv[2] == "auto" else int(sys.argv[2])) if len(sys.argv) > 2 else 16
+for rep in range(3):
     sim = phys.Simulation(cl_on=True, seed=7, steps_per_launch=K)
     sim.add_objs(light.generate_photons_bulk(n, min=1.0, max=1.0, seed=7))
     sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
@@ -15,6 +15,8 @@ for rep in range(2):
     sim.add_step(2, light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
     m = light.ScatterMeasureStep(None, True, [[1.0 / (0.001 * 0.001), np.nan, np.nan]])
     sim.add_step(3, m)
+    sim._to_device()
+    sim._dev.sync()
     t0 = time.perf_counter()
     pr = cProfile.Profile()
     pr.runcall(sim.run)
