@@ -54,7 +54,7 @@ class AheadView:
     (``refresh()`` copies them from the simulation: they are read once per planned pass), everything else goes through
     ``__getattr__``."""
     __slots__ = ("_sim", "_count", "t", "dt", "ts", "objects")
-    READABLE = frozenset(("bounds", "cl_on", "seed", "rng", "device", "start_time", "running", "steps_per_launch", "fuse",
+    READABLE = frozenset(("bounds", "cl_on", "seed", "rng", "device", "devices", "start_time", "running", "steps_per_launch", "fuse",
                           "state_need_lock"))
 
     def __init__(self, sim, count):

@@ -209,6 +209,11 @@ class Simulation(threading.Thread):
 
     Extra keyword attributes understood by this build (all optional):
       device   HIP device index (default 0, or LOCAL_RANK when ``comm`` is given)
+      devices  a list of HIP device indices: the particles are sharded by index over that many GPUs INSIDE this
+               process (one library context per entry, launches issued side by side from a thread pool, counters summed
+               on the host: physicl_amd/multidev.py).  A script or a notebook scales over a node's GPUs this way without
+               a launcher; every row, ``len(sim.objects)``, ``get_state()`` and the objects themselves are global, and
+               the results are those of one device.  ``devices=[0, 0]`` makes two contexts on one GPU.
       rng      "numpy": the light steps draw their randoms from ``np.random`` on the host, in the
                reference's order (3 per photon per step: rtheta, rphi, rand; 1 for delete), so a
                seeded run reproduces the reference's OpenCL path;  "philox": drawn in-kernel,
@@ -256,6 +261,7 @@ class Simulation(threading.Thread):
                                    "run_time": time.time() - x.start_time}
         self.state_need_lock = False
         self.device = None
+        self.devices = None
         self.rng = None
         self.seed = 0
         self.fuse = True
@@ -349,8 +355,14 @@ class Simulation(threading.Thread):
     def _open_device(self):
         from . import _hip
         self._hip = _hip
-        dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
-        self._dev = _hip.Device(dev_index)
+        if self.devices is not None:
+            if self.comm is not None:
+                raise ValueError("devices=[...] shards inside this process; comm=... shards across processes: give one of them")
+            from .multidev import MultiDevice
+            self._dev = MultiDevice(self.devices, _hip)
+        else:
+            dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
+            self._dev = _hip.Device(dev_index)
         # a variable_n_fn of one of the reference's example shapes starts at once on the ahead-of-time kernels while
         # hipRTC compiles its specialisation beside the run (~2 s; same bits, about the same speed)
         self._dev.set_rtc_background(bool(getattr(self, "rtc_background", True)))

@@ -1,0 +1,78 @@
+"""GPU: ``Simulation(devices=[...])`` -- several library contexts inside ONE process, particles sharded by index,
+counters summed on the host (physicl_amd/multidev.py).  The reference is one process with one simulation thread
+(physicl/__init__.py:400-432, 501-524); this is how a script written against it uses a node's GPUs without a launcher.
+
+On the one-GPU test box the contexts share device 0 (``devices=[0, 0]``, ``[0, 0, 0]``): the sharding, the fan-out and
+the host-side reduction are exactly those of N GPUs.  Everything observable must equal the single-context run: ``ts``,
+every measure row, ``hits``, what host plugins saw, ``len(sim.objects)``, the position of the global ``np.random``
+stream, and the final state of every object bit for bit -- for the randomly drawn simulations of
+tests/test_gpu_random_simulations.py (explicit objects and bulk batches, host plugins that read, edit and remove
+objects, host-drawn and device randoms, every launch formulation)."""
+import numpy as np
+import pytest
+
+import physicl as phys
+import physicl.light
+import physicl.newton
+
+from test_gpu_random_simulations import assert_same, build_and_run, draw_config
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_sharded_in_process_equals_one_context(seed):
+    cfg = draw_config(np.random.RandomState(500 + seed))
+    one = build_and_run(cfg, "default", True)
+    two = build_and_run(cfg, "default", True, devices=[0, 0])
+    assert_same(one, two, ("devices=[0, 0]", cfg))
+    assert one["schedule"] == two["schedule"]                  # the same launch formulations were chosen
+    if seed % 3 == 0:
+        three = build_and_run(cfg, 1, True, devices=[0, 0, 0])
+        assert_same(one, three, ("devices=[0, 0, 0], one launch per light step", cfg))
+
+
+def test_bulk_run_on_two_contexts_rows_counts_and_state():
+    """configs[2]-style bulk run and a delete-until-empty run, 200k photons over two contexts: rows, counts while
+    running (get_state from the main thread) and downloaded state equal the one-context run."""
+    def run(**kw):
+        out = {}
+        sim = phys.Simulation(seed=5, exit=lambda s: len(s.ts) >= 40, **kw)
+        sim.add_objs(phys.light.generate_photons_bulk(200_001, min=phys.light.E_from_wavelength(700e-9),
+                                                      max=phys.light.E_from_wavelength(200e-9), seed=5))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(1e-9)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        sim.add_step(2, phys.light.ScatterIsotropicStep(n=1e-15, A=1e-19, wavelength_dep_scattering=True, variable_n=True,
+                                                        variable_n_fn="0.000000001 * exp(r0[gid] - 5)"))
+        m = phys.light.ScatterSignMeasureStep(None, True)
+        sim.add_step(3, m)
+        sim.start()
+        sim.join()
+        assert sim.error is None, sim.error
+        out["iso"] = ([list(map(float, r)) for r in m.data], sim.hits, len(sim.objects), dict(sim.schedule),
+                      {f: sim.download(f) for f in ("r", "v", "dr", "dv", "E", "id")})
+        sim.close(download=False)
+        sim = phys.Simulation(seed=5, **kw)                                   # default exit: no objects left
+        sim.add_objs(phys.light.generate_photons_bulk(200_001, min=1.0, max=1.0, seed=5))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        m = phys.light.ScatterMeasureStep(None, True, [[1.0e6, np.nan, np.nan]])
+        sim.add_step(3, m)
+        sim.start()
+        sim.join()
+        assert sim.error is None, sim.error
+        out["del"] = ([list(map(float, r)) for r in m.data], len(sim.ts), len(sim.objects), dict(sim.schedule))
+        sim.close(download=False)
+        return out
+    a, b = run(), run(devices=[0, 0])
+    assert a["iso"][:4] == b["iso"][:4] and a["iso"][3] == {"fused_multi": 2}
+    for f in a["iso"][4]:
+        assert np.array_equal(a["iso"][4][f], b["iso"][4][f]), f
+    assert a["del"] == b["del"] and a["del"][2] == 0 and a["del"][3].get("fused_delete_multi", 0) >= 1
+
+
+def test_devices_and_comm_exclude_each_other():
+    from physicl_amd.dist import CounterComm
+    with pytest.raises(ValueError):
+        phys.Simulation(devices=[0, 0], comm=CounterComm(0, 1, "gloo"))

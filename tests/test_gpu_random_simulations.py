@@ -94,7 +94,7 @@ class Count(phys.Step):
         self.seen.append(len(s.objects))
 
 
-def build_and_run(cfg, steps_per_launch, fuse):
+def build_and_run(cfg, steps_per_launch, fuse, **sim_kw):
     T = cfg["passes"]
     np.random.seed(cfg["seed"] % (1 << 31))
     measures = []
@@ -108,7 +108,7 @@ def build_and_run(cfg, steps_per_launch, fuse):
     else:
         exit_fn = lambda s: len(s.ts) >= T or len(s.objects) == 0   # noqa: E731
     kw = {} if steps_per_launch == "default" else {"steps_per_launch": steps_per_launch}     # "default": the constructor's own
-    sim = phys.Simulation(cl_on=True, rng=cfg["rng"], seed=cfg["seed"], fuse=fuse, exit=exit_fn, **kw)
+    sim = phys.Simulation(cl_on=True, rng=cfg["rng"], seed=cfg["seed"], fuse=fuse, exit=exit_fn, **kw, **sim_kw)
     rs = np.random.RandomState(cfg["seed"])
     if cfg["source"] == "batch":
         sim.add_objs(phys.light.generate_photons_bulk(cfg["n"], min=phys.light.E_from_wavelength(700e-9),
