@@ -101,6 +101,9 @@ def parse_args(argv=None):
                          "error); gloo = rehearsal on CPU tensors, must be asked for")
     ap.add_argument("--device", type=int, default=None,
                     help="HIP device index for EVERY rank (default LOCAL_RANK); rehearsals put all ranks on device 0")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="bring up the ranks, the collective backend and its start-up all-reduce, report every rank's "
+                         "device and stop: nothing is allocated, nothing is timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the single_step, delete and api legs (N=1)")
     ap.add_argument("--cpu-photons", type=float, default=1e8)
@@ -156,6 +159,7 @@ class Bench:
         self.S = max(1, min(64, args.steps_per_launch)) if args.mode == "fused" else 1
         self.sim_t = 0.0
         self.totals = None
+        self.local_block_s = []        # this rank's own wall time of every timed block (the line reports min / max over ranks)
 
     def fill(self):
         self.dev.store_alloc(self.N, self.args.dtype)
@@ -249,6 +253,7 @@ class Bench:
             comm.barrier()
             dt = time.perf_counter() - t0
             el.append(comm.allreduce_max(dt))
+            self.local_block_s.append(dt)
             hits.append(h)
             kern.append({name: dev.prof_read(kid) for kid, name in self.hip.PROF_NAMES.items()})
             k += steps
@@ -303,11 +308,26 @@ def run_rank(args):
     hip = b.hip
     f32 = args.dtype == "f32"
     bscale = 0.5 if f32 else 1.0
+    if args.dry_run:
+        # the collective is up (Bench() raised otherwise): one all-reduce of a per-rank vector as a last check, then out
+        devices = comm.allgather_object({"rank": rank, "device": b.dev_index, "pci": dev.info().get("pci_bus_id")})
+        probe = comm.allreduce_sum(np.array([1, rank], dtype=np.int64))
+        dev.close()
+        comm.close()
+        if rank == 0:
+            ok = int(probe[0]) == world and int(probe[1]) == world * (world - 1) // 2
+            os.write(json_fd, (json.dumps({"dry_run": True, "n_gpus": world, "ok": ok, "collective": dict(comm.info(), devices=devices),
+                                           "distinct_pci": len({d["pci"] for d in devices})}) + "\n").encode())
+            if not ok:
+                sys.exit(1)
+        return
     b.fill()
     slab_info = dev.alloc_info()
 
-    # every rank reports which physical device it drives: N ranks on N distinct devices is what RCCL needs
-    devices = comm.allgather_object({"rank": rank, "device": b.dev_index, "pci": dev.info().get("pci_bus_id")})
+    # every rank reports which physical device it drives (N ranks on N distinct devices is what RCCL needs) and which
+    # memory its store got: an imbalance between ranks is visible in the line
+    devices = comm.allgather_object({"rank": rank, "device": b.dev_index, "pci": dev.info().get("pci_bus_id"),
+                                     "slab_selection": slab_info})
 
     dev.prof_enable(True)
     b.run_steps(0, args.warmup)
@@ -316,6 +336,7 @@ def run_rank(args):
     R = max(1, args.repeats)
     el, hits, kern, k_next = b.timed_blocks(args.warmup, args.steps, R)
     totals_main = b.totals
+    rank_blocks = comm.allgather_object([round(x / args.steps * 1e3, 5) for x in b.local_block_s[:R]])
     mi = median_index(el)
     elapsed = el[mi]
     dominant = ("k_multi" if S > 1 else "k_fused") if args.mode.startswith("fused") else "k_scatter"
@@ -386,7 +407,13 @@ def run_rank(args):
                        # which memory the store's slab got (outside the timed region): the library measures a few candidate
                        # blocks with a write sweep when a big store is created and keeps the fastest ("Placement")
                        "slab_selection": slab_info},
-            "collective": dict(comm.info(), devices=devices) if world > 1 else None,
+            "collective": (dict(comm.info(), devices=devices,
+                                # every rank's own time of every block (ms per step, barrier to barrier): min = max means the
+                                # ranks ran in step, a straggler shows as one rank's row
+                                per_rank_block_ms_per_step=rank_blocks,
+                                block_min_ms_per_step=[min(r[i] for r in rank_blocks) for i in range(R)],
+                                block_max_ms_per_step=[max(r[i] for r in rank_blocks) for i in range(R)])
+                           if world > 1 else None),
             "roofline": {"bound": "hbm",
                          "kernel": (("k_multi (pcl_rtc_multi_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "
                                      "store, dr/dv implicit; arithmetic-bound by construction -- the HBM-bound formulation "

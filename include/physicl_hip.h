@@ -258,6 +258,13 @@ int pcl_store_alloc_info(pcl_ctx *ctx, int *n_candidates_out, double *rates_gbps
 /* Random inputs for PCL_RNG_INPUT: which = 0 rtheta, 1 rphi, 2 rand; n values for particles
  * [0, n) in store order (entries of non-photon particles are ignored). */
 int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n);
+/* The three inputs of an isotropic scatter step at once, from the uniforms as the reference draws them: per photon three
+ * np.random.random() in the order rtheta, rphi, rand (physicl/__init__.py:606-619), i.e. the (n, 3) row-major array of
+ * np.random.random((n, 3)).  u3_host holds the rows of particles [offset, offset + n), n <= 2**20 per call; calls follow
+ * one another in particle order starting at offset 0 (the same stream as one big draw).  The scaling of light.py:285,
+ * rtheta = (u * 2) * pi and rphi = u * pi, is done on the device with those very operations.  The call returns when the
+ * chunk has been staged (two pinned slots): the caller draws the next chunk while this one is copied.               */
+int pcl_store_upload_rand3(pcl_ctx *ctx, const double *u3_host, int64_t offset, int64_t n);
 
 /* Bulk creation on the device of ``n`` photons at r = 0 with v = (c, 0, 0), dr = dv = 0 and
  * E = e_min + (e_max - e_min) * U^(1/3) -- the SoA equivalent of light.generate_photons with its

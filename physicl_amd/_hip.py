@@ -97,6 +97,7 @@ _PROTOTYPES = {
     "pcl_store_field_ptr": [_vp, c_int, POINTER(_vp)],
     "pcl_store_layout": [_vp, POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_upload_rand": [_vp, c_int, _vp, c_int64],
+    "pcl_store_upload_rand3": [_vp, _vp, c_int64, c_int64],
     "pcl_store_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
     "pcl_store_fill_photons_table": [_vp, c_int64, c_int64, c_double, _vp, _vp, c_int, c_uint64],
     "pcl_step_newton": [_vp, c_double],
@@ -444,6 +445,14 @@ class Device:
     def upload_rand(self, which, host):
         a, hp = _host(host, self.np_dtype)
         check(self.lib.pcl_store_upload_rand(self.ctx, which, hp, a.size))
+
+    RAND3_CHUNK = 1 << 20
+
+    def upload_rand3(self, u3, offset=0):
+        """Rows [offset, offset + len(u3)) of the reference's per-photon draws (rtheta-, rphi-, rand-uniform): ``u3`` is
+        what ``np.random.random((n, 3))`` returns, at most RAND3_CHUNK rows per call, chunks in particle order from 0."""
+        a = np.ascontiguousarray(u3, dtype=np.float64).reshape(-1, 3)
+        check(self.lib.pcl_store_upload_rand3(self.ctx, a.ctypes.data, int(offset), len(a)))
 
     def fill_photons(self, n, id_base, c, e_min, e_max, seed):
         check(self.lib.pcl_store_fill_photons(self.ctx, int(n), int(id_base), c, e_min, e_max, int(seed)))

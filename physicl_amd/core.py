@@ -24,6 +24,7 @@ created when the first device step needs it, and ``cl_ctx`` / ``cl_q`` stay None
 """
 import copy
 import collections
+import os
 import threading
 import time
 
@@ -522,7 +523,13 @@ class Simulation(threading.Thread):
         else:
             ph = dev.download_kind(n) != 0 if n else np.zeros(0, bool)
             m = int(ph.sum())
-        if which == "iso":
+        if which == "iso" and self._all_photons and os.environ.get("PCL_RAND3", "1") != "0":   # ("0": the three-array path, for A/B)
+            # the raw uniforms go over in chunks, as they are drawn (consecutive draws are the one big draw's stream);
+            # the copy of a chunk runs while the next one is drawn, and the split / scaling happens on the device
+            ch = dev.RAND3_CHUNK
+            for off in range(0, n, ch):
+                dev.upload_rand3(np.random.random((min(ch, n - off), 3)), off)
+        elif which == "iso":
             u = np.random.random((m, 3))
             full = np.zeros((n, 3))
             full[ph, 0] = u[:, 0] * 2 * np.pi
@@ -530,6 +537,8 @@ class Simulation(threading.Thread):
             full[ph, 2] = u[:, 2]
             for w in range(3):
                 dev.upload_rand(w, np.ascontiguousarray(full[:, w]))
+        elif self._all_photons:
+            dev.upload_rand(2, np.random.random(n))
         else:
             full = np.zeros(n)
             full[ph] = np.random.random(m)

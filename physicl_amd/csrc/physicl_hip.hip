@@ -1905,6 +1905,22 @@ __global__ void __launch_bounds__(kBlock) k_counters(counter_args<T> a) {
     }
 }
 
+// ---- host-drawn randoms of a ScatterIsotropicStep, as the reference draws them: per photon rtheta-, rphi-, rand-uniform
+//   (physicl/__init__.py:606-619: three np.random.random() per photon, in that order; light.py:285 scales the first two).
+//   The host hands over the raw uniforms U[n][3] exactly as np.random.random((n, 3)) returns them; the split into the three
+//   input arrays and the scaling -- (u * 2) * pi and u * pi, the reference's own operations, rounded to the store's
+//   precision afterwards -- happen here instead of in three strided numpy passes.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_rand3_split(const double *__restrict__ u3, T *__restrict__ rtheta, T *__restrict__ rphi,
+                                                        T *__restrict__ rand, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double u0 = u3[3 * i], u1 = u3[3 * i + 1], u2 = u3[3 * i + 2];
+        rtheta[i] = (T)__dmul_rn(__dmul_rn(u0, 2.0), PCL_PI);
+        rphi[i] = (T)__dmul_rn(u1, PCL_PI);
+        rand[i] = (T)u2;
+    }
+}
+
 // ---- bulk photon creation --------------------------------------------------------------------------
 template <typename T>
 struct fill_args {
@@ -2149,6 +2165,12 @@ struct pcl_ctx {
     double lam4_h = 0.0, lam4_c = 0.0;
     void *rnd[3] = {nullptr, nullptr, nullptr};
     int64_t rnd_n[3] = {0, 0, 0};
+    // pcl_store_upload_rand3: two pinned host slots + two device slots of kRand3Chunk photons, used alternately so that
+    // the copy of one chunk runs while the caller draws the next
+    double *r3_host[2] = {nullptr, nullptr};
+    double *r3_dev[2] = {nullptr, nullptr};
+    hipEvent_t r3_ev[2] = {nullptr, nullptr};
+    int r3_slot = 0;
 
     // compaction scratch (sized for scratch_cap particles)
     int64_t scratch_cap = 0;
@@ -4423,6 +4445,11 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_count) (void)hipEventDestroy(ctx->ev_count);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->r3_host[k]) (void)hipHostFree(ctx->r3_host[k]);
+        if (ctx->r3_dev[k]) (void)hipFree(ctx->r3_dev[k]);
+        if (ctx->r3_ev[k]) (void)hipEventDestroy(ctx->r3_ev[k]);
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return PCL_OK;
@@ -4916,6 +4943,49 @@ int pcl_store_upload_rand(pcl_ctx *ctx, int which, const void *host, int64_t n) 
     if (!ctx->rnd[which]) PCL_TRY(dev_alloc_bytes(&ctx->rnd[which], ctx->capacity, ctx->esz));
     ctx->rnd_n[which] = n;
     return pcl_h2d(ctx, ctx->rnd[which], host, n * (int64_t)ctx->esz);
+}
+
+constexpr int64_t kRand3Chunk = (int64_t)1 << 20; // photons per pcl_store_upload_rand3 call (24 MB of uniforms)
+
+int pcl_store_upload_rand3(pcl_ctx *ctx, const double *u3_host, int64_t offset, int64_t n) {
+    PCL_TRY(need_store(ctx));
+    if (n < 0 || n > kRand3Chunk) return fail(PCL_ERR_ARG, "n outside [0, %lld] per call", (long long)kRand3Chunk);
+    PCL_TRY(check_range(ctx, offset, n, u3_host));
+    for (int w = 0; w < 3; ++w) {
+        if (!ctx->rnd[w]) PCL_TRY(dev_alloc_bytes(&ctx->rnd[w], ctx->capacity, ctx->esz));
+        if (offset != 0 && ctx->rnd_n[w] != offset)
+            return fail(PCL_ERR_ARG, "chunks must follow one another: %lld particles are in, this chunk starts at %lld",
+                        (long long)ctx->rnd_n[w], (long long)offset);
+    }
+    if (n == 0) {
+        if (offset == 0) ctx->rnd_n[0] = ctx->rnd_n[1] = ctx->rnd_n[2] = 0;
+        return PCL_OK;
+    }
+    const int slot = ctx->r3_slot;
+    ctx->r3_slot ^= 1;
+    if (!ctx->r3_host[slot]) {
+        PCL_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->r3_host[slot]), (size_t)kRand3Chunk * 3 * sizeof(double)));
+        PCL_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->r3_dev[slot]), (size_t)kRand3Chunk * 3 * sizeof(double)));
+        PCL_HIP(hipEventCreateWithFlags(&ctx->r3_ev[slot], hipEventDisableTiming));
+    } else {
+        PCL_HIP(hipEventSynchronize(ctx->r3_ev[slot])); // the slot's previous chunk has left the pinned buffer
+    }
+    memcpy(ctx->r3_host[slot], u3_host, (size_t)n * 3 * sizeof(double));
+    PCL_HIP(hipMemcpyAsync(ctx->r3_dev[slot], ctx->r3_host[slot], (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCL_HIP(hipEventRecord(ctx->r3_ev[slot], ctx->stream));
+    const int grid = grid_for(ctx, n, kBlock);
+    if (ctx->dtype == PCL_DTYPE_F64)
+        hipLaunchKernelGGL(k_rand3_split<double>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->r3_dev[slot],
+                           static_cast<double *>(ctx->rnd[0]) + offset, static_cast<double *>(ctx->rnd[1]) + offset,
+                           static_cast<double *>(ctx->rnd[2]) + offset, n);
+    else
+        hipLaunchKernelGGL(k_rand3_split<float>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->r3_dev[slot],
+                           static_cast<float *>(ctx->rnd[0]) + offset, static_cast<float *>(ctx->rnd[1]) + offset,
+                           static_cast<float *>(ctx->rnd[2]) + offset, n);
+    PCL_TRY(launch_check("k_rand3_split"));
+    // (the device slot is reused two calls later: by then this kernel has run -- same stream, in order)
+    ctx->rnd_n[0] = ctx->rnd_n[1] = ctx->rnd_n[2] = offset + n;
+    return PCL_OK;
 }
 
 int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, double e_min, double e_max,

@@ -25,6 +25,15 @@ def shard_range(n_global, rank, world):
     return (n_global * rank) // world, (n_global * (rank + 1)) // world
 
 
+def _pci_of(torch, index):
+    """PCI address of torch's device ``index`` ("0000:05:00.0"), or "?"."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, p.pci_device_id)
+    except Exception:                           # noqa: BLE001 -- diagnostics only
+        return "?"
+
+
 class CollectiveError(RuntimeError):
     """The requested collective backend could not be brought up on every rank."""
 
@@ -74,6 +83,9 @@ class CounterComm:
             self.ranks_seen = int(probe[0])
             return
         ok, why, g = 0, "", None
+        # the first RCCL communicator of the process: let the library say why it fails, should it fail (read at
+        # communicator creation; a caller's own NCCL_DEBUG wins)
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
         try:
             g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
             probe = torch.ones(1, dtype=torch.int64, device=self._dev)
@@ -92,10 +104,24 @@ class CounterComm:
         agree = torch.tensor([ok], dtype=torch.int64)
         dist.all_reduce(agree, op=dist.ReduceOp.MIN)          # every rank takes the same decision
         if int(agree[0]) != 1:
+            # one failure report that carries EVERY rank's view (over the gloo control plane, which works): which device
+            # and PCI function each rank drove, whether its own bring-up succeeded, and the first line of its error --
+            # the first real multi-GPU run must not need a second run to be understood
+            mine = {"rank": self.rank, "device": self.device_index, "pci": _pci_of(torch, self.device_index), "ok": bool(ok),
+                    "ranks_seen": self.ranks_seen, "error": why}
+            try:
+                views = [None] * self.world
+                dist.all_gather_object(views, mine)
+            except Exception:                   # noqa: BLE001 -- the report is best effort
+                views = [mine]
             dist.destroy_process_group()
+            lines = ["  rank %(rank)d: device %(device)s pci %(pci)s ok=%(ok)s ranks_seen=%(ranks_seen)s %(error)s" % v
+                     for v in views if v]
             raise CollectiveError("RCCL process group could not be brought up on every rank (rank %d of %d, device %d%s); "
-                                  "pass backend='gloo' explicitly to rehearse without RCCL"
-                                  % (self.rank, self.world, self.device_index, ": " + why if why else ""))
+                                  "pass backend='gloo' explicitly to rehearse without RCCL\n%s\n  (NCCL_DEBUG=%s; RCCL's own "
+                                  "messages are on stderr above)"
+                                  % (self.rank, self.world, self.device_index, ": " + why if why else "", "\n".join(lines),
+                                     os.environ.get("NCCL_DEBUG")))
         self._group = g
 
     @classmethod

@@ -177,6 +177,18 @@ class MultiDevice:
     def upload_rand(self, which, host):
         self._each(lambda s, h: s.upload_rand(which, np.ascontiguousarray(h)), self._split(host))
 
+    RAND3_CHUNK = 1 << 20
+
+    def upload_rand3(self, u3, offset=0):
+        """A chunk of the global (n, 3) draw: its rows go to the shards that own particles [offset, offset + len(u3))."""
+        u3 = np.ascontiguousarray(u3, dtype=np.float64).reshape(-1, 3)
+        at = 0
+        for s, c in zip(self.shards, self._counts()):
+            lo, hi = max(offset, at), min(offset + len(u3), at + c)
+            if hi > lo:
+                s.upload_rand3(u3[lo - offset:hi - offset], lo - at)
+            at += c
+
     def upload_kind(self, host, offset=0):
         if offset:
             raise NotImplementedError("partial kind uploads on a multi-device store")

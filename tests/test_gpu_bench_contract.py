@@ -80,6 +80,12 @@ def test_two_ranks_started_by_bench_itself_gloo_rehearsal_on_one_device():
     assert two["n_gpus"] == 2 and two["collective"]["backend"] == "gloo" and two["collective"]["ranks_seen"] == 2
     assert [d["rank"] for d in two["collective"]["devices"]] == [0, 1]
     assert "gloo all-reduce" in two["config"]["workload"] and "cpu_baseline" not in two and "single_step" not in two
+    # every rank's own block times and the memory its store got are in the line: a straggler or an unlucky slab shows
+    c = two["collective"]
+    assert len(c["per_rank_block_ms_per_step"]) == 2 and all(len(r) == 3 for r in c["per_rank_block_ms_per_step"])
+    assert all(lo <= hi for lo, hi in zip(c["block_min_ms_per_step"], c["block_max_ms_per_step"]))
+    assert max(c["block_max_ms_per_step"]) <= max(two["repeat_ms_per_step"]) + 1e-3
+    assert all("slab_selection" in d and "pci" in d for d in c["devices"])
     one = run_bench("--no-cpu-baseline", "--no-extra")
     assert two["counters_last_step"] == one["counters_last_step"]
 
@@ -110,3 +116,14 @@ def test_two_ranks_started_by_torchrun_the_way_the_driver_documents_it():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["collective"]["backend"] == "gloo" and d["collective"]["ranks_seen"] == 2
     assert d["counters_last_step"]["N"] == 300000 and d["repeats"] == 2
+
+
+def test_dry_run_brings_the_ranks_and_the_collective_up_and_stops():
+    """``bench.py --gpus N --dry-run``: ranks, process groups and one all-reduce, every rank's device in the line, no store."""
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device", "0",
+                                   "--dry-run"], cwd=ROOT, timeout=600)
+    lines = [ln for ln in out.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["ok"] is True and d["n_gpus"] == 2 and d["collective"]["ranks_seen"] == 2
+    assert [x["rank"] for x in d["collective"]["devices"]] == [0, 1] and d["distinct_pci"] == 1      # both ranks on the one GPU here
