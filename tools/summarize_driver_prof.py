@@ -53,7 +53,7 @@ def main():
     shutil.copy(os.path.join(src, "trace_bench.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
     line = json.loads([ln for ln in open(os.path.join(src, "trace_bench.json")) if ln.strip()][-1])
     N, steps, warmup, R = line["config"]["photons_per_gpu"], line["steps"], line["warmup"], line["repeats"]
-    S = line["config"]["steps_per_launch"]
+    S = line["config"].get("steps_per_launch_max", line["config"].get("steps_per_launch"))
     # ---- per-dispatch trace
     rows = list(csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))))
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
@@ -72,9 +72,10 @@ def main():
          "Four runs of the same command (`--kernel-trace --stats`; `--kernel-trace --pmc FETCH_SIZE`; `... WRITE_SIZE`; "
          "`... SQ_*` -- the PMC passes with `--no-cpu-baseline`, which launches no kernel).  Schedule of the run: %d warm-up "
          "steps (one K = %d launch of the K-step kernel), %d timed blocks of %d steps (one K = %d launch each), then the "
-         "`single_step` leg (3 + %d x %d launches of the one-step kernel), the `delete` legs and the `api` leg."
+         "`single_step` leg (3 + %d x %d launches of the one-step kernel), the `delete`, `iso_1e7` and `mixed` legs and the `api` leg "
+         "(three 500-pass simulations and a delete-until-empty run through the plugin API)."
          % (warmup, min(S, warmup), R, steps, min(S, steps), R, steps), "",
-         "## K-step kernel `pcl_rtc_multi_e1`, every dispatch (bench.py's own launches; the last two belong to the `api` leg)", "",
+         "## K-step kernel `pcl_rtc_multi_e1`, every dispatch (bench.py's own launches first; the later ones belong to the `api` leg)", "",
          "Bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); "
          "lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64); VALU instr / particle-step = SQ_INSTS_VALU x 64 / (N x K).", "",
          "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
@@ -82,7 +83,7 @@ def main():
     km = "pcl_rtc_multi_e1"
     ks = [min(S, warmup)] + [min(S, steps)] * R
     multi_rows = []
-    for i, d in enumerate(disp.get(km, [])):
+    for i, d in enumerate(disp.get(km, [])[:len(ks) + 2]):
         K = ks[i] if i < len(ks) else None
         fb = fetch[km][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(km, [])) else 0
         wb = write[km][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(km, [])) else 0
@@ -118,12 +119,33 @@ def main():
               "`single_step.roofline.frac` %.4f); PMC: %.1f B / photon per launch (algorithmic 104); valu_busy %.3f."
               % (avg * 1e-6, min(single) * 1e-6, max(single) * 1e-6, 104.0 * N / (avg * 1e-9) / 1e9, 104.0 * N / (avg * 1e-9) / 1e9 / HBM_PEAK,
                  line["single_step"]["roofline"]["frac"], tot / N, busy)]
-    # ---- delete legs: totals per kernel
+    # ---- delete legs: the alive-mask kernel dispatch by dispatch (the first run of the 1e8 leg), then totals per kernel
+    ka = [k for k in disp if k.startswith("k_delete_alive<double, true")]
+    if ka:
+        ka = ka[0]
+        big = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == ka and int(r["Grid_Size_X"]) >= 4000000]
+        L += ["", "## `k_delete_alive<double, true>` (one delete loop body on the alive mask; counters + plane crossings): the 1e8-photon "
+              "dispatches of the `delete` leg", "",
+              "A dispatch sweeps ``slots`` = the store's extent; algorithmic bytes per SLOT: alive bit read + written (0.25), v (24), r (24), "
+              "the id (8) once ids are explicit.  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (16-byte loads: the calibrated case).", "",
+              "| dispatch | grid (threads) | duration us | HBM bytes (MB) | GB/s (PMC bytes / duration) | frac of 8 TB/s |", "|---|---|---|---|---|---|"]
+        idx_of = {}
+        for j, r in enumerate(rows):
+            if short(r["Kernel_Name"]) == ka:
+                idx_of[j] = len(idx_of)
+        for j in big[:8]:
+            i = idx_of[j]
+            d = int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"])
+            fb = fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(ka, [])) else 0
+            wb = write[ka][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(ka, [])) else 0
+            g = (fb + wb) / (d * 1e-9) / 1e9
+            L.append("| %d | %s | %.1f | %.1f | %.0f | %.3f |" % (i, rows[j]["Grid_Size_X"], d * 1e-3, (fb + wb) / 1e6, g, g / HBM_PEAK))
     L += ["", "## Delete legs (`delete` record): kernel totals over the whole run (warm-up repetition included; of the two pass-3 "
           "kernels enqueued per compaction the one the scan did not choose returns at once)", "",
           "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
     for k in sorted(disp):
-        if any(t in k for t in ("k_newton_mask", "k_flag_mask2", "k_compact_count", "k_compact_lds", "k_tile_scan", "k_mixed", "k_any_nonzero", "k_delete_onepass")):
+        if any(t in k for t in ("k_delete_alive", "k_apply_pending", "k_newton_mask", "k_flag_mask2", "k_compact_count", "k_compact_lds", "k_tile_scan",
+                                "k_mixed", "k_any_nonzero", "k_delete_onepass")):
             fb = sum(x.get("FETCH_SIZE", 0) for x in fetch.get(k, [])) * 2 * 1024 / 1e9
             wb = sum(x.get("WRITE_SIZE", 0) for x in write.get(k, [])) * 1024 / 1e9
             L.append("| `%s` | %d | %.3f | %.2f | %.2f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, fb, wb))
@@ -131,10 +153,12 @@ def main():
     for size, rec in dl.items():
         p = rec["per_step"]
         L.append("")
-        L.append("`delete` %s photons under the profiler, per_step: %.4g particle-steps/s; pass 3 (`k_compact_*`) %.0f GB/s algorithmic = %.3f of "
-                 "peak, pass 1 (`k_flag_mask2`) %.0f GB/s = %.3f; multi (K = %d): %.4g particle-steps/s."
-                 % (size, p["value"], p["roofline"]["achieved"], p["roofline"]["frac"], p["roofline_pass1"]["achieved"],
-                    p["roofline_pass1"]["frac"], rec["multi"]["steps_per_launch"], rec["multi"]["value"]))
+        L.append("`delete` %s photons under the profiler, per_step: %.4g particle-steps/s in %d loop bodies (%d of them compact); "
+                 "`k_delete_alive` %.0f GB/s on the slots it sweeps = %.3f of peak, the compactions %.0f GB/s = %.3f; %.1f B per alive "
+                 "particle-step; multi (K = %d): %.4g particle-steps/s."
+                 % (size, p["value"], p["loop_bodies"], p["roofline_compaction"]["compactions"], p["roofline"]["achieved"], p["roofline"]["frac"],
+                    p["roofline_compaction"]["achieved"], p["roofline_compaction"]["frac"], p["roofline"]["bytes_per_alive_particle_step"],
+                    rec["multi"]["steps_per_launch"], rec["multi"]["value"]))
     L += ["", "## All kernels of the trace pass (count, total ms)", "", "| kernel | dispatches | total ms | avg ms |", "|---|---|---|---|"]
     for k in sorted(disp, key=lambda k: -sum(disp[k])):
         L.append("| `%s` | %d | %.3f | %.4f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, sum(disp[k]) / len(disp[k]) * 1e-6))
