@@ -135,3 +135,87 @@ def test_config2_delete_at_full_size_windows_vs_oracle(hip, N):
     p = 1e-3 * 1e-3 * C_LIT * dt
     assert abs(rows["multi"][0][1] - N * p) < 5 * np.sqrt(N * p * (1 - p))           # the expected removal rate
     assert any(r[3][0] > 0 for r in rows["multi"])                                    # the plane was crossed (x = 1e6 after 4 moves)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_config4_mixed_loop_at_1e8_windows_vs_oracle(hip, dtype):
+    """BASELINE configs[4] in its 1-GPU form: [Newton, ScatterIsotropic(A = n = 1e-3), Newton, ScatterDelete(pcoll 6e-3)] x K
+    on 1e8 photons, fp64 and fp32 (the oracle's float32 restatement), K = 12 iterations as ONE k_mixed launch.  Rows
+    agree between a second store run one launch per light step and the K-pass launch; the survivors of the id windows,
+    their positions and velocities agree with the oracle's chain on exactly those ids."""
+    N, K, seed, dt = 100_000_000, 12, 11, 1e-3
+    np_t = np.float64 if dtype == "f64" else np.float32
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=seed)
+    A_del, n_del = 2e-5, 1e-3
+    wins = windows(N)
+    with hip.Device(0) as d:
+        d.store_alloc(N, dtype)
+        d.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, seed)
+        E = [d.download(hip.E, n, off) for off, n in wins]
+        rows = d.step_mixed_multi(dt, K, ("iso", "delete"), sc, (A_del, n_del), (), seed, 2)
+        ids = d.download_ids()
+        assert len(ids) == rows[-1]["N"] and np.all(np.diff(ids) > 0)
+        got = []
+        for off, cnt in wins:
+            lo, hi = np.searchsorted(ids, off), np.searchsorted(ids, off + cnt)
+            got.append((ids[lo:hi], [d.download(hip.R0 + k, hi - lo, lo) for k in range(3)], [d.download(hip.V0 + k, hi - lo, lo) for k in range(3)]))
+        # the same loop one launch per light step on the same store: identical rows
+        d.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, seed)
+        single = []
+        for k in range(3):
+            o = d.step_fused(dt, dict(sc, step=2 + 2 * k), (), lazy=True)
+            single.append((o["N"], o["hits"], tuple(int(x) for x in o["sign"])))
+            o = d.step_fused_delete(dt, A_del, n_del, hip.RNG_PHILOX, seed, 3 + 2 * k, [], lazy=True)
+            single.append((o["N"], o["removed"], tuple(int(x) for x in o["sign"])))
+        assert single == [(o["N"], o.get("hits", o.get("removed")), tuple(int(x) for x in o["sign"])) for o in rows[:6]]
+    ulp_c = float(np.spacing(np_t(C_LIT)))
+    for (off, cnt), e0, (g_ids, g_r, g_v) in zip(wins, E, got):
+        w_ids = np.arange(off, off + cnt, dtype=np.int64)
+        z = lambda: np.zeros(cnt, dtype=np_t)
+        st = {"r": [z(), z(), z()], "v": [np.full(cnt, C_LIT, dtype=np_t), z(), z()], "dr": [z(), z(), z()], "dv": [z(), z(), z()],
+              "E": e0.astype(np_t), "id": w_ids}
+        for k in range(K):
+            orc.step_newton(st, dt, np_t)
+            orc.step_scatter_isotropic(st, orc.philox_draws(seed, 2 + 2 * k, st["id"], np_t), 1e-3, 1e-3, C_LIT, dtype=np_t)
+            orc.step_newton(st, dt, np_t)
+            orc.step_scatter_delete(st, orc.philox_draws(seed, 3 + 2 * k, st["id"], np_t)[2], A_del, n_del, np_t)
+        assert np.array_equal(g_ids, st["id"]), (dtype, off)                   # the very photons the oracle keeps
+        assert 0 < len(g_ids) < cnt
+        v, v_ref = np.stack(g_v, 1).astype(np.float64), np.stack(st["v"], 1).astype(np.float64)
+        r, r_ref = np.stack(g_r, 1).astype(np.float64), np.stack(st["r"], 1).astype(np.float64)
+        assert np.max(np.abs(v - v_ref)) <= 4 * ulp_c, (dtype, off)
+        slack = 2 * K * float(np.spacing(np_t(np.max(np.abs(r_ref)))))
+        assert np.max(np.abs(r - r_ref)) <= 2 * K * dt * 4 * ulp_c + slack + 1e-12, (dtype, off)
+
+
+def test_config2_isotropic_at_1e7_windows_vs_oracle(hip):
+    """BASELINE configs[1](i): 1e7 photons, E = 1, v = (c,0,0), dt = 1e-3, ScatterIsotropicStep(A = n = 1e-3), 100 steps
+    (test/test_light.py:27-45) as four K-step launches; windows against the oracle; the hit fraction is the reference's
+    expected 0.2998 within its +-10 % test threshold."""
+    N, steps, seed, dt = 10_000_000, 100, 1234, 1e-3
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=hip.RNG_PHILOX, seed=seed)
+    wins = windows(N)
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        d.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
+        hits, k = 0, 0
+        while k < steps:
+            ks = min(32, steps - k)
+            hits += sum(o["hits"] for o in d.step_fused_multi(dt, ks, dict(sc, step=k)))
+            k += ks
+        state = [{f: [d.download(fid, n, off) for fid in hip.FIELD_GROUPS[f]] for f in ("r", "v")} for off, n in wins]
+    p = 1e-3 * 1e-3 * C_LIT * dt
+    assert abs(hits / (N * steps) - p) < 0.1 * p                              # test/test_light.py:44-45
+    ulp_c = float(np.spacing(C_LIT))
+    for (off, cnt), s in zip(wins, state):
+        ids = np.arange(off, off + cnt, dtype=np.int64)
+        z = lambda: np.zeros(cnt)
+        st = {"r": [z(), z(), z()], "v": [np.full(cnt, C_LIT), z(), z()], "dr": [z(), z(), z()], "dv": [z(), z(), z()], "E": np.ones(cnt), "id": ids}
+        for k in range(steps):
+            orc.step_newton(st, dt)
+            orc.step_scatter_isotropic(st, orc.philox_draws(seed, k, ids), 1e-3, 1e-3, C_LIT)
+        v, v_ref = np.stack(s["v"], 1), np.stack(st["v"], 1)
+        r, r_ref = np.stack(s["r"], 1), np.stack(st["r"], 1)
+        assert np.max(np.abs(v - v_ref)) <= 4 * ulp_c, off
+        slack = steps * float(np.spacing(np.max(np.abs(r_ref))))
+        assert np.max(np.abs(r - r_ref)) <= steps * dt * 4 * ulp_c + slack + 1e-12, off
