@@ -3,7 +3,8 @@
 crossing the plane x = 1/(nA) is compared with N/e (the reference's test/test_light.py:45-66 and
 examples/code_unit_scale_test.ipynb), here with the code scale of the metre set to 1e-3.
 
-    python examples/delete_until_empty.py [steps_per_launch]
+    python examples/delete_until_empty.py [steps_per_launch]      (default: the constructor's own choice -- exit only asks
+                                                                  whether objects are left, so up to 64 passes run per launch)
 """
 import os
 import sys
@@ -17,7 +18,7 @@ import physicl.light as light   # noqa: E402
 import physicl.newton as newton  # noqa: E402
 
 N = 1_000_000
-spl = int(sys.argv[1]) if len(sys.argv) > 1 else 16            # passes of the loop per launch (1 = one launch per pass)
+spl = int(sys.argv[1]) if len(sys.argv) > 1 else None          # passes of the loop per launch (1 = one launch per pass)
 sim = phys.Simulation(cl_on=True, seed=7, exit=lambda cond: len(cond.objects) == 0, steps_per_launch=spl)
 sim.add_objs(light.generate_photons_bulk(N, min=light.E_from_wavelength(phys.Measurement(700e-9, "m**1")),
                                          max=light.E_from_wavelength(phys.Measurement(200e-9, "m**1")), seed=7))
