@@ -23,6 +23,7 @@ typedef unsigned int pcl_u32;
 #define PCL_RNG_IN 0
 #define PCL_RNG_PHX 1
 #define PCL_MAXPL 12
+#define PCL_PEND_MAX 8 /* Newton moves a store behind an alive mask may owe its r rows (kPendMax of physicl_hip.hip) */
 
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Counter (c0..c3), key (k0,k1).
@@ -710,6 +711,13 @@ struct pcl_fast_args {
     // bytes, dense arrays padded to whole 64-element groups; NULL = implicit ids / every particle is a photon
     const pcl_i64 *ids;
     const unsigned char *kind;
+    // GEN variants on a store behind an alive mask (the delete path keeps removed photons' slots, pcl_step_fused_delete):
+    // one bit per slot, set = a photon is there; N is then the store's extent.  Dead slots are moved like everybody else
+    // (nobody reads them again) but neither scatter nor count.  r may lag behind by n_pend Newton moves (their dt in
+    // pend_dt[]): they are applied first, with the velocity the photon had all along -- this step may change it.
+    const pcl_u64 *alive;
+    int n_pend;
+    T pend_dt[PCL_PEND_MAX];
     pcl_nprof<T> np;          // ahead-of-time VAR_N kernels only
 };
 
@@ -718,6 +726,7 @@ struct pcl_fast_tile {
     T R[3][VEC], V[3][VEC], L4[VEC];
     pcl_i64 ID[VEC];          // GEN only
     unsigned char KD[VEC];    // GEN only
+    pcl_u64 AL;               // GEN only: the alive word of the lane's group (VEC divides 64: one word)
 };
 
 // q = the lane's group in the tiled rows, qd = the same group in the dense id / kind arrays (GEN)
@@ -737,6 +746,7 @@ __device__ __forceinline__ void pcl_fast_load(const pcl_fast_args<T> &a, pcl_i64
             t.ID[e] = a.ids ? a.ids[qd * VEC + e] : (pcl_i64)0;
             t.KD[e] = a.kind ? a.kind[qd * VEC + e] : (unsigned char)1;
         }
+        t.AL = a.alive ? a.alive[(qd * VEC) >> 6] : ~(pcl_u64)0;
     }
 }
 
@@ -779,7 +789,15 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const pcl_i64 i = q * VEC + e;
-            const bool live = live_q && i < a.N;
+            bool live = live_q && i < a.N;
+            if constexpr (GEN) {
+                live = live && ((cur.AL >> (i & 63)) & 1ull);
+                for (int p = 0; p < a.n_pend; ++p) { // moves of earlier delete bodies that r has not seen yet
+                    cur.R[0][e] = R::add(cur.R[0][e], R::mul(cur.V[0][e], a.pend_dt[p]));
+                    cur.R[1][e] = R::add(cur.R[1][e], R::mul(cur.V[1][e], a.pend_dt[p]));
+                    cur.R[2][e] = R::add(cur.R[2][e], R::mul(cur.V[2][e], a.pend_dt[p]));
+                }
+            }
             // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
             const T d0 = R::mul(cur.V[0][e], a.dt), d1 = R::mul(cur.V[1][e], a.dt), d2 = R::mul(cur.V[2][e], a.dt);
             cur.R[0][e] = R::add(cur.R[0][e], d0);

@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(kBlock) k_flag_mask2(newtonmask_args<T> a) {
 //   r is not touched either: a photon of a delete run keeps its velocity, so the moves of the bodies since r was last
 //   written (at most kPendMax, their dt in pend_dt[]) are applied in registers, in order, with the operations of
 //   newton.py:15-16 -- to whoever needs r: the plane counters here (NEED_R), the compaction, k_apply_pending.
-constexpr int kPendMax = 8;
+constexpr int kPendMax = PCL_PEND_MAX;
 template <typename T>
 struct alive_args {
     const T *v[3];
@@ -3490,8 +3490,9 @@ int step_scatter_t(pcl_ctx *ctx, double A, double n, bool use_e, bool var_n, rtc
 template <typename T>
 int ensure_lam4_t(pcl_ctx *ctx, double h, double c) {
     if (ctx->lam4_valid && ctx->lam4_h == h && ctx->lam4_c == c) return PCL_OK;
-    hipLaunchKernelGGL(k_lam4<T>, dim3(grid_for(ctx, ctx->count, kBlock)), dim3(kBlock), 0, ctx->stream,
-                       (const T *)F<T>(ctx, PCL_E), static_cast<T *>(ctx->lam4), (T)h, (T)c, ctx->count, tile_stride(ctx));
+    const int64_t n = ctx->holes ? ctx->slots : ctx->count; // (behind an alive mask: every slot of the extent)
+    hipLaunchKernelGGL(k_lam4<T>, dim3(grid_for(ctx, n, kBlock)), dim3(kBlock), 0, ctx->stream,
+                       (const T *)F<T>(ctx, PCL_E), static_cast<T *>(ctx->lam4), (T)h, (T)c, n, tile_stride(ctx));
     PCL_TRY(launch_check("k_lam4"));
     ctx->lam4_valid = true;
     ctx->lam4_h = h;
@@ -3502,7 +3503,7 @@ int ensure_lam4_t(pcl_ctx *ctx, double h, double c) {
 template <typename T>
 int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool var_n, rtc_entry *ent, double c, double h,
                 uint64_t seed, uint32_t step) {
-    const int64_t N = ctx->count;
+    const int64_t N = ctx->holes ? ctx->slots : ctx->count; // behind an alive mask the kernel sweeps the extent
     if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
     pcl_fast_args<T> f{};
     f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
@@ -3521,7 +3522,12 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     // two more streams (8 B of id, 1 B of kind per particle)
     f.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
     f.kind = ctx->kind;
-    const bool gen = f.ids || f.kind;
+    if (ctx->holes) { // the store keeps removed photons' slots: the kernel reads the alive bits, and r catches up first
+        f.alive = reinterpret_cast<const pcl_u64 *>(ctx->masks);
+        f.n_pend = ctx->pend_n;
+        for (int q = 0; q < ctx->pend_n; ++q) f.pend_dt[q] = (T)ctx->pend_dt[q];
+    }
+    const bool gen = f.ids || f.kind || f.alive;
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_FUSED);
@@ -3536,6 +3542,7 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
         PCL_TRY(launch_check("k_fast"));
     }
     prof_end(ctx, ps);
+    if (ctx->holes) ctx->pend_n = 0; // the kernel wrote r with every pending move (and this step's) applied
     return PCL_OK;
 }
 
@@ -5143,11 +5150,15 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N | PCL_FUSED_LAZY))
         return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool lazy = flags & PCL_FUSED_LAZY;
+    static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
+    const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && n_planes <= 0 && !no_fast;
     if (lazy) {
         // a Newton-only pass keeps the dv of a still-implicit scatter step implicit (dv = v - vprev): only the source of
         // dr changes, to the current v rows
         PCL_TRY(need_store_raw(ctx));
-        PCL_TRY(densify(ctx)); // (a store behind an alive mask: dense first; dr / dv stay implicit)
+        // a store behind an alive mask: the fast kernels read the mask (all photons: a mask only exists on such stores);
+        // every other formulation sees the dense store (dr / dv stay implicit)
+        if (!(fast && !ctx->kind)) PCL_TRY(densify(ctx));
     } else {
         PCL_TRY(need_store(ctx));
     }
@@ -5184,8 +5195,6 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
     PCL_HIP(hipMemsetAsync(ctx->cnt_target, 0, (size_t)(4 + np) * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = bank;
-    static const bool no_fast = getenv("PCL_NO_FAST") != nullptr; // perf-experiment hook
-    const bool fast = lazy && do_scatter && rng_mode == PCL_RNG_PHILOX && n_planes <= 0 && !no_fast;
     if (fast) {
         // device RNG, implicit dr/dv, sign counters only (any store: explicit ids / plain Objects take k_fastg)
         PCL_TRY(PCL_DISPATCH(ctx, step_fast_t<double>(ctx, dt, A, n, use_e, var_n, ent, c, h, seed, step),
