@@ -409,6 +409,49 @@ int pcl_step_plane_energies(pcl_ctx *ctx, const double *plane_host, void *E_out_
  * defining the plane.  out_host: int64[PCL_CNT_PLANE0 + n_planes].  Synchronises. */
 int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int64_t *out_host);
 
+/* ---- Device groups: several GPUs from ONE process ---------------------------------------------------------------
+ * The reference is a single process with one simulation thread (physicl/__init__.py:400-432, 501-524); this is how
+ * a host written against this ABI uses a node's GPUs the same way, without one process per GPU.  A group owns one
+ * context (device, stream, store) and one worker thread per entry of device_ids (an id may repeat: two contexts on one
+ * GPU).  Particles are sharded by GLOBAL index in contiguous blocks -- shard g of G owns [g*N/G, (g+1)*N/G) -- and ids
+ * are global, so the id-keyed device RNG gives exactly the rows and the per-photon histories of a one-device run.  A
+ * group step hands the call to every shard's worker, waits for all of them, and returns the SUM of the int64 counter
+ * rows (same layout as the per-context call): the rows are in host memory when a launch returns, so this sum is the
+ * group's collective (the counters are the only global quantities of the path).  Windows of the
+ * particle order are read shard after shard (contiguous blocks + stable compaction = global particle order).
+ * pcl_group_ctx gives the i-th context for anything per shard (uploads, pcl_store_*).  One group call at a time.
+ * Errors: the first failing shard's code; pcl_last_error() names the shard.                                      */
+typedef struct pcl_group pcl_group;
+int pcl_group_create(int n_dev, const int *device_ids, pcl_group **group_out);
+int pcl_group_destroy(pcl_group *group);
+int pcl_group_size(pcl_group *group, int *n_out);
+int pcl_group_ctx(pcl_group *group, int i, pcl_ctx **ctx_out);
+int pcl_group_shard(pcl_group *group, int64_t n_global, int i, int64_t *lo_out, int64_t *hi_out);
+int pcl_group_store_alloc(pcl_group *group, int64_t capacity_global, int dtype);
+int pcl_group_fill_photons(pcl_group *group, int64_t n_global, int64_t id_base, double c, double e_min, double e_max,
+                           uint64_t seed);
+int pcl_group_count(pcl_group *group, int64_t *count_out);
+int pcl_group_sync(pcl_group *group);
+int pcl_group_reserve_compaction(pcl_group *group);
+/* the steps: arguments and out_host layout of pcl_step_fused (synchronous form: out_host and n_planes >= 0 required),
+ * pcl_step_fused_delete, pcl_step_fused_multi, pcl_step_fused_delete_multi, pcl_step_mixed_multi; counters summed     */
+int pcl_group_step_fused(pcl_group *group, double dt, int do_scatter, double A, double n, int flags, double c, double h,
+                         const char *n_expr, int rng_mode, uint64_t seed, uint32_t step, const double *planes_host,
+                         int n_planes, int64_t *out_host);
+int pcl_group_step_fused_delete(pcl_group *group, double dt, double A, double n, int flags, int rng_mode, uint64_t seed,
+                                uint32_t step, const double *planes_host, int n_planes, int64_t *out_host);
+int pcl_group_step_fused_multi(pcl_group *group, double dt, int k_steps, double A, double n, int flags, double c, double h,
+                               const char *n_expr, uint64_t seed, uint32_t step0, const double *planes_host, int n_planes,
+                               int64_t *out_host);
+int pcl_group_step_fused_delete_multi(pcl_group *group, double dt, int k_steps, double A, double n, uint64_t seed,
+                                      uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host);
+int pcl_group_step_mixed_multi(pcl_group *group, double dt, int k_passes, int n_phases, const int *phase_kinds_host, double A,
+                               double n, int flags, double c, double h, const char *n_expr, double A_del, double n_del,
+                               uint64_t seed, uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host);
+/* elements [offset, offset + n) of a field / of the ids in GLOBAL particle order (host pointers, store dtype / int64) */
+int pcl_group_download(pcl_group *group, int field, void *host, int64_t offset, int64_t n);
+int pcl_group_download_ids(pcl_group *group, int64_t *host, int64_t offset, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

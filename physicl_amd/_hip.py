@@ -121,6 +121,27 @@ _PROTOTYPES = {
     "pcl_step_fused_delete": [_vp, c_double, c_double, c_double, c_int, c_int, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_store_last_delete_flags": [_vp, _vp, c_int64],
     "pcl_step_counters": [_vp, _vp, c_int, _vp],
+    # device groups: several GPUs from one process (the C-level counterpart of physicl_amd.multidev.MultiDevice)
+    "pcl_group_create": [c_int, POINTER(c_int), POINTER(_vp)],
+    "pcl_group_destroy": [_vp],
+    "pcl_group_size": [_vp, POINTER(c_int)],
+    "pcl_group_ctx": [_vp, c_int, POINTER(_vp)],
+    "pcl_group_shard": [_vp, c_int64, c_int, POINTER(c_int64), POINTER(c_int64)],
+    "pcl_group_store_alloc": [_vp, c_int64, c_int],
+    "pcl_group_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
+    "pcl_group_count": [_vp, POINTER(c_int64)],
+    "pcl_group_sync": [_vp],
+    "pcl_group_reserve_compaction": [_vp],
+    "pcl_group_step_fused": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_int, c_uint64,
+                             c_uint32, _vp, c_int, _vp],
+    "pcl_group_step_fused_delete": [_vp, c_double, c_double, c_double, c_int, c_int, c_uint64, c_uint32, _vp, c_int, _vp],
+    "pcl_group_step_fused_multi": [_vp, c_double, c_int, c_double, c_double, c_int, c_double, c_double, c_char_p, c_uint64,
+                                   c_uint32, _vp, c_int, _vp],
+    "pcl_group_step_fused_delete_multi": [_vp, c_double, c_int, c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
+    "pcl_group_step_mixed_multi": [_vp, c_double, c_int, c_int, _vp, c_double, c_double, c_int, c_double, c_double, c_char_p,
+                                   c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
+    "pcl_group_download": [_vp, c_int, _vp, c_int64, c_int64],
+    "pcl_group_download_ids": [_vp, _vp, c_int64, c_int64],
 }
 EXPORTS = sorted(list(_PROTOTYPES) + ["pcl_last_error"])
 
@@ -668,4 +689,102 @@ class Device:
         out = np.zeros(CNT_PLANE0 + len(planes), dtype=np.int64)
         check(self.lib.pcl_step_counters(self.ctx, planes.ctypes.data_as(c_void_p) if len(planes) else None,
                                          len(planes), out.ctypes.data_as(c_void_p)))
+        return out
+
+
+class DeviceGroup:
+    """``pcl_group_*``: several contexts in one process, sharded by global index, behind the C ABI (the shim owns the
+    contexts and one worker thread per context, fans every step out and sums the counter rows).  The Python host layer
+    uses physicl_amd.multidev.MultiDevice, which does the same over ``Device`` objects; this class binds the C-level
+    form a non-Python host would use, for tests and scripts."""
+
+    def __init__(self, devices):
+        self.lib = load()
+        ids = (c_int * len(devices))(*[int(d) for d in devices])
+        g = c_void_p()
+        check(self.lib.pcl_group_create(len(devices), ids, byref(g)))
+        self.g, self.n = g, len(devices)
+
+    def close(self):
+        if getattr(self, "g", None):
+            self.lib.pcl_group_destroy(self.g)
+            self.g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard(self, n_global, i):
+        lo, hi = c_int64(), c_int64()
+        check(self.lib.pcl_group_shard(self.g, int(n_global), int(i), byref(lo), byref(hi)))
+        return lo.value, hi.value
+
+    def store_alloc(self, capacity, dtype="f64"):
+        check(self.lib.pcl_group_store_alloc(self.g, int(capacity), DTYPE_F64 if dtype == "f64" else DTYPE_F32))
+
+    def fill_photons(self, n, id_base, c, e_min, e_max, seed):
+        check(self.lib.pcl_group_fill_photons(self.g, int(n), int(id_base), c, e_min, e_max, int(seed)))
+
+    @property
+    def count(self):
+        v = c_int64()
+        check(self.lib.pcl_group_count(self.g, byref(v)))
+        return v.value
+
+    def sync(self):
+        check(self.lib.pcl_group_sync(self.g))
+
+    def step_fused_multi(self, dt, k_steps, sc, planes=()):
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros((k_steps, 5 + len(pl)), dtype=np.int64)
+        expr = sc.get("n_expr")
+        check(self.lib.pcl_group_step_fused_multi(self.g, float(dt), int(k_steps), float(sc["A"]), float(sc["n"]), int(sc.get("flags", 0)),
+                                                  float(sc.get("c", 0.0)), float(sc.get("h", 0.0)), expr.encode() if expr else None,
+                                                  int(sc.get("seed", 0)), int(sc.get("step", 0)) & 0xFFFFFFFF,
+                                                  pl.ctypes.data if len(pl) else None, len(pl), out.ctypes.data))
+        return out
+
+    def step_fused_delete(self, dt, A, n, seed, step, planes=(), lazy=True):
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros(5 + len(pl), dtype=np.int64)
+        check(self.lib.pcl_group_step_fused_delete(self.g, float(dt), float(A), float(n), FUSED_LAZY if lazy else 0, RNG_PHILOX, int(seed),
+                                                   int(step) & 0xFFFFFFFF, pl.ctypes.data if len(pl) else None, len(pl), out.ctypes.data))
+        return out
+
+    def step_fused_delete_multi(self, dt, k_steps, A, n, seed, step, planes=()):
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros((k_steps, 5 + len(pl)), dtype=np.int64)
+        check(self.lib.pcl_group_step_fused_delete_multi(self.g, float(dt), int(k_steps), float(A), float(n), int(seed), int(step) & 0xFFFFFFFF,
+                                                         pl.ctypes.data if len(pl) else None, len(pl), out.ctypes.data))
+        return out
+
+    def step_mixed_multi(self, dt, k_passes, phases, sc, delete, seed, step, planes=()):
+        kinds = np.array([{"iso": PHASE_ISOTROPIC, "delete": PHASE_DELETE}[p] for p in phases], dtype=np.int32)
+        pl = np.ascontiguousarray(np.asarray(planes, dtype=np.float64).reshape(-1, 3))
+        out = np.zeros((k_passes * len(kinds), 5 + len(pl)), dtype=np.int64)
+        expr = sc.get("n_expr")
+        check(self.lib.pcl_group_step_mixed_multi(self.g, float(dt), int(k_passes), len(kinds), kinds.ctypes.data, float(sc.get("A", 0.0)),
+                                                  float(sc.get("n", 0.0)), int(sc.get("flags", 0)), float(sc.get("c", 0.0)), float(sc.get("h", 0.0)),
+                                                  expr.encode() if expr else None, float(delete[0]), float(delete[1]), int(seed),
+                                                  int(step) & 0xFFFFFFFF, pl.ctypes.data if len(pl) else None, len(pl), out.ctypes.data))
+        return out
+
+    def download(self, field, n=None, offset=0, dtype=np.float64):
+        n = self.count - offset if n is None else n
+        out = np.empty(n, dtype=dtype)
+        check(self.lib.pcl_group_download(self.g, int(field), out.ctypes.data, int(offset), int(n)))
+        return out
+
+    def download_ids(self, n=None, offset=0):
+        n = self.count - offset if n is None else n
+        out = np.empty(n, dtype=np.int64)
+        check(self.lib.pcl_group_download_ids(self.g, out.ctypes.data, int(offset), int(n)))
         return out

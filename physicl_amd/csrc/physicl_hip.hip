@@ -37,6 +37,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
 #include <thread>
 #include <memory>
 #include <atomic>
@@ -5671,6 +5673,265 @@ int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int
     ctx->hits_on_host = true;
     for (int k = 0; k < nc; ++k) out_host[1 + k] = (int64_t)ctx->h_cnt[1 + k];
     return PCL_OK;
+}
+
+} // extern "C"
+
+// =================================================================================================
+// Device groups: several GPUs from ONE process (SURVEY.md 8(b) ``pcl_init(n_dev, dev_ids)``, 8(e))
+// =================================================================================================
+// The reference is one process with one simulation thread (physicl/__init__.py:400-432).  A group owns one context
+// (HIP device, stream, store) and one worker thread per entry of its device list; particles are sharded by global index
+// in contiguous blocks (shard g of G owns [g*N/G, (g+1)*N/G), ids global, so the id-keyed RNG gives the rows of a
+// one-device run); a group call hands the same step to every worker, waits for all, and SUMS the int64 counter rows
+// the shards return -- they are in host memory when a launch returns, so that sum is the group's collective.
+struct pcl_group {
+    std::vector<pcl_ctx *> ctx;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<int(int, pcl_ctx *)> job; // guarded by mu
+    uint64_t generation = 0;
+    int pending = 0;
+    bool quit = false;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+};
+
+namespace {
+
+void group_worker(pcl_group *g, int i) {
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(int, pcl_ctx *)> job;
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_go.wait(lk, [&] { return g->quit || g->generation != seen; });
+            if (g->quit) return;
+            seen = g->generation;
+            job = g->job;
+        }
+        const int rc = job(i, g->ctx[i]);
+        const std::string err = rc != PCL_OK ? g_err : std::string(); // (thread-local: this worker's last error)
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->rc[i] = rc;
+            g->err[i] = err;
+            if (--g->pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
+// job(i, ctx) on every shard, concurrently; the first failure (lowest shard) is the call's result and error text
+int group_run(pcl_group *g, std::function<int(int, pcl_ctx *)> job) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->job = std::move(job);
+    g->pending = (int)g->ctx.size();
+    ++g->generation;
+    g->cv_go.notify_all();
+    g->cv_done.wait(lk, [&] { return g->pending == 0; });
+    for (size_t i = 0; i < g->ctx.size(); ++i)
+        if (g->rc[i] != PCL_OK) return fail(g->rc[i], "shard %d: %s", (int)i, g->err[i].c_str());
+    return PCL_OK;
+}
+
+inline void shard_of(int64_t n, int i, int G, int64_t *lo, int64_t *hi) {
+    *lo = n * i / G;
+    *hi = n * (i + 1) / G;
+}
+
+// sum of the shards' int64 rows
+int group_sum(pcl_group *g, int64_t *out_host, size_t n, const std::vector<std::vector<int64_t>> &part) {
+    if (!out_host) return PCL_OK;
+    for (size_t k = 0; k < n; ++k) {
+        int64_t t = 0;
+        for (const auto &p : part) t += p[k];
+        out_host[k] = t;
+    }
+    return PCL_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int pcl_group_create(int n_dev, const int *device_ids, pcl_group **group_out) {
+    if (n_dev < 1 || n_dev > 64 || !device_ids || !group_out) return fail(PCL_ERR_ARG, "n_dev outside [1, 64] or NULL argument");
+    std::unique_ptr<pcl_group> g(new (std::nothrow) pcl_group);
+    if (!g) return fail(PCL_ERR_NOMEM, "out of host memory");
+    for (int i = 0; i < n_dev; ++i) {
+        pcl_ctx *c = nullptr;
+        const int rc = pcl_ctx_create(device_ids[i], nullptr, &c);
+        if (rc != PCL_OK) {
+            for (pcl_ctx *d : g->ctx) pcl_ctx_destroy(d);
+            return rc;
+        }
+        g->ctx.push_back(c);
+    }
+    g->rc.assign(n_dev, PCL_OK);
+    g->err.assign(n_dev, std::string());
+    for (int i = 0; i < n_dev; ++i) g->workers.emplace_back(group_worker, g.get(), i);
+    *group_out = g.release();
+    return PCL_OK;
+}
+
+int pcl_group_destroy(pcl_group *g) {
+    if (!g) return PCL_OK;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->quit = true;
+    }
+    g->cv_go.notify_all();
+    for (auto &w : g->workers) w.join();
+    for (pcl_ctx *c : g->ctx) pcl_ctx_destroy(c);
+    delete g;
+    return PCL_OK;
+}
+
+int pcl_group_size(pcl_group *g, int *n_out) {
+    if (!g || !n_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *n_out = (int)g->ctx.size();
+    return PCL_OK;
+}
+
+int pcl_group_ctx(pcl_group *g, int i, pcl_ctx **ctx_out) {
+    if (!g || !ctx_out || i < 0 || i >= (int)g->ctx.size()) return fail(PCL_ERR_ARG, "shard index outside the group");
+    *ctx_out = g->ctx[i];
+    return PCL_OK;
+}
+
+int pcl_group_shard(pcl_group *g, int64_t n_global, int i, int64_t *lo_out, int64_t *hi_out) {
+    if (!g || !lo_out || !hi_out || i < 0 || i >= (int)g->ctx.size() || n_global < 0) return fail(PCL_ERR_ARG, "bad argument");
+    shard_of(n_global, i, (int)g->ctx.size(), lo_out, hi_out);
+    return PCL_OK;
+}
+
+int pcl_group_store_alloc(pcl_group *g, int64_t capacity_global, int dtype) {
+    if (!g || capacity_global <= 0) return fail(PCL_ERR_ARG, "capacity must be positive");
+    const int G = (int)g->ctx.size();
+    return group_run(g, [=](int i, pcl_ctx *c) {
+        int64_t lo, hi;
+        shard_of(capacity_global, i, G, &lo, &hi);
+        return pcl_store_alloc_dtype(c, hi - lo > 0 ? hi - lo : 1, dtype);
+    });
+}
+
+int pcl_group_fill_photons(pcl_group *g, int64_t n_global, int64_t id_base, double c_light, double e_min, double e_max, uint64_t seed) {
+    if (!g || n_global < 0) return fail(PCL_ERR_ARG, "bad argument");
+    const int G = (int)g->ctx.size();
+    return group_run(g, [=](int i, pcl_ctx *c) {
+        int64_t lo, hi;
+        shard_of(n_global, i, G, &lo, &hi);
+        return pcl_store_fill_photons(c, hi - lo, id_base + lo, c_light, e_min, e_max, seed);
+    });
+}
+
+int pcl_group_count(pcl_group *g, int64_t *count_out) {
+    if (!g || !count_out) return fail(PCL_ERR_ARG, "NULL argument");
+    int64_t t = 0;
+    for (pcl_ctx *c : g->ctx) t += c->count;
+    *count_out = t;
+    return PCL_OK;
+}
+
+int pcl_group_sync(pcl_group *g) {
+    return group_run(g, [](int, pcl_ctx *c) { return pcl_ctx_sync(c); });
+}
+
+int pcl_group_reserve_compaction(pcl_group *g) {
+    return group_run(g, [](int, pcl_ctx *c) { return pcl_store_reserve_compaction(c); });
+}
+
+int pcl_group_step_fused(pcl_group *g, double dt, int do_scatter, double A, double n, int flags, double c, double h, const char *n_expr,
+                         int rng_mode, uint64_t seed, uint32_t step, const double *planes_host, int n_planes, int64_t *out_host) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    if (!out_host || n_planes < 0) return fail(PCL_ERR_ARG, "the group form is synchronous: out_host and n_planes >= 0 are required");
+    const size_t w = 5 + (size_t)n_planes;
+    std::vector<std::vector<int64_t>> part(g->ctx.size(), std::vector<int64_t>(w, 0));
+    PCL_TRY(group_run(g, [&](int i, pcl_ctx *cx) {
+        return pcl_step_fused(cx, dt, do_scatter, A, n, flags, c, h, n_expr, rng_mode, seed, step, planes_host, n_planes, part[i].data());
+    }));
+    return group_sum(g, out_host, w, part);
+}
+
+int pcl_group_step_fused_delete(pcl_group *g, double dt, double A, double n, int flags, int rng_mode, uint64_t seed, uint32_t step,
+                                const double *planes_host, int n_planes, int64_t *out_host) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    const size_t w = 5 + (size_t)(n_planes > 0 ? n_planes : 0);
+    std::vector<std::vector<int64_t>> part(g->ctx.size(), std::vector<int64_t>(w, 0));
+    PCL_TRY(group_run(g, [&](int i, pcl_ctx *cx) {
+        return pcl_step_fused_delete(cx, dt, A, n, flags, rng_mode, seed, step, planes_host, n_planes, part[i].data());
+    }));
+    return group_sum(g, out_host, w, part);
+}
+
+int pcl_group_step_fused_multi(pcl_group *g, double dt, int k_steps, double A, double n, int flags, double c, double h, const char *n_expr,
+                               uint64_t seed, uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    if (k_steps < 1 || k_steps > PCL_MULTI_MAX || n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "k_steps or n_planes out of range");
+    const size_t w = (size_t)k_steps * (5 + (size_t)n_planes);
+    std::vector<std::vector<int64_t>> part(g->ctx.size(), std::vector<int64_t>(w, 0));
+    PCL_TRY(group_run(g, [&](int i, pcl_ctx *cx) {
+        return pcl_step_fused_multi(cx, dt, k_steps, A, n, flags, c, h, n_expr, seed, step0, planes_host, n_planes, part[i].data());
+    }));
+    return group_sum(g, out_host, w, part);
+}
+
+int pcl_group_step_fused_delete_multi(pcl_group *g, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step0,
+                                      const double *planes_host, int n_planes, int64_t *out_host) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    if (k_steps < 1 || k_steps > PCL_MULTI_MAX || n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "k_steps or n_planes out of range");
+    const size_t w = (size_t)k_steps * (5 + (size_t)(n_planes > 0 ? n_planes : 0));
+    std::vector<std::vector<int64_t>> part(g->ctx.size(), std::vector<int64_t>(w, 0));
+    PCL_TRY(group_run(g, [&](int i, pcl_ctx *cx) {
+        return pcl_step_fused_delete_multi(cx, dt, k_steps, A, n, seed, step0, planes_host, n_planes, part[i].data());
+    }));
+    return group_sum(g, out_host, w, part);
+}
+
+int pcl_group_step_mixed_multi(pcl_group *g, double dt, int k_passes, int n_phases, const int *phase_kinds_host, double A, double n, int flags,
+                               double c, double h, const char *n_expr, double A_del, double n_del, uint64_t seed, uint32_t step0,
+                               const double *planes_host, int n_planes, int64_t *out_host) {
+    if (!g) return fail(PCL_ERR_ARG, "group is NULL");
+    if (k_passes < 1 || n_phases < 1 || k_passes * n_phases > PCL_MULTI_MAX || n_planes < 0 || n_planes > PCL_MAX_PLANES)
+        return fail(PCL_ERR_ARG, "k_passes * n_phases or n_planes out of range");
+    const size_t w = (size_t)k_passes * n_phases * (5 + (size_t)n_planes);
+    std::vector<std::vector<int64_t>> part(g->ctx.size(), std::vector<int64_t>(w, 0));
+    PCL_TRY(group_run(g, [&](int i, pcl_ctx *cx) {
+        return pcl_step_mixed_multi(cx, dt, k_passes, n_phases, phase_kinds_host, A, n, flags, c, h, n_expr, A_del, n_del, seed, step0,
+                                    planes_host, n_planes, part[i].data());
+    }));
+    return group_sum(g, out_host, w, part);
+}
+
+// a window [offset, offset + n) of the GLOBAL particle order, shard after shard (contiguous blocks + stable compaction)
+static int group_window(pcl_group *g, int64_t offset, int64_t n, size_t esz, char *host,
+                        const std::function<int(pcl_ctx *, void *, int64_t, int64_t)> &get) {
+    if (!g || offset < 0 || n < 0 || (n > 0 && !host)) return fail(PCL_ERR_ARG, "bad argument");
+    int64_t at = 0, total = 0;
+    for (pcl_ctx *c : g->ctx) total += c->count;
+    if (offset + n > total) return fail(PCL_ERR_ARG, "window [%lld, %lld) outside the %lld particles of the group", (long long)offset,
+                                        (long long)(offset + n), (long long)total);
+    for (pcl_ctx *c : g->ctx) {
+        const int64_t cnt = c->count;
+        const int64_t lo = offset > at ? offset : at, hi = offset + n < at + cnt ? offset + n : at + cnt;
+        if (hi > lo) PCL_TRY(get(c, host + (size_t)(lo - offset) * esz, lo - at, hi - lo));
+        at += cnt;
+    }
+    return PCL_OK;
+}
+
+int pcl_group_download(pcl_group *g, int field, void *host, int64_t offset, int64_t n) {
+    if (!g || g->ctx.empty()) return fail(PCL_ERR_ARG, "group is NULL");
+    return group_window(g, offset, n, g->ctx[0]->esz, static_cast<char *>(host),
+                        [field](pcl_ctx *c, void *h, int64_t off, int64_t cnt) { return pcl_store_download(c, field, h, off, cnt); });
+}
+
+int pcl_group_download_ids(pcl_group *g, int64_t *host, int64_t offset, int64_t n) {
+    if (!g || g->ctx.empty()) return fail(PCL_ERR_ARG, "group is NULL");
+    return group_window(g, offset, n, sizeof(int64_t), reinterpret_cast<char *>(host),
+                        [](pcl_ctx *c, void *h, int64_t off, int64_t cnt) { return pcl_store_download_ids(c, static_cast<int64_t *>(h), off, cnt); });
 }
 
 } // extern "C"

@@ -17,13 +17,14 @@ from oracle import physicl_oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "native", "abi_consumer.c")
+GROUP_SRC = os.path.join(ROOT, "tests", "native", "abi_group_consumer.c")
 LIBDIR = os.path.join(ROOT, "physicl_amd", "_lib")
 
 
-def build(tmp_path):
-    exe = str(tmp_path / "abi_consumer")
+def build(tmp_path, src=SRC, name="abi_consumer"):
+    exe = str(tmp_path / name)
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-O1", "-I", os.path.join(ROOT, "include"),
-                           SRC, "-o", exe, "-L", LIBDIR, "-lphysicl_hip", "-Wl,-rpath," + LIBDIR])
+                           src, "-o", exe, "-L", LIBDIR, "-lphysicl_hip", "-Wl,-rpath," + LIBDIR, "-lm"])
     return exe
 
 
@@ -44,6 +45,7 @@ def lcg_inputs(N):
 def test_header_is_plain_c_and_the_program_links(tmp_path):
     """No GPU needed: C99 -pedantic -Werror compile of the header's user and a link against every symbol it uses."""
     assert os.path.exists(build(tmp_path))
+    assert os.path.exists(build(tmp_path, GROUP_SRC, "abi_group_consumer"))
 
 
 @pytest.mark.gpu
@@ -67,3 +69,28 @@ def test_c_host_program_gets_the_oracles_results(tmp_path, N):
     assert rec["r"] == hexes(rn)
     assert rec["dr"] == hexes(dr)
     assert rec["counters"] == "%d %d %d %d" % ((N,) + orc.sign_counts(v))
+
+
+@pytest.mark.gpu
+def test_c_host_program_on_a_device_group_gets_the_one_context_rows(tmp_path):
+    """pcl_group_*: several contexts in one process behind the C ABI (SURVEY.md 8(b) ``pcl_init(n_dev, dev_ids)``).  The
+    plain-C program prints the rows of a K-step scatter launch, of a delete-until-empty run one call per body, and the
+    survivors' ids in global order; with 1, 2 and 3 contexts on device 0 the output must be identical line for line,
+    and the one-context rows are those of the Python binding on a single ``Device``."""
+    from physicl_amd import _hip as hip
+    exe = build(tmp_path, GROUP_SRC, "abi_group_consumer")
+    N = 150_001
+    outs = [subprocess.check_output([exe, str(N), str(g)], timeout=600).decode() for g in (1, 2, 3)]
+    assert outs[0] == outs[1] == outs[2]
+    lines = outs[0].splitlines()
+    iso = [[int(x) for x in ln.split()[2:]] for ln in lines if ln.startswith("iso")]
+    dele = [[int(x) for x in ln.split()[2:]] for ln in lines if ln.startswith("del")]
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        d.fill_photons(N, 1000, 299792458.0, 2.8e-19, 9.9e-19, 77)
+        rows = d.step_fused_multi(1e-3, 6, dict(A=1e-3, n=1e-3, flags=0, c=299792458.0, h=6.62607015e-34, seed=77, step=1))
+        assert iso == [[o["N"]] + [int(x) for x in o["sign"]] + [o["hits"]] for o in rows]
+        for body in range(len(dele)):
+            o = d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 77, 100 + body, [[2.0e6, np.nan, np.nan]], lazy=True)
+            assert dele[body] == [o["N"]] + [int(x) for x in o["sign"]] + [int(o["planes"][0]), o["removed"]], body
+    assert 0 < iso[0][4] < N and dele[0][5] > 0 and int([ln for ln in lines if ln.startswith("bodies")][0].split()[1]) > 20

@@ -76,3 +76,37 @@ def test_devices_and_comm_exclude_each_other():
     from physicl_amd.dist import CounterComm
     with pytest.raises(ValueError):
         phys.Simulation(devices=[0, 0], comm=CounterComm(0, 1, "gloo"))
+
+
+def test_device_group_of_the_c_abi_equals_multidevice_and_one_device():
+    """``pcl_group_*`` (the shim owns the contexts and their worker threads) against ``MultiDevice`` (Python fan-out) and
+    one ``Device``: K-step scatter rows, K-body delete rows, a mixed launch, windows of ids and positions."""
+    from physicl_amd import _hip as hip
+    from physicl_amd.multidev import MultiDevice
+    N, seed = 120_003, 9
+    C, H = 299792458.0, 6.62607015e-34
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C, h=H, seed=seed, step=3)
+    res = {}
+    for name, make in (("one", lambda: hip.Device(0)), ("multidev", lambda: MultiDevice([0, 0, 0])), ("group", lambda: hip.DeviceGroup([0, 0, 0]))):
+        with make() as d:
+            d.store_alloc(N)
+            d.fill_photons(N, 50, C, 2.8e-19, 9.9e-19, seed)
+            if name == "group":
+                a = d.step_fused_multi(1e-3, 5, sc)
+                b = d.step_mixed_multi(1e-3, 3, ("iso", "delete"), dict(sc, step=0), (1e-3, 0.4e-3), seed, 20)
+                c = d.step_fused_delete_multi(1e-3, 4, 1e-3, 0.5e-3, seed, 40, [[1e6, np.nan, np.nan]])
+                o = d.step_fused_delete(1e-3, 1e-3, 0.5e-3, seed, 60, [[1e6, np.nan, np.nan]])
+                assert d.shard(N, 1) == (N // 3, 2 * N // 3)
+            else:
+                a = d.step_fused_multi(1e-3, 5, sc, (), True, True)
+                b = d.step_mixed_multi(1e-3, 3, ("iso", "delete"), dict(sc, step=0), (1e-3, 0.4e-3), (), seed, 20, True)
+                c = d.step_fused_delete_multi(1e-3, 4, 1e-3, 0.5e-3, seed, 40, [[1e6, np.nan, np.nan]], True)
+                od = d.step_fused_delete(1e-3, 1e-3, 0.5e-3, hip.RNG_PHILOX, seed, 60, [[1e6, np.nan, np.nan]], lazy=True)
+                o = np.array([od["N"]] + [int(x) for x in od["sign"]] + [int(od["planes"][0]), od["removed"]])
+            n = d.count
+            res[name] = (np.asarray(a), np.asarray(b), np.asarray(c), np.asarray(o), n, d.download_ids(), d.download(hip.R0),
+                         d.download(hip.V1, 1000, n // 2))
+    for name in ("multidev", "group"):
+        for x, y in zip(res["one"], res[name]):
+            assert np.array_equal(x, y), name
+    assert 0 < res["one"][4] < N
