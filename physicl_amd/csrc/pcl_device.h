@@ -1585,13 +1585,19 @@ PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float,
 #if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
 #endif
-#ifdef PCL_MULTI_NQ2 /* experiment: two groups per lane and trip */
+// two VEC groups per lane and trip (256 photons per wave): the dense hit pass costs the same for 20 hits as for 64, so at
+// LOW hit fractions a wave that owns twice the photons fills its passes better (+5 .. +13 % below 23 % hits) -- at the
+// price of the fourth wave per SIMD (-8 % above 27 %).  pcl_step_fused_multi picks per launch, by the hit fraction of the
+// launch before ("K steps per pass").
 #ifndef PCL_MULTI2_ATTR
 #define PCL_MULTI2_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
 #endif
+#if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e0(pcl_multi_args<double> a) {
     pcl_multi_body_nq<double, false, true, 2, 2>(a);
 }
+#endif
+#if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e1(pcl_multi_args<double> a) {
     pcl_multi_body_nq<double, true, true, 2, 2>(a);
 }

@@ -2124,7 +2124,7 @@ struct rtc_entry {
     hipFunction_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-    hipFunction_t multi2[2] = {nullptr, nullptr}; // experiment (PCL_RTC_EXTRA=PCL_MULTI_NQ2): two groups per lane, fp64
+    hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
     std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
 
@@ -2184,6 +2184,7 @@ struct pcl_ctx {
     // ``slots`` (alive + dead), ``count`` is the alive count, ``masks`` holds the alive bits and ``tile_keep`` the alive
     // count per tile; r lags pend_n moves behind.  Every entry point but pcl_step_fused_delete makes the store dense
     // again first (densify, through need_store / ensure_scratch).
+    double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
     int64_t slots = 0;
@@ -3308,7 +3309,7 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
             snprintf(nm, sizeof nm, "pcl_rtc_mixed_%se%d", dt_tag[d], e);
             get(&ent.mixed[d][e], nm);
         }
-    for (int e = 0; e < 2; ++e) { // optional kernels: absent unless the experiment define was given
+    for (int e = 0; e < 2; ++e) { // fp64 modules only
         char nm[64];
         snprintf(nm, sizeof nm, "pcl_rtc_multi2_e%d", e);
         if (hipModuleGetFunction(&ent.multi2[e], ent.module, nm) != hipSuccess) ent.multi2[e] = nullptr;
@@ -3577,7 +3578,13 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    static const bool nq2 = getenv("PCL_MULTI_NQ2") != nullptr; // perf-experiment hook
+    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 25 % of the photons
+    // (fuller dense passes; slower above that: one wave per SIMD fewer).  PCL_MULTI_NQ2=1 always, =0 never.
+    static const int nq2_mode = [] {
+        const char *e = getenv("PCL_MULTI_NQ2");
+        return !e ? -1 : (e[0] == '0' ? 0 : 1);
+    }();
+    const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < 0.25);
     set_np(f.np, ent);
     if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
@@ -3957,6 +3964,7 @@ int wait_alive(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 }
 
 void drop_holes(pcl_ctx *ctx) {
+    ctx->multi_last_h = -1.0; // (called whenever the population is replaced)
     ctx->holes = false;
     ctx->slots = 0;
     ctx->pend_n = 0;
@@ -5286,6 +5294,9 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
             for (int j = 0; j < 3 + np; ++j) out_host[(5 + np) * k + 1 + j] = (int64_t)ctx->h_multi[nslots * k + 1 + j];
             out_host[(5 + np) * k + 4 + np] = (int64_t)ctx->h_multi[nslots * k];
         }
+        ctx->multi_last_h = (double)ctx->h_multi[nslots * (k_steps - 1)] / (double)N; // what the next launch's form goes by
+    } else {
+        ctx->multi_last_h = -1.0;
     }
     return PCL_OK;
 }

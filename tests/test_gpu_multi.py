@@ -260,3 +260,49 @@ def test_full_size_delete_multi_equals_single_steps_at_1e8(make_store, hip):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert all(np.array_equal(a, b) for a, b in zip(out[0][2], out[1][2]))
     assert abs(out[0][1] / N - 0.7002 ** K) < 1e-3
+
+
+@pytest.mark.parametrize("mode", ["1", "0"])
+def test_the_k_step_tests_with_256_and_with_128_photons_per_wave(mode):
+    """pcl_step_fused_multi picks one of two formulations of the K-step pass per launch -- 128 photons per wave, or 256
+    when the previous launch's last step scattered fewer than a quarter of the photons (fuller dense passes at low hit
+    fractions).  Same operations per photon either way: the K-step tests must pass with either form forced
+    (PCL_MULTI_NQ2=1 / 0) as they do with the automatic choice."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("PCL_NQ2_RERUN"):
+        pytest.skip("already inside the re-run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_multi.py", "tests/test_gpu_bench_regime.py",
+                        "tests/test_gpu_rtc_background.py", "-k", "not photons_per_wave"],
+                       cwd=root, env=dict(os.environ, PCL_NQ2_RERUN="1", PCL_MULTI_NQ2=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=1200)
+    assert p.returncode == 0, p.stdout[-4000:]
+    assert " passed" in p.stdout
+
+
+def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
+    """Three launches of 8 steps on the bench's workload (hit fraction 1.0 in the first step, falling below 25 % later with a
+    small time step): whatever form each launch took, the rows and the state equal 24 single steps."""
+    N, seed = 200_000, 5
+    expr = "0.000000001 * exp(r0[gid] - 5)"
+    sc = lambda k: dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=299792458.0, h=6.62607015e-34,
+                        n_expr=expr, rng_mode=hip.RNG_PHILOX, seed=seed, step=k)
+    out = {}
+    for how in ("multi", "single"):
+        with hip.Device(0) as d:
+            d.store_alloc(N)
+            d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
+            rows = []
+            if how == "multi":
+                for k in range(0, 24, 8):
+                    rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 8, sc(k))]
+            else:
+                rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(24))]
+            out[how] = (rows, d.download_state())
+    assert out["multi"][0] == out["single"][0]
+    assert out["multi"][0][7][0] < 0.5 * N                    # the later launches did start from a low hit fraction
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)
