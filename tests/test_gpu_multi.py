@@ -283,8 +283,9 @@ def test_the_k_step_tests_with_256_and_with_128_photons_per_wave(mode):
 
 
 def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
-    """Three launches of 8 steps on the bench's workload (hit fraction 1.0 in the first step, falling below 25 % later with a
-    small time step): whatever form each launch took, the rows and the state equal 24 single steps."""
+    """Four launches of 24 steps on the bench's workload (hit fraction 1.0 in the first step, below 25 % after ~70 steps):
+    whatever form each launch took -- the last one starts below the threshold --, the rows and the state equal 96 single
+    steps."""
     N, seed = 200_000, 5
     expr = "0.000000001 * exp(r0[gid] - 5)"
     sc = lambda k: dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=299792458.0, h=6.62607015e-34,
@@ -296,13 +297,13 @@ def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
             d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
             rows = []
             if how == "multi":
-                for k in range(0, 24, 8):
-                    rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 8, sc(k))]
+                for k in range(0, 96, 24):
+                    rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
             else:
-                rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(24))]
+                rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
             out[how] = (rows, d.download_state())
     assert out["multi"][0] == out["single"][0]
-    assert out["multi"][0][7][0] < 0.5 * N                    # the later launches did start from a low hit fraction
+    assert out["multi"][0][71][0] < 0.25 * N < out["multi"][0][23][0]     # the last launch started below the threshold, the second above
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)
