@@ -1586,7 +1586,7 @@ PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float,
 PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
 #endif
 // two VEC groups per lane and trip (256 photons per wave): the dense hit pass costs the same for 20 hits as for 64, so at
-// LOW hit fractions a wave that owns twice the photons fills its passes better (+5 .. +13 % below 23 % hits) -- at the
+// LOW hit fractions a wave that owns twice the photons fills its passes better (+5 .. +13 % below ~25 % hits) -- at the
 // price of the fourth wave per SIMD (-8 % above 27 %).  pcl_step_fused_multi picks per launch, by the hit fraction of the
 // launch before ("K steps per pass").
 #ifndef PCL_MULTI2_ATTR

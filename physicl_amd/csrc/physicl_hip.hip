@@ -3578,13 +3578,17 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 25 % of the photons
+    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 28 % of the photons
     // (fuller dense passes; slower above that: one wave per SIMD fewer).  PCL_MULTI_NQ2=1 always, =0 never.
     static const int nq2_mode = [] {
         const char *e = getenv("PCL_MULTI_NQ2");
         return !e ? -1 : (e[0] == '0' ? 0 : 1);
     }();
-    const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < 0.25);
+    static const double nq2_below = [] {
+        const char *e = getenv("PCL_MULTI_NQ2_BELOW");
+        return e ? atof(e) : 0.28; // (sweep of 0.22 .. 0.36 on three bench configurations: profiles/r03_experiments/README.md)
+    }();
+    const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < nq2_below);
     set_np(f.np, ent);
     if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
