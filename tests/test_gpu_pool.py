@@ -91,7 +91,7 @@ def test_temporaries_of_big_stores_go_back_where_they_came_from():
     """The staging buffers of last_delete_flags / step_delete_flags / scatter_pcoll / fill_photons_table come from the
     same allocator as the store (big blocks: mapped virtual-memory ranges, pooled): freeing them any other way leaks the
     physical handles.  PCL_BIG_MIN_MB=1 takes a 300k-photon store through the big-block paths; free device memory plus
-    what idles in the pool must be back where it started after every call."""
+    what idles in the pool must not have shrunk after the calls."""
     code = ("import numpy as np\n"
             "from physicl_amd import _hip as hip\n"
             "N = 300_000\n"
@@ -102,7 +102,7 @@ def test_temporaries_of_big_stores_go_back_where_they_came_from():
             "d.fill_photons_table(N, 0, 299792458.0, cdf, grid, 3)\n"      # 2 x 1.6 MB table: a big block under the knob
             "t0 = avail()\n"
             "for k in range(6): d.fill_photons_table(N, 0, 299792458.0, cdf, grid, 3)\n"
-            "assert abs(avail() - t0) <= (2 << 20), (t0, avail())\n"
+            "assert t0 - avail() <= (2 << 20), (t0, avail())\n"             # (one-sided: the driver may still be reclaiming an earlier process's memory)
             "d.step_newton(1e-3)\n"
             "o = d.step_fused_delete(1e-3, 1e-3, 1e-3, hip.RNG_PHILOX, 3, 0, [], lazy=True)\n"   # second slab, scratch
             "n = o['N']; d.sync()\n"
@@ -119,7 +119,7 @@ def test_temporaries_of_big_stores_go_back_where_they_came_from():
             "    m = d.count; flags = np.zeros(m, np.int32); flags[::3] = 1\n"
             "    alive, removed = d.step_delete_flags(flags); assert alive + removed == m\n"
             "a1 = avail()\n"
-            "assert abs(a1 - a0) <= (2 << 20), (a0, a1)\n"
+            "assert a0 - a1 <= (2 << 20), (a0, a1)\n"
             "d.close(); print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_BIG_MIN_MB="1"), timeout=300)
     assert out.decode().strip().endswith("ok")
