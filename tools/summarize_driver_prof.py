@@ -43,6 +43,21 @@ def read_counter(path):
     return out
 
 
+def read_counter_seq(path, kernels):
+    """[(kernel, {counter: value})] of the dispatches of ``kernels``, in dispatch order"""
+    per, order = {}, []
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        if k not in kernels:
+            continue
+        key = int(r["Dispatch_Id"])
+        if key not in per:
+            per[key] = (k, {})
+            order.append(key)
+        per[key][1][r["Counter_Name"]] = per[key][1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    return [per[k] for k in sorted(order)]
+
+
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
@@ -75,26 +90,35 @@ def main():
          "`single_step` leg (3 + %d x %d launches of the one-step kernel), the `delete`, `iso_1e7` and `mixed` legs and the `api` leg "
          "(three 500-pass simulations and a delete-until-empty run through the plugin API)."
          % (warmup, min(S, warmup), R, steps, min(S, steps), R, steps), "",
-         "## K-step kernel `pcl_rtc_multi_e1`, every dispatch (bench.py's own launches first; the later ones belong to the `api` leg)", "",
+         "## K-step pass (`pcl_rtc_multi_e1`: 128 photons per wave, `pcl_rtc_multi2_e1`: 256), every dispatch in order (bench.py's own "
+         "launches first; the later ones belong to the `api` leg); the form is in brackets behind K", "",
          "Bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); "
          "lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64); VALU instr / particle-step = SQ_INSTS_VALU x 64 / (N x K).", "",
          "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
          "|---|---|---|---|---|---|---|---|---|"]
-    km = "pcl_rtc_multi_e1"
+    # the K-step pass has two forms (128 / 256 photons per wave: pcl_rtc_multi_e1 / pcl_rtc_multi2_e1), picked per launch
+    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1")
+    seq = sorted(((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                  for r in rows if short(r["Kernel_Name"]) in kms))
+    f_seq = read_counter_seq(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"), kms)
+    w_seq = read_counter_seq(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"), kms)
+    s_seq = read_counter_seq(os.path.join(src, "pmc_sq", "pmc_counter_collection.csv"), kms)
     ks = [min(S, warmup)] + [min(S, steps)] * R
     multi_rows = []
-    for i, d in enumerate(disp.get(km, [])[:len(ks) + 2]):
+    forms = []
+    for i, (_, kname, d) in enumerate(seq[:len(ks) + 2]):
         K = ks[i] if i < len(ks) else None
-        fb = fetch[km][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(km, [])) else 0
-        wb = write[km][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(km, [])) else 0
-        c = sq[km][i] if i < len(sq.get(km, [])) else {}
+        forms.append("256" if kname.endswith("multi2_e1") else "128")
+        fb = f_seq[i][1].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(f_seq) else 0
+        wb = w_seq[i][1].get("WRITE_SIZE", 0) * 1024 if i < len(w_seq) else 0
+        c = s_seq[i][1] if i < len(s_seq) else {}
         busy = c.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) if c.get("GRBM_GUI_ACTIVE") else 0
         util = c.get("SQ_THREAD_CYCLES_VALU", 0) / (c["SQ_ACTIVE_INST_VALU"] * 64) if c.get("SQ_ACTIVE_INST_VALU") else 0
         per_ps = c.get("SQ_INSTS_VALU", 0) * 64 / (N * K) if K else 0
         gb = 128.0 * N / (d * 1e-9) / 1e9
         multi_rows.append((K, d, fb + wb, busy, util, per_ps))
-        L.append("| %d | %s | %.3f | %.1f | %.0f | %.4f | %.3f | %.3f | %s |" % (i, K if K else "api", d * 1e-6, (fb + wb) / N, gb, gb / HBM_PEAK, busy, util,
-                                                                              "%.1f" % per_ps if K else "-"))
+        L.append("| %d | %s | %.3f | %.1f | %.0f | %.4f | %.3f | %.3f | %s |" % (i, ("%d (%s)" % (K, forms[-1])) if K else "api (%s)" % forms[-1], d * 1e-6,
+                                                                              (fb + wb) / N, gb, gb / HBM_PEAK, busy, util, "%.1f" % per_ps if K else "-"))
     timed = [r for r in multi_rows[1:1 + R]]
     if timed:
         avg = sum(r[1] for r in timed) / len(timed)
