@@ -396,7 +396,7 @@ class Simulation(threading.Thread):
         # a step list with a delete step will compact the store sooner or later: its second slab is allocated (and
         # chosen among candidates) now, with the upload, not inside the loop body that first needs it
         if self._residency == DEVICE and dev.capacity > 0 and \
-                any(getattr(s, "_fuse_role", None) == "scatter_delete" or getattr(s, "_compacts", False) for s in self.steps.values()):
+                any(getattr(s, "_fuse_role", None) == "scatter_delete" for s in self.steps.values()):
             dev.reserve_compaction()
 
     def _upload_locked(self, dev):
