@@ -22,12 +22,15 @@ def main():
     ap.add_argument("--photons", type=float, default=1e7)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-plane", action="store_true")
+    ap.add_argument("--no-counters", action="store_true", help="planes=None: no measure counters at all (timing experiment)")
     ap.add_argument("--no-prof", action="store_true", help="no HIP-event pairs around the kernels (pcl_prof_*)")
     a = ap.parse_args()
     N = int(a.photons)
     dev = _hip.Device(0)
     dev.store_alloc(N)
     plane = np.zeros((0, 3)) if a.no_plane else np.array([[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])
+    if a.no_counters:
+        plane = None
     for rep in range(a.reps + 1):
         dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, 1234)
         dev.prof_enable(not a.no_prof)
