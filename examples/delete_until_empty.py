@@ -4,7 +4,7 @@ crossing the plane x = 1/(nA) is compared with N/e (the reference's test/test_li
 examples/code_unit_scale_test.ipynb), here with the code scale of the metre set to 1e-3.
 
     python examples/delete_until_empty.py [steps_per_launch]      (default: the constructor's own choice -- exit only asks
-                                                                  whether objects are left, so up to 64 passes run per launch)
+                                                                  whether objects are left, so up to 32 passes run per launch)
 """
 import os
 import sys

@@ -728,11 +728,10 @@ class Simulation(threading.Thread):
         phases = ["iso" if s._fuse_role == "scatter_iso" else "delete" for s in lights]
         has_delete = "delete" in phases
         n_ts = len(self.ts)
-        # PCL_MULTI_MAX = 64 rows per launch.  Automatic mode: 32 passes, but a delete-only loop takes all 64 -- a photon
-        # of such a run is three adds and half a Philox block per pass, and delete-until-empty (test/test_light.py:52-59:
-        # ~50 passes at a survival of 0.7) then is ONE launch and one compaction
-        k_cap = self._k_wanted() if self.steps_per_launch is not None or phases != ["delete"] else 64
-        times, dt0 = self._plan_passes(upd, max(1, min(k_cap, 64 // P)), has_delete)
+        # PCL_MULTI_MAX = 64 rows per launch (a delete-only loop with all 64 in one launch was measured no faster than two
+        # launches of 32: 0.96 vs 0.85 ms for the 1e7-photon run of test/test_light.py:52-59 -- the planning of the passes
+        # is serial host work in front of the launch)
+        times, dt0 = self._plan_passes(upd, max(1, min(self._k_wanted(), 64 // P)), has_delete)
         k = len(times)
         if k == 0:
             return False                              # nothing could be planned ahead: this pass runs the plain way
