@@ -26,9 +26,15 @@ particle-step, which turns the step from HBM-bound into VALU-bound).  The K time
 --steps-per-launch 1 is the one-launch-per-step, HBM-bound path; with N=1 it is also measured in the same run
 and reported under "single_step", and the delete/compaction path (BASELINE configs[1](ii)) under "delete".
 
-Prints ONE JSON line on rank 0.  Every number in `roofline`, `single_step` and `delete` is measured in THIS run
-(HIP event pairs recorded on the library's stream around every launch, pcl_prof_*); PMC-counter figures from
-committed rocprofv3 profiles appear only under `static_profile`, labelled with their source.
+Prints ONE JSON line on rank 0.  Every number in `roofline`, `single_step`, `delete`, `iso_1e7`, `mixed` and `api` is
+measured in THIS run (wall clock, and HIP event pairs recorded on the library's stream around every launch,
+pcl_prof_*); PMC-counter figures from committed rocprofv3 profiles appear only under `static_profile`, labelled with
+their source.  `roofline` refers to the MEDIAN block, the one `value` is taken from.  With N=1 the other BASELINE
+configurations ride along: `delete` = configs[1](ii) at 1e7 and 1e8 (one call per loop body on the store's alive mask,
+and K bodies per launch), `iso_1e7` = configs[1](i), `mixed` = configs[4] in its 1-GPU form (fp64 and fp32, with the
+fp32-vs-fp64 error figures), `api` = configs[2]'s 500 passes through physicl_amd.Simulation with the constructor exactly
+as a script written against the reference calls it.  `--gpus N --dry-run` brings the ranks and the collective up and
+stops.
 `cpu_baseline` = the oracle's C/OpenMP port of the same step timed on this box's host cores on a
 bounded sample of the same photons (rank 0, N=1 only).
 """
