@@ -110,3 +110,41 @@ def test_device_group_of_the_c_abi_equals_multidevice_and_one_device():
         for x, y in zip(res["one"], res[name]):
             assert np.array_equal(x, y), name
     assert 0 < res["one"][4] < N
+
+
+def test_cl_off_semantics_on_two_contexts_equal_one_context():
+    """``Simulation(cl_on=False, devices=[0, 0])``: the reference's CPU-path semantics (data-dependent np.random order of
+    ScatterIsotropicStep.__run_py, physicl/light.py:335-350; the skip-after-removal iteration of
+    ScatterDeleteStepReference.__run_py, light.py:216-223) on a store sharded over two contexts: same decisions, same
+    state, same position of the np.random stream as on one context."""
+    def run(**kw):
+        np.random.seed(99)
+        rs = np.random.RandomState(3)
+        sim = phys.Simulation(cl_on=False, exit=lambda s: len(s.ts) >= 6, **kw)
+        objs = []
+        for i in range(3001):
+            d = np.zeros(3)
+            d[rs.randint(3)] = rs.choice([-1.0, 1.0])
+            if i % 7 == 3:
+                objs.append(phys.Object(v=phys.Measurement(rs.normal(size=3), "m**1 s**-1"), uid=i))
+            else:
+                objs.append(phys.light.PhotonObject(v=d * 299792458.0, E=np.double(rs.uniform(2.8e-19, 9.9e-19)), uid=i))
+        sim.add_objs(objs)
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+        sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+        sg = phys.light.ScatterSignMeasureStep(None, True)
+        sim.add_step(3, sg)
+        sim.add_step(4, phys.light.ScatterDeleteStepReference(np.double(0.001), np.double(0.0004)))
+        sim.start()
+        sim.join()
+        assert sim.error is None, sim.error
+        left = list(sim.objects)
+        out = ([[float(x) for x in r] for r in sg.data], [o.uid for o in left],
+               np.array([np.asarray(o.r, dtype=float) for o in left]), np.array([np.asarray(o.v, dtype=float) for o in left]),
+               float(np.random.random_sample()))
+        sim.close()
+        return out
+    a, b = run(), run(devices=[0, 0])
+    assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4] and 0 < len(a[1]) < 3001
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
