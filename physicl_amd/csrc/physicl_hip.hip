@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     const int64_t per = div_up(n_tiles, 1024);
     const int64_t lo = (int64_t)t * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
     int64_t sum = 0;
-    for (int64_t k = lo; k < hi; ++k) sum += tile_keep[k];
+#pragma unroll 8
+    for (int64_t k = lo; k < hi; ++k) sum += tile_keep[k]; // (independent loads: unrolled, they are in flight together)
     // inclusive scan of the 1024 partial sums: wave shuffle scan, then scan of the 16 wave totals
     int64_t inc = sum;
     for (int off = 1; off < 64; off <<= 1) {
@@ -396,6 +397,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(const int32_t *__restrict__ 
     }
     __syncthreads();
     int64_t run = (wave ? s_wave[wave - 1] : 0) + inc - sum; // exclusive prefix of this thread's chunk
+#pragma unroll 8
     for (int64_t k = lo; k < hi; ++k) {
         tile_off[k] = run;
         run += tile_keep[k];
