@@ -1334,39 +1334,7 @@ struct compact_counter_args {
     int move;      // 1: pass 1 only flagged; the survivors' Newton move r = r + v*dt (newton.py:15-16) happens here
     int n_pend;    // alive-mask stores: moves of earlier loop bodies that r has not seen yet, applied first, in order
     T pend_dt[kPendMax];
-    // report != 0 (alive-mask path): the LAST workgroup to finish copies the counters cnt[1 .. 3 + n_planes] to the host's
-    // pinned block and then writes ``seq`` to host[kCounterSlots - 6], which the host polls -- no copy to enqueue, no
-    // stream synchronise (the pattern of k_delete_alive)
-    int report;
-    unsigned long long *ticket;
-    uint64_t *host;
-    uint64_t seq;
 };
-
-// the epilogue both pass-3 kernels share: this workgroup's counters into the grid totals, then (report) the hand-over
-__device__ __forceinline__ void compact_counters_out(unsigned long long *cnt, const uint32_t *s_cnt, int n_planes, int report,
-                                                     unsigned long long *ticket, uint64_t *host, uint64_t seq, int *s_last) {
-    const int nslots = 4 + (n_planes > 0 ? n_planes : 0);
-    unsigned long long seen = 0;
-    if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
-        seen = __hip_atomic_fetch_add(&cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!report) return;
-    asm volatile("" ::"v"(seen) : "memory"); // the add has returned: it is in place before the ticket is drawn
-    __syncthreads();
-    if (threadIdx.x == 0) *s_last = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull;
-    __syncthreads();
-    if (!*s_last) return;
-    if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots) {
-        volatile uint64_t *h = host;
-        h[threadIdx.x] = __hip_atomic_load(&cnt[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_exchange(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&host[kCounterSlots - 6], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
 
 template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
 template <> __device__ __forceinline__ double word_as<double, uint64_t>(uint64_t w) { return __longlong_as_double((long long)w); }
@@ -1441,11 +1409,12 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
         dest += __popcll(m);
     }
     if (c.n_planes >= 0) {
-        __shared__ int s_last;
         if (lane == 0)
             for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
         __syncthreads();
-        compact_counters_out(reinterpret_cast<unsigned long long *>(c.cnt), s_cnt, c.n_planes, c.report, c.ticket, c.host, c.seq, &s_last);
+        const int nslots = 4 + (c.n_planes > 0 ? c.n_planes : 0);
+        if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+            atomicAdd(&c.cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
@@ -1612,11 +1581,12 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
         }
     }
     if (counters) {
-        __shared__ int s_last;
         if (lane == 0)
             for (int k = 0; k < 3; ++k) atomicAdd(&s_cnt[1 + k], w_s[k]);
         __syncthreads();
-        compact_counters_out(reinterpret_cast<unsigned long long *>(c.cnt), s_cnt, c.n_planes, c.report, c.ticket, c.host, c.seq, &s_last);
+        const int nslots = 4 + (c.n_planes > 0 ? c.n_planes : 0);
+        if ((int)threadIdx.x >= 1 && (int)threadIdx.x < nslots && s_cnt[threadIdx.x])
+            atomicAdd(&c.cnt[threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
     }
 }
 
@@ -3954,16 +3924,10 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, bool wri
 // scan + stable compaction of a store in the alive-mask state into the other slab: the survivors' r catches up with the
 // pending moves (and, ``move``, with this body's) on the way.  The caller adopts the result.
 template <typename T>
-int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const double *planes_host, int n_planes, bool report = false) {
+int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const double *planes_host, int n_planes) {
     PCL_TRY(scan_tiles(ctx, ctx->count));
     compact_counter_args<T> cc{};
     cc.cnt = ctx->d_cnt;
-    if (report) { // the counters reach the host through the last workgroup, not through a copy (fused_delete_alive polls)
-        cc.report = 1;
-        cc.ticket = reinterpret_cast<unsigned long long *>(ctx->d_cnt + kCounterSlots); // k_delete_alive's ticket: same discipline
-        cc.host = ctx->h_cnt;
-        cc.seq = ++ctx->alive_seq;
-    }
     cc.n_planes = n_planes;
     cc.dt = (T)dt;
     cc.move = move ? 1 : 0;
@@ -4086,25 +4050,15 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         if (rc == PCL_OK)
             rc = PCL_DISPATCH(ctx, delete_alive_t<double>(ctx, slots, fresh, false, false, dt, A, n, seed, step, planes_host, n_planes),
                               delete_alive_t<float>(ctx, slots, fresh, false, false, dt, A, n, seed, step, planes_host, n_planes));
-        static const bool poll_compaction = [] { // 0: copy + stream synchronise, as the round-2 pipeline does (A/B)
-            const char *e = getenv("PCL_ALIVE_POLL");
-            return !(e && e[0] == '0');
-        }();
-        const bool report = n_planes >= 0 && poll_compaction;
         if (rc == PCL_OK)
-            rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, true, dt, planes_host, n_planes, report),
-                              compact_alive_t<float>(ctx, dv_mode, true, dt, planes_host, n_planes, report));
-        if (rc == PCL_OK && n_planes >= 0 && !report) {
+            rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, true, dt, planes_host, n_planes),
+                              compact_alive_t<float>(ctx, dv_mode, true, dt, planes_host, n_planes));
+        if (rc == PCL_OK && n_planes >= 0) {
             rc = hipMemcpyAsync(ctx->h_cnt + 1, ctx->d_cnt + 1, (size_t)(3 + np) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                          hipStreamSynchronize(ctx->stream) == hipSuccess
                      ? PCL_OK : fail(PCL_ERR_HIP, "reading the counters failed");
         }
-        if (rc == PCL_OK && report) {
-            // the compaction's last workgroup reports the counters; the scan wrote the count before it (same stream)
-            rc = wait_alive(ctx, before, &alive);
-        } else if (rc == PCL_OK) {
-            rc = wait_count(ctx, before, &alive);
-        }
+        if (rc == PCL_OK) rc = wait_count(ctx, before, &alive);
         if (rc != PCL_OK) {
             ctx->holes = !fresh;
             ctx->count = before;
