@@ -688,8 +688,7 @@ class Simulation(threading.Thread):
                 break
             self.dt = dt                              # UpdateTimeStep.run (physicl/__init__.py:337-343)
             self.t += dt
-            t_now = _snap(self.t)
-            ts.append(t_now)
+            ts.append(_snap(self.t))                  # (its own copy: a Measurement clock is advanced IN PLACE by the next pass)
             code = float(dt) if type(dt) in _PLAIN_FLOATS else self._dt_code()
             if dt0 is None:
                 dt0 = code
@@ -697,7 +696,7 @@ class Simulation(threading.Thread):
                 self.t, self.dt = t_before, dt_before
                 ts.pop()
                 break
-            times.append((t_now, dt))
+            times.append((_snap(self.t), dt))         # ... and another one for the row replay, which re-installs it as sim.t
             if len(times) < k_max:
                 try:
                     view.refresh()

@@ -171,3 +171,21 @@ def test_the_static_guard_runs_once_per_function_and_plan():
     assert not sim._ahead_agreed(sim.steps[0]) and "closes over 'm'" in sim.launch_note
     sim.exit = lambda s: len(s.ts) >= 3                 # a new function is judged afresh
     assert sim._ahead_agreed(sim.steps[0]) and sim.launch_note is None
+
+
+def test_a_measurement_clock_is_not_shared_between_ts_and_the_replay():
+    """``t += dt`` is IN PLACE when the time step is a Measurement (an ndarray subclass; physicl/__init__.py:343 deep-copies t
+    into ts for that reason).  The planner hands out two separate copies per pass -- one for ``ts``, one for the replay, which
+    re-installs it as ``sim.t`` -- so advancing the clock for the next launch must not move an entry of ``ts``."""
+    import physicl_amd as phys
+    sim, _ = _sim(lambda s: len(s.ts) >= 50)
+    dt = phys.Measurement(np.double(0.25), "s**1")
+    upd = phys.UpdateTimeStep(lambda s: dt)
+    times, dt0 = sim._plan_passes(upd, 3, False)
+    assert len(times) == 3 and dt0 == 0.25
+    sim.t, sim.dt = times[-1]                          # what the row replay leaves behind
+    assert all(times[i][0] is not sim.ts[i] for i in range(3))
+    times2, _ = sim._plan_passes(upd, 2, False)
+    assert [float(np.asarray(t)) for t in sim.ts] == [0.25, 0.5, 0.75, 1.0, 1.25]
+    assert [float(np.asarray(t)) for t, _ in times + times2] == [0.25, 0.5, 0.75, 1.0, 1.25]
+    assert len({id(t) for t in sim.ts}) == 5
