@@ -83,6 +83,9 @@ def draw_config(rs):
     # one launch per light step without showing: a measure step's rows through a closure, ``sim.hits`` through the
     # argument, a threshold on the object count
     cfg["exit_kind"] = str(rs.choice(["clock", "closure_rows", "sim_hits", "count"], p=[0.55, 0.15, 0.15, 0.15]))
+    # a time step with units: the clock is then a Measurement, which ``t += dt`` advances IN PLACE (physicl/__init__.py:343
+    # deep-copies it into ts for that reason) -- every schedule must leave the same ts behind
+    cfg["dt_measurement"] = bool(rs.random_sample() < 0.3)
     return cfg
 
 
@@ -123,10 +126,11 @@ def build_and_run(cfg, steps_per_launch, fuse, **sim_kw):
             else:
                 objs.append(phys.light.PhotonObject(v=d * C_LIT, E=np.double(rs.uniform(2.8e-19, 9.9e-19)), uid=i))
         sim.add_objs(objs)
+    wrap = (lambda x: phys.Measurement(np.double(x), "s**1")) if cfg.get("dt_measurement") else np.double
     if cfg["dt_kind"] == "const":
-        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: wrap(0.001)))
     else:
-        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001) if len(s.ts) % 3 else np.double(0.0005)))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: wrap(0.001) if len(s.ts) % 3 else wrap(0.0005)))
     steps = []
     for light, ms in cfg["groups"]:
         steps.append(phys.newton.NewtonianKinematicsStep())
