@@ -3077,8 +3077,9 @@ bool read_file(const std::string &path, std::vector<char> *out) {
 }
 
 void write_file_atomic(const std::string &path, const std::vector<char> &data) {
-    char tmp[32];
-    snprintf(tmp, sizeof tmp, ".tmp%ld", (long)getpid());
+    // (process AND thread: the contexts of a device group compile the same text side by side on their own threads)
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp%ld.%zx", (long)getpid(), std::hash<std::thread::id>()(std::this_thread::get_id()));
     const std::string t = path + tmp;
     FILE *f = fopen(t.c_str(), "wb");
     if (!f) return; // read-only home, full disk ...: the cache is an optimisation only
