@@ -95,6 +95,12 @@ typedef struct pcl_ctx pcl_ctx; /* opaque */
 int         pcl_abi_version(void);
 const char *pcl_last_error(void);                 /* thread-local, never NULL */
 int         pcl_device_count(int *n_out);         /* host pointer */
+/* A/B switches ("knobs").  Every PCL_* environment variable the library reads at call time (the delete path's: PCL_ALIVE,
+ * PCL_ALIVE_RATIO, PCL_ALIVE_MIN_SLOTS, PCL_ALIVE_POLL, PCL_ALIVE_FLUSH_KERNEL, PCL_AHEAD, PCL_AHEAD_K,
+ * PCL_AHEAD_MAX_SLOTS; the K-step pass's: PCL_MULTI_NQ2, PCL_MULTI_NQ2_BELOW) can also be set from the program:
+ * value = its text, NULL = back to the environment.  Process-wide, takes effect at the next call; results never depend
+ * on a knob (that is what the tests that flip them check), only which formulation runs.                            */
+int         pcl_set_knob(const char *name, const char *value);
 /* Device blocks of >= 64 MB (stores, scratch, pcl_dev_alloc buffers) are not handed back to the driver when freed: the
  * process keeps up to PCL_POOL_GB (environment; default a third of the device's memory, 0 = off; without PCL_POOL_GB a freed
  * block is only kept while at least a quarter of the device stays free) of them for its next store of about that size --
@@ -154,6 +160,7 @@ int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
 #define PCL_PROF_FUSED       5 /* k_fused / hipRTC specialisation  */
 #define PCL_PROF_MULTI       6 /* k_multi / k_mixed / hipRTC specialisations */
 #define PCL_PROF_ONEPASS     7 /* k_delete_onepass                 */
+#define PCL_PROF_DELETE_AHEAD 8 /* k_delete_ahead: K delete loop bodies of a small store worked out in one launch */
 int pcl_prof_enable(pcl_ctx *ctx, int on);
 int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out,
                   double *min_ms_out, double *max_ms_out);
@@ -231,6 +238,14 @@ int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, n
  * count when it is dense); *pending_moves_out (may be NULL) = Newton moves r has not been given yet.  Every other entry
  * point sees the dense store: it is compacted first, survivors in order, r up to date.                               */
 int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
+/* Small stores (extent <= PCL_AHEAD_MAX_SLOTS, default 2^20 slots): when a pcl_step_fused_delete call repeats the
+ * previous one with ``step`` advanced by one -- a run's loop, physicl/__init__.py:512-516 -- the library works out that
+ * body AND the next PCL_AHEAD_K - 1 (default 16) in one launch that leaves the store untouched, and answers the following
+ * calls, if they are the predicted ones, from those rows without a launch (a loop body of a small store is a 20 us round
+ * trip to the host, not bytes).  Any other call first makes the state after the bodies handed out so far real (one small
+ * kernel), so nothing but timing ever shows.  Statistics since the context was created (host pointers, any may be NULL):
+ * launches of the K-body kernel, bodies answered (the launching one included), launches whose rows were not all used. */
+int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_out, int64_t *missed_out);
 /* Allocate now what the first compaction of the store would allocate on demand (the second slab -- chosen among a few
  * candidates like the first, tens of ms for a big store --, the id arrays, the mask scratch), so that a run whose step
  * list holds a delete step pays for it at set-up and not inside its third loop body.  Optional.                        */
@@ -341,6 +356,13 @@ int pcl_store_is_uniform(pcl_ctx *ctx, int *uniform_out);
 int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, int flags, double c, double h,
                          const char *n_expr, uint64_t seed, uint32_t step0, const double *planes_host, int n_planes,
                          int64_t *out_host);
+/* The work the last pcl_step_fused_multi launch did, as its kernel tallied it (host pointers, any may be NULL): the
+ * K-step pass is bound by VALU issue, not by HBM, and its instruction count per wave is
+ *   (instructions of a step's decision part) x wave-steps + (instructions of a dense pass) x dense passes,
+ * the two static counts being properties of the code object (profiles/isa_counts.json).  *dense_passes_out = passes of
+ * the waves' hit queues (ceil(hits of the wave in that step / 64) summed over waves and steps), *wave_steps_out = waves x
+ * K, *photons_per_wave_out = 128 or 256 (fp64; the form the launch took).                                          */
+int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out);
 
 /* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
  * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --

@@ -22,10 +22,11 @@ DTYPE_F64, DTYPE_F32 = 0, 1
 _NP_DTYPE = {DTYPE_F64: np.float64, DTYPE_F32: np.float32}
 CNT_N, CNT_XP, CNT_YP, CNT_ZP, CNT_PLANE0 = 0, 1, 2, 3, 4
 MAX_PLANES = 12
-PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED, PROF_MULTI, PROF_ONEPASS = range(8)
+PROF_NEWTON, PROF_SCATTER, PROF_DELETE_MASK, PROF_COMPACT, PROF_COUNTERS, PROF_FUSED, PROF_MULTI, PROF_ONEPASS, \
+    PROF_DELETE_AHEAD = range(9)
 PROF_NAMES = {PROF_NEWTON: "k_newton", PROF_SCATTER: "k_scatter", PROF_DELETE_MASK: "k_delete_mask",
               PROF_COMPACT: "k_compact", PROF_COUNTERS: "k_counters", PROF_FUSED: "k_fused", PROF_MULTI: "k_multi",
-              PROF_ONEPASS: "k_delete_onepass"}
+              PROF_ONEPASS: "k_delete_onepass", PROF_DELETE_AHEAD: "k_delete_ahead"}
 ERR_NAMES = {-1: "PCL_ERR_HIP", -2: "PCL_ERR_ARG", -3: "PCL_ERR_STATE", -4: "PCL_ERR_RTC", -5: "PCL_ERR_EXPR",
              -6: "PCL_ERR_NOMEM"}
 
@@ -49,6 +50,9 @@ _vp = c_void_p
 _PROTOTYPES = {
     "pcl_abi_version": [],
     "pcl_device_count": [POINTER(c_int)],
+    "pcl_set_knob": [c_char_p, c_char_p],
+    "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)],
+    "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
     "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
@@ -174,6 +178,11 @@ def check(rc):
     if rc != 0:
         msg = (_lib.pcl_last_error() or b"").decode("utf-8", "replace")
         raise (ExpressionError if rc in (-4, -5) else HipError)(rc, msg)
+
+
+def set_knob(name, value=None):
+    """An A/B switch of the library (pcl_set_knob): ``value`` = its text, None = back to the environment variable."""
+    check(load().pcl_set_knob(name.encode(), None if value is None else str(value).encode()))
 
 
 def device_count():
@@ -406,6 +415,18 @@ class Device:
         v = c_int64()
         check(self.lib.pcl_store_slots(self.ctx, byref(v), None))
         return v.value
+
+    def last_multi_work(self):
+        """(dense passes, wave-steps, photons per wave) of the last step_fused_multi launch (pcl_store_last_multi_work)."""
+        a, b, c = c_int64(), c_int64(), c_int()
+        check(self.lib.pcl_store_last_multi_work(self.ctx, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
+    def ahead_stats(self):
+        """(launches, bodies answered, launches not used up) of the delete bodies worked out ahead (pcl_store_ahead_stats)."""
+        a, b, c = c_int64(), c_int64(), c_int64()
+        check(self.lib.pcl_store_ahead_stats(self.ctx, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
 
     def reserve_compaction(self):
         """Allocate the second slab, id arrays and mask scratch of the delete path now (pcl_store_reserve_compaction)."""

@@ -31,7 +31,7 @@ import time
 import numpy as np
 
 from .units import Measurement
-from .ahead import AheadView as _AheadView, NotAhead as _NotAhead, clock_only as _clock_only
+from .ahead import AheadView as _AheadView, NotAhead as _NotAhead, clock_only as _clock_only, count_use as _count_use
 
 HOST, DEVICE, BOTH = "host", "device", "both"   # where the authoritative particle state is
 _IMMUTABLE = (int, float, complex, np.generic)  # values later in-place arithmetic cannot change: no copy needed to keep them
@@ -233,8 +233,10 @@ class Simulation(threading.Thread):
                device store (photons do not interact; state, ``hits`` and every measure row are bit-identical to one
                launch per step).  The host side of those passes -- the time update and ``exit(sim)`` -- is evaluated
                ahead of the launch on a view of the simulation that exposes exactly those things; a function that
-               touches anything else (measured rows, the objects, ``hits``), or whose verdict depends on HOW MANY
-               objects are left rather than on whether any are, silently gets one launch per light step instead
+               touches anything else (measured rows, the objects, ``hits``), that reaches ``time``, ``random``,
+               ``np.random``, ``os`` ... or keeps state of its own between calls (both functions are called exactly as
+               often as the reference's loop calls them, but K of those calls come before the launch), or whose verdict
+               depends on HOW MANY objects are left rather than on whether any are, silently gets one launch per light step instead
                (``sim.launch_note`` says why).  K > 1: the same with up to K passes.  1: always one launch per light step.
                For loops without a ScatterDeleteStep ``exit`` is evaluated ahead of the launch only; with one it is also
                replayed on the returned rows and the run is cut at the pass that emptied the store.
@@ -290,6 +292,7 @@ class Simulation(threading.Thread):
         self._ahead_ok = True         # exit / the time-step function can be evaluated ahead of a launch (until one cannot)
         self.launch_note = None       # why the run fell back to one launch per light step, if it did
         self._ahead_key = None
+        self._count_key, self._count_why = None, None
         self._readonly_scope = False  # inside a host step that promises not to modify objects
         self._dev_lock = threading.RLock()   # one device call in flight per context (include/physicl_hip.h)
         self._uploaded, self._upload_lo = [], 0
@@ -667,17 +670,36 @@ class Simulation(threading.Thread):
         self._ahead_ok = False
         self.launch_note = "one launch per light step: %s %s, which is not known ahead of a launch" % (what, name)
 
+    def _count_known_ahead(self, upd):
+        """Loops with a ScatterDeleteStep: the object count a later pass of the launch will see is not known ahead of it --
+        only that a store that is not empty now stays "not empty" until the returned rows say otherwise.  ``exit`` and the
+        time-step function may therefore ask ``sim.objects`` whether it is empty and nothing else; the use is read off their
+        bytecode (ahead.count_use), once per pair of functions, before anything has advanced."""
+        key = (id(self.exit), id(upd.fn))
+        if key != self._count_key:
+            self._count_key = key
+            self._count_why = None
+            for what, fn in (("exit(sim)", self.exit), ("the time-step function", upd.fn)):
+                if _count_use(fn) == "other":
+                    self._count_why = what
+                    break
+        if self._count_why is not None:
+            self._ahead_off(self._count_why + " depends on", "how many objects are left")
+            return False
+        return True
+
     def _plan_passes(self, upd, k_max, count_matters):
         """Host part of up to ``k_max`` passes, ahead of the launch: the time update of each pass, then the exit test
-        the outer loop would make before the next one -- both on an _AheadView of the simulation.  Returns [(t, dt)]
-        per pass and the code dt.  Planning stops early (and for good: ``_ahead_ok``) as soon as one of the two
-        functions looks at something the view does not have; the passes planned so far still run as one launch, and the
-        outer loop makes its next exit test on the real simulation.  ``count_matters`` (a ScatterDeleteStep is in the
-        loop): the object count a later pass will see is not known yet, so an exit whose verdict for a NON-EMPTY store
-        depends on the count cannot be evaluated ahead either."""
+        the outer loop would make before the next one -- both on an _AheadView of the simulation, each ONCE per pass as
+        in the reference's loop (physicl/__init__.py:512-516).  Returns [(t, dt)] per pass and the code dt.  Planning
+        stops early (and for good: ``_ahead_ok``) as soon as one of the two functions looks at something the view does
+        not have; the passes planned so far still run as one launch, and the outer loop makes its next exit test on the
+        real simulation.  ``count_matters`` (a ScatterDeleteStep is in the loop): nothing is planned unless both
+        functions use the object count for emptiness only (_count_known_ahead)."""
         times, dt0 = [], None
+        if count_matters and not self._count_known_ahead(upd):
+            return times, dt0
         view = _AheadView(self, self._alive)
-        view1 = _AheadView(self, 1) if count_matters and self._alive > 1 else None
         fn, exit_fn, ts = upd.fn, self.exit, self.ts
         while len(times) < k_max:
             t_before, dt_before = _snap(self.t), self.dt   # ``t += dt`` is in place on an ndarray
@@ -701,11 +723,6 @@ class Simulation(threading.Thread):
                 try:
                     view.refresh()
                     stop = exit_fn(view)
-                    if not stop and view1 is not None:
-                        view1.refresh()
-                        if exit_fn(view1):
-                            self._ahead_off("exit(sim) depends on", "how many objects are left")
-                            break
                 except _NotAhead as e:
                     self._ahead_off("exit(sim) reads", "sim." + str(e.args[0]))
                     break
@@ -718,8 +735,9 @@ class Simulation(threading.Thread):
         (_plan_passes); the device then advances the particles through all of them in one pass over the store (and one
         compaction if a ScatterDeleteStep is in the loop) and returns one counter row per light step per pass.
         ``exit`` usually waits for the store to empty, which the host cannot know ahead of the launch: the rows are
-        replayed afterwards and the run is cut at the first pass whose exit test is true -- valid because that can only
-        be a pass that left nothing alive (checked)."""
+        replayed afterwards and, from the pass that left nothing alive on, the exit test is made again on the real
+        simulation; the run is cut at the first pass where it is true (while photons are alive the planned verdicts hold:
+        the functions ask the object list for emptiness only, _count_known_ahead)."""
         self._to_device()             # a host plugin or another thread may have taken the objects back since the last pass
         dev, hip = self._dev, self._hip
         P = len(groups)
@@ -782,15 +800,15 @@ class Simulation(threading.Thread):
                     n_m = m._n_planes()
                     m._record(self, row[0], row[2:5], row[at:at + n_m])
                     at += n_m
-            if has_delete and i + 1 < k:
-                later = ts[n_ts + i + 1:]             # ... and exit sees ``ts`` as it stood after that pass
+            if has_delete and i + 1 < k and self._alive == 0:
+                # The planned exit tests were made for a store that is not empty (the functions ask for emptiness only:
+                # _count_known_ahead); this pass emptied it, so its test -- the one the outer loop would make here -- is made
+                # again, on the simulation as it stood after this pass.  The later passes of the launch ran on an empty store:
+                # if the loop stops here their times are dropped.
+                later = ts[n_ts + i + 1:]
                 del ts[n_ts + i + 1:]
-                if self.exit(self):                   # the outer loop would have stopped here
-                    if self._alive != 0:
-                        raise RuntimeError("steps_per_launch: exit(sim) became true after pass %d of a %d-pass launch while %d "
-                                           "objects were alive; with ScatterDeleteStep the exit test may depend on t/ts/dt and on "
-                                           "the store being empty only" % (i + 1, k, self._alive))
-                    break                             # the later passes ran on an empty store: their times are dropped
+                if self.exit(self):
+                    break
                 ts.extend(later)
         return True
 

@@ -854,6 +854,7 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
 // 128/K B (fp64).  The velocity is updated in place and the velocity before the LAST step goes to the vp
 // rows, so dr = vp*dt and dv = v - vp stay implicit exactly as after a single lazy step.
 // cnt[(4 + n_planes)*k + {0: hits, 1..3: sign counts, 4..: plane crossings}] for k = 0..K-1.
+// cnt[(4 + n_planes)*K] = dense passes of the hit queues over the whole launch (the work tally of the VALU roofline record).
 // ------------------------------------------------------------------------------------------------
 #define PCL_MULTI_MAX 64
 template <typename T>
@@ -896,12 +897,15 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
+    __shared__ pcl_u32 s_pass;
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
+    if (threadIdx.x == 0) s_pass = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
+    pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform: a scalar add per step)
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
@@ -986,6 +990,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const pcl_u32 n_hit = qbase + w_hits;
+            w_passes += (w_hits + 63u) >> 6;
             // the scatter itself, densely: item j by lane j                                light.py:309-311
             for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
                 const pcl_u32 o = s_q.owner[j];
@@ -1035,9 +1040,11 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             VV::st(a.v2, qs, V[2]);
         }
     }
+    if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
     __syncthreads();
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
+    if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
 }
 
 // NQ: VEC-wide groups per lane and trip (photons per lane = VEC * NQ).  The dense pass costs the same whether 5 or 64
@@ -1052,12 +1059,15 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
+    __shared__ pcl_u32 s_pass;
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
+    if (threadIdx.x == 0) s_pass = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x * NQ;
+    pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform)
     const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
     constexpr pcl_u32 QCAP = 64u * VEC;
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x * NQ; base < nq; base += stride) {
@@ -1178,6 +1188,7 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
+                w_passes += (wbase - qbase + 63u) >> 6;
                 // the scatter itself, densely: item j by lane j                                light.py:309-311
                 for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
                     const pcl_u32 o = s_q.owner[j];
@@ -1245,9 +1256,11 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 VV::st(a.v2, qs[g], t5);
             }
     }
+    if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
     __syncthreads();
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
+    if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,6 +91,43 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 // =================================================================================================
+// knobs: the A/B switches of the library.  A knob's value is the override set with pcl_set_knob(name, value) if there
+// is one, else the environment variable of that name, else unset.  The delete path's switches are read at every call
+// (``knob`` objects below: a cached value re-read when any override changes), so that one process can run the same
+// program under several settings (tests/conftest.py ``pcl_knobs``); the remaining getenv() switches are read once.
+// =================================================================================================
+std::mutex g_knob_mu;
+std::map<std::string, std::string> g_knob_over; // name -> value ("" erases)
+std::atomic<int> g_knob_gen{1};
+
+struct knob {
+    const char *name;
+    std::atomic<int> gen{0};
+    std::atomic<bool> has{false};
+    std::atomic<double> num{0.0};
+    std::atomic<bool> zero{false}; // the text starts with '0' (the "=0 switches off" convention)
+    explicit knob(const char *n) : name(n) {}
+    void refresh() {
+        const int g = g_knob_gen.load(std::memory_order_acquire);
+        if (gen.load(std::memory_order_acquire) == g) return;
+        std::lock_guard<std::mutex> lk(g_knob_mu);
+        const char *v = nullptr;
+        auto it = g_knob_over.find(name);
+        if (it != g_knob_over.end())
+            v = it->second.c_str();
+        else
+            v = getenv(name);
+        has.store(v != nullptr);
+        num.store(v ? atof(v) : 0.0);
+        zero.store(v && v[0] == '0');
+        gen.store(g, std::memory_order_release);
+    }
+    bool set() { refresh(); return has.load(); }
+    bool off() { refresh(); return has.load() && zero.load(); }       // NAME=0
+    double value(double dflt) { refresh(); return has.load() ? num.load() : dflt; }
+};
+
+// =================================================================================================
 // geometry
 // =================================================================================================
 constexpr int kBlock = 256;           // 4 wave64 per workgroup
@@ -670,6 +707,7 @@ struct alive_args {
     uint64_t *zero_cnt;         // count == 0: counter slots the compaction behind this launch adds into, cleared here
     int n_zero;
     uint64_t seq;               // count == 1: written to host[kCounterSlots - 6] after the totals -- the host polls for it
+    int r_axes;                 // NEED_R: bit k = component k of r is read (a plane lies on that axis, or write_r: all three)
     int write_r;                // NEED_R: store r with every move up to and including this body's applied (the list of
                                 // pending moves was full): the caller starts a new, empty list
     int fresh;                  // 1: the store is dense -- every slot below ``slots`` is alive, masks are not read
@@ -723,11 +761,14 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                     const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
                     vv[u][k][0] = q.x, vv[u][k][1] = q.y;
                 }
-                if constexpr (NEED_R) {
+                if constexpr (NEED_R) { // only the components somebody looks at: the planes' axes, or all three for write_r
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
-                        xx[u][k][0] = q.x, xx[u][k][1] = q.y;
+                        xx[u][k][0] = xx[u][k][1] = (T)0;
+                        if ((a.r_axes >> k) & 1) { // (uniform)
+                            const T2 q = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+                            xx[u][k][0] = q.x, xx[u][k][1] = q.y;
+                        }
                     }
                 } else {
 #pragma unroll
@@ -763,7 +804,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                     if constexpr (NEED_R) { // r as the reference holds it after this body's move: earlier bodies' moves first
                         for (int q = 0; q < a.n_pend; ++q) {
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) xx[u][k][e] = R::add(xx[u][k][e], R::mul(vv[u][k][e], a.pend_dt[q]));
+                            for (int k = 0; k < 3; ++k)
+                                if ((a.r_axes >> k) & 1) xx[u][k][e] = R::add(xx[u][k][e], R::mul(vv[u][k][e], a.pend_dt[q]));
                         }
                         xx[u][0][e] = R::add(xx[u][0][e], d0);                                                                // newton.py:16
                         xx[u][1][e] = R::add(xx[u][1][e], d1);
@@ -869,6 +911,225 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
             }
             *reinterpret_cast<T2 *>(a.r[k] + ti) = x;
         }
+    }
+}
+
+// ---- delete loop bodies AHEAD of their calls (small stores) -----------------------------------------------------------
+//   A loop body of a small store is latency: a 5-10 us kernel and a 15-20 us round trip to the host, which has to learn
+//   the alive count before it can ask ``exit``.  But the bodies of a delete run are a deterministic function of the
+//   store and of the call's arguments, and a run repeats the call with the launch number advanced by one.  When the
+//   library has seen that pattern and the extent is small (pcl_step_fused_delete, "ahead"), ONE launch of this kernel
+//   works out the next K bodies WITHOUT touching the store: per slot the body it is removed in (``death``: 0 = was dead,
+//   k = removed by the k-th body from here, 255 = survives all K) and one counter row per body in the host's pinned
+//   block.  The following K - 1 calls -- if they are the predicted ones -- are answered from those rows without a launch;
+//   whenever anything else looks at the store, k_ahead_commit first makes the state after the bodies handed out so far
+//   real (masks, masks_prev, tile counts, r).  Nothing is guessed: a call that does not match simply commits and runs
+//   the ordinary way.  Same operations per photon as k_delete_alive (tests/test_gpu_alive_mask.py runs both).
+constexpr int kAheadMax = 32;                       // bodies per launch, at most
+constexpr int kAheadRow = 4 + PCL_MAX_PLANES;       // counters per body: alive, sign x 3, planes
+template <typename T>
+struct ahead_args {
+    const T *v[3];
+    T *r[3];
+    const int64_t *ids;
+    const uint64_t *masks;      // alive bits before the first body (unless fresh)
+    uint8_t *death;
+    unsigned long long *acc;    // device accumulators: [0] ticket, [1 + k * kAheadRow + c]
+    uint64_t *host;             // pinned: [k * kAheadRow + c]; [kAheadMax * kAheadRow] = the launch's sequence number
+    int64_t id_base, slots, ts;
+    T dt, An;
+    T pend_dt[kPendMax];
+    int n_pend;
+    uint64_t seed;
+    uint32_t step0;
+    int K;
+    int fresh;
+    int r_axes;
+    int n_planes;               // -1: no measure step (alive counts only)
+    int plane_ax[PCL_MAX_PLANES];
+    T plane_L[PCL_MAX_PLANES];
+    uint64_t seq;
+    int j;                      // k_ahead_commit: bodies handed out
+    uint64_t *masks_out, *masks_prev;
+    int32_t *tile_keep;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    __shared__ uint32_t s_cnt[kAheadMax * kAheadRow];
+    __shared__ int s_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < kAheadMax * kAheadRow; q += kBlock) s_cnt[q] = 0;
+    __syncthreads();
+    const bool hi = lane >= 32;
+    const int bit = 2 * (lane & 31);
+    const int64_t n_tiles = (a.slots + kTile - 1) / kTile;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll 1
+        for (int pp = 0; pp < kTileRows / 8; ++pp) {
+            const int row = (wave * (kTileRows / 8) + pp) * 2;
+            const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane; // the lane's two slots: i, i + 1
+            uint64_t m_lo, m_hi;
+            if (a.fresh) {
+                const int64_t left = a.slots - (tile * kTile + (int64_t)row * 64);
+                m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+                m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
+            } else {
+                m_lo = a.masks[tile * kTileRows + row];
+                m_hi = a.masks[tile * kTileRows + row + 1];
+            }
+            uchar2 dth;
+            dth.x = dth.y = 0;
+            if ((m_lo | m_hi) != 0ull) { // (wave-uniform)
+                const int64_t ti = pcl_tix(i, a.ts);
+                T vv[3][2], xx[3][2], dd[3][2], pcoll[2];
+                uint64_t id[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+                    vv[k][0] = q.x, vv[k][1] = q.y;
+                    xx[k][0] = xx[k][1] = (T)0;
+                    if ((a.r_axes >> k) & 1) {
+                        const T2 x = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+                        xx[k][0] = x.x, xx[k][1] = x.y;
+                    }
+                }
+                if (a.ids) {
+                    const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + (i < a.slots ? i : 0));
+                    id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+                } else {
+                    id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                }
+                const uint64_t mm = hi ? m_hi : m_lo;
+                bool al[2] = {(bool)((mm >> bit) & 1ull), (bool)((mm >> (bit + 1)) & 1ull)};
+                uint32_t dth_e[2] = {al[0] ? 255u : 0u, al[1] ? 255u : 0u};
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) dd[k][e] = R::mul(vv[k][e], a.dt);                                           // newton.py:15
+                    pcoll[e] = R::mul(a.An, pcl_step_norm<T>(dd[0][e], dd[1][e], dd[2][e]));                                 // light.py:241-247
+                    for (int q = 0; q < a.n_pend; ++q) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                    }
+                }
+                for (int b = 0; b < a.K; ++b) {
+                    if (__ballot(al[0] || al[1]) == 0ull) break; // nobody of these 128 slots is left (wave-uniform)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], dd[k][e]);                                  // newton.py:16
+                        const T rand = pcl_draw_rand<T>(id[e], a.step0 + (uint32_t)b, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                        const bool kp = !(pcoll[e] >= rand);
+                        if (al[e] && !kp) dth_e[e] = (uint32_t)(b + 1);
+                        al[e] = al[e] && kp;
+                    }
+                    const uint64_t b0 = __ballot(al[0]), b1 = __ballot(al[1]);
+                    uint32_t *row_cnt = s_cnt + b * kAheadRow;
+                    const uint32_t kept = (uint32_t)(__popcll(b0) + __popcll(b1));
+                    if (lane == 0 && kept) atomicAdd(&row_cnt[0], kept);
+                    if (a.n_planes >= 0) { // (uniform)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {                                                                        // light.py:424-426
+                            const uint32_t w = (uint32_t)__popcll(__ballot(al[0] && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(al[1] && vv[k][1] > (T)0));
+                            if (lane == 0 && w) atomicAdd(&row_cnt[1 + k], w);
+                        }
+                        for (int p = 0; p < a.n_planes; ++p) {                                                               // light.py:385-399
+                            const int ax = a.plane_ax[p];
+                            const T L = a.plane_L[p];
+                            uint32_t np = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
+                                const T prev = R::sub(x, pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]));
+                                np += (uint32_t)__popcll(__ballot(al[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                            }
+                            if (lane == 0 && np) atomicAdd(&row_cnt[4 + p], np);
+                        }
+                    }
+                }
+                dth.x = (unsigned char)dth_e[0], dth.y = (unsigned char)dth_e[1];
+            }
+            *reinterpret_cast<uchar2 *>(a.death + i) = dth; // (whole tiles exist in the buffer)
+        }
+    }
+    __syncthreads();
+    // grid totals as in k_delete_alive: returning agent-scope atomics, the last workgroup reports
+    const int nrow = 4 + (a.n_planes > 0 ? a.n_planes : 0);
+    unsigned long long seen = 0;
+    for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
+        if ((q % kAheadRow) < nrow && s_cnt[q])
+            seen += __hip_atomic_fetch_add(&a.acc[1 + q], (unsigned long long)s_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(seen) : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&a.acc[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!s_last) return;
+    volatile uint64_t *h = a.host;
+    for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
+        h[q] = (q % kAheadRow) < nrow ? __hip_atomic_exchange(&a.acc[1 + q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_exchange(&a.acc[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.host[kAheadMax * kAheadRow], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// the state after ``j`` of the bodies k_delete_ahead worked out, made real: alive bits (masks_out), the alive bits before
+// the j-th body (masks_prev: pcl_store_last_delete_flags), alive counts per tile, and r with the pending moves and the j
+// moves of those bodies applied (newton.py:15-16, one rounded multiply and one rounded add per move, in order)
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    __shared__ uint32_t s_keep[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_tiles = (a.slots + kTile - 1) / kTile;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        uint32_t kept = 0;
+#pragma unroll 1
+        for (int pp = 0; pp < kTileRows / 8; ++pp) {
+            const int row = (wave * (kTileRows / 8) + pp) * 2;
+            const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane;
+            const uchar2 d = *reinterpret_cast<const uchar2 *>(a.death + i);
+            const uint32_t j = (uint32_t)a.j;
+            const uint64_t b0 = __ballot(d.x > j), b1 = __ballot(d.y > j);
+            const uint64_t p0 = __ballot(d.x >= j && d.x != 0), p1 = __ballot(d.y >= j && d.y != 0);
+            if (lane == 0) {
+                a.masks_out[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
+                a.masks_out[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
+                a.masks_prev[tile * kTileRows + row] = spread_bits((uint32_t)p0) | (spread_bits((uint32_t)p1) << 1);
+                a.masks_prev[tile * kTileRows + row + 1] = spread_bits((uint32_t)(p0 >> 32)) | (spread_bits((uint32_t)(p1 >> 32)) << 1);
+            }
+            kept += (uint32_t)(__popcll(b0) + __popcll(b1));
+            if ((p0 | p1) == 0ull) continue; // nobody was alive before that body: r of these slots is never read again
+            const int64_t ti = pcl_tix(i, a.ts);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const T2 v = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+                T2 x = *reinterpret_cast<const T2 *>(a.r[k] + ti);
+                for (int q = 0; q < a.n_pend; ++q) {
+                    x.x = R::add(x.x, R::mul(v.x, a.pend_dt[q]));
+                    x.y = R::add(x.y, R::mul(v.y, a.pend_dt[q]));
+                }
+                const T dx = R::mul(v.x, a.dt), dy = R::mul(v.y, a.dt);
+                for (int q = 0; q < a.j; ++q) {
+                    x.x = R::add(x.x, dx);
+                    x.y = R::add(x.y, dy);
+                }
+                *reinterpret_cast<T2 *>(a.r[k] + ti) = x;
+            }
+        }
+        if (lane == 0) s_keep[wave] = kept;
+        __syncthreads();
+        if (threadIdx.x == 0) a.tile_keep[tile] = (int32_t)(s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3]);
+        __syncthreads();
     }
 }
 
@@ -2186,6 +2447,7 @@ struct pcl_ctx {
     // ``slots`` (alive + dead), ``count`` is the alive count, ``masks`` holds the alive bits and ``tile_keep`` the alive
     // count per tile; r lags pend_n moves behind.  Every entry point but pcl_step_fused_delete makes the store dense
     // again first (densify, through need_store / ensure_scratch).
+    int64_t multi_work[3] = {0, 0, 0}; // last pcl_step_fused_multi launch: dense passes, wave-steps, photons per wave (pcl_store_last_multi_work)
     double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
@@ -2195,11 +2457,32 @@ struct pcl_ctx {
     uint64_t *masks_prev = nullptr;  // alive bits before the last body of the alive path (last_delete_flags)
     bool last_delete_masked = false; // the last delete was such a body: flags come from masks_prev / masks
     int64_t last_delete_slots = 0;
+    // delete loop bodies worked out ahead of their calls (k_delete_ahead): while ``ahead.active`` the arrays and the
+    // holes / slots / pend_* fields above describe the store BEFORE the first of those bodies, ``count`` follows the
+    // bodies handed out; ahead_commit makes that state real.  ``ahead_last``: the previous call (pattern detection).
+    struct ahead_state {
+        bool active = false;
+        int K = 0, used = 0, n_planes = -1;
+        double dt = 0, A = 0, n = 0, planes[3 * PCL_MAX_PLANES] = {};
+        uint64_t seed = 0;
+        uint32_t step0 = 0;
+        int64_t before0 = 0, slots = 0;
+        bool fresh = false;
+    } ahead, ahead_last;
+    bool ahead_last_valid = false;
+    uint8_t *ahead_death = nullptr;          // one byte per slot
+    int64_t ahead_cap = 0;
+    unsigned long long *ahead_acc = nullptr; // device accumulators of k_delete_ahead
+    uint64_t *ahead_host = nullptr;          // pinned rows + sequence word
+    uint64_t ahead_seq = 0;
+    int64_t ahead_launches = 0, ahead_served = 0, ahead_missed = 0; // statistics (pcl_store_ahead_stats)
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
     int64_t lb_units = 0;
     // Rows that are known to hold nothing but +0.0 need not travel through a compaction: in a run that never scatters
     // (delete-until-empty, BASELINE configs[1](ii)) that is dv, 24 of the 88 bytes a survivor costs.
     int dv_zero = 0;              // 0 unknown (checked on the device when it matters), 1 every live dv element is +0.0, 2 not
+    int64_t dv_zero_n = 0;        // leading elements of THIS slab's dv rows known to be +0.0 (>= count while dv_zero == 1; a
+                                  // high-water mark: whatever was zero beyond the live range stays zero until somebody writes dv)
     int64_t alt_dv_zero_n = 0;    // leading elements of the OTHER slab's dv rows known to be +0.0
     int compact_dv_mode = 0;      // how the last compaction launch treated dv (kDvMove / kDvVprev / kDvSkip), for adopt_compacted
 
@@ -2240,6 +2523,13 @@ struct pcl_ctx {
 namespace {
 
 template <typename T> T *F(pcl_ctx *c, int f) { return static_cast<T *>(c->field[f]); }
+
+// what is known about the live dv rows (pcl_ctx::dv_zero).  1 = "[0, n) was just written with / found to hold +0.0";
+// 0 (unknown) and 2 (not zero) forget the slab's high-water mark: somebody wrote dv.
+void set_dv_zero(pcl_ctx *c, int state, int64_t n = 0) {
+    c->dv_zero = state;
+    c->dv_zero_n = state == 1 ? (c->dv_zero_n > n ? c->dv_zero_n : n) : 0;
+}
 
 // bytes between the rows of a tile beyond the row's own kTileT elements (EXPERIMENT hook PCL_ROW_PAD, multiple of 16)
 inline size_t row_pad_bytes() {
@@ -2852,14 +3142,18 @@ int materialize_t(pcl_ctx *ctx) {
 int materialize(pcl_ctx *ctx) {
     if (!ctx->lazy_dr && !ctx->lazy_dv) return PCL_OK;
     PCL_TRY(PCL_DISPATCH(ctx, materialize_t<double>(ctx), materialize_t<float>(ctx)));
-    if (ctx->lazy_dv) ctx->dv_zero = 2; // real dv values were just written
+    if (ctx->lazy_dv) set_dv_zero(ctx, 2); // real dv values were just written
     ctx->lazy_dr = ctx->lazy_dv = ctx->lazy_dr_vprev = false;
     return PCL_OK;
 }
 
-int need_store_raw(pcl_ctx *ctx) {
+int ahead_commit(pcl_ctx *ctx);
+
+// ``keep_ahead``: pcl_step_fused_delete itself asking -- it may be the call the bodies worked out ahead are waiting for
+int need_store_raw(pcl_ctx *ctx, bool keep_ahead = false) {
     PCL_TRY(bind(ctx));
     if (ctx->capacity <= 0) return fail(PCL_ERR_STATE, "no particle store: call pcl_store_alloc first");
+    if (ctx->ahead.active && !keep_ahead) PCL_TRY(ahead_commit(ctx));
     return PCL_OK;
 }
 
@@ -3390,8 +3684,16 @@ void adopt_compacted(pcl_ctx *ctx, int64_t alive, int64_t last_delete_n) {
     // dv bookkeeping.  The slab left behind keeps zero dv rows over the old count if the live dv rows were all zero.  The
     // new slab's dv rows hold what was moved (zero iff it was zero), zeros that were there (skip), or -- vprev travelled in
     // their place -- whatever the other slab held, in which case "all zero" is no longer known.
-    if (ctx->compact_dv_mode == 1 /* kDvVprev */ && ctx->dv_zero == 1 && ctx->alt_dv_zero_n < alive) ctx->dv_zero = 0;
-    ctx->alt_dv_zero_n = ctx->dv_zero == 1 ? ctx->count : 0;
+    // Both slabs carry a high-water mark "elements [0, z) of my dv rows are +0.0": rows nobody writes keep what they hold, so
+    // a store that is filled again (the second run of a script, a bench repetition) finds the other slab's dv rows still
+    // zero over everything and skips them in its FIRST compaction too.
+    const int64_t left_behind = ctx->dv_zero == 1 ? (ctx->dv_zero_n > ctx->count ? ctx->dv_zero_n : ctx->count) : 0;
+    int64_t dest = ctx->alt_dv_zero_n;                                   // kDvSkip, kDvVprev: the destination's dv rows were not touched
+    if (ctx->compact_dv_mode == 0 /* kDvMove */)
+        dest = ctx->dv_zero == 1 ? (dest > alive ? dest : alive) : 0;    // zeros (or not) were moved into [0, alive)
+    if (ctx->compact_dv_mode == 1 /* kDvVprev */ && ctx->dv_zero == 1 && dest < alive) ctx->dv_zero = 0;
+    ctx->alt_dv_zero_n = left_behind;
+    ctx->dv_zero_n = ctx->dv_zero == 1 ? dest : 0;
     ctx->compact_dv_mode = 0;
     std::swap(ctx->slab, ctx->slab_alt);
     refresh_rows(ctx);
@@ -3583,17 +3885,14 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
     // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 28 % of the photons
     // (fuller dense passes; slower above that: one wave per SIMD fewer).  PCL_MULTI_NQ2=1 always, =0 never.
-    static const int nq2_mode = [] {
-        const char *e = getenv("PCL_MULTI_NQ2");
-        return !e ? -1 : (e[0] == '0' ? 0 : 1);
-    }();
-    static const double nq2_below = [] {
-        const char *e = getenv("PCL_MULTI_NQ2_BELOW");
-        return e ? atof(e) : 0.28; // (sweep of 0.22 .. 0.36 on three bench configurations: profiles/r03_experiments/README.md)
-    }();
+    static knob k_nq2("PCL_MULTI_NQ2"), k_below("PCL_MULTI_NQ2_BELOW");
+    const int nq2_mode = !k_nq2.set() ? -1 : (k_nq2.off() ? 0 : 1);
+    const double nq2_below = k_below.value(0.28); // (sweep of 0.22 .. 0.36 on three bench configurations: profiles/r03_experiments/README.md)
     const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < nq2_below);
     set_np(f.np, ent);
+    ctx->multi_work[2] = 64 * pcl_rt<T>::VEC;
     if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
+        ctx->multi_work[2] = 128 * pcl_rt<T>::VEC;
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
         PCL_TRY(launch_module(ctx, ent->multi2[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 (hipRTC)"));
     } else if (var_n && ent->module) {
@@ -3820,7 +4119,7 @@ int decide_dv_mode(pcl_ctx *ctx, bool lazy, int *mode_out) {
         PCL_TRY(launch_check("k_any_nonzero"));
         PCL_HIP(hipMemcpyAsync(ctx->h_cnt + kCounterSlots - 5, flag, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->dv_zero = ctx->h_cnt[kCounterSlots - 5] ? 2 : 1;
+        set_dv_zero(ctx, ctx->h_cnt[kCounterSlots - 5] ? 2 : 1, ctx->count);
     }
     if (ctx->dv_zero == 1) *mode_out = kDvSkip;
     return PCL_OK;
@@ -3830,27 +4129,18 @@ int decide_dv_mode(pcl_ctx *ctx, bool lazy, int *mode_out) {
 // fewer than 1/kAliveRatio of the slots alive -> the next body compacts; stores below kAliveMinSlots never do (their
 // kernels are latency, not bytes).  PCL_ALIVE=0 switches the path off (every body compacts, as in round 2).
 bool alive_enabled() {
-    static const bool on = [] {
-        const char *e = getenv("PCL_ALIVE");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+    static knob k("PCL_ALIVE");
+    return !k.off();
 }
 double alive_ratio() {
-    static const double r = [] {
-        const char *e = getenv("PCL_ALIVE_RATIO");
-        const double v = e ? atof(e) : 0.5;
-        return v > 0.0 && v <= 1.0 ? v : 0.5;
-    }();
-    return r;
+    static knob k("PCL_ALIVE_RATIO");
+    const double v = k.value(0.5);
+    return v > 0.0 && v <= 1.0 ? v : 0.5;
 }
 int64_t alive_min_slots() {
-    static const int64_t n = [] {
-        const char *e = getenv("PCL_ALIVE_MIN_SLOTS");
-        const long long v = e ? atoll(e) : 65536;
-        return (int64_t)(v >= 0 ? v : 65536);
-    }();
-    return n;
+    static knob k("PCL_ALIVE_MIN_SLOTS");
+    const double v = k.value(65536.0);
+    return (int64_t)(v >= 0 ? v : 65536);
 }
 
 template <typename T>
@@ -3902,6 +4192,8 @@ int delete_alive_t(pcl_ctx *ctx, int64_t slots, bool fresh, bool count, bool wri
     a.zero_cnt = ctx->d_cnt + 1;
     a.n_zero = 3 + (n_planes > 0 ? n_planes : 0);
     plane_table<T>(planes_host, n_planes, a.plane_ax, a.plane_L);
+    a.r_axes = write_r ? 7 : 0; // a plane counter needs r along its own axis only (8 instead of 24 B per slot for one plane)
+    for (int p = 0; count && p < n_planes; ++p) a.r_axes |= 1 << a.plane_ax[p];
     // A workgroup's sums reach the grid totals with one atomic per counter, so the grid is capped (64 workgroups per
     // CU, PCL_ALIVE_WG_PER_CU) and workgroups walk the tiles with the grid's stride -- every one of them the SAME number
     // of tiles (k = ceil(tiles / cap), grid = ceil(tiles / k)): a grid just below the tile count leaves a second, nearly
@@ -3943,10 +4235,8 @@ int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const doubl
 // the completion signal's way to a blocked host thread takes longer than that.  The stream is asked now and then, so a
 // failed launch ends the wait with its error (PCL_ALIVE_POLL=0: hipStreamSynchronize).
 int wait_alive(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
-    static const bool poll = [] {
-        const char *e = getenv("PCL_ALIVE_POLL");
-        return !(e && e[0] == '0');
-    }();
+    static knob k_poll("PCL_ALIVE_POLL");
+    const bool poll = !k_poll.off();
     volatile uint64_t *seq = ctx->h_cnt + kCounterSlots - 6;
     if (!poll) {
         PCL_HIP(hipStreamSynchronize(ctx->stream));
@@ -3970,8 +4260,153 @@ int wait_alive(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
     return PCL_OK;
 }
 
+// ---- delete loop bodies ahead of their calls (k_delete_ahead) ---------------------------------------------------------
+// PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 16, at most kAheadMax); extents up to
+// PCL_AHEAD_MAX_SLOTS (default 2^20: a sweep of that many slots takes about as long as a launch's way to the host and back)
+int ahead_k() {
+    static knob k_on("PCL_AHEAD"), k_k("PCL_AHEAD_K");
+    if (k_on.off()) return 0;
+    const int k = (int)k_k.value(16.0);
+    return k < 2 ? 0 : (k > kAheadMax ? kAheadMax : k);
+}
+int64_t ahead_max_slots() {
+    static knob k("PCL_AHEAD_MAX_SLOTS");
+    const double v = k.value(1048576.0);
+    return (int64_t)(v > 0 ? v : 0);
+}
+
+bool ahead_same_call(const pcl_ctx::ahead_state &s, double dt, double A, double n, uint64_t seed, const double *planes_host, int n_planes) {
+    if (s.dt != dt || s.A != A || s.n != n || s.seed != seed || s.n_planes != n_planes) return false;
+    return n_planes <= 0 || memcmp(s.planes, planes_host, (size_t)n_planes * 3 * sizeof(double)) == 0; // (bitwise: NaN marks the free axes)
+}
+
+template <typename T>
+void fill_ahead_args(pcl_ctx *ctx, ahead_args<T> &a) {
+    const pcl_ctx::ahead_state &s = ctx->ahead;
+    for (int k = 0; k < 3; ++k) {
+        a.v[k] = F<T>(ctx, PCL_V0 + k);
+        a.r[k] = F<T>(ctx, PCL_R0 + k);
+    }
+    a.ids = ctx->ids_iota ? nullptr : ctx->ids;
+    a.masks = ctx->masks;
+    a.death = ctx->ahead_death;
+    a.acc = ctx->ahead_acc;
+    a.host = ctx->ahead_host;
+    a.id_base = ctx->id_base;
+    a.slots = s.slots;
+    a.ts = tile_stride(ctx);
+    a.dt = (T)s.dt;
+    a.An = (T)s.A * (T)s.n;
+    a.n_pend = ctx->pend_n;
+    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q];
+    a.seed = s.seed;
+    a.step0 = s.step0;
+    a.K = s.K;
+    a.fresh = s.fresh ? 1 : 0;
+    a.n_planes = s.n_planes;
+    plane_table<T>(s.planes, s.n_planes, a.plane_ax, a.plane_L);
+    a.r_axes = 0;
+    for (int p = 0; p < s.n_planes; ++p) a.r_axes |= 1 << a.plane_ax[p];
+    a.masks_out = ctx->masks;
+    a.masks_prev = ctx->masks_prev;
+    a.tile_keep = ctx->tile_keep;
+}
+
+template <typename T>
+int ahead_launch_t(pcl_ctx *ctx) {
+    ahead_args<T> a{};
+    fill_ahead_args<T>(ctx, a);
+    a.seq = ++ctx->ahead_seq;
+    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile);
+    const int ps = prof_begin(ctx, PCL_PROF_DELETE_AHEAD);
+    hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, a);
+    prof_end(ctx, ps);
+    return launch_check("k_delete_ahead");
+}
+
+template <typename T>
+int ahead_commit_t(pcl_ctx *ctx) {
+    ahead_args<T> a{};
+    fill_ahead_args<T>(ctx, a);
+    a.j = ctx->ahead.used;
+    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile);
+    hipLaunchKernelGGL(k_ahead_commit<T>, dim3((unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, a);
+    return launch_check("k_ahead_commit");
+}
+
+// make the state after the bodies handed out so far real (asynchronous: one small kernel on the stream)
+int ahead_commit(pcl_ctx *ctx) {
+    pcl_ctx::ahead_state &s = ctx->ahead;
+    if (!s.active) return PCL_OK;
+    if (s.used < s.K) ++ctx->ahead_missed;
+    PCL_TRY(PCL_DISPATCH(ctx, ahead_commit_t<double>(ctx), ahead_commit_t<float>(ctx)));
+    s.active = false;
+    ctx->holes = true;
+    ctx->slots = s.slots;
+    ctx->pend_n = 0; // the kernel wrote r with every move applied
+    ctx->last_delete_masked = true;
+    ctx->last_delete_slots = s.slots;
+    return PCL_OK;
+}
+
+int ahead_wait(pcl_ctx *ctx) {
+    volatile uint64_t *seq = ctx->ahead_host + kAheadMax * kAheadRow;
+    for (uint64_t spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != ctx->ahead_seq; ++spins) {
+        if ((spins & 0x3FFF) == 0) {
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != ctx->ahead_seq) return fail(PCL_ERR_HIP, "k_delete_ahead did not report");
+                break;
+            }
+            if (e != hipErrorNotReady) return fail(PCL_ERR_HIP, "k_delete_ahead failed: %s", hipGetErrorString(e));
+        }
+    }
+    return PCL_OK;
+}
+
+// hand out the next of the bodies worked out ahead: count, counters (into h_cnt[1..], where pcl_step_fused_delete reads them)
+int ahead_serve(pcl_ctx *ctx, int64_t *alive_out) {
+    pcl_ctx::ahead_state &s = ctx->ahead;
+    const uint64_t *row = ctx->ahead_host + (size_t)s.used * kAheadRow;
+    const int64_t before = ctx->count, alive = (int64_t)row[0];
+    if (alive < 0 || alive > before)
+        return fail(PCL_ERR_HIP, "a body worked out ahead holds an impossible count %lld of %lld", (long long)alive, (long long)before);
+    for (int k = 0; k < 3 + (s.n_planes > 0 ? s.n_planes : 0); ++k) ctx->h_cnt[1 + k] = row[1 + k];
+    ++s.used;
+    ++ctx->ahead_served;
+    ctx->count = alive;
+    ctx->last_delete_n = before;
+    *alive_out = alive;
+    if (s.used == s.K) PCL_TRY(ahead_commit(ctx));
+    return PCL_OK;
+}
+
+int ahead_resources(pcl_ctx *ctx, int64_t slots) {
+    if (!ctx->ahead_acc) {
+        const size_t n = (size_t)(1 + kAheadMax * kAheadRow);
+        PCL_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->ahead_acc), n * sizeof(unsigned long long)));
+        PCL_HIP(hipMemsetAsync(ctx->ahead_acc, 0, n * sizeof(unsigned long long), ctx->stream));
+        PCL_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->ahead_host), n * sizeof(uint64_t)));
+        memset(ctx->ahead_host, 0, n * sizeof(uint64_t));
+    }
+    const int64_t need = div_up(slots, kTile) * kTile;
+    if (need > ctx->ahead_cap) {
+        if (ctx->ahead_death) {
+            PCL_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->ahead_death);
+            ctx->ahead_death = nullptr;
+            ctx->ahead_cap = 0;
+        }
+        PCL_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->ahead_death), (size_t)need));
+        ctx->ahead_cap = need;
+    }
+    return PCL_OK;
+}
+
 void drop_holes(pcl_ctx *ctx) {
     ctx->multi_last_h = -1.0; // (called whenever the population is replaced)
+    ctx->ahead.active = false;
+    ctx->ahead_last_valid = false;
     ctx->holes = false;
     ctx->slots = 0;
     ctx->pend_n = 0;
@@ -4014,16 +4449,49 @@ int densify(pcl_ctx *ctx) {
 int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t seed, uint32_t step, const double *planes_host,
                        int n_planes, int64_t *alive_out) {
     const int64_t before = ctx->count;
+    pcl_ctx::ahead_state &sp = ctx->ahead;
+    if (sp.active) { // bodies were worked out ahead: is this the call they are waiting for?
+        if (ahead_same_call(sp, dt, A, n, seed, planes_host, n_planes) && step == sp.step0 + (uint32_t)sp.used) {
+            ctx->ahead_last.step0 = step;
+            return ahead_serve(ctx, alive_out);
+        }
+        PCL_TRY(ahead_commit(ctx));
+    }
     const bool fresh = !ctx->holes;
     const int64_t slots = fresh ? ctx->count : ctx->slots;
     const int np = n_planes > 0 ? n_planes : 0;
     PCL_TRY(ensure_scratch(ctx, slots, true));
     const bool compact_now = slots > alive_min_slots() && (double)before < alive_ratio() * (double)slots;
+    // the same call as last time with the launch number advanced by one: a run's loop
+    const bool repeat = ctx->ahead_last_valid && ahead_same_call(ctx->ahead_last, dt, A, n, seed, planes_host, n_planes) &&
+                        step == ctx->ahead_last.step0 + 1u;
+    {
+        pcl_ctx::ahead_state &l = ctx->ahead_last;
+        l.dt = dt, l.A = A, l.n = n, l.seed = seed, l.n_planes = n_planes, l.step0 = step;
+        if (n_planes > 0) memcpy(l.planes, planes_host, (size_t)n_planes * 3 * sizeof(double));
+        ctx->ahead_last_valid = true;
+    }
     int64_t alive = 0;
+    if (!compact_now && repeat && ahead_k() > 0 && slots <= ahead_max_slots()) {
+        // small store, predictable caller: this body and the next K - 1 in one launch that leaves the store as it is
+        PCL_TRY(ahead_resources(ctx, slots));
+        sp = ctx->ahead_last;
+        sp.K = ahead_k();
+        sp.used = 0;
+        sp.before0 = before;
+        sp.slots = slots;
+        sp.fresh = fresh;
+        PCL_TRY(PCL_DISPATCH(ctx, ahead_launch_t<double>(ctx), ahead_launch_t<float>(ctx)));
+        PCL_TRY(ahead_wait(ctx));
+        sp.active = true;
+        ++ctx->ahead_launches;
+        return ahead_serve(ctx, alive_out);
+    }
     if (!compact_now) {
         // the list of moves r has not seen is full: this body's kernel writes r back, this body's move included
         // (PCL_ALIVE_FLUSH_KERNEL: a separate k_apply_pending launch first, for A/B)
-        static const bool flush_kernel = getenv("PCL_ALIVE_FLUSH_KERNEL") != nullptr;
+        static knob k_flush("PCL_ALIVE_FLUSH_KERNEL");
+        const bool flush_kernel = k_flush.set();
         bool write_r = ctx->pend_n == kPendMax;
         if (write_r && flush_kernel) {
             ctx->slots = slots;
@@ -4341,6 +4809,33 @@ extern "C" {
 int pcl_abi_version(void) { return PCL_ABI_VERSION; }
 const char *pcl_last_error(void) { return g_err.c_str(); }
 
+int pcl_set_knob(const char *name, const char *value) {
+    if (!name || strncmp(name, "PCL_", 4) != 0) return fail(PCL_ERR_ARG, "a knob's name starts with PCL_");
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    if (value)
+        g_knob_over[name] = value;
+    else
+        g_knob_over.erase(name);
+    g_knob_gen.fetch_add(1, std::memory_order_acq_rel);
+    return PCL_OK;
+}
+
+int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out) {
+    if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
+    if (dense_passes_out) *dense_passes_out = ctx->multi_work[0];
+    if (wave_steps_out) *wave_steps_out = ctx->multi_work[1];
+    if (photons_per_wave_out) *photons_per_wave_out = (int)ctx->multi_work[2];
+    return PCL_OK;
+}
+
+int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_out, int64_t *missed_out) {
+    if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
+    if (launches_out) *launches_out = ctx->ahead_launches;
+    if (served_out) *served_out = ctx->ahead_served;
+    if (missed_out) *missed_out = ctx->ahead_missed;
+    return PCL_OK;
+}
+
 int pcl_ctx_set_rtc_background(pcl_ctx *ctx, int on) {
     if (!ctx) return fail(PCL_ERR_ARG, "ctx is NULL");
     ctx->rtc_background = on != 0;
@@ -4462,6 +4957,9 @@ int pcl_ctx_destroy(pcl_ctx *ctx) {
     if (ctx->h_cnt) (void)hipHostFree(ctx->h_cnt);
     if (ctx->d_multi) (void)hipFree(ctx->d_multi);
     if (ctx->h_multi) (void)hipHostFree(ctx->h_multi);
+    if (ctx->ahead_acc) (void)hipFree(ctx->ahead_acc);
+    if (ctx->ahead_host) (void)hipHostFree(ctx->ahead_host);
+    if (ctx->ahead_death) (void)hipFree(ctx->ahead_death);
     for (int b = 0; b < 2; ++b) {
         if (ctx->d_bank[b]) (void)hipFree(ctx->d_bank[b]);
         if (ctx->h_bank[b]) (void)hipHostFree(ctx->h_bank[b]);
@@ -4793,7 +5291,7 @@ int pcl_store_alloc_dtype(pcl_ctx *ctx, int64_t capacity, int dtype) {
     ctx->count = 0;
     ctx->id_base = 0;
     ctx->ids_iota = true;
-    ctx->dv_zero = 0;
+    set_dv_zero(ctx, 0);
     ctx->alt_dv_zero_n = 0;
     return PCL_OK;
 }
@@ -4833,7 +5331,7 @@ int pcl_store_free(pcl_ctx *ctx) {
     dev_free(ctx->lb_status);
     drop_holes(ctx);
     ctx->lb_units = 0;
-    ctx->dv_zero = 0;
+    set_dv_zero(ctx, 0);
     ctx->alt_dv_zero_n = 0;
     ctx->scratch_cap = 0;
     ctx->capacity = ctx->count = 0;
@@ -4863,6 +5361,11 @@ int pcl_store_reserve_compaction(pcl_ctx *ctx) {
 
 int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out) {
     if (!ctx || !slots_out) return fail(PCL_ERR_ARG, "NULL argument");
+    if (ctx->ahead.active) { // (bodies worked out ahead: the extent they swept; r is owed the moves of those handed out)
+        *slots_out = ctx->ahead.slots;
+        if (pending_moves_out) *pending_moves_out = ctx->pend_n + ctx->ahead.used;
+        return PCL_OK;
+    }
     *slots_out = ctx->holes ? ctx->slots : ctx->count;
     if (pending_moves_out) *pending_moves_out = ctx->holes ? ctx->pend_n : 0;
     return PCL_OK;
@@ -4876,7 +5379,7 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
     ctx->lam4_valid = false;
-    ctx->dv_zero = 0;
+    set_dv_zero(ctx, 0);
     ctx->alt_dv_zero_n = 0;
     // a new population: every particle is a photon again until pcl_store_upload_kind says otherwise (a kind array left
     // over from an earlier, mixed upload would silently switch the light steps off for whoever sits at those indices)
@@ -4891,7 +5394,7 @@ int pcl_store_upload(pcl_ctx *ctx, int field, const void *host, int64_t offset, 
     if (field < 0 || field >= PCL_NFIELDS) return fail(PCL_ERR_ARG, "unknown field %d", field);
     PCL_TRY(check_range(ctx, offset, n, host));
     if (field == PCL_E) ctx->lam4_valid = false;
-    if (field >= PCL_DV0 && field <= PCL_DV2) ctx->dv_zero = 0; // unknown again: looked at on the device when it matters
+    if (field >= PCL_DV0 && field <= PCL_DV2) set_dv_zero(ctx, 0); // unknown again: looked at on the device when it matters
     return copy_row(ctx, ctx->field[field], const_cast<void *>(host), offset, n, true);
 }
 
@@ -4944,7 +5447,7 @@ int pcl_store_field_ptr(pcl_ctx *ctx, int field, void **dev_out) {
     PCL_TRY(need_store(ctx));
     if (field < 0 || field >= PCL_NFIELDS || !dev_out) return fail(PCL_ERR_ARG, "bad argument");
     if (field == PCL_E) ctx->lam4_valid = false; // the caller may write through the pointer
-    if (field >= PCL_DV0 && field <= PCL_DV2) ctx->dv_zero = 0;
+    if (field >= PCL_DV0 && field <= PCL_DV2) set_dv_zero(ctx, 0);
     *dev_out = ctx->field[field];
     return PCL_OK;
 }
@@ -5033,7 +5536,7 @@ int pcl_store_fill_photons(pcl_ctx *ctx, int64_t n, int64_t id_base, double c, d
     ctx->id_base = id_base;
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
-    ctx->dv_zero = 1; // the fill wrote +0.0 into every dv element
+    set_dv_zero(ctx, 1, n); // the fill wrote +0.0 into every dv element
     return PCL_OK;
 }
 
@@ -5062,7 +5565,7 @@ int pcl_store_fill_photons_table(pcl_ctx *ctx, int64_t n, int64_t id_base, doubl
     ctx->id_base = id_base;
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
-    ctx->dv_zero = 1;
+    set_dv_zero(ctx, 1, n);
     return PCL_OK;
 }
 
@@ -5091,7 +5594,7 @@ int pcl_step_scatter_isotropic(pcl_ctx *ctx, double A, double n, int flags, doub
     PCL_HIP(hipMemsetAsync(ctx->d_cnt, 0, sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
-    ctx->dv_zero = 2; // the step writes dv
+    set_dv_zero(ctx, 2); // the step writes dv
     PCL_TRY(PCL_DISPATCH(ctx, step_scatter_t<double>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv),
                          step_scatter_t<float>(ctx, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, py_dv)));
     if (hits_out) {
@@ -5221,7 +5724,7 @@ int pcl_step_fused(pcl_ctx *ctx, double dt, int do_scatter, double A, double n, 
             ctx, step_fused_t<double>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy),
             step_fused_t<float>(ctx, dt, do_scatter, A, n, use_e, var_n, ent, c, h, rng_mode, seed, step, planes_host, n_planes, lazy)));
     }
-    if (!lazy && do_scatter) ctx->dv_zero = 2; // the eager step wrote dv
+    if (!lazy && do_scatter) set_dv_zero(ctx, 2); // the eager step wrote dv
     if (lazy) {
         if (do_scatter) {
             for (int k = 0; k < 3; ++k) std::swap(ctx->row[PCL_V0 + k], ctx->row[kRowVprev + k]); // V rows = new v
@@ -5281,7 +5784,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
         }
     if (N == 0) return PCL_OK;
     // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
-    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)nslots * k_steps * sizeof(uint64_t), ctx->stream));
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + 1) * sizeof(uint64_t), ctx->stream)); // rows + the work tally
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
     PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np),
@@ -5294,13 +5797,15 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + nslots * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice,
                            ctx->stream));
     if (out_host) {
-        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)nslots * k_steps * sizeof(uint64_t), hipMemcpyDeviceToHost,
+        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)(nslots * k_steps + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < k_steps; ++k) {
             for (int j = 0; j < 3 + np; ++j) out_host[(5 + np) * k + 1 + j] = (int64_t)ctx->h_multi[nslots * k + 1 + j];
             out_host[(5 + np) * k + 4 + np] = (int64_t)ctx->h_multi[nslots * k];
         }
+        ctx->multi_work[0] = (int64_t)ctx->h_multi[nslots * k_steps];                                  // dense passes
+        ctx->multi_work[1] = div_up(N, (int64_t)ctx->multi_work[2]) * (int64_t)k_steps;                // wave-steps
         ctx->multi_last_h = (double)ctx->h_multi[nslots * (k_steps - 1)] / (double)N; // what the next launch's form goes by
     } else {
         ctx->multi_last_h = -1.0;
@@ -5392,7 +5897,7 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
                           uint32_t step, const double *planes_host, int n_planes, int64_t *out_host) {
     if (flags & ~PCL_FUSED_LAZY) return fail(PCL_ERR_ARG, "unknown flag bits");
     const bool lazy = flags & PCL_FUSED_LAZY;
-    PCL_TRY(need_store_raw(ctx));
+    PCL_TRY(need_store_raw(ctx, true)); // (bodies worked out ahead stay: fused_delete_alive decides whether this call is theirs)
     // every check comes before the first change of the store's state: a refused call leaves it as it was
     if (rng_mode != PCL_RNG_INPUT && rng_mode != PCL_RNG_PHILOX) return fail(PCL_ERR_ARG, "unknown rng_mode %d", rng_mode);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
@@ -5421,6 +5926,7 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
         }
         return PCL_OK;
     }
+    PCL_TRY(ahead_commit(ctx));
     PCL_TRY(densify(ctx));
     PCL_TRY(ensure_scratch(ctx, N));
     PCL_TRY(ensure_alt(ctx));

@@ -51,12 +51,15 @@ def assert_state(d, st, hip, what):
     assert np.array_equal(s["E"], st["E"]), what
 
 
+@pytest.mark.parametrize("look", [True, False], ids=["flags_every_body", "rows_only"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("N,pdel", [(300_000, 0.3), (200_001, 0.04), (70_000, 0.55)])
-def test_delete_bodies_on_the_alive_mask_vs_oracle(N, pdel, dtype):
+def test_delete_bodies_on_the_alive_mask_vs_oracle(N, pdel, dtype, look):
     """Chains of bodies at three removal rates: 0.3 compacts every third body, 0.04 lets more than 8 moves pile up
     (k_apply_pending) before the first compaction, 0.55 compacts every second body.  Rows and flags are compared after
-    every body (looking at the flags does not disturb the store), the whole state at a few points and at the end."""
+    every body (looking at the flags does not disturb the store), the whole state at a few points and at the end.
+    ``rows_only``: nothing but the rows is looked at between the bodies -- the pattern the library answers from bodies
+    worked out ahead (k_delete_ahead: these stores are below 2^20 slots), committed when the state is downloaded."""
     from physicl_amd import _hip as hip
     np_t = np.float64 if dtype == "f64" else np.float32
     rs = np.random.RandomState(N)
@@ -80,12 +83,16 @@ def test_delete_bodies_on_the_alive_mask_vs_oracle(N, pdel, dtype):
             assert device_row(o) == row, (step, device_row(o), row)
             extents.append(d.slots)
             assert d.count == row[0] and d.slots >= d.count
-            assert np.array_equal(d.last_delete_flags(before), flags), step
-            assert d.slots == extents[-1]                                     # looking at the flags moved nothing
+            if look or step == bodies - 2:
+                assert np.array_equal(d.last_delete_flags(before), flags), step
+                assert d.slots == extents[-1]                                 # looking at the flags moved nothing
             if step in (3, bodies - 1):
                 assert_state(d, st, hip, (step, "download"))
                 assert d.slots == d.count                                     # ... a download compacts
-        if pdel < 0.1:      # nothing was compacted by the path itself for more than 8 bodies: the pending moves were flushed
+        launches, served, missed = d.ahead_stats()
+        if not look:
+            assert launches >= 2 and served > 2 * launches, (launches, served, missed)   # most bodies came without a launch
+        elif pdel < 0.1:      # nothing was compacted by the path itself for more than 8 bodies: the pending moves were flushed
             assert extents[4:13] == [extents[4]] * 9 and extents[4] > d.count
         elif pdel < 0.5:
             assert extents[0] == N and extents[1] == N and extents[2] < N    # the third body starts below 50 % and compacts
@@ -176,3 +183,73 @@ def test_the_delete_tests_of_the_suite_under_other_compaction_rules(env):
                        text=True, timeout=1500)
     assert p.returncode == 0, p.stdout[-4000:]
     assert " passed" in p.stdout
+
+
+def _ahead_run(hip, N, dtype, script):
+    """Run ``script`` (a list of actions) on a fresh store; returns (rows, final state, ahead statistics)."""
+    rows = []
+    with hip.Device(0) as d:
+        d.store_alloc(N, dtype)
+        d.fill_photons(N, 77, C_LIT, 1.0, 2.0, 21)
+        step = 0
+        for act in script:
+            if act[0] == "delete":
+                _, dt, pdel, planes = act
+                o = d.step_fused_delete(dt, pdel / (1e-3 * C_LIT * dt), 1e-3, hip.RNG_PHILOX, 21, step, planes, lazy=True)
+                rows.append(device_row(o) if planes is not None else [o["N"], o["removed"]])
+            elif act[0] == "skip":                      # the caller's launch counter jumps (another kernel ran elsewhere)
+                step += act[1] - 1
+                continue
+            elif act[0] == "iso":
+                o = d.step_fused(1e-3, dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=6.62607015e-34, rng_mode=hip.RNG_PHILOX, seed=21, step=step), (), lazy=True)
+                rows.append([o["N"], o["hits"]])
+            elif act[0] == "flags":
+                rows.append(d.last_delete_flags(act[1] if act[1] else rows[-1][0] + rows[-1][1]).tolist())
+            elif act[0] == "peek":
+                rows.append([d.count, float(d.download(hip.R0, 1)[0])])
+            step += 1
+        s = d.download_state()
+        stats = d.ahead_stats()
+    return rows, s, stats
+
+
+PL1 = [[3.0e5, np.nan, np.nan]]
+PL3 = [[3.0e5, np.nan, np.nan], [np.nan, 0.0, np.nan], [np.nan, np.nan, -2.0e5]]
+AHEAD_SCRIPTS = {
+    "until_empty": [("delete", 1e-3, 0.3, PL1)] * 60,
+    "no_measure": [("delete", 1e-3, 0.25, None)] * 40,
+    "three_planes_then_flags": [("delete", 1e-3, 0.2, PL3)] * 11 + [("flags", 0)] + [("delete", 1e-3, 0.2, PL3)] * 9,
+    "dt_changes": [("delete", 1e-3, 0.2, PL1)] * 7 + [("delete", 2e-3, 0.2, PL1)] * 9 + [("delete", 1e-3, 0.1, PL3)] * 5,
+    "launch_counter_jumps": [("delete", 1e-3, 0.2, PL1)] * 6 + [("skip", 3)] + [("delete", 1e-3, 0.2, PL1)] * 8,
+    "scatter_in_between": [("delete", 1e-3, 0.15, PL1)] * 5 + [("iso",)] + [("delete", 1e-3, 0.15, PL1)] * 6 + [("iso",)] * 2 + [("delete", 1e-3, 0.15, PL1)] * 4,
+    "peeks": [("delete", 1e-3, 0.1, PL1)] * 4 + [("peek",)] + [("delete", 1e-3, 0.1, PL1)] * 20 + [("peek",)] + [("delete", 1e-3, 0.1, PL1)] * 3,
+}
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", sorted(AHEAD_SCRIPTS))
+def test_bodies_worked_out_ahead_change_nothing_but_the_number_of_launches(name, dtype):
+    """pcl_step_fused_delete on a small store answers a run's loop from K bodies worked out in one launch (k_delete_ahead)
+    and makes the state real when anything else is asked (k_ahead_commit).  Every script -- a run until the store is empty,
+    calls that stop matching the prediction (another dt, other planes, a jump of the launch counter), scatter steps, flag
+    and position reads in between -- must give the rows, flags and final state of the same script with PCL_AHEAD=0, bit
+    for bit; the oracle pins the plain path in the tests above."""
+    from physicl_amd import _hip as hip
+    N = 260_000 if name != "until_empty" else 90_000
+    try:
+        hip.set_knob("PCL_AHEAD", "0")
+        rows0, s0, st0 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
+        hip.set_knob("PCL_AHEAD", None)
+        hip.set_knob("PCL_AHEAD_K", "5" if name == "peeks" else None)
+        rows1, s1, st1 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
+    finally:
+        hip.set_knob("PCL_AHEAD", None)
+        hip.set_knob("PCL_AHEAD_K", None)
+    assert st0 == (0, 0, 0) and st1[0] >= 1 and st1[1] > st1[0], (st0, st1)
+    assert rows0 == rows1
+    assert np.array_equal(s0["id"], s1["id"]) and np.array_equal(s0["E"], s1["E"])
+    for f in ("r", "v", "dr", "dv"):
+        for k in range(3):
+            assert np.array_equal(s0[f][k], s1[f][k]), (f, k)
+    if name == "until_empty":
+        assert rows1[-1][0] == 0 and len(s1["id"]) == 0
