@@ -55,6 +55,8 @@ sys.path.insert(0, ROOT)
 C_LIT = 299792458.0            # str(light.c)          physicl/light.py:14
 H_LIT = 6.62607015e-34         # str(light.h).upper()  physicl/light.py:15
 HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
+VALU_PEAK = N_SIMD * CLOCK_GHZ * 1e9 / 4.0     # a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles: 6.14e11 wave-instr/s
 
 PROFILES = {
     # examples/variable_n_scattering.ipynb:30,52-56.  User n=1e-15, A=1e-19; the reference swaps them
@@ -166,6 +168,7 @@ class Bench:
         self.sim_t = 0.0
         self.totals = None
         self.local_block_s = []        # this rank's own wall time of every timed block (the line reports min / max over ranks)
+        self.work_log = []             # K-step launches: what each kernel tallied of its own work (pcl_store_last_multi_work)
 
     def fill(self):
         self.dev.store_alloc(self.N, self.args.dtype)
@@ -208,6 +211,7 @@ class Bench:
             rows = self.dev.step_fused_multi(self.prof["dt"], ks, self.sc(k))
             c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
             hits += int(c[:, 1].sum())
+            self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work())   # steps, hits, dense passes, wave-steps, photons per wave
             self.totals = self.comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
             k += ks
         return hits
@@ -246,8 +250,10 @@ class Bench:
         Returns per-block wall seconds (MAX over ranks), local hit counts and per-kernel HIP-event samples."""
         comm, dev = self.comm, self.dev
         el, hits, kern = [], [], []
+        self.block_work = []
         k = k_start
         for _ in range(repeats):
+            w0 = len(self.work_log)
             dev.prof_enable(True)                   # clears the samples; synchronises (outside the timed region)
             comm.barrier()
             dev.sync()
@@ -262,9 +268,44 @@ class Bench:
             self.local_block_s.append(dt)
             hits.append(h)
             kern.append({name: dev.prof_read(kid) for kid, name in self.hip.PROF_NAMES.items()})
+            self.block_work.append(self.work_log[w0:])
             k += steps
         dev.prof_enable(False)
         return el, hits, kern, k
+
+
+def tame_leg(b, args, R):
+    """SURVEY.md 8(d) config 3's SECOND profile: the same photons under ``2.5E+25 * exp(r2[gid] / 8600.0)``
+    (examples/presentation_example_2.ipynb:41's atmosphere, kernel constant chosen so that pcoll spans 0.03 .. 1.8: exp never
+    saturates, the hit fraction is position dependent and falls slowly) -- the branchy regime, where the example's own
+    constants give inf / 0 after the first step.  Same store, filled again; same K-step pass, R blocks of --steps steps."""
+    saved = b.prof
+    b.prof = PROFILES["tame"]
+    try:
+        N, prof = b.N, b.prof
+        b.dev.fill_photons(N, b.rank * N, C_LIT, b.e_lo, b.e_hi, args.seed)
+        b.run_steps(0, args.warmup)                     # (includes the hipRTC lookup of the second expression)
+        el, hits, kern, _ = b.timed_blocks(args.warmup, args.steps, R)
+        mi = median_index(el)
+        kb = kern[mi]["k_multi"]
+        valu = valu_roofline(b.block_work[mi], kb["total_ms"], prof["expr"], False)
+        hbm = N * 128.0 / (kb["avg_ms"] * 1e-3) / 1e9 if kb["launches"] else 0.0
+        rec = {"workload": "SURVEY 8(d) config 3, tame profile: %.0e photons, variable_n_fn = %s, dt = %g, A (kernel) = %g"
+                           % (N, prof["expr"], prof["dt"], prof["A_kernel"]),
+               "value": N * args.steps / el[mi], "unit": "particle-steps/s", "ms_per_step": el[mi] / args.steps * 1e3, "steps": args.steps,
+               "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el],
+               "repeat_hit_fraction": [round(h / float(N * args.steps), 6) for h in hits],
+               "roofline": (dict(valu, bound="valu", kernel="k_multi (hipRTC specialisation of the tame expression)",
+                                 traffic=pmc_traffic("pcl_rtc_multi_e1", N), avg_launch_ms=kb["avg_ms"], launches=kb["launches"],
+                                 hbm={"achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
+                                      "algorithmic_bytes_per_particle": 128.0})
+                            if valu is not None else
+                            {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
+                             "traffic": pmc_traffic("pcl_rtc_multi_e1", N), "algorithmic_bytes_per_particle": 128.0,
+                             "avg_launch_ms": kb["avg_ms"], "launches": kb["launches"]})}
+        return rec
+    finally:
+        b.prof = saved
 
 
 def kernel_summary(kern_blocks, name):
@@ -300,6 +341,58 @@ def static_profile(profile, mode, dtype, N, S, steps):
             return dict(table[key], key=key, file="profiles/pmc_traffic.json",
                         note="from a committed rocprofv3 --pmc run of this configuration, not from this process")
     return None
+
+
+def _json_file(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_traffic(kernel, units):
+    """HBM bytes of one launch of ``kernel`` from the COMMITTED rocprofv3 --pmc run (profiles/pmc_traffic.json, section
+    "kernels": bytes per photon or per slot = FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md, separate passes, and
+    the commit / profile file they were measured at) x the units this launch processed.  PMC counters cannot be read
+    from inside the process: the record says where the figure comes from."""
+    rec = _json_file("pmc_traffic.json").get("kernels", {}).get(kernel)
+    if not rec:
+        return None
+    return {"bytes": rec["bytes_per_unit"] * units, "bytes_per_unit": rec["bytes_per_unit"], "unit": rec["unit"],
+            "source": rec["source"], "measured_at_commit": rec.get("commit"), "note": "committed rocprofv3 --pmc run, not this process"}
+
+
+def valu_roofline(work, kern_ms, expr, f32):
+    """VALU-issue roofline of the K-step pass over a set of launches.  ``work``: per launch (steps, hits, dense passes,
+    wave-steps, photons per wave) as the kernel tallied them; ``kern_ms``: the sum of those launches' durations (HIP
+    events).  Wave-instructions = decision instructions x wave-steps + dense-pass instructions x dense passes, the two
+    counts per code object from profiles/isa_counts.json (tools/isa_count.py: the hipRTC translation unit's gfx950
+    assembly; the decision count is the dynamic one, calibrated against SQ_INSTS_VALU of the committed PMC run, the
+    dense pass is a straight-line loop body).  Peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
+    table = _json_file("isa_counts.json").get(expr, {}).get("kernels", {})
+    instr = dec = 0.0
+    useful = 0.0
+    forms = {}
+    for steps, hits, passes, wsteps, ppw in work:
+        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi2_e1" if ppw == 256 else "pcl_rtc_multi_e1")
+        c = table.get(name)
+        if c is None:
+            return None
+        A, B = c["decision_valu_per_wave_step"], c["dense_pass_valu"]
+        instr += A * wsteps + B * passes
+        useful += A * wsteps + B * hits / 64.0
+        forms[name] = forms.get(name, 0) + 1
+    if not instr or not kern_ms:
+        return None
+    achieved = instr / (kern_ms * 1e-3)
+    return {"achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": achieved / VALU_PEAK,
+            "lane_util": useful / instr, "wave_instructions": instr, "dense_passes": sum(w[2] for w in work),
+            "wave_steps": sum(w[3] for w in work), "dense_passes_per_wave_step": sum(w[2] for w in work) / float(sum(w[3] for w in work)),
+            "kernel_forms": forms, "instruction_counts": {k: {"decision_valu_per_wave_step": table[k]["decision_valu_per_wave_step"],
+                                                             "dense_pass_valu": table[k]["dense_pass_valu"]} for k in forms},
+            "instruction_counts_source": "profiles/isa_counts.json (tools/isa_count.py)",
+            "peak_note": "%d SIMDs x %.1f GHz / 4 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ)}
 
 
 def run_rank(args):
@@ -341,6 +434,7 @@ def run_rank(args):
 
     R = max(1, args.repeats)
     el, hits, kern, k_next = b.timed_blocks(args.warmup, args.steps, R)
+    b.block_work_main = b.block_work
     totals_main = b.totals
     rank_blocks = comm.allgather_object([round(x / args.steps * 1e3, 5) for x in b.local_block_s[:R]])
     mi = median_index(el)
@@ -369,10 +463,16 @@ def run_rank(args):
                   "steps": args.steps, "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el1],
                   "roofline": {"bound": "hbm", "kernel": "k_fast (pcl_rtc_fast_e1): one launch per step, dr/dv implicit",
                                "achieved": a1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a1 / HBM_PEAK_GBPS,
-                               "traffic": None, "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1b["avg_ms"],
+                               "traffic": pmc_traffic("pcl_rtc_fast_f_e1" if f32 else "pcl_rtc_fast_e1", N),
+                               "algorithmic_bytes_per_particle": b1, "avg_launch_ms": k1b["avg_ms"],
                                "min_launch_ms": k1b["min_ms"], "max_launch_ms": k1b["max_ms"], "launches": k1b["launches"],
                                "all_blocks_avg_launch_ms": k1["avg_ms"], "per_block_avg_launch_ms": k1["per_block_avg_ms"],
                                "hit_fraction": hits1[m1] / float(N * args.steps)}}
+        b.totals = totals_main
+
+    tame = None
+    if extra and S > 1 and args.profile == "example" and not f32:
+        tame = tame_leg(b, args, R)
         b.totals = totals_main
 
     info = dev.info()
@@ -385,6 +485,44 @@ def run_rank(args):
     dev.close()
     if extra and not f32:
         api = api_leg(args, prof)
+
+    dom_rtc = {"k_multi": "pcl_rtc_multi_%se1" % ("f_" if f32 else ""), "k_fused": "pcl_rtc_fast_%se1" % ("f_" if f32 else "")}.get(dominant)
+    hbm_rec = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+               "traffic": pmc_traffic(dom_rtc, N) if (dom_rtc and args.mode == "fused") else None, "algorithmic_bytes_per_particle": bpp,
+               "algorithmic_bytes_note": "per LAUNCH of the K-step pass (r, v, lam4 read; r, v, vprev written)" if S > 1 else "per particle-step"}
+    valu = valu_roofline(b.block_work_main[mi], kb["total_ms"], prof["expr"], f32) if S > 1 else None
+    common = {"hit_fraction": h_blocks[mi], "avg_launch_ms": kb["avg_ms"], "min_launch_ms": kb["min_ms"], "max_launch_ms": kb["max_ms"],
+              "launches": kb["launches"], "block": "median block (index %d), as value" % mi, "all_blocks_avg_launch_ms": ks["avg_ms"],
+              "all_blocks_launches": ks["launches"], "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch_max": S,
+              "steps_per_timed_launch": steps_per_timed_launch, "warmup_launches": warm[dominant]["launches"],
+              "warmup_avg_launch_ms": warm[dominant]["avg_ms"]}
+    if valu is not None:
+        # The K-step pass moves 128 B per photon per LAUNCH and is bound by VALU issue: the record
+        # says so.  ``traffic`` (HBM bytes of one launch, committed PMC run) and the HBM form of the same launch ride along.
+        roofline = dict(valu, bound="valu",
+                        kernel="k_multi (pcl_rtc_multi_e1 / multi2_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "
+                               "store, dr/dv implicit; bound by VALU issue -- the HBM-bound formulation is roofline_hbm" % S,
+                        traffic=hbm_rec["traffic"], hbm=hbm_rec,
+                        # SURVEY 8(d)'s per-step form: what the same particle-steps would have had to move one launch per step
+                        # (104 B each).  > peak is possible precisely because the pass does not move those bytes.
+                        per_step_form={"bytes_per_particle_step": 104.0 * bscale,
+                                       "GBps": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9,
+                                       "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                        per_block=[(lambda v: None if v is None else {"frac": round(v["frac"], 4), "lane_util": round(v["lane_util"], 4),
+                                                                         "dense_passes_per_wave_step": round(v["dense_passes_per_wave_step"], 4),
+                                                                         "forms": v["kernel_forms"]})(
+                            valu_roofline(b.block_work_main[i], kern[i][dominant]["total_ms"], prof["expr"], f32)) for i in range(R)],
+                        **common)
+    else:
+        roofline = dict(hbm_rec, bound="hbm",
+                        kernel=(("k_multi: %d x (Newton + ScatterIsotropic + counters) per pass over the store, dr/dv implicit; "
+                                 "arithmetic-bound by construction (no instruction counts committed for this code object: HBM form only)" % S)
+                                if S > 1 else
+                                "k_fast/k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
+                                % (", dr/dv implicit" if args.mode == "fused" else "")
+                                if args.mode.startswith("fused") else
+                                "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
+                        **common)
 
     out = None
     if rank == 0:
@@ -420,31 +558,10 @@ def run_rank(args):
                                 block_min_ms_per_step=[min(r[i] for r in rank_blocks) for i in range(R)],
                                 block_max_ms_per_step=[max(r[i] for r in rank_blocks) for i in range(R)])
                            if world > 1 else None),
-            "roofline": {"bound": "hbm",
-                         "kernel": (("k_multi (pcl_rtc_multi_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "
-                                     "store, dr/dv implicit; arithmetic-bound by construction -- the HBM-bound formulation "
-                                     "is single_step" % S)
-                                    if S > 1 else
-                                    "k_fast/k_fused: Newton + ScatterIsotropic + counters in one pass (hipRTC variable-n)%s"
-                                    % (", dr/dv implicit" if args.mode == "fused" else "")
-                                    if args.mode.startswith("fused") else
-                                    "k_scatter: ScatterIsotropicStep kernel + write-back (hipRTC variable-n)"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "algorithmic_bytes_per_particle": bpp,
-                         "algorithmic_bytes_note": "per LAUNCH of the K-step pass (r, v, lam4 read; r, v, vprev written)" if S > 1
-                                                   else "per particle-step",
-                         "hit_fraction": h_blocks[mi], "avg_launch_ms": kb["avg_ms"], "min_launch_ms": kb["min_ms"],
-                         "max_launch_ms": kb["max_ms"], "launches": kb["launches"], "block": "median block (index %d), as value" % mi,
-                         "all_blocks_avg_launch_ms": ks["avg_ms"], "all_blocks_launches": ks["launches"],
-                         "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch_max": S,
-                         "steps_per_timed_launch": steps_per_timed_launch,
-                         # SURVEY 8(d)'s per-step form: what the same particle-steps would have had to move one launch per
-                         # step (104 B each).  > peak is possible precisely because the pass does not move those bytes.
-                         "per_step_form": ({"bytes_per_particle_step": 104.0 * bscale,
-                                            "GBps": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9,
-                                            "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-                                           if (S > 1 and kb["launches"]) else None),
-                         "warmup_launches": warm[dominant]["launches"], "warmup_avg_launch_ms": warm[dominant]["avg_ms"]},
+            "roofline": roofline,
+            # the north_star's HBM target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons) is about the
+            # one-launch-per-step kernel: the same workload run that way in this same process (the single_step leg)
+            "roofline_hbm": (dict(single["roofline"], value=single["value"], ms_per_step=single["ms_per_step"]) if single is not None else None),
             "static_profile": static_profile(args.profile, args.mode, args.dtype, N, S, args.steps),
             # north_star target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons): carried by the
             # one-launch-per-step kernel, measured in this same run (single_step); the K-step pass trades those bytes away
@@ -457,6 +574,8 @@ def run_rank(args):
         }
         if single is not None:
             out["single_step"] = single
+        if tame is not None:
+            out["tame"] = tame
         if delete is not None:
             out["delete"] = delete
         if iso is not None:
@@ -469,7 +588,8 @@ def run_rank(args):
             dev2 = hip.Device(b.dev_index)
             try:
                 out["cpu_baseline"] = cpu_baseline(dev2, args, prof)
-                out["cpu_baseline_python"] = cpu_baseline_python(dev2, args, prof)
+                out["cpu_baseline_python"] = cpu_baseline_python(dev2, args, prof, 10_000)        # 1e4 and 1e5
+                out["cpu_baseline_python_1e5"] = cpu_baseline_python(dev2, args, prof, 100_000)
                 out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev2, args, prof)
             finally:
                 dev2.close()
@@ -513,6 +633,9 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 t0 = time.perf_counter()
                 work, per_step, k = 0, [], 0
                 nb = sb = N                                   # alive photons / slots of the store (dense after the fill)
+                track = rep == repeats + 1 and mode == "per_step"       # the instrumented run also notes how each body was answered
+                if track:
+                    how, st_prev = [], dev.ahead_stats()
                 while nb > 0 and k < 4096:
                     if mode == "multi":
                         for o in dev.step_fused_delete_multi(dt, K, A, n, seed, k, plane):
@@ -525,10 +648,16 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                         work += nb
                         sa = dev.slots
                         per_step.append((nb, o["N"], sb, sa))             # alive before / after, slots before / after
+                        if track:                                         # "kernel": k_delete_alive ran; "ahead_launch": k_delete_ahead
+                            st_now = dev.ahead_stats()                    # ran (this body + the next ones); "ahead": no launch at all
+                            how.append("ahead_launch" if st_now[0] > st_prev[0] else ("ahead" if st_now[1] > st_prev[1] else "kernel"))
+                            st_prev = st_now
                         nb, sb = o["N"], sa
                         k += 1
                 dev.sync()
                 el = time.perf_counter() - t0
+                if mode == "multi":
+                    how = []
                 if rep == repeats + 1:
                     kern = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
                     instrumented_ms = el * 1e3
@@ -547,32 +676,56 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                  "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
                  "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
             if mode == "per_step":
-                b1 = b3 = 0.0
-                slots_swept = compactions = 0
+                b1 = b2 = b3 = 0.0
+                slots_swept = slots_ahead = compactions = 0
                 explicit_ids = False
-                for nb, na, sb, sa in per_step:
+                big = []                                          # the compactions of >= 1e7 slots, one by one
+                for (nb, na, sb, sa), h in zip(per_step, how + ["kernel"] * len(per_step)):
                     if not nb:
                         continue
                     compacting = sa < sb                           # the body ended on a smaller extent: it compacted
-                    slots_swept += sb
-                    # k_delete_alive: alive bit read + written, v, the id once explicit; r only when it counts the plane
-                    # crossings itself (a compacting body leaves the counters to the compaction)
-                    b1 += sb * (0.25 + 24.0 + (8.0 if explicit_ids else 0.0) + (0.0 if compacting else 24.0))
+                    # k_delete_alive: alive bit read + written, v, the id once explicit; r ALONG THE PLANE'S AXIS (8 of its 24
+                    # bytes) only when it counts the plane crossings itself (a compacting body leaves the counters to the
+                    # compaction).  k_delete_ahead (K bodies of a small store in one launch): the same reads once + a byte written.
+                    per_slot = 0.125 + 24.0 + (8.0 if explicit_ids else 0.0) + (0.0 if compacting else 8.0)
+                    if h == "kernel":
+                        slots_swept += sb
+                        b1 += sb * (per_slot + 0.125)
+                    elif h == "ahead_launch":
+                        slots_ahead += sb
+                        b2 += sb * (per_slot + 1.0)
                     if compacting:
                         compactions += 1
-                        b3 += sb * 0.125 + na * 2.0 * 64.0 + (0.0 if explicit_ids else na * 2.0 * 24.0)
+                        cb = sb * 0.125 + na * 2.0 * 64.0
+                        b3 += cb
+                        if sb >= 10_000_000:
+                            big.append({"slots": sb, "survivors": na, "algorithmic_bytes": cb,
+                                        "source_bytes_at_line_granularity": sb * 56.0 + (sb * 8.0 if explicit_ids else 0.0) + na * 64.0})
                         explicit_ids = True
-                p1_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_compact"]["total_ms"]
+                p1_ms, p2_ms, p3_ms = kern["k_delete_mask"]["total_ms"], kern["k_delete_ahead"]["total_ms"], kern["k_compact"]["total_ms"]
                 g1 = b1 / (p1_ms * 1e-3) / 1e9 if p1_ms else 0.0
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
+                answered = {h: how.count(h) for h in ("kernel", "ahead_launch", "ahead")}
+                r["bodies_answered_by"] = dict(answered, note="kernel: one k_delete_alive launch (or flag + scan + compaction); ahead_launch: "
+                                               "one k_delete_ahead launch worked out this body and the next ones of a small store; ahead: "
+                                               "answered from those rows, no launch")
                 r["roofline"] = {"bound": "hbm", "kernel": "k_delete_alive (one loop body on the alive mask: Newton + delete flag + counters, nothing moves)",
-                                 "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS, "traffic": None,
+                                 "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
+                                 "traffic": pmc_traffic("k_delete_alive<double, true>", slots_swept),
                                  "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
-                                 "bytes_per_alive_particle_step": (b1 + b3) / tot if tot else 0.0}
+                                 "bytes_per_alive_particle_step": (b1 + b2 + b3) / tot if tot else 0.0}
+                r["ahead"] = {"kernel": "k_delete_ahead (K = 16 loop bodies of a store of <= 2^20 slots in one launch; the store is not written)",
+                              "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
+                              "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"]}
                 r["roofline_compaction"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction of the survivors, %d of %d bodies)"
                                                                       % (compactions, r["loop_bodies"]),
                                             "achieved": g3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS,
-                                            "traffic": None, "algorithmic_bytes": b3, "total_ms": p3_ms, "compactions": compactions}
+                                            "traffic": pmc_traffic("k_compact_lds<double, unsigned long, 7>", sum(c["slots"] for c in big)) if big else None,
+                                            "algorithmic_bytes": b3, "total_ms": p3_ms, "compactions": compactions,
+                                            # the bytes HBM cannot avoid serving: survivors are scattered at random, so every 128-byte
+                                            # line of the seven source rows holds one (P(16 neighbours all removed) < 0.2 % at 34 %
+                                            # survivors) and is read whole -- 56 B per SLOT, not 56 B per survivor
+                                            "compactions_of_1e7_slots_or_more": big}
             else:
                 r["steps_per_launch"] = K
             rec[mode] = r
@@ -754,10 +907,10 @@ def cpu_baseline(dev, args, prof):
 
 
 def cpu_baseline_numpy(dev, args, prof):
-    """Third CPU figure: the numpy-vectorised oracle (oracle/physicl_oracle.py) on the first 1e6 photons, 1 core
-    (BASELINE.md section 4, item 2)."""
+    """Third CPU figure: the numpy-vectorised oracle (oracle/physicl_oracle.py) on the first 1e7 photons, 1 core
+    (--cpu-photons bounds it for the small test runs)."""
     from oracle import physicl_oracle as orc
-    n = int(min(1_000_000, args.photons))
+    n = int(min(10_000_000, args.photons, max(args.cpu_photons, 1000)))
     dev.store_alloc(n)
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     st = {g: [dev.download(f, n) for f in fids] for g, fids in
@@ -776,14 +929,14 @@ def cpu_baseline_numpy(dev, args, prof):
             "sample": "%d photons x %d steps, numpy-vectorised oracle, %.1f s" % (n, steps, el)}
 
 
-def cpu_baseline_python(dev, args, prof):
+def cpu_baseline_python(dev, args, prof, photons=10000):
     """Second CPU figure, for scale: the reference-SHAPED path (one Python object per photon, a Python loop
-    per step, oracle/pyloop.py) on the first 1e4 photons of the same workload, 1 core -- the cost model of
+    per step, oracle/pyloop.py) on the first 1e4 / 1e5 photons of the same workload, 1 core -- the cost model of
     the reference's own CPU path (BASELINE.md section 2 measured 1.5e4..2.4e4 particle-steps/s for it)."""
     from oracle import pyloop
     if prof["c_profile"] is None:
         return None
-    n = int(min(10000, args.photons))
+    n = int(min(photons, args.photons, max(args.cpu_photons, 1000)))
     dev.store_alloc(n)
     dev.fill_photons(n, 0, C_LIT, H_LIT * C_LIT / 700e-9, H_LIT * C_LIT / 200e-9, args.seed)
     E = dev.download(12, n)

@@ -991,6 +991,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             __builtin_amdgcn_wave_barrier();
             const pcl_u32 n_hit = qbase + w_hits;
             w_passes += (w_hits + 63u) >> 6;
+            asm volatile("" : "+v"(w_passes)); // lives in a VGPR (one is free, the scalar file is not): no lane spill for a tally
             // the scatter itself, densely: item j by lane j                                light.py:309-311
             for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
                 const pcl_u32 o = s_q.owner[j];
@@ -1189,6 +1190,7 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 w_passes += (wbase - qbase + 63u) >> 6;
+                asm volatile("" : "+v"(w_passes));
                 // the scatter itself, densely: item j by lane j                                light.py:309-311
                 for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
                     const pcl_u32 o = s_q.owner[j];

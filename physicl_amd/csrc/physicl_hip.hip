@@ -1016,14 +1016,24 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                             if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
                     }
                 }
+                pcl_u32 wodd[2][2] = {{0u, 0u}, {0u, 0u}}; // the decision block's second half, waiting for the odd step
                 for (int b = 0; b < a.K; ++b) {
                     if (__ballot(al[0] || al[1]) == 0ull) break; // nobody of these 128 slots is left (wave-uniform)
+                    const uint32_t st = a.step0 + (uint32_t)b;
+                    const bool new_block = (st & 1u) == 0u || b == 0; // (uniform) one Philox block decides steps 2m and 2m + 1
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
                             if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], dd[k][e]);                                  // newton.py:16
-                        const T rand = pcl_draw_rand<T>(id[e], a.step0 + (uint32_t)b, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                        T rand;
+                        if (new_block) { // what pcl_draw_rand computes, the odd step's half kept
+                            const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                            rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                            wodd[e][0] = w.z, wodd[e][1] = w.w;
+                        } else {
+                            rand = R::uniform(wodd[e][0], wodd[e][1]);
+                        }
                         const bool kp = !(pcoll[e] >= rand);
                         if (al[e] && !kp) dth_e[e] = (uint32_t)(b + 1);
                         al[e] = al[e] && kp;
@@ -2476,6 +2486,8 @@ struct pcl_ctx {
     uint64_t *ahead_host = nullptr;          // pinned rows + sequence word
     uint64_t ahead_seq = 0;
     int64_t ahead_launches = 0, ahead_served = 0, ahead_missed = 0; // statistics (pcl_store_ahead_stats)
+    int ahead_wait = 0, ahead_backoff = 0;   // bodies to run the plain way before the next attempt / the last such pause (doubles per
+                                             // launch that was cut short: a loop that looks at the store between its bodies)
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
     int64_t lb_units = 0;
     // Rows that are known to hold nothing but +0.0 need not travel through a compaction: in a run that never scatters
@@ -4339,6 +4351,12 @@ int ahead_commit(pcl_ctx *ctx) {
     pcl_ctx::ahead_state &s = ctx->ahead;
     if (!s.active) return PCL_OK;
     if (s.used < s.K) ++ctx->ahead_missed;
+    if (2 * s.used < s.K && ctx->count > 0) { // most of the launch's work was for nothing: pause, longer every time in a row
+        ctx->ahead_backoff = ctx->ahead_backoff ? (ctx->ahead_backoff < 256 ? 2 * ctx->ahead_backoff : 256) : 4;
+        ctx->ahead_wait = ctx->ahead_backoff;
+    } else {
+        ctx->ahead_backoff = 0;
+    }
     PCL_TRY(PCL_DISPATCH(ctx, ahead_commit_t<double>(ctx), ahead_commit_t<float>(ctx)));
     s.active = false;
     ctx->holes = true;
@@ -4407,6 +4425,7 @@ void drop_holes(pcl_ctx *ctx) {
     ctx->multi_last_h = -1.0; // (called whenever the population is replaced)
     ctx->ahead.active = false;
     ctx->ahead_last_valid = false;
+    ctx->ahead_wait = ctx->ahead_backoff = 0;
     ctx->holes = false;
     ctx->slots = 0;
     ctx->pend_n = 0;
@@ -4472,7 +4491,8 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         ctx->ahead_last_valid = true;
     }
     int64_t alive = 0;
-    if (!compact_now && repeat && ahead_k() > 0 && slots <= ahead_max_slots()) {
+    if (ctx->ahead_wait > 0) --ctx->ahead_wait;
+    if (!compact_now && repeat && ahead_k() > 0 && slots <= ahead_max_slots() && ctx->ahead_wait == 0) {
         // small store, predictable caller: this body and the next K - 1 in one launch that leaves the store as it is
         PCL_TRY(ahead_resources(ctx, slots));
         sp = ctx->ahead_last;

@@ -36,18 +36,38 @@ def test_bench_line_has_the_contract_keys(extra):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
-    assert r["traffic"] is None and "valu" not in r          # nothing from a committed profile inside the measured record
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if not extra:
+        # the K-step pass says what binds it: VALU issue.  achieved = (decision instructions x wave-steps + dense-pass
+        # instructions x dense passes, both tallied by the kernel itself) / launch time; the HBM form rides along
+        assert r["bound"] == "valu" and r["unit"] == "wave-instr/s" and r["peak"] == 1024 * 2.4e9 / 4
+        assert 0 < r["lane_util"] <= 1 and r["wave_steps"] == -(-300000 // 128) * 6 and r["dense_passes"] > 0
+        ic = r["instruction_counts"]["pcl_rtc_multi_e1"]
+        assert abs(r["wave_instructions"] - (ic["decision_valu_per_wave_step"] * r["wave_steps"] + ic["dense_pass_valu"] * r["dense_passes"])) < 1
+        assert r["hbm"]["peak"] == 8000.0 and r["hbm"]["algorithmic_bytes_per_particle"] == 128.0 and len(r["per_block"]) == 3
+        assert r["traffic"]["source"].startswith("profiles/") and abs(r["traffic"]["bytes"] / 300000 - 128) < 2
+        h = d["roofline_hbm"]                                # the north_star kernel's own record, in the line and not in an extra key
+        assert h["bound"] == "hbm" and h["peak"] == 8000.0 and h["algorithmic_bytes_per_particle"] == 104.0 and h["frac"] > 0
+        assert abs(h["traffic"]["bytes_per_unit"] - 104) < 1 and h == dict(d["single_step"]["roofline"], value=h["value"], ms_per_step=h["ms_per_step"])
+        t = d["tame"]                                        # SURVEY 8(d) config 3's second profile
+        assert t["roofline"]["bound"] == "valu" and "exp(r2[gid] / 8600.0)" in t["workload"] and len(t["repeat_hit_fraction"]) == 3
+        assert 0 < min(t["repeat_hit_fraction"]) and max(t["repeat_hit_fraction"]) < 1 and t["value"] > 0
+    else:
+        assert r["bound"] == "hbm" and r["peak"] == 8000.0
     assert r["launches"] == (1 if "--mode" not in extra else 6) or "--steps-per-launch" in extra        # of the median block
     assert d["counters_last_step"]["N"] == 300000 and d["collective"] is None
     if "--dtype" not in extra:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+        for key in ("cpu_baseline_python", "cpu_baseline_python_1e5", "cpu_baseline_numpy"):   # BASELINE.md section 4's other sizes
+            assert d[key]["cores"] == 1 and d[key]["value"] > 0
         for size, rec in d["delete"]["sizes"].items():
             for mode in ("per_step", "multi"):
                 assert rec[mode]["value"] > 0 and rec[mode]["particle_steps"] >= 30000
             assert rec["per_step"]["particle_steps"] == rec["multi"]["particle_steps"]       # same photons removed at the same steps
             assert rec["per_step"]["roofline"]["bound"] == "hbm" and rec["per_step"]["roofline"]["achieved"] > 0
+            by = rec["per_step"]["bodies_answered_by"]
+            assert by["kernel"] + by["ahead_launch"] + by["ahead"] == rec["per_step"]["loop_bodies"] and by["ahead"] > by["ahead_launch"] >= 1
         assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
         # the constructor as a reference script calls it takes the K-pass launches by itself
         assert d["api"]["default"]["steps"] == 6 and d["api"]["default"]["schedule"] == {"fused_multi": 1} and d["api"]["default"]["note"] is None

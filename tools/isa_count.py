@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Static instruction counts of the K-step kernels, read off the gfx950 assembly of the very translation unit hipRTC
+compiles for an expression (``#define PCL_N_EXPR ...`` + physicl_amd/csrc/pcl_device.h, same options), compiled offline:
+
+    python tools/isa_count.py ["<variable_n_fn>"] [--json profiles/isa_counts.json] [--md]
+
+For each kernel (pcl_rtc_multi_e1: 128 photons per wave, pcl_rtc_multi2_e1: 256) the loop nest is recovered from the
+backward branches: the grid-stride loop, the K loop inside it, the dense pass of the hit queue inside that.  Reported per
+kernel: VALU instructions (v_*) of the K loop's body outside the dense-pass loop, split into the blocks every step runs and
+the blocks only some steps run (the Philox decision block: every second step; the vprev store: the last step), and of one
+dense pass; v_readlane / v_writelane inside the K loop; registers and spills from the metadata.  The bench's VALU roofline
+record multiplies these with the wave-steps and dense passes the kernel itself tallies (pcl_store_last_multi_work).
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def rtc_source(expr, expr_f32=None, dt=0, use_e=1, extra=()):
+    from physicl_amd import build
+    build._generate_rtc_source()
+    inc = open(os.path.join(ROOT, "physicl_amd", "csrc", "pcl_rtc_source.inc")).read()
+    text = inc[inc.index('R"PCLRTC(') + 9:inc.rindex(')PCLRTC"')]
+    if expr_f32 is None:
+        expr_f32 = re.sub(r"(?<![\w.])(\d+\.\d*|\d*\.\d+|\d+)([eE][-+]?\d+)?(?![\w.])",
+                          lambda m: m.group(0) + ("f" if ("." in m.group(0) or m.group(2)) else ".0f"), expr)
+    head = "#define PCL_RTC 1\n#define PCL_RTC_DT %d\n#define PCL_RTC_E %d\n" % (dt, use_e)
+    head += "".join("#define %s 1\n" % x for x in extra)
+    return head + "#define PCL_N_EXPR (%s)\n#define PCL_N_EXPR_F (%s)\n" % (expr, expr_f32) + text
+
+
+def compile_asm(src, workdir):
+    hip, asm = os.path.join(workdir, "tu.hip"), os.path.join(workdir, "tu.s")
+    open(hip, "w").write(src)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-include", "hip/hip_runtime.h", "--offload-arch=gfx950", "-O3",
+                           "-ffp-contract=off", "-std=c++17", "--cuda-device-only", "-Wno-unused-command-line-argument", "-S", "-o", asm, hip],
+                          stderr=subprocess.DEVNULL)
+    return open(asm).read()
+
+
+def function_body(asm, name):
+    lines = asm.splitlines()
+    start = lines.index(next(ln for ln in lines if ln.startswith(name + ":")))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    return lines[start + 1:end]
+
+
+def analyse(asm, name):
+    body = function_body(asm, name)
+    ins, labels = [], {}
+    for ln in body:
+        t = ln.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            m = re.match(r"^(\.LBB\d+_\d+):", t)
+            if m:
+                labels[m.group(1)] = len(ins)
+            continue
+        ins.append(t.split(";")[0].strip())
+    loops = []                     # (first instruction, branch instruction) of every backward branch
+    for i, t in enumerate(ins):
+        m = re.match(r"^s_c?branch\S*\s+(\.LBB\d+_\d+)", t)
+        if m and m.group(1) in labels and labels[m.group(1)] <= i:
+            loops.append((labels[m.group(1)], i))
+    head = {}                      # several backward branches to one header are one loop: keep the last
+    for a, b in loops:
+        head[a] = max(b, head.get(a, b))
+    loops = sorted(head.items(), key=lambda lp: (lp[0], -lp[1]))
+
+    def depth_of(lp):
+        return sum(1 for o in loops if o != lp and o[0] <= lp[0] and lp[1] <= o[1])
+
+    def count(lo, hi, pred, skip=()):
+        return sum(1 for i in range(lo, hi + 1) if pred(ins[i]) and not any(a <= i <= b for a, b in skip))
+
+    valu = lambda t: t.startswith("v_")                                  # noqa: E731
+    grid = max((lp for lp in loops if depth_of(lp) == 0), key=lambda lp: lp[1] - lp[0])
+    inner1 = [lp for lp in loops if lp != grid and grid[0] <= lp[0] and lp[1] <= grid[1] and depth_of(lp) == 1]
+    kloop = max(inner1, key=lambda lp: lp[1] - lp[0])
+    inner2 = [lp for lp in loops if lp != kloop and kloop[0] <= lp[0] and lp[1] <= kloop[1]]
+    # the dense pass: the inner loop that holds the direction block's Philox multiplies and the sincos polynomials
+    dense = max(inner2, key=lambda lp: count(lp[0], lp[1], valu))
+    others = [lp for lp in inner2 if lp != dense and not (dense[0] <= lp[0] and lp[1] <= dense[1])]
+    # basic blocks of the K loop outside its inner loops, with what they hold
+    starts = sorted({kloop[0]} | {v for v in labels.values() if kloop[0] <= v <= kloop[1]} |
+                    {i + 1 for i in range(kloop[0], kloop[1]) if re.match(r"^s_c?branch", ins[i])})
+    blocks = []
+    for a, b in zip(starts, starts[1:] + [kloop[1] + 1]):
+        if any(x <= a and b - 1 <= y for x, y in inner2):
+            continue
+        n = count(a, b - 1, valu)
+        if n == 0:
+            continue
+        mads = count(a, b - 1, lambda t: t.startswith("v_mad_u64_u32"))
+        stores = count(a, b - 1, lambda t: t.startswith("global_store") or t.startswith("buffer_store"))
+        blocks.append({"first": a - kloop[0], "valu": n, "philox_mads": mads, "global_stores": stores})
+    # the Philox decision block of a photon (ten rounds: >= 10 v_mad_u64_u32) and its tail block; run on every second step
+    philox = 0
+    for i, b in enumerate(blocks):
+        if b["philox_mads"] >= 10:
+            philox += b["valu"]
+            if i + 1 < len(blocks) and 1 <= blocks[i + 1]["philox_mads"] < 10:
+                philox += blocks[i + 1]["valu"]
+    last_step = sum(b["valu"] for b in blocks if b["global_stores"] >= 3 and b["philox_mads"] < 10)
+    always = sum(b["valu"] for b in blocks) - philox - last_step
+    meta = {}
+    m = re.search(r"\.name:\s+%s\n(.*?)\n\s+- \.", asm[asm.index(".amdgpu_metadata") if ".amdgpu_metadata" in asm else 0:] + "\n  - .", re.S)
+    md = asm[asm.rindex(".name:           %s" % name):]
+    for key in ("sgpr_count", "sgpr_spill_count", "vgpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+        mm = re.search(r"\.%s:\s+(\d+)" % key, md)
+        if mm:
+            meta[key] = int(mm.group(1))
+    lanes = lambda t: t.startswith("v_readlane") or t.startswith("v_writelane")   # noqa: E731
+    return {
+        "kernel": name,
+        "k_loop": {"instructions": kloop[1] - kloop[0] + 1, "valu_total_static": count(kloop[0], kloop[1], valu)},
+        "decision_blocks": blocks,
+        "decision_valu_every_step": always,
+        "decision_valu_philox_block_every_second_step": philox,
+        "decision_valu_last_step_only": last_step,
+        # a static estimate of what a wave-step costs: every block outside the dense pass once, the Philox decision block
+        # every second step (it serves two consecutive steps).  Blocks that exclude each other (the odd step's R::uniform
+        # against the even step's block tail, the per-counter "if (w_x)" adds) make this an upper estimate; the bench uses
+        # "decision_valu_per_wave_step", which tools/calibrate_isa_counts.py sets from SQ_INSTS_VALU of a rocprofv3 run
+        # together with the dense passes the kernel tallied in that run (and which must lie below this figure).
+        "decision_valu_per_wave_step_static": always + 0.5 * philox,
+        "decision_valu_per_wave_step": always + 0.5 * philox,
+        "dense_pass_valu": count(dense[0], dense[1], valu),
+        "other_inner_loops_valu": [count(lp[0], lp[1], valu) for lp in others],
+        "readlane_in_k_loop": count(kloop[0], kloop[1], lambda t: t.startswith("v_readlane")),
+        "writelane_in_k_loop": count(kloop[0], kloop[1], lambda t: t.startswith("v_writelane")),
+        "readlane_writelane_in_dense_pass": count(dense[0], dense[1], lanes),
+        "registers": meta,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("expr", nargs="?", default="0.000000001 * exp(r0[gid] - 5)")
+    ap.add_argument("--json", default=None, help="merge the result into this file under the expression's text")
+    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multi2_e1")
+    ap.add_argument("--extra", default="", help="comma separated PCL_RTC_EXTRA names")
+    ap.add_argument("--keep", default=None, help="directory to keep tu.hip / tu.s in")
+    a = ap.parse_args()
+    work = a.keep or tempfile.mkdtemp(prefix="pcl_isa_")
+    os.makedirs(work, exist_ok=True)
+    asm = compile_asm(rtc_source(a.expr, extra=[x for x in a.extra.split(",") if x]), work)
+    out = {k: analyse(asm, k) for k in a.kernels.split(",")}
+    hipcc = subprocess.check_output(["/opt/rocm/bin/hipcc", "--version"]).decode().splitlines()[0]
+    rec = {"expression": a.expr, "compiler": hipcc, "options": "--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17", "kernels": out}
+    print(json.dumps(rec, indent=1))
+    if a.json:
+        table = json.load(open(a.json)) if os.path.exists(a.json) else {}
+        table[a.expr] = rec
+        json.dump(table, open(a.json, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
