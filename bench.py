@@ -562,6 +562,9 @@ def run_rank(args):
             # the north_star's HBM target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons) is about the
             # one-launch-per-step kernel: the same workload run that way in this same process (the single_step leg)
             "roofline_hbm": (dict(single["roofline"], value=single["value"], ms_per_step=single["ms_per_step"]) if single is not None else None),
+            # every K-step launch of this process in order (warm-up, the timed blocks, the tame leg): steps, hits, dense passes,
+            # wave-steps, photons per wave -- what tools/summarize_driver_prof.py lines up with the profiler's dispatches
+            "k_step_launch_work": [list(w) for w in b.work_log],
             "static_profile": static_profile(args.profile, args.mode, args.dtype, N, S, args.steps),
             # north_star target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons): carried by the
             # one-launch-per-step kernel, measured in this same run (single_step); the K-step pass trades those bytes away

@@ -450,6 +450,7 @@ int pcl_group_size(pcl_group *group, int *n_out);
 int pcl_group_ctx(pcl_group *group, int i, pcl_ctx **ctx_out);
 int pcl_group_shard(pcl_group *group, int64_t n_global, int i, int64_t *lo_out, int64_t *hi_out);
 int pcl_group_store_alloc(pcl_group *group, int64_t capacity_global, int dtype);
+int pcl_group_store_dtype(pcl_group *group, int *dtype_out);      /* PCL_DTYPE_F64 / PCL_DTYPE_F32 of the shards' stores */
 int pcl_group_fill_photons(pcl_group *group, int64_t n_global, int64_t id_base, double c, double e_min, double e_max,
                            uint64_t seed);
 int pcl_group_count(pcl_group *group, int64_t *count_out);

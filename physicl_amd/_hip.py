@@ -132,6 +132,7 @@ _PROTOTYPES = {
     "pcl_group_ctx": [_vp, c_int, POINTER(_vp)],
     "pcl_group_shard": [_vp, c_int64, c_int, POINTER(c_int64), POINTER(c_int64)],
     "pcl_group_store_alloc": [_vp, c_int64, c_int],
+    "pcl_group_store_dtype": [_vp, POINTER(c_int)],
     "pcl_group_fill_photons": [_vp, c_int64, c_int64, c_double, c_double, c_double, c_uint64],
     "pcl_group_count": [_vp, POINTER(c_int64)],
     "pcl_group_sync": [_vp],
@@ -798,8 +799,12 @@ class DeviceGroup:
                                                   int(step) & 0xFFFFFFFF, pl.ctypes.data if len(pl) else None, len(pl), out.ctypes.data))
         return out
 
-    def download(self, field, n=None, offset=0, dtype=np.float64):
+    def download(self, field, n=None, offset=0, dtype=None):
         n = self.count - offset if n is None else n
+        if dtype is None:                         # the store's own element type (pcl_group_store_dtype)
+            d = c_int()
+            check(self.lib.pcl_group_store_dtype(self.g, byref(d)))
+            dtype = np.float32 if d.value == DTYPE_F32 else np.float64
         out = np.empty(n, dtype=dtype)
         check(self.lib.pcl_group_download(self.g, int(field), out.ctypes.data, int(offset), int(n)))
         return out

@@ -6230,6 +6230,7 @@ int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int
 // one-device run); a group call hands the same step to every worker, waits for all, and SUMS the int64 counter rows
 // the shards return -- they are in host memory when a launch returns, so that sum is the group's collective.
 struct pcl_group {
+    int dtype = PCL_DTYPE_F64; // element type of the shards' stores (pcl_group_store_alloc)
     std::vector<pcl_ctx *> ctx;
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -6354,11 +6355,17 @@ int pcl_group_shard(pcl_group *g, int64_t n_global, int i, int64_t *lo_out, int6
 int pcl_group_store_alloc(pcl_group *g, int64_t capacity_global, int dtype) {
     if (!g || capacity_global <= 0) return fail(PCL_ERR_ARG, "capacity must be positive");
     const int G = (int)g->ctx.size();
-    return group_run(g, [=](int i, pcl_ctx *c) {
-        int64_t lo, hi;
-        shard_of(capacity_global, i, G, &lo, &hi);
-        return pcl_store_alloc_dtype(c, hi - lo > 0 ? hi - lo : 1, dtype);
-    });
+    // ceil(capacity / G) slots per shard: the sizes of shard_of(n, i, G) are not monotone in n, so a later fill of fewer
+    // photons must find room for the largest shard any n <= capacity can produce
+    const int64_t per_shard = (capacity_global + G - 1) / G;
+    g->dtype = dtype;
+    return group_run(g, [=](int i, pcl_ctx *c) { return pcl_store_alloc_dtype(c, per_shard, dtype); });
+}
+
+int pcl_group_store_dtype(pcl_group *g, int *dtype_out) {
+    if (!g || !dtype_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *dtype_out = g->dtype;
+    return PCL_OK;
 }
 
 int pcl_group_fill_photons(pcl_group *g, int64_t n_global, int64_t id_base, double c_light, double e_min, double e_max, uint64_t seed) {

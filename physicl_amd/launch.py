@@ -46,38 +46,51 @@ def spawn_ranks(world, cmd, env=None, poll_s=0.05, grace_s=10.0):
     port = free_port()
     procs = []
     # a SIGTERM / SIGHUP / SIGINT to this process (a driver's timeout, Ctrl-C of a wrapper) must take the ranks down
-    # with it: they would otherwise sit in a collective, holding their GPUs, until its timeout.  The handlers turn the
-    # signal into an exception so that the ``finally`` below runs; should this process die without running it (SIGKILL),
+    # with it: they would otherwise sit in a collective, holding their GPUs, until its timeout.  The handlers only RECORD
+    # the signal -- nothing is raised inside Popen (a rank forked but not yet in ``procs`` would be lost) or inside the
+    # clean-up -- and the loops below look at the record; should this process die without running its clean-up (SIGKILL),
     # the kernel sends every rank SIGTERM (PR_SET_PDEATHSIG, set in the child between fork and exec).
     try:
         _libc()                                  # loaded here, not between fork and exec
     except OSError:
         pass
+    got = []                                     # signal numbers, in order of arrival
+
+    def _record(signum, frame):
+        got.append(signum)
+
     old_handlers = {}
     if threading.current_thread() is threading.main_thread():
         for sig in (signal.SIGTERM, signal.SIGHUP, signal.SIGINT):
-            old_handlers[sig] = signal.signal(sig, _raise_interrupted)
+            old_handlers[sig] = signal.signal(sig, _record)
     rc = 0
     captured, reader = [], None
+    parent = os.getpid()
     try:
-        for r in range(world):
-            procs.append(subprocess.Popen(list(cmd), env=rank_env(base, r, world, port), preexec_fn=_die_with_parent,
-                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-        reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
-        reader.start()
-        while True:
-            states = [p.poll() for p in procs]
-            bad = [s for s in states if s not in (None, 0)]
-            if bad:
-                rc = bad[0] if bad[0] > 0 else 1          # killed by a signal -> 1
-                break
-            if all(s == 0 for s in states):
-                break
-            time.sleep(poll_s)
-    except _Interrupted as e:
-        rc = 128 + e.args[0]
+        try:
+            for r in range(world):
+                if got:
+                    break
+                procs.append(subprocess.Popen(list(cmd), env=rank_env(base, r, world, port),
+                                              preexec_fn=lambda: _die_with_parent(parent),
+                                              stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+            if procs:
+                reader = threading.Thread(target=lambda: captured.append(procs[0].stdout.read()), daemon=True)
+                reader.start()
+            while not got:
+                states = [p.poll() for p in procs]
+                bad = [s for s in states if s not in (None, 0)]
+                if bad:
+                    rc = bad[0] if bad[0] > 0 else 1          # killed by a signal -> 1
+                    break
+                if all(s == 0 for s in states):
+                    break
+                time.sleep(poll_s)
+            if got:
+                rc = 128 + got[0]
+        finally:
+            _stop(procs, grace_s)                # (a second signal during the clean-up is recorded, not raised)
     finally:
-        _stop(procs, grace_s)
         for sig, h in old_handlers.items():
             signal.signal(sig, h)
     if reader is not None:
@@ -86,20 +99,15 @@ def spawn_ranks(world, cmd, env=None, poll_s=0.05, grace_s=10.0):
     return rc, out.decode("utf-8", "replace")
 
 
-class _Interrupted(Exception):
-    """A terminating signal arrived while the ranks were running (args[0] = signal number)."""
-
-
-def _raise_interrupted(signum, frame):
-    raise _Interrupted(signum)
-
-
-def _die_with_parent():
-    """In the child, before exec: ask the kernel for SIGTERM when the launching process dies (Linux prctl)."""
+def _die_with_parent(parent_pid=None):
+    """In the child, before exec: ask the kernel for SIGTERM when the launching process dies (Linux prctl).  A launcher
+    that died between the fork and the prctl is noticed by comparing the parent's pid afterwards."""
     try:
         _libc().prctl(1, int(signal.SIGTERM), 0, 0, 0)     # PR_SET_PDEATHSIG = 1
     except Exception:                            # noqa: BLE001 -- not Linux / no prctl: the handlers above still apply
-        pass
+        return
+    if parent_pid is not None and os.getppid() != parent_pid:
+        os._exit(1)
 
 
 _LIBC = []

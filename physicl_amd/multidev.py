@@ -117,9 +117,11 @@ class MultiDevice:
 
     # ---------------------------------------------------------------- store
     def store_alloc(self, capacity, dtype="f64"):
+        # every shard gets ceil(capacity / G): the shard sizes of shard_range(n, g, G) are not monotone in n (8 objects on 5
+        # devices are (1, 2, 1, 2, 2), 7 are (1, 1, 2, 1, 2)), so a re-upload of fewer objects into the same store must
+        # find room for the largest shard any n <= capacity can produce
         G = len(self.shards)
-        caps = [max(shard_range(capacity, g, G)[1] - shard_range(capacity, g, G)[0], 1) for g in range(G)]
-        self._each(lambda s, c: s.store_alloc(c, dtype), caps)
+        self._each(lambda s: s.store_alloc(max(-(-capacity // G), 1), dtype))
 
     def store_free(self):
         self._each(lambda s: s.store_free())
@@ -133,8 +135,9 @@ class MultiDevice:
 
     @property
     def capacity(self):
+        """Objects the store takes whatever their number's split over the shards is: G x the smallest shard."""
         caps = [s.capacity for s in self.shards]
-        return 0 if min(caps) == 0 else sum(caps)
+        return len(caps) * min(caps)
 
     @property
     def count(self):
@@ -205,7 +208,8 @@ class MultiDevice:
         out, at = [], 0
         for c in counts:
             lo, hi = max(offset, at), min(offset + n, at + c)
-            out.append((max(hi - lo, 0), max(lo - at, 0)))
+            # (a shard wholly outside the window: n = 0 at offset 0 -- the window's own offset may lie beyond its capacity)
+            out.append((hi - lo, lo - at) if hi > lo else (0, 0))
             at += c
         return out
 

@@ -1,4 +1,5 @@
 import os
+import re
 import sys
 
 import pytest
@@ -26,3 +27,63 @@ def golden():
         return cache[name]
 
     return load
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The library's A/B switches ("knobs", pcl_set_knob): which formulation runs must never show in a result.  Instead of
+# re-running whole test files in child pytest processes under other environment variables (rounds 2-3), the tests that
+# delete, and the tests of the K-step pass, are parametrised over the knob sets below: every case is its own test id.
+# ---------------------------------------------------------------------------------------------------------------------
+DELETE_KNOBS = [
+    # compaction allowed at any size (the suite's stores are mostly below the 65536 slots where the alive path never
+    # compacts by itself), pending moves flushed by a separate kernel, the host waits on the stream instead of polling
+    ("any_size-flush_kernel-no_poll", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_FLUSH_KERNEL": "1", "PCL_ALIVE_POLL": "0"}),
+    ("any_size-ratio_0.95", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}),         # nearly every body compacts
+    ("alive_off", {"PCL_ALIVE": "0"}),                                                         # the round-2 pipeline
+]
+# bodies worked out ahead (k_delete_ahead) only exist on the one-call-per-body path: the files that take it
+AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"})]
+AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py"}
+KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"})]
+DELETE_FILES = {"test_gpu_parity.py", "test_gpu_multi.py", "test_gpu_mixed.py", "test_gpu_simulation.py", "test_gpu_random_programs.py",
+                "test_gpu_fp32.py"}
+KSTEP_FILES = {"test_gpu_multi.py", "test_gpu_bench_regime.py", "test_gpu_rtc_background.py"}
+
+
+def pytest_generate_tests(metafunc):
+    if "pcl_knobs" not in metafunc.fixturenames:
+        return
+    fname = os.path.basename(getattr(metafunc.module, "__file__", ""))
+    node = (fname + "::" + metafunc.function.__name__).lower()
+    sets = []
+    if fname in DELETE_FILES and re.search("delete|random|mixed|program", node):
+        sets += DELETE_KNOBS + (AHEAD_KNOBS if fname in AHEAD_FILES else [])
+    if fname in KSTEP_FILES and "photons_per_wave" not in node:
+        sets += KSTEP_KNOBS
+    if sets:
+        sets = [("default", {})] + sets
+        metafunc.parametrize("pcl_knobs", [v for _, v in sets], ids=[k for k, _ in sets], indirect=True)
+
+
+@pytest.fixture(autouse=True)
+def pcl_knobs(request):
+    """Sets the knobs of this case for the duration of the test -- through pcl_set_knob (this process) and the
+    environment (processes the test starts) -- and takes them back afterwards."""
+    knobs = getattr(request, "param", None) or {}
+    if not knobs:
+        yield knobs
+        return
+    from physicl_amd import _hip
+    saved = {k: os.environ.get(k) for k in knobs}
+    for k, v in knobs.items():
+        _hip.set_knob(k, v)
+        os.environ[k] = v
+    try:
+        yield knobs
+    finally:
+        for k, v in saved.items():
+            _hip.set_knob(k, None)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

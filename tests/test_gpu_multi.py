@@ -262,26 +262,6 @@ def test_full_size_delete_multi_equals_single_steps_at_1e8(make_store, hip):
     assert abs(out[0][1] / N - 0.7002 ** K) < 1e-3
 
 
-@pytest.mark.parametrize("mode", ["1", "0"])
-def test_the_k_step_tests_with_256_and_with_128_photons_per_wave(mode):
-    """pcl_step_fused_multi picks one of two formulations of the K-step pass per launch -- 128 photons per wave, or 256
-    when the previous launch's last step scattered fewer than a quarter of the photons (fuller dense passes at low hit
-    fractions).  Same operations per photon either way: the K-step tests must pass with either form forced
-    (PCL_MULTI_NQ2=1 / 0) as they do with the automatic choice."""
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("PCL_NQ2_RERUN"):
-        pytest.skip("already inside the re-run")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_multi.py", "tests/test_gpu_bench_regime.py",
-                        "tests/test_gpu_rtc_background.py", "-k", "not photons_per_wave"],
-                       cwd=root, env=dict(os.environ, PCL_NQ2_RERUN="1", PCL_MULTI_NQ2=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       text=True, timeout=1200)
-    assert p.returncode == 0, p.stdout[-4000:]
-    assert " passed" in p.stdout
-
-
 def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
     """Four launches of 24 steps on the bench's workload (hit fraction 1.0 in the first step, below 25 % after ~70 steps):
     whatever form each launch took -- the last one starts below the threshold --, the rows and the state equal 96 single

@@ -73,7 +73,7 @@ def test_shards_are_contiguous_index_blocks_with_global_ids():
     FakeDevice.made.clear()
     md = MultiDevice([0, 1, 2], hip=FakeHip)
     md.store_alloc(10)
-    assert [d.capacity for d in FakeDevice.made] == [3, 3, 4] and md.capacity == 10
+    assert [d.capacity for d in FakeDevice.made] == [4, 4, 4] and md.capacity == 12      # ceil(10 / 3) slots on every shard
     md.fill_photons(10, 100, 1.0, 1.0, 1.0, 0)
     assert [list(d.ids) for d in FakeDevice.made] == [[100, 101, 102], [103, 104, 105], [106, 107, 108, 109]]
     assert [shard_range(10, g, 3) for g in range(3)] == [(0, 3), (3, 6), (6, 10)]
@@ -81,8 +81,25 @@ def test_shards_are_contiguous_index_blocks_with_global_ids():
     assert list(md.download_ids()) == list(range(100, 110))
     assert list(md.download_ids(4, 2)) == [102, 103, 104, 105]          # a window across two shards
     assert list(md.download(0, 3, 6)) == [1060.0, 1070.0, 1080.0] and len(md.download(0, 0, 10)) == 0
+    # a window that starts in the last shard: the shards before it are asked for nothing AT OFFSET 0 (the window's
+    # own offset can lie beyond an earlier shard's capacity, which the library's range check refuses even for n = 0)
+    assert md._window(2, 7) == [(0, 0), (0, 0), (2, 1)] and list(md.download_ids(2, 7)) == [107, 108]
     md.close()
     assert all(d.closed for d in FakeDevice.made)
+
+
+def test_a_store_takes_every_count_up_to_its_capacity_whatever_the_split():
+    """the shard sizes of shard_range(n, g, G) are not monotone in n -- 8 objects on 5 devices are (1, 2, 1, 2, 2),
+    7 are (1, 1, 2, 1, 2) -- so shards sized for 8 could not take a re-upload of 7.  Every shard gets ceil(capacity / G)."""
+    FakeDevice.made.clear()
+    md = MultiDevice([0] * 5, hip=FakeHip)
+    md.store_alloc(8)
+    caps = [d.capacity for d in FakeDevice.made]
+    assert caps == [2] * 5 and md.capacity == 10
+    for n in range(1, md.capacity + 1):
+        sizes = [shard_range(n, g, 5)[1] - shard_range(n, g, 5)[0] for g in range(5)]
+        assert sum(sizes) == n and all(sz <= c for sz, c in zip(sizes, caps)), (n, sizes)
+    md.close()
 
 
 def test_uploads_are_split_and_counters_are_summed():

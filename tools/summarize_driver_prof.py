@@ -104,6 +104,44 @@ def main():
     w_seq = read_counter_seq(os.path.join(src, "pmc_write", "pmc_counter_collection.csv"), kms)
     s_seq = read_counter_seq(os.path.join(src, "pmc_sq", "pmc_counter_collection.csv"), kms)
     ks = [min(S, warmup)] + [min(S, steps)] * R
+    # the kernel's own work tallies of the SQ pass's process (bench line key k_step_launch_work), launch by launch
+    sq_line = json.loads([ln for ln in open(os.path.join(src, "pmc_sq.json")) if ln.strip()][-1])
+    work = sq_line.get("k_step_launch_work", [])
+    isa = json.load(open(os.path.join(dst, "isa_counts.json"))) if os.path.exists(os.path.join(dst, "isa_counts.json")) else {}
+    exprs = [line["config"]["variable_n_fn"]] * (1 + R) + ["2.5E+25 * exp(r2[gid] / 8600.0)"] * (1 + R)
+    calib = collections.defaultdict(list)
+    W = ["", "### The same dispatches against the kernel's own work tally (SQ pass): wave-instructions = SQ_INSTS_VALU", "",
+         "model = decision instructions x wave-steps + dense-pass instructions x dense passes (profiles/isa_counts.json; the dense "
+         "pass is a straight-line loop body counted in the assembly, the decision count is what this table calibrates: "
+         "(SQ_INSTS_VALU - dense x passes) / wave-steps).", "",
+         "| # | expression | form | K | hit fraction | wave-steps | dense passes | passes / wave-step | SQ_INSTS_VALU | (INSTS - dense x passes) / wave-steps | static upper estimate |",
+         "|---|---|---|---|---|---|---|---|---|---|---|"]
+    for i, wk in enumerate(work):
+        if i >= len(s_seq):
+            break
+        kname, c = s_seq[i]
+        e = exprs[i] if i < len(exprs) else "?"
+        cnt = isa.get(e, {}).get("kernels", {}).get(kname)
+        if not cnt or not c.get("SQ_INSTS_VALU"):
+            continue
+        steps_i, hits_i, passes_i, ws_i, ppw_i = wk
+        a_dyn = (c["SQ_INSTS_VALU"] - cnt["dense_pass_valu"] * passes_i) / ws_i
+        calib[(e, kname)].append((steps_i, a_dyn))
+        W.append("| %d | `%s` | %d | %d | %.3f | %d | %d | %.3f | %.0f | %.1f | %.1f |" % (i, e[:24], ppw_i, steps_i, hits_i / float(N * steps_i), ws_i, passes_i,
+                                                                                          passes_i / float(ws_i), c["SQ_INSTS_VALU"], a_dyn,
+                                                                                          cnt.get("decision_valu_per_wave_step_static", 0)))
+    for (e, kname), vals in sorted(calib.items()):
+        # launches of the block length only (the short warm-up launch carries its prologue over fewer steps)
+        full = [a for st, a in vals if st == max(st2 for st2, _ in vals)]
+        a_fit = sum(full) / len(full)
+        W.append("")
+        W.append("`%s`, `%s`: decision instructions per wave-step = **%.1f** (mean of %d launches of %d steps, min %.1f, max %.1f)"
+                 % (kname, e, a_fit, len(full), max(st for st, _ in vals), min(full), max(full)))
+        isa[e]["kernels"][kname]["decision_valu_per_wave_step"] = round(a_fit, 1)
+        isa[e]["kernels"][kname]["decision_valu_calibration"] = {"source": "profiles/%s_pmc.md" % tag, "launches": len(full), "min": round(min(full), 1),
+                                                                   "max": round(max(full), 1)}
+    if calib:
+        json.dump(isa, open(os.path.join(dst, "isa_counts.json"), "w"), indent=1, sort_keys=True)
     multi_rows = []
     forms = []
     for i, (_, kname, d) in enumerate(seq[:len(ks) + 2]):
@@ -119,13 +157,15 @@ def main():
         multi_rows.append((K, d, fb + wb, busy, util, per_ps))
         L.append("| %d | %s | %.3f | %.1f | %.0f | %.4f | %.3f | %.3f | %s |" % (i, ("%d (%s)" % (K, forms[-1])) if K else "api (%s)" % forms[-1], d * 1e-6,
                                                                               (fb + wb) / N, gb, gb / HBM_PEAK, busy, util, "%.1f" % per_ps if K else "-"))
+    L += W
     timed = [r for r in multi_rows[1:1 + R]]
+    hbm_line = line["roofline"].get("hbm", line["roofline"])
     if timed:
         avg = sum(r[1] for r in timed) / len(timed)
         L += ["", "Timed launches (rows 1..%d): average %.3f ms -> 128 B x N / t = %.0f GB/s = **%.4f** of peak (bench line under rocprof: "
-              "`roofline.avg_launch_ms` %.3f, `frac` %.4f); in the per-step form 104 B x %d x N / t = %.0f GB/s."
+              "`roofline.avg_launch_ms` %.3f, `roofline.hbm.frac` %.4f); in the per-step form 104 B x %d x N / t = %.0f GB/s."
               % (R, avg * 1e-6, 128.0 * N / (avg * 1e-9) / 1e9, 128.0 * N / (avg * 1e-9) / 1e9 / HBM_PEAK, line["roofline"]["avg_launch_ms"],
-                 line["roofline"]["frac"], min(S, steps), 104.0 * min(S, steps) * N / (avg * 1e-9) / 1e9)]
+                 hbm_line["frac"], min(S, steps), 104.0 * min(S, steps) * N / (avg * 1e-9) / 1e9)]
     # ---- one-step kernel
     kf = "pcl_rtc_fast_e1"
     d_f = disp.get(kf, [])
@@ -145,13 +185,14 @@ def main():
                  line["single_step"]["roofline"]["frac"], tot / N, busy)]
     # ---- delete legs: the alive-mask kernel dispatch by dispatch (the first run of the 1e8 leg), then totals per kernel
     ka = [k for k in disp if k.startswith("k_delete_alive<double, true")]
+    big, idx_of = [], {}
     if ka:
         ka = ka[0]
         big = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == ka and int(r["Grid_Size_X"]) >= 4000000]
         L += ["", "## `k_delete_alive<double, true>` (one delete loop body on the alive mask; counters + plane crossings): the 1e8-photon "
               "dispatches of the `delete` leg", "",
-              "A dispatch sweeps ``slots`` = the store's extent; algorithmic bytes per SLOT: alive bit read + written (0.25), v (24), r (24), "
-              "the id (8) once ids are explicit.  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (16-byte loads: the calibrated case).", "",
+              "A dispatch sweeps ``slots`` = the store's extent; algorithmic bytes per SLOT: alive bit read + written (0.25), v (24), r along the "
+              "plane's axis (8; all of r, 24, until round 4), the id (8) once ids are explicit.  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024 (16-byte loads: the calibrated case).", "",
               "| dispatch | grid (threads) | duration us | HBM bytes (MB) | GB/s (PMC bytes / duration) | frac of 8 TB/s |", "|---|---|---|---|---|---|"]
         idx_of = {}
         for j, r in enumerate(rows):
@@ -164,6 +205,28 @@ def main():
             wb = write[ka][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(ka, [])) else 0
             g = (fb + wb) / (d * 1e-9) / 1e9
             L.append("| %d | %s | %.1f | %.1f | %.0f | %.3f |" % (i, rows[j]["Grid_Size_X"], d * 1e-3, (fb + wb) / 1e6, g, g / HBM_PEAK))
+    # ---- the compactions of >= 1e7 slots, dispatch by dispatch
+    kc = [k for k in disp if k.startswith("k_compact_lds<double")]
+    comp_rows = []
+    for k in kc:
+        js = [j for j, r in enumerate(rows) if short(r["Kernel_Name"]) == k]
+        for i, j in enumerate(js):
+            slots = int(rows[j]["Grid_Size_X"]) * 8
+            d = int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"])
+            if slots < 10_000_000 or d < 20_000:
+                continue
+            fb = fetch[k][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(k, [])) else 0
+            wb = write[k][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(k, [])) else 0
+            comp_rows.append((k, slots, d, fb, wb))
+    if comp_rows:
+        L += ["", "## `k_compact_lds` (stable compaction, pass 3): the dispatches of >= 1e7 slots of the `delete` leg", "",
+              "slots = grid x 8 (one 256-thread workgroup per 2048-slot tile).  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  The kernel "
+              "reads every 128-byte line of its seven source rows (56 B per SLOT: at a third of the photons surviving at random every line "
+              "holds a survivor) and writes 64 B per survivor.", "",
+              "| kernel | slots | duration us | FETCH x2 MB | WRITE MB | HBM B / slot | HBM GB/s | frac of 8 TB/s |", "|---|---|---|---|---|---|---|---|"]
+        for k, slots, d, fb, wb in comp_rows[:12]:
+            L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.0f | %.3f |" % (k, slots, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / slots,
+                                                                               (fb + wb) / (d * 1e-9) / 1e9, (fb + wb) / (d * 1e-9) / 1e9 / HBM_PEAK))
     L += ["", "## Delete legs (`delete` record): kernel totals over the whole run (warm-up repetition included; of the two pass-3 "
           "kernels enqueued per compaction the one the scan did not choose returns at once)", "",
           "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
@@ -190,6 +253,28 @@ def main():
     # ---- static_profile entry of bench.py
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    # per-kernel HBM bytes per unit of work: what bench.py's records carry as ``traffic`` (with this file and commit as source)
+    commit = os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
+    kern_t = allt.setdefault("kernels", {})
+    src_md = "profiles/%s_pmc.md" % tag
+    for i, (K, d, b_hbm, busy, util, per_ps) in enumerate(multi_rows[1:1 + R]):
+        kern_t["pcl_rtc_multi2_e1" if forms[1 + i] == "256" else "pcl_rtc_multi_e1"] = {
+            "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
+    if single:
+        kern_t["pcl_rtc_fast_e1"] = {"bytes_per_unit": round(tot / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
+    if ka and big:
+        per = []
+        for j in big[:8]:
+            i = idx_of[j]
+            if i < len(fetch.get(ka, [])) and i < len(write.get(ka, [])):
+                per.append((fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 + write[ka][i].get("WRITE_SIZE", 0) * 1024) / (int(rows[j]["Grid_Size_X"]) / 256 * 2048))
+        if per:
+            kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit}
+    if comp_rows:
+        first = [r for r in comp_rows if r[1] >= 90_000_000]
+        if first:
+            kern_t["k_compact_lds<double, unsigned long, 7>"] = {"bytes_per_unit": round(sum((r[3] + r[4]) / r[1] for r in first) / len(first), 2),
+                                                                  "unit": "slot (a third of the slots survive)", "source": src_md, "commit": commit}
     if timed:
         t_ok = [r for r in timed if r[0]]
         ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps),
