@@ -475,6 +475,25 @@ int pcl_group_step_mixed_multi(pcl_group *group, double dt, int k_passes, int n_
 int pcl_group_download(pcl_group *group, int field, void *host, int64_t offset, int64_t n);
 int pcl_group_download_ids(pcl_group *group, int64_t *host, int64_t offset, int64_t n);
 
+/* ---------------------------------------------------------------- the counters' collective (one process per GPU)
+ * The path shards by global index with no data-path exchange; the only global quantities are the int64
+ * counter rows a step returns (alive, hits / removed, sign counts, plane crossings) -- they are in host memory when the
+ * call returns.  A host that runs ONE PROCESS PER GPU sums them over its ranks with RCCL (over xGMI inside a node):
+ *   rank 0:      pcl_comm_unique_id(id)      and ships the PCL_COMM_ID_BYTES bytes to the other ranks by whatever it has
+ *   every rank:  pcl_comm_create(ctx, id, rank, world, &comm)   -- collective: returns when all ranks have arrived and a
+ *                                                                   one-element all-reduce has seen every one of them
+ *   per launch:  pcl_comm_allreduce_sum_i64(comm, rows, n)       -- in place, host pointer, on the context's stream
+ * librccl is loaded at run time (PCL_RCCL_LIB overrides the search).  There is no fallback: a missing library or a
+ * failed bring-up is PCL_ERR_STATE / PCL_ERR_HIP, and the caller must treat it as fatal (physicl_amd/dist.py does).
+ * One process on several GPUs needs none of this: pcl_group_* sums on the host.                                       */
+#define PCL_COMM_ID_BYTES 128
+typedef struct pcl_comm pcl_comm;
+int pcl_comm_unique_id(void *id_out_host);                                                      /* PCL_COMM_ID_BYTES bytes */
+int pcl_comm_create(pcl_ctx *ctx, const void *id_host, int rank, int world, pcl_comm **comm_out);
+int pcl_comm_allreduce_sum_i64(pcl_comm *comm, int64_t *inout_host, int n);                     /* n <= 2048 */
+int pcl_comm_info(pcl_comm *comm, int *rank_out, int *world_out, int *rccl_version_out, int64_t *reduces_out);
+int pcl_comm_destroy(pcl_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,11 @@ _PROTOTYPES = {
     "pcl_abi_version": [],
     "pcl_device_count": [POINTER(c_int)],
     "pcl_set_knob": [c_char_p, c_char_p],
+    "pcl_comm_unique_id": [_vp],
+    "pcl_comm_create": [_vp, c_char_p, c_int, c_int, POINTER(_vp)],
+    "pcl_comm_allreduce_sum_i64": [_vp, _vp, c_int],
+    "pcl_comm_info": [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
+    "pcl_comm_destroy": [_vp],
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],

@@ -223,7 +223,8 @@ class Simulation(threading.Thread):
       seed     Philox seed
       fuse     True (default): consecutive Newton / ScatterIsotropic / counting-measure steps run
                as ONE kernel (bit-identical results)
-      comm     a physicl_amd.dist.CounterComm: this process owns one index shard of the particles;
+      comm     a physicl_amd.dist.CounterComm (torch.distributed) or physicl_amd.comm.NativeCounterComm (the library's own
+               RCCL entry points, no torch): this process owns one index shard of the particles;
                counters (alive, hits, measure rows) are all-reduced
       steps_per_launch
                How many passes of the loop one launch may carry.  Default (None): automatic -- when every pass is exactly
@@ -367,6 +368,8 @@ class Simulation(threading.Thread):
         else:
             dev_index = self.device if self.device is not None else (self.comm.local_rank if self.comm else 0)
             self._dev = _hip.Device(dev_index)
+            if hasattr(self.comm, "attach"):         # physicl_amd.comm.NativeCounterComm: its communicator lives on this context
+                self.comm.attach(self._dev)
         # a variable_n_fn of one of the reference's example shapes starts at once on the ahead-of-time kernels while
         # hipRTC compiles its specialisation beside the run (~2 s; same bits, about the same speed)
         self._dev.set_rtc_background(bool(getattr(self, "rtc_background", True)))

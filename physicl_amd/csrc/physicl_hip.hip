@@ -6486,3 +6486,186 @@ int pcl_group_download_ids(pcl_group *g, int64_t *host, int64_t offset, int64_t 
 }
 
 } // extern "C"
+
+// =================================================================================================
+// pcl_comm_*: the counters' collective for hosts that run ONE PROCESS PER GPU and are not Python
+// ("RCCL all-reduce over xGMI only for the global scatter / escape counters").  librccl is loaded at run
+// time (dlopen: the library does not link it, a single-GPU host never needs it), the communicator is created from a
+// unique id the caller ships to its ranks by whatever it has (a file, a socket, MPI, an environment variable), and the
+// one collective there is sums an int64 vector on the context's stream.  Nothing falls back: a missing librccl, a failed
+// bring-up or a failed all-reduce is an error (a throughput number must not hide a collective that did not run) --
+// physicl_amd/dist.py behaves the same way on the Python side.
+// =================================================================================================
+namespace {
+
+struct rccl_id { char internal[128]; }; // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed BY VALUE to ncclCommInitRank
+static_assert(sizeof(rccl_id) == PCL_COMM_ID_BYTES, "pcl_comm_unique_id hands out an ncclUniqueId");
+
+struct rccl_api {
+    void *lib = nullptr;
+    std::string path, why;
+    int (*GetVersion)(int *) = nullptr;
+    int (*GetUniqueId)(rccl_id *) = nullptr;
+    int (*CommInitRank)(void **, int, rccl_id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+rccl_api &rccl() {
+    static rccl_api api = [] {
+        rccl_api a;
+        std::vector<std::string> names;
+        if (const char *e = getenv("PCL_RCCL_LIB")) names.push_back(e);
+        for (const char *n : {"librccl.so.1", "librccl.so"}) { // a copy the process already holds (torch ships one) comes first
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) {
+                a.lib = h;
+                a.path = n;
+                break;
+            }
+        }
+        if (!a.lib) {
+            names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+            if (const char *r = getenv("ROCM_PATH")) names.push_back(std::string(r) + "/lib/librccl.so.1");
+            names.push_back("/opt/rocm/lib/librccl.so.1");
+            for (const std::string &n : names) {
+                if (void *h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+                    a.lib = h;
+                    a.path = n;
+                    break;
+                }
+                a.why = dlerror() ? dlerror() : "";
+            }
+        }
+        if (!a.lib) return a;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(a.lib, n);
+            if (!p) a.why = std::string("symbol ") + n + " is missing from " + a.path;
+            return p;
+        };
+        a.GetVersion = reinterpret_cast<decltype(a.GetVersion)>(sym("ncclGetVersion"));
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!a.GetVersion || !a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString) {
+            dlclose(a.lib);
+            a.lib = nullptr;
+        }
+        return a;
+    }();
+    return api;
+}
+
+int need_rccl() {
+    if (!rccl().lib) return fail(PCL_ERR_STATE, "librccl could not be loaded (%s): no collective, and no fallback", rccl().why.c_str());
+    return PCL_OK;
+}
+
+#define PCL_RCCL(expr)                                                                                          \
+    do {                                                                                                        \
+        int r__ = (expr);                                                                                       \
+        if (r__ != 0) return fail(PCL_ERR_HIP, "%s failed: %s (RCCL result %d)", #expr, rccl().GetErrorString(r__), r__); \
+    } while (0)
+
+} // namespace
+
+struct pcl_comm {
+    pcl_ctx *ctx = nullptr;
+    void *nccl = nullptr;
+    int rank = 0, world = 1;
+    int64_t *d_buf = nullptr, *h_buf = nullptr; // the vector on the device / pinned on the host
+    int cap = 0;
+    int64_t reduces = 0;
+};
+
+extern "C" {
+
+int pcl_comm_unique_id(void *id_out_host) {
+    if (!id_out_host) return fail(PCL_ERR_ARG, "NULL argument");
+    PCL_TRY(need_rccl());
+    rccl_id id;
+    memset(&id, 0, sizeof id);
+    PCL_RCCL(rccl().GetUniqueId(&id));
+    memcpy(id_out_host, &id, sizeof id);
+    return PCL_OK;
+}
+
+int pcl_comm_create(pcl_ctx *ctx, const void *id_host, int rank, int world, pcl_comm **comm_out) {
+    if (!ctx || !id_host || !comm_out) return fail(PCL_ERR_ARG, "NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(PCL_ERR_ARG, "rank %d outside a world of %d", rank, world);
+    PCL_TRY(need_rccl());
+    PCL_TRY(bind(ctx));
+    rccl_id id;
+    memcpy(&id, id_host, sizeof id);
+    std::unique_ptr<pcl_comm> c(new (std::nothrow) pcl_comm);
+    if (!c) return fail(PCL_ERR_NOMEM, "out of host memory");
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    PCL_RCCL(rccl().CommInitRank(&c->nccl, world, id, rank)); // (blocks until every rank of the id has arrived)
+    c->cap = kCounterSlots * PCL_MULTI_MAX;                     // a K-pass launch's rows and more
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_buf), (size_t)c->cap * sizeof(int64_t)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_buf), (size_t)c->cap * sizeof(int64_t)) != hipSuccess) {
+        if (c->d_buf) (void)hipFree(c->d_buf);
+        (void)rccl().CommDestroy(c->nccl);
+        return fail(PCL_ERR_NOMEM, "buffers of the communicator");
+    }
+    // the proof that the collective is up and sees every rank: sum of ones == world (what dist.py's start-up probe does)
+    c->h_buf[0] = 1;
+    PCL_HIP(hipMemcpyAsync(c->d_buf, c->h_buf, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PCL_RCCL(rccl().AllReduce(c->d_buf, c->d_buf, 1, 4 /* ncclInt64 */, 0 /* ncclSum */, c->nccl, ctx->stream));
+    PCL_HIP(hipMemcpyAsync(c->h_buf, c->d_buf, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    if (c->h_buf[0] != world) {
+        const long long seen = (long long)c->h_buf[0];
+        (void)rccl().CommDestroy(c->nccl);
+        (void)hipFree(c->d_buf);
+        (void)hipHostFree(c->h_buf);
+        return fail(PCL_ERR_HIP, "the start-up all-reduce saw %lld of %d ranks", seen, world);
+    }
+    *comm_out = c.release();
+    return PCL_OK;
+}
+
+int pcl_comm_allreduce_sum_i64(pcl_comm *comm, int64_t *inout_host, int n) {
+    if (!comm || (n > 0 && !inout_host)) return fail(PCL_ERR_ARG, "NULL argument");
+    if (n < 0 || n > comm->cap) return fail(PCL_ERR_ARG, "n outside [0, %d]", comm->cap);
+    if (n == 0) return PCL_OK;
+    pcl_ctx *ctx = comm->ctx;
+    PCL_TRY(bind(ctx));
+    memcpy(comm->h_buf, inout_host, (size_t)n * sizeof(int64_t));
+    PCL_HIP(hipMemcpyAsync(comm->d_buf, comm->h_buf, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PCL_RCCL(rccl().AllReduce(comm->d_buf, comm->d_buf, (size_t)n, 4 /* ncclInt64 */, 0 /* ncclSum */, comm->nccl, ctx->stream));
+    PCL_HIP(hipMemcpyAsync(comm->h_buf, comm->d_buf, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(inout_host, comm->h_buf, (size_t)n * sizeof(int64_t));
+    ++comm->reduces;
+    return PCL_OK;
+}
+
+int pcl_comm_info(pcl_comm *comm, int *rank_out, int *world_out, int *rccl_version_out, int64_t *reduces_out) {
+    if (!comm) return fail(PCL_ERR_ARG, "NULL argument");
+    if (rank_out) *rank_out = comm->rank;
+    if (world_out) *world_out = comm->world;
+    if (rccl_version_out) {
+        *rccl_version_out = 0;
+        (void)rccl().GetVersion(rccl_version_out);
+    }
+    if (reduces_out) *reduces_out = comm->reduces;
+    return PCL_OK;
+}
+
+int pcl_comm_destroy(pcl_comm *comm) {
+    if (!comm) return PCL_OK;
+    (void)hipSetDevice(comm->ctx->device);
+    (void)hipStreamSynchronize(comm->ctx->stream);
+    if (comm->nccl) (void)rccl().CommDestroy(comm->nccl);
+    if (comm->d_buf) (void)hipFree(comm->d_buf);
+    if (comm->h_buf) (void)hipHostFree(comm->h_buf);
+    delete comm;
+    return PCL_OK;
+}
+
+} // extern "C"
