@@ -211,7 +211,7 @@ class Bench:
             rows = self.dev.step_fused_multi(self.prof["dt"], ks, self.sc(k))
             c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
             hits += int(c[:, 1].sum())
-            self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work())   # steps, hits, dense passes, wave-steps, photons per wave
+            self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work())   # steps, hits, dense passes, wave-steps, photons per wave, wave-steps on exp's shortcut (-1: no probe)
             self.totals = self.comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
             k += ks
         return hits
@@ -374,14 +374,16 @@ def valu_roofline(work, kern_ms, expr, f32):
     instr = dec = 0.0
     useful = 0.0
     forms = {}
-    for steps, hits, passes, wsteps, ppw in work:
-        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi2_e1" if ppw == 256 else "pcl_rtc_multi_e1")
+    for steps, hits, passes, wsteps, ppw, sat in work:
+        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi2_e1" if ppw == 256 else ("pcl_rtc_multis_e1" if sat >= 0 else "pcl_rtc_multi_e1"))
         c = table.get(name)
         if c is None:
             return None
         A, B = c["decision_valu_per_wave_step"], c["dense_pass_valu"]
-        instr += A * wsteps + B * passes
-        useful += A * wsteps + B * hits / 64.0
+        # the variant with the saturation probe: wave-steps on exp's shortcut run the shorter decision part
+        dec = A * wsteps if sat < 0 else c.get("decision_valu_per_wave_step_shortcut", A) * sat + A * (wsteps - sat)
+        instr += dec + B * passes
+        useful += dec + B * hits / 64.0
         forms[name] = forms.get(name, 0) + 1
     if not instr or not kern_ms:
         return None
@@ -389,8 +391,9 @@ def valu_roofline(work, kern_ms, expr, f32):
     return {"achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": achieved / VALU_PEAK,
             "lane_util": useful / instr, "wave_instructions": instr, "dense_passes": sum(w[2] for w in work),
             "wave_steps": sum(w[3] for w in work), "dense_passes_per_wave_step": sum(w[2] for w in work) / float(sum(w[3] for w in work)),
-            "kernel_forms": forms, "instruction_counts": {k: {"decision_valu_per_wave_step": table[k]["decision_valu_per_wave_step"],
-                                                             "dense_pass_valu": table[k]["dense_pass_valu"]} for k in forms},
+            "saturated_wave_steps": sum(max(w[5], 0) for w in work),
+            "kernel_forms": forms, "instruction_counts": {k: {key: table[k][key] for key in ("decision_valu_per_wave_step", "decision_valu_per_wave_step_shortcut",
+                                                                                           "dense_pass_valu") if key in table[k]} for k in forms},
             "instruction_counts_source": "profiles/isa_counts.json (tools/isa_count.py)",
             "peak_note": "%d SIMDs x %.1f GHz / 4 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ)}
 
@@ -563,7 +566,8 @@ def run_rank(args):
             # one-launch-per-step kernel: the same workload run that way in this same process (the single_step leg)
             "roofline_hbm": (dict(single["roofline"], value=single["value"], ms_per_step=single["ms_per_step"]) if single is not None else None),
             # every K-step launch of this process in order (warm-up, the timed blocks, the tame leg): steps, hits, dense passes,
-            # wave-steps, photons per wave -- what tools/summarize_driver_prof.py lines up with the profiler's dispatches
+            # wave-steps, photons per wave, wave-steps on exp's saturation shortcut (-1: the variant without the probe) -- what
+            # tools/summarize_driver_prof.py lines up with the profiler's dispatches
             "k_step_launch_work": [list(w) for w in b.work_log],
             "static_profile": static_profile(args.profile, args.mode, args.dtype, N, S, args.steps),
             # north_star target (>= 60 % of the HBM roofline on the photon-scatter step at 1e8 photons): carried by the

@@ -97,7 +97,7 @@ const char *pcl_last_error(void);                 /* thread-local, never NULL */
 int         pcl_device_count(int *n_out);         /* host pointer */
 /* A/B switches ("knobs").  Every PCL_* environment variable the library reads at call time (the delete path's: PCL_ALIVE,
  * PCL_ALIVE_RATIO, PCL_ALIVE_MIN_SLOTS, PCL_ALIVE_POLL, PCL_ALIVE_FLUSH_KERNEL, PCL_AHEAD, PCL_AHEAD_K,
- * PCL_AHEAD_MAX_SLOTS; the K-step pass's: PCL_MULTI_NQ2, PCL_MULTI_NQ2_BELOW) can also be set from the program:
+ * PCL_AHEAD_MAX_SLOTS; the K-step pass's: PCL_MULTI_NQ2, PCL_MULTI_NQ2_BELOW, PCL_MULTI_SAT) can also be set from the program:
  * value = its text, NULL = back to the environment.  Process-wide, takes effect at the next call; results never depend
  * on a knob (that is what the tests that flip them check), only which formulation runs.                            */
 int         pcl_set_knob(const char *name, const char *value);
@@ -361,8 +361,11 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
  *   (instructions of a step's decision part) x wave-steps + (instructions of a dense pass) x dense passes,
  * the two static counts being properties of the code object (profiles/isa_counts.json).  *dense_passes_out = passes of
  * the waves' hit queues (ceil(hits of the wave in that step / 64) summed over waves and steps), *wave_steps_out = waves x
- * K, *photons_per_wave_out = 128 or 256 (fp64; the form the launch took).                                          */
-int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out);
+ * K, *photons_per_wave_out = 128 or 256 (fp64; the form the launch took), *saturated_wave_steps_out = wave-steps whose
+ * variable_n_fn values came from exp's saturation shortcut instead of its polynomial (-1: the launch ran the variant
+ * without the probe; the library picks per launch, PCL_MULTI_SAT = 1 / 0 forces).                                    */
+int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out,
+                              int64_t *saturated_wave_steps_out);
 
 /* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
  * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --

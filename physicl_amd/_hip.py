@@ -56,7 +56,7 @@ _PROTOTYPES = {
     "pcl_comm_allreduce_sum_i64": [_vp, _vp, c_int],
     "pcl_comm_info": [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
     "pcl_comm_destroy": [_vp],
-    "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int)],
+    "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
@@ -423,10 +423,11 @@ class Device:
         return v.value
 
     def last_multi_work(self):
-        """(dense passes, wave-steps, photons per wave) of the last step_fused_multi launch (pcl_store_last_multi_work)."""
-        a, b, c = c_int64(), c_int64(), c_int()
-        check(self.lib.pcl_store_last_multi_work(self.ctx, byref(a), byref(b), byref(c)))
-        return a.value, b.value, c.value
+        """(dense passes, wave-steps, photons per wave, wave-steps on exp's saturation shortcut or -1) of the last
+        step_fused_multi launch (pcl_store_last_multi_work)."""
+        a, b, c, e = c_int64(), c_int64(), c_int(), c_int64()
+        check(self.lib.pcl_store_last_multi_work(self.ctx, byref(a), byref(b), byref(c), byref(e)))
+        return a.value, b.value, c.value, e.value
 
     def ahead_stats(self):
         """(launches, bodies answered, launches not used up) of the delete bodies worked out ahead (pcl_store_ahead_stats)."""

@@ -330,6 +330,39 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
 }
 #undef exp
 
+// The K-step pass's "saturation probe" (hipRTC builds; pcl_multi_body<..., SATP = true>).  Where its argument lies beyond
+// the range in which exp saturates, the result is exactly +inf or +0 in any IEEE libm (fp64: x > 709.79 / x < -745.14;
+// fp32: 88.73 / -103.98).  The expression is first evaluated with exp() replaced by that shortcut for BOTH photons of a
+// lane, noting whether any argument was NOT that far out; when no lane of the wave noted one -- the state of
+// examples/variable_n_scattering.ipynb after its first step: every photon is 1.5e6 m from the origin -- those values ARE the
+// expression's values and the ~25-instruction polynomial is never run; otherwise the wave evaluates the expression the
+// ordinary way.  One wave-uniform branch per step around both photons' polynomials (round 2's per-call branch,
+// PCL_EXP_WAVE above, split the two photons' dependency chains and cost 40 VGPRs).  Same values either way.
+#ifdef PCL_N_EXPR
+__device__ __forceinline__ double pcl_exp_sat(double x, bool &unsat) {
+    unsat = unsat || !(__builtin_fabs(x) > 750.0);
+    return x > 0.0 ? __builtin_inf() : 0.0;
+}
+__device__ __forceinline__ float pcl_exp_sat(float x, bool &unsat) {
+    unsat = unsat || !(__builtin_fabsf(x) > 105.0f);
+    return x > 0.0f ? __builtin_inff() : 0.0f;
+}
+__device__ __forceinline__ double pcl_exp_sat(int x, bool &unsat) { return pcl_exp_sat((double)x, unsat); }
+#define exp(x) pcl_exp_sat(x, pcl_unsat)
+template <typename T>
+__device__ __forceinline__ T pcl_n_expr_sat(T r0v, T r1v, T r2v, T d0v, T d1v, T d2v, T Ev, bool &pcl_unsat) {
+    const T r0[1] = {r0v}, r1[1] = {r1v}, r2[1] = {r2v}, d0[1] = {d0v}, d1[1] = {d1v}, d2[1] = {d2v}, E[1] = {Ev};
+    const int gid = 0;
+    (void)r0; (void)r1; (void)r2; (void)d0; (void)d1; (void)d2; (void)E; (void)gid;
+    if constexpr (sizeof(T) == 8) {
+        return (T)(PCL_N_EXPR);
+    } else {
+        return (T)(PCL_N_EXPR_F);
+    }
+}
+#undef exp
+#endif
+
 // pcoll exactly as the generated kernel text multiplies it            physicl/light.py:299-306
 //   A * n * norm  |  A * (<expr>) * norm  [ * pow((h*c)/E, -4) ]   -- left to right
 // (the norm is passed in: a K-step pass keeps it in a register between the photon's hits)
@@ -854,7 +887,8 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
 // 128/K B (fp64).  The velocity is updated in place and the velocity before the LAST step goes to the vp
 // rows, so dr = vp*dt and dv = v - vp stay implicit exactly as after a single lazy step.
 // cnt[(4 + n_planes)*k + {0: hits, 1..3: sign counts, 4..: plane crossings}] for k = 0..K-1.
-// cnt[(4 + n_planes)*K] = dense passes of the hit queues over the whole launch (the work tally of the VALU roofline record).
+// cnt[(4 + n_planes)*K] = dense passes of the hit queues over the whole launch (the work tally of the VALU roofline record);
+// cnt[(4 + n_planes)*K + 1] = wave-steps that took the saturation shortcut (SATP variants).
 // ------------------------------------------------------------------------------------------------
 #define PCL_MULTI_MAX 64
 template <typename T>
@@ -890,22 +924,23 @@ struct pcl_hit_queue {
     T out[4][256 * VEC];      // the new velocity and its step length |v' * dt|
 };
 
-template <typename T, bool USE_E, int VAR_N, int VEC>
+template <typename T, bool USE_E, int VAR_N, int VEC, bool SATP = false>
 __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
-    __shared__ pcl_u32 s_pass;
+    __shared__ pcl_u32 s_pass, s_sat;
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
-    if (threadIdx.x == 0) s_pass = 0;
+    if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
     pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform: a scalar add per step)
+    pcl_u32 w_sat = 0;    // SATP: wave-steps whose expression values came from the saturation shortcut
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < nq; base += stride) {
         const pcl_i64 q = base + threadIdx.x;
         const bool live_q = q < nq;
@@ -936,12 +971,14 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             bool hit[VEC];
             pcl_u32 slot[VEC];
             const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
+            T nv[VEC], dd[3][VEC];
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const pcl_i64 i = q * VEC + e;
                 const bool live = live_q && i < a.N;
                 // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
                 const T d0 = R::mul(V[0][e], a.dt), d1 = R::mul(V[1][e], a.dt), d2 = R::mul(V[2][e], a.dt);
+                dd[0][e] = d0, dd[1][e] = d1, dd[2][e] = d2;
                 Rr[0][e] = R::add(Rr[0][e], d0);
                 Rr[1][e] = R::add(Rr[1][e], d1);
                 Rr[2][e] = R::add(Rr[2][e], d2);
@@ -954,9 +991,36 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
                     const pcl_u32 nc = (pcl_u32)__popcll(__ballot(live && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                     if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + p], nc);
                 }
+            }
+#ifdef PCL_N_EXPR
+            if constexpr (SATP && VAR_N != 0) { // the expression of all of the lane's photons by the saturation shortcut, if it holds wave-wide
+                bool unsat = false;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    nv[e] = pcl_n_expr_sat<T>(Rr[0][e], Rr[1][e], Rr[2][e], dd[0][e], dd[1][e], dd[2][e], Ev[e], unsat);
+                if (__ballot(unsat) != 0ull) { // (wave-uniform) some argument is in exp's working range: the ordinary way
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        nv[e] = pcl_n_expr_val<T, VAR_N>(a.np, Rr[0][e], Rr[1][e], Rr[2][e], dd[0][e], dd[1][e], dd[2][e], Ev[e]);
+                } else {
+                    ++w_sat;
+                    asm volatile("" : "+v"(w_sat));
+                }
+            }
+#endif
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const pcl_i64 i = q * VEC + e;
+                const bool live = live_q && i < a.N;
+                const T d0 = dd[0][e], d1 = dd[1][e], d2 = dd[2][e];
                 // scatter decision                                                       light.py:303-308
-                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e],
-                                                       Ev[e]);
+                T pc;
+#ifdef PCL_N_EXPR
+                if constexpr (SATP && VAR_N != 0)
+                    pc = R::mul(R::mul(a.A, nv[e]), NM[e]); // pcl_pcoll_norm with the expression's value in hand
+                else
+#endif
+                    pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e], Ev[e]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
                 T rand;
@@ -1042,10 +1106,12 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         }
     }
     if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
+    if (lane0 && w_sat) atomicAdd(&s_sat, w_sat);
     __syncthreads();
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
     if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
+    if (threadIdx.x == 0 && s_sat) atomicAdd(&a.cnt[nslots * a.K + 1], (pcl_u64)s_sat);
 }
 
 // NQ: VEC-wide groups per lane and trip (photons per lane = VEC * NQ).  The dense pass costs the same whether 5 or 64
@@ -1592,6 +1658,16 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e1(pcl_multi_args<double> a) {
     pcl_multi_body<double, true, true, 2>(a);
+}
+#endif
+#if PCL_RTC_WANT(0, 0)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multis_e0(pcl_multi_args<double> a) {
+    pcl_multi_body<double, false, true, 2, true>(a); // with the saturation probe (pcl_n_expr_sat)
+}
+#endif
+#if PCL_RTC_WANT(0, 1)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multis_e1(pcl_multi_args<double> a) {
+    pcl_multi_body<double, true, true, 2, true>(a);
 }
 #endif
 #if PCL_RTC_WANT(1, 0)

@@ -2398,6 +2398,7 @@ struct rtc_entry {
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
+    hipFunction_t multis[2] = {nullptr, nullptr}; // 128 photons per wave with the saturation probe (pcl_n_expr_sat), fp64
     std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
 
@@ -2457,7 +2458,11 @@ struct pcl_ctx {
     // ``slots`` (alive + dead), ``count`` is the alive count, ``masks`` holds the alive bits and ``tile_keep`` the alive
     // count per tile; r lags pend_n moves behind.  Every entry point but pcl_step_fused_delete makes the store dense
     // again first (densify, through need_store / ensure_scratch).
-    int64_t multi_work[3] = {0, 0, 0}; // last pcl_step_fused_multi launch: dense passes, wave-steps, photons per wave (pcl_store_last_multi_work)
+    int64_t multi_work[4] = {0, 0, 0, 0}; // last pcl_step_fused_multi launch: dense passes, wave-steps, photons per wave, wave-steps that took
+                                          // the saturation shortcut (-1: the launch did not probe) (pcl_store_last_multi_work)
+    int64_t multi_launches = 0;      // pcl_step_fused_multi launches on this population
+    bool multi_sat_on = false, multi_sat_used = false; // the probing variant paid on its last launch / the current launch uses it
+    int multi_sat_next = 0;          // launches until the probing variant is tried again
     double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
@@ -3622,6 +3627,8 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
         char nm[64];
         snprintf(nm, sizeof nm, "pcl_rtc_multi2_e%d", e);
         if (hipModuleGetFunction(&ent.multi2[e], ent.module, nm) != hipSuccess) ent.multi2[e] = nullptr;
+        snprintf(nm, sizeof nm, "pcl_rtc_multis_e%d", e);
+        if (hipModuleGetFunction(&ent.multis[e], ent.module, nm) != hipSuccess) ent.multis[e] = nullptr;
     }
     (void)hipGetLastError();
     return PCL_OK;
@@ -3895,15 +3902,34 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 28 % of the photons
+    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 21.5 % of the photons
     // (fuller dense passes; slower above that: one wave per SIMD fewer).  PCL_MULTI_NQ2=1 always, =0 never.
     static knob k_nq2("PCL_MULTI_NQ2"), k_below("PCL_MULTI_NQ2_BELOW");
     const int nq2_mode = !k_nq2.set() ? -1 : (k_nq2.off() ? 0 : 1);
-    const double nq2_below = k_below.value(0.28); // (sweep of 0.22 .. 0.36 on three bench configurations: profiles/r03_experiments/README.md)
+    // The hit fraction falls along a launch, so the previous launch's last step is (nearly) this launch's FIRST and
+    // busiest step: the form pays while the 256 photons of a wave seldom hold more than the 64 hits of one dense pass --
+    // 256 h + 2 sqrt(256 h (1 - h)) < 64, h < 0.21.  (Round 3 switched at 0.28: the driver's 20-step block that starts at
+    // h = 0.25 then ran at 1.25 passes per wave-step, 0.649 instead of 0.573 ms per step -- profiles/r04_driver_cmd_pmc.md.)
+    const double nq2_below = k_below.value(0.215);
     const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < nq2_below);
     set_np(f.np, ent);
     ctx->multi_work[2] = 64 * pcl_rt<T>::VEC;
-    if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
+    // The saturation probe (pcl_n_expr_sat; 128-photon form, fp64): worth its dozen instructions per wave-step only where
+    // exp's arguments are out of range for (nearly) whole waves.  The kernel says how many wave-steps took the shortcut;
+    // the host tries the probing variant on a store's second launch, keeps it while more than half of them did, and
+    // tries again every 16th launch otherwise.  PCL_MULTI_SAT=1 always, =0 never.
+    static knob k_sat("PCL_MULTI_SAT");
+    const int sat_mode = !k_sat.set() ? -1 : (k_sat.off() ? 0 : 1);
+    bool sat = false;
+    if (var_n && ent->module && d == 0 && ent->multis[use_e ? 1 : 0] && !nq2) {
+        const bool due = ctx->multi_sat_on || ctx->multi_sat_next <= 0;
+        sat = sat_mode == 1 || (sat_mode == -1 && ctx->multi_launches >= 1 && due);
+    }
+    ctx->multi_sat_used = sat;
+    ++ctx->multi_launches;
+    if (sat) {
+        PCL_TRY(launch_module(ctx, ent->multis[use_e ? 1 : 0], grid, f, "step_fused_multi with the saturation probe (hipRTC)"));
+    } else if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
         ctx->multi_work[2] = 128 * pcl_rt<T>::VEC;
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
         PCL_TRY(launch_module(ctx, ent->multi2[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 (hipRTC)"));
@@ -4423,6 +4449,9 @@ int ahead_resources(pcl_ctx *ctx, int64_t slots) {
 
 void drop_holes(pcl_ctx *ctx) {
     ctx->multi_last_h = -1.0; // (called whenever the population is replaced)
+    ctx->multi_launches = 0;
+    ctx->multi_sat_on = false;
+    ctx->multi_sat_next = 0;
     ctx->ahead.active = false;
     ctx->ahead_last_valid = false;
     ctx->ahead_wait = ctx->ahead_backoff = 0;
@@ -4840,11 +4869,13 @@ int pcl_set_knob(const char *name, const char *value) {
     return PCL_OK;
 }
 
-int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out) {
+int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out,
+                              int64_t *saturated_wave_steps_out) {
     if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
     if (dense_passes_out) *dense_passes_out = ctx->multi_work[0];
     if (wave_steps_out) *wave_steps_out = ctx->multi_work[1];
     if (photons_per_wave_out) *photons_per_wave_out = (int)ctx->multi_work[2];
+    if (saturated_wave_steps_out) *saturated_wave_steps_out = ctx->multi_work[3];
     return PCL_OK;
 }
 
@@ -5804,7 +5835,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
         }
     if (N == 0) return PCL_OK;
     // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
-    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + 1) * sizeof(uint64_t), ctx->stream)); // rows + the work tally
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + 2) * sizeof(uint64_t), ctx->stream)); // rows + the two work tallies
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
     PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np),
@@ -5817,7 +5848,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + nslots * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice,
                            ctx->stream));
     if (out_host) {
-        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)(nslots * k_steps + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)(nslots * k_steps + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < k_steps; ++k) {
@@ -5826,9 +5857,17 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
         }
         ctx->multi_work[0] = (int64_t)ctx->h_multi[nslots * k_steps];                                  // dense passes
         ctx->multi_work[1] = div_up(N, (int64_t)ctx->multi_work[2]) * (int64_t)k_steps;                // wave-steps
+        ctx->multi_work[3] = ctx->multi_sat_used ? (int64_t)ctx->h_multi[nslots * k_steps + 1] : -1;
+        if (ctx->multi_sat_used) { // did the probe pay?  (more than half of the wave-steps took the shortcut)
+            ctx->multi_sat_on = 2 * ctx->multi_work[3] > ctx->multi_work[1];
+            ctx->multi_sat_next = ctx->multi_sat_on ? 0 : 16;
+        } else if (ctx->multi_sat_next > 0) {
+            --ctx->multi_sat_next;
+        }
         ctx->multi_last_h = (double)ctx->h_multi[nslots * (k_steps - 1)] / (double)N; // what the next launch's form goes by
     } else {
         ctx->multi_last_h = -1.0;
+        ctx->multi_sat_on = false; // (the tallies of a launch whose rows nobody read are not known)
     }
     return PCL_OK;
 }

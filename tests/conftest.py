@@ -44,7 +44,10 @@ DELETE_KNOBS = [
 # bodies worked out ahead (k_delete_ahead) only exist on the one-call-per-body path: the files that take it
 AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"})]
 AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py"}
-KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"})]
+KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
+               # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's
+               # photons start at the origin and fly out of exp's range), never
+               ("saturation_probe", {"PCL_MULTI_SAT": "1", "PCL_MULTI_NQ2": "0"}), ("no_saturation_probe", {"PCL_MULTI_SAT": "0"})]
 DELETE_FILES = {"test_gpu_parity.py", "test_gpu_multi.py", "test_gpu_mixed.py", "test_gpu_simulation.py", "test_gpu_random_programs.py",
                 "test_gpu_fp32.py"}
 KSTEP_FILES = {"test_gpu_multi.py", "test_gpu_bench_regime.py", "test_gpu_rtc_background.py"}

@@ -6,6 +6,8 @@ every scatter variant and ragged sizes; and, against the CPU oracle run K steps 
 sign counters per step with positions within K * dt * 4 ulp(c) (the oracle's libm sin/cos differ from
 OCML's by <= 4 ulp of c in a scattered velocity, which then feeds the later Euler steps).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -270,20 +272,27 @@ def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
     expr = "0.000000001 * exp(r0[gid] - 5)"
     sc = lambda k: dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=299792458.0, h=6.62607015e-34,
                         n_expr=expr, rng_mode=hip.RNG_PHILOX, seed=seed, step=k)
-    out = {}
-    for how in ("multi", "single"):
-        with hip.Device(0) as d:
-            d.store_alloc(N)
-            d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
-            rows = []
-            if how == "multi":
-                for k in range(0, 96, 24):
-                    rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
-            else:
-                rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
-            out[how] = (rows, d.download_state())
+    out, forms = {}, []
+    hip.set_knob("PCL_MULTI_NQ2_BELOW", "0.25")       # (the shipped switch-over is 0.215, reached after ~100 steps of this workload)
+    try:
+        for how in ("multi", "single"):
+            with hip.Device(0) as d:
+                d.store_alloc(N)
+                d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
+                rows = []
+                if how == "multi":
+                    for k in range(0, 96, 24):
+                        rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
+                        forms.append(d.last_multi_work()[2])
+                else:
+                    rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
+                out[how] = (rows, d.download_state())
+    finally:
+        hip.set_knob("PCL_MULTI_NQ2_BELOW", None)
     assert out["multi"][0] == out["single"][0]
     assert out["multi"][0][71][0] < 0.25 * N < out["multi"][0][23][0]     # the last launch started below the threshold, the second above
+    if "PCL_MULTI_NQ2" not in os.environ:                                 # (the knob cases of conftest.py force one form)
+        assert forms == [128, 128, 128, 256]                              # ... and the kernel's own tally says which form ran
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)

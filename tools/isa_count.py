@@ -144,7 +144,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("expr", nargs="?", default="0.000000001 * exp(r0[gid] - 5)")
     ap.add_argument("--json", default=None, help="merge the result into this file under the expression's text")
-    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multi2_e1")
+    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1")
     ap.add_argument("--extra", default="", help="comma separated PCL_RTC_EXTRA names")
     ap.add_argument("--keep", default=None, help="directory to keep tu.hip / tu.s in")
     a = ap.parse_args()
@@ -157,6 +157,12 @@ def main():
     print(json.dumps(rec, indent=1))
     if a.json:
         table = json.load(open(a.json)) if os.path.exists(a.json) else {}
+        old = table.get(a.expr, {}).get("kernels", {})
+        for k, v in rec["kernels"].items():        # calibrated counts (tools/summarize_driver_prof.py) survive a re-count of the statics
+            for key, val in old.get(k, {}).items():
+                if "calibration" in key or (key.startswith("decision_valu_per_wave_step") and not key.endswith("_static") and
+                                            ("decision_valu_calibration" + key[len("decision_valu_per_wave_step"):]) in old.get(k, {})):
+                    v[key] = val
         table[a.expr] = rec
         json.dump(table, open(a.json, "w"), indent=1, sort_keys=True)
 

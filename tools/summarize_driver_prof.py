@@ -97,7 +97,7 @@ def main():
          "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
          "|---|---|---|---|---|---|---|---|---|"]
     # the K-step pass has two forms (128 / 256 photons per wave: pcl_rtc_multi_e1 / pcl_rtc_multi2_e1), picked per launch
-    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1")
+    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multis_e1")
     seq = sorted(((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                   for r in rows if short(r["Kernel_Name"]) in kms))
     f_seq = read_counter_seq(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"), kms)
@@ -124,29 +124,34 @@ def main():
         cnt = isa.get(e, {}).get("kernels", {}).get(kname)
         if not cnt or not c.get("SQ_INSTS_VALU"):
             continue
-        steps_i, hits_i, passes_i, ws_i, ppw_i = wk
+        steps_i, hits_i, passes_i, ws_i, ppw_i = wk[:5]
+        sat_i = wk[5] if len(wk) > 5 else -1
         a_dyn = (c["SQ_INSTS_VALU"] - cnt["dense_pass_valu"] * passes_i) / ws_i
-        calib[(e, kname)].append((steps_i, a_dyn))
-        W.append("| %d | `%s` | %d | %d | %.3f | %d | %d | %.3f | %.0f | %.1f | %.1f |" % (i, e[:24], ppw_i, steps_i, hits_i / float(N * steps_i), ws_i, passes_i,
+        regime = "" if sat_i < 0 else ("_shortcut" if sat_i > 0.99 * ws_i else ("" if sat_i < 0.01 * ws_i else "_mixed"))
+        calib[(e, kname, regime)].append((steps_i, a_dyn))
+        W.append("| %d | `%s` | %s | %d | %.3f | %d | %d | %.3f | %.0f | %.1f | %.1f |" % (i, e[:24], "%d%s" % (ppw_i, "" if sat_i < 0 else " probe %.0f %%" % (100.0 * sat_i / ws_i)),
+                                                                                          steps_i, hits_i / float(N * steps_i), ws_i, passes_i,
                                                                                           passes_i / float(ws_i), c["SQ_INSTS_VALU"], a_dyn,
                                                                                           cnt.get("decision_valu_per_wave_step_static", 0)))
-    for (e, kname), vals in sorted(calib.items()):
+    for (e, kname, regime), vals in sorted(calib.items()):
+        if regime == "_mixed":
+            continue
         # launches of the block length only (the short warm-up launch carries its prologue over fewer steps)
         full = [a for st, a in vals if st == max(st2 for st2, _ in vals)]
         a_fit = sum(full) / len(full)
         W.append("")
-        W.append("`%s`, `%s`: decision instructions per wave-step = **%.1f** (mean of %d launches of %d steps, min %.1f, max %.1f)"
-                 % (kname, e, a_fit, len(full), max(st for st, _ in vals), min(full), max(full)))
-        isa[e]["kernels"][kname]["decision_valu_per_wave_step"] = round(a_fit, 1)
-        isa[e]["kernels"][kname]["decision_valu_calibration"] = {"source": "profiles/%s_pmc.md" % tag, "launches": len(full), "min": round(min(full), 1),
-                                                                   "max": round(max(full), 1)}
+        W.append("`%s`%s, `%s`: decision instructions per wave-step = **%.1f** (mean of %d launches of %d steps, min %.1f, max %.1f)"
+                 % (kname, " on exp's saturation shortcut" if regime else "", e, a_fit, len(full), max(st for st, _ in vals), min(full), max(full)))
+        isa[e]["kernels"][kname]["decision_valu_per_wave_step" + regime] = round(a_fit, 1)
+        isa[e]["kernels"][kname]["decision_valu_calibration" + regime] = {"source": "profiles/%s_pmc.md" % tag, "launches": len(full),
+                                                                            "min": round(min(full), 1), "max": round(max(full), 1)}
     if calib:
         json.dump(isa, open(os.path.join(dst, "isa_counts.json"), "w"), indent=1, sort_keys=True)
     multi_rows = []
     forms = []
     for i, (_, kname, d) in enumerate(seq[:len(ks) + 2]):
         K = ks[i] if i < len(ks) else None
-        forms.append("256" if kname.endswith("multi2_e1") else "128")
+        forms.append("256" if kname.endswith("multi2_e1") else ("128 probe" if kname.endswith("multis_e1") else "128"))
         fb = f_seq[i][1].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(f_seq) else 0
         wb = w_seq[i][1].get("WRITE_SIZE", 0) * 1024 if i < len(w_seq) else 0
         c = s_seq[i][1] if i < len(s_seq) else {}
@@ -258,7 +263,7 @@ def main():
     kern_t = allt.setdefault("kernels", {})
     src_md = "profiles/%s_pmc.md" % tag
     for i, (K, d, b_hbm, busy, util, per_ps) in enumerate(multi_rows[1:1 + R]):
-        kern_t["pcl_rtc_multi2_e1" if forms[1 + i] == "256" else "pcl_rtc_multi_e1"] = {
+        kern_t[{"256": "pcl_rtc_multi2_e1", "128 probe": "pcl_rtc_multis_e1"}.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
             "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
     if single:
         kern_t["pcl_rtc_fast_e1"] = {"bytes_per_unit": round(tot / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
