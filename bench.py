@@ -375,7 +375,7 @@ def valu_roofline(work, kern_ms, expr, f32):
     useful = 0.0
     forms = {}
     for steps, hits, passes, wsteps, ppw, sat in work:
-        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi2_e1" if ppw == 256 else ("pcl_rtc_multis_e1" if sat >= 0 else "pcl_rtc_multi_e1"))
+        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi%s%s_e1" % ("2" if ppw == 256 else "", "s" if sat >= 0 else ""))
         c = table.get(name)
         if c is None:
             return None
@@ -851,25 +851,32 @@ def api_leg(args, prof):
         out[name] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s", "steps": len(sim.ts),
                      "run_time_s": sim.run_time, "rows": len(m.data), "schedule": dict(sim.schedule), "note": sim.launch_note}
         sim.close(download=False)
-    # the delete loop of test/test_light.py:52-59 with the constructor's defaults (exit: no objects left)
+    # the delete loop of test/test_light.py:52-59 with the constructor's defaults (exit: no objects left).  The whole run is
+    # under a millisecond at 1e7 photons: three simulations, the median run time (every run listed; the first one of a
+    # process also pays for Python's own first pass through the host layer)
     Nd = int(float(args.delete_photons.split(",")[0]))
-    sim = phys.Simulation(seed=args.seed)
-    sim.add_objs(light.generate_photons_bulk(Nd, min=1.0, max=1.0, seed=args.seed))
-    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
-    sim.add_step(1, newton.NewtonianKinematicsStep())
-    sim.add_step(2, light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
-    m = light.ScatterMeasureStep(None, True, [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])
-    sim.add_step(3, m)
-    sim._to_device()
-    sim._dev.sync()
-    sim.start()
-    sim.join()
-    if sim.error is not None:
-        raise sim.error
-    work = int(sum(int(np.asarray(row)[1]) for row in m.data)) + Nd - (int(np.asarray(m.data[-1])[1]) if m.data else 0)
-    out["delete_default"] = {"photons": Nd, "value": work / sim.run_time, "unit": "particle-steps/s", "particle_steps": work,
-                             "passes": len(sim.ts), "run_time_s": sim.run_time, "schedule": dict(sim.schedule), "note": sim.launch_note}
-    sim.close(download=False)
+    runs = []
+    for _ in range(3):
+        sim = phys.Simulation(seed=args.seed)
+        sim.add_objs(light.generate_photons_bulk(Nd, min=1.0, max=1.0, seed=args.seed))
+        sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+        sim.add_step(1, newton.NewtonianKinematicsStep())
+        sim.add_step(2, light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        m = light.ScatterMeasureStep(None, True, [[1.0 / (1e-3 * 1e-3), np.nan, np.nan]])
+        sim.add_step(3, m)
+        sim._to_device()
+        sim._dev.sync()
+        sim.start()
+        sim.join()
+        if sim.error is not None:
+            raise sim.error
+        work = int(sum(int(np.asarray(row)[1]) for row in m.data)) + Nd - (int(np.asarray(m.data[-1])[1]) if m.data else 0)
+        runs.append((sim.run_time, work, len(sim.ts), dict(sim.schedule), sim.launch_note))
+        sim.close(download=False)
+    rt, work, passes, schedule, note = sorted(runs, key=lambda r: r[0])[1]
+    out["delete_default"] = {"photons": Nd, "value": work / rt, "unit": "particle-steps/s", "particle_steps": work,
+                             "passes": passes, "run_time_s": rt, "run_times_s": [r[0] for r in runs], "timing": "median of 3 simulations",
+                             "schedule": schedule, "note": note}
     return out
 
 

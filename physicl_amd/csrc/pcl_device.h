@@ -1118,7 +1118,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
 // of its lanes carry a hit, so the more photons a wave queues per step the fuller its passes: with NQ = 2 a wave owns
 // 128 * NQ photons per trip and, while their hits fit the queue (<= 64 * VEC), handles them in ONE round of
 // ceil(hits / 64) passes; a busier step falls back to one round per group.  Same operations per photon either way.
-template <typename T, bool USE_E, int VAR_N, int VEC, int NQ>
+template <typename T, bool USE_E, int VAR_N, int VEC, int NQ, bool SATP = false>
 __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
@@ -1126,15 +1126,16 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
-    __shared__ pcl_u32 s_pass;
+    __shared__ pcl_u32 s_pass, s_sat;
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
-    if (threadIdx.x == 0) s_pass = 0;
+    if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x * NQ;
     pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform)
+    pcl_u32 w_sat = 0;    // SATP: wave-steps whose expression values came from the saturation shortcut
     const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
     constexpr pcl_u32 QCAP = 64u * VEC;
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x * NQ; base < nq; base += stride) {
@@ -1183,6 +1184,28 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
             pcl_u32 slot[NP];
             pcl_u64 ballot[NP];
             const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
+#ifdef PCL_N_EXPR
+            T nv[NP];
+            if constexpr (SATP && VAR_N != 0) { // Newton for all of the lane's photons first, then the expression by the saturation
+                bool unsat = false;             // shortcut if it holds wave-wide (pcl_n_expr_sat)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    Rr[0][p] = R::add(Rr[0][p], R::mul(V[0][p], a.dt));
+                    Rr[1][p] = R::add(Rr[1][p], R::mul(V[1][p], a.dt));
+                    Rr[2][p] = R::add(Rr[2][p], R::mul(V[2][p], a.dt));
+                    nv[p] = pcl_n_expr_sat<T>(Rr[0][p], Rr[1][p], Rr[2][p], R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt), R::mul(V[2][p], a.dt), Ev[p], unsat);
+                }
+                if (__ballot(unsat) != 0ull) {
+#pragma unroll
+                    for (int p = 0; p < NP; ++p)
+                        nv[p] = pcl_n_expr_val<T, VAR_N>(a.np, Rr[0][p], Rr[1][p], Rr[2][p], R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt),
+                                                         R::mul(V[2][p], a.dt), Ev[p]);
+                } else {
+                    ++w_sat;
+                    asm volatile("" : "+v"(w_sat));
+                }
+            }
+#endif
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int g = p / VEC, e = p % VEC;
@@ -1190,9 +1213,14 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 const bool live = live_q[g] && i < a.N;
                 // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
                 const T d0 = R::mul(V[0][p], a.dt), d1 = R::mul(V[1][p], a.dt), d2 = R::mul(V[2][p], a.dt);
-                Rr[0][p] = R::add(Rr[0][p], d0);
-                Rr[1][p] = R::add(Rr[1][p], d1);
-                Rr[2][p] = R::add(Rr[2][p], d2);
+#ifdef PCL_N_EXPR
+                if constexpr (!(SATP && VAR_N != 0))
+#endif
+                {
+                    Rr[0][p] = R::add(Rr[0][p], d0);
+                    Rr[1][p] = R::add(Rr[1][p], d1);
+                    Rr[2][p] = R::add(Rr[2][p], d2);
+                }
                 // plane crossings of this step's move (r - dr, r)                        light.py:385-399
                 for (int pl = 0; pl < a.n_planes; ++pl) {
                     const int ax = a.plane_ax[pl];
@@ -1203,8 +1231,13 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                     if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
                 }
                 // scatter decision                                                       light.py:303-308
-                T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p],
-                                                       Ev[p]);
+                T pc;
+#ifdef PCL_N_EXPR
+                if constexpr (SATP && VAR_N != 0)
+                    pc = R::mul(R::mul(a.A, nv[p]), NM[p]); // pcl_pcoll_norm with the expression's value in hand
+                else
+#endif
+                    pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p], Ev[p]);
                 if constexpr (USE_E) pc = R::mul(pc, L4[p]);
                 const pcl_u64 id = (pcl_u64)(a.id_base + i);
                 T rand;
@@ -1325,10 +1358,12 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
             }
     }
     if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
+    if (lane0 && w_sat) atomicAdd(&s_sat, w_sat);
     __syncthreads();
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
     if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
+    if (threadIdx.x == 0 && s_sat) atomicAdd(&a.cnt[nslots * a.K + 1], (pcl_u64)s_sat);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1691,6 +1726,16 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e1(pcl_multi_args<double> a) {
     pcl_multi_body_nq<double, true, true, 2, 2>(a);
+}
+#endif
+#if PCL_RTC_WANT(0, 0)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2s_e0(pcl_multi_args<double> a) {
+    pcl_multi_body_nq<double, false, true, 2, 2, true>(a); // 256 photons per wave with the saturation probe
+}
+#endif
+#if PCL_RTC_WANT(0, 1)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2s_e1(pcl_multi_args<double> a) {
+    pcl_multi_body_nq<double, true, true, 2, 2, true>(a);
 }
 #endif
 #endif

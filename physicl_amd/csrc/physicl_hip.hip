@@ -867,6 +867,13 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
     // accumulators zero for the next launch.  Agent-scope atomics only (they are coherent across the XCDs' L2s by
     // themselves); NO fence: an agent-scope release would write the L2's dirty lines back once per workgroup.  The sums
     // are in place before the ticket is drawn because the adds return (their data comes back before the barrier).
+    // What this relies on (gfx942 / gfx950 ISA, not the HIP memory model -- ADVICE r3): a RETURNING global atomic is
+    // performed at the memory side (agent scope: in the device-coherent L2 / MALL path shared by the XCDs) before its value
+    // travels back, and s_waitcnt vmcnt(0) -- which the consumed return value forces ahead of the s_barrier -- waits for that
+    // value; the ticket's own atomic is issued after the barrier, so whoever draws the last ticket finds every sum applied.
+    // The host double-checks the one number that matters (wait_alive: the alive count can only fall; densify: the
+    // compaction must find exactly ``count`` photons), and a launch that dies midway has its accumulators cleared
+    // (reset_alive_acc) so that the next launch's totals start from zero.
     const int nslots = 4 + (a.n_planes > 0 ? a.n_planes : 0);
     unsigned long long seen = 0;
     if ((int)threadIdx.x < nslots && s_cnt[threadIdx.x])
@@ -2399,6 +2406,7 @@ struct rtc_entry {
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
     hipFunction_t multis[2] = {nullptr, nullptr}; // 128 photons per wave with the saturation probe (pcl_n_expr_sat), fp64
+    hipFunction_t multi2s[2] = {nullptr, nullptr}; // 256 photons per wave with the probe
     std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
 
@@ -3629,6 +3637,8 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
         if (hipModuleGetFunction(&ent.multi2[e], ent.module, nm) != hipSuccess) ent.multi2[e] = nullptr;
         snprintf(nm, sizeof nm, "pcl_rtc_multis_e%d", e);
         if (hipModuleGetFunction(&ent.multis[e], ent.module, nm) != hipSuccess) ent.multis[e] = nullptr;
+        snprintf(nm, sizeof nm, "pcl_rtc_multi2s_e%d", e);
+        if (hipModuleGetFunction(&ent.multi2s[e], ent.module, nm) != hipSuccess) ent.multi2s[e] = nullptr;
     }
     (void)hipGetLastError();
     return PCL_OK;
@@ -3921,13 +3931,17 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     static knob k_sat("PCL_MULTI_SAT");
     const int sat_mode = !k_sat.set() ? -1 : (k_sat.off() ? 0 : 1);
     bool sat = false;
-    if (var_n && ent->module && d == 0 && ent->multis[use_e ? 1 : 0] && !nq2) {
+    if (var_n && ent->module && d == 0 && ent->multis[use_e ? 1 : 0] && ent->multi2s[use_e ? 1 : 0]) {
         const bool due = ctx->multi_sat_on || ctx->multi_sat_next <= 0;
         sat = sat_mode == 1 || (sat_mode == -1 && ctx->multi_launches >= 1 && due);
     }
     ctx->multi_sat_used = sat;
     ++ctx->multi_launches;
-    if (sat) {
+    if (sat && nq2) {
+        ctx->multi_work[2] = 128 * pcl_rt<T>::VEC;
+        grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
+        PCL_TRY(launch_module(ctx, ent->multi2s[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 with the saturation probe (hipRTC)"));
+    } else if (sat) {
         PCL_TRY(launch_module(ctx, ent->multis[use_e ? 1 : 0], grid, f, "step_fused_multi with the saturation probe (hipRTC)"));
     } else if (var_n && ent->module && nq2 && d == 0 && ent->multi2[use_e ? 1 : 0]) {
         ctx->multi_work[2] = 128 * pcl_rt<T>::VEC;
@@ -4272,7 +4286,20 @@ int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const doubl
 // totals, system-scope release) instead of waiting for the stream -- a loop body of a small store is a 5 us kernel, and
 // the completion signal's way to a blocked host thread takes longer than that.  The stream is asked now and then, so a
 // failed launch ends the wait with its error (PCL_ALIVE_POLL=0: hipStreamSynchronize).
+// after a failed launch: ticket and sums of k_delete_alive / k_delete_ahead back to zero (best effort, on the stream)
+void reset_alive_acc(pcl_ctx *ctx) {
+    (void)hipMemsetAsync(ctx->d_cnt + kCounterSlots, 0, (size_t)kAccSlots * sizeof(uint64_t), ctx->stream);
+    if (ctx->ahead_acc) (void)hipMemsetAsync(ctx->ahead_acc, 0, (size_t)(1 + kAheadMax * kAheadRow) * sizeof(unsigned long long), ctx->stream);
+}
+
+int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out);
 int wait_alive(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
+    const int rc = wait_alive_inner(ctx, before, alive_out);
+    if (rc != PCL_OK) reset_alive_acc(ctx);
+    return rc;
+}
+
+int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
     static knob k_poll("PCL_ALIVE_POLL");
     const bool poll = !k_poll.off();
     volatile uint64_t *seq = ctx->h_cnt + kCounterSlots - 6;
@@ -4393,7 +4420,14 @@ int ahead_commit(pcl_ctx *ctx) {
     return PCL_OK;
 }
 
+int ahead_wait_inner(pcl_ctx *ctx);
 int ahead_wait(pcl_ctx *ctx) {
+    const int rc = ahead_wait_inner(ctx);
+    if (rc != PCL_OK) reset_alive_acc(ctx);
+    return rc;
+}
+
+int ahead_wait_inner(pcl_ctx *ctx) {
     volatile uint64_t *seq = ctx->ahead_host + kAheadMax * kAheadRow;
     for (uint64_t spins = 1; __atomic_load_n(seq, __ATOMIC_ACQUIRE) != ctx->ahead_seq; ++spins) {
         if ((spins & 0x3FFF) == 0) {

@@ -11,6 +11,7 @@ evaluated ahead of a K-pass launch) and requires IDENTICAL results: ``ts``, ever
 plugins saw, and the final r, v, dr, dv, E of every object, bit for bit.
 """
 import os
+import time
 
 import numpy as np
 import pytest
@@ -86,6 +87,10 @@ def draw_config(rs):
     # a time step with units: the clock is then a Measurement, which ``t += dt`` advances IN PLACE (physicl/__init__.py:343
     # deep-copies it into ts for that reason) -- every schedule must leave the same ts behind
     cfg["dt_measurement"] = bool(rs.random_sample() < 0.3)
+    # (round 4, drawn after everything else) an exit that ALSO asks the wall clock, the global random stream, or counts its
+    # own calls -- never true here, but evaluated K times ahead of a launch it would be another program than the
+    # reference's loop, which asks once per pass (physicl/__init__.py:512-516): one launch per light step, silently
+    cfg["exit_extra"] = str(rs.choice(["none", "wall_clock", "np_random", "counting"], p=[0.64, 0.12, 0.12, 0.12]))
     return cfg
 
 
@@ -110,6 +115,17 @@ def build_and_run(cfg, steps_per_launch, fuse, **sim_kw):
         exit_fn = lambda s: len(s.ts) >= T or len(s.objects) * 100 < cfg["n"] * 45   # noqa: E731
     else:
         exit_fn = lambda s: len(s.ts) >= T or len(s.objects) == 0   # noqa: E731
+    extra = cfg.get("exit_extra", "none")
+    if extra != "none":
+        inner, t0, calls = exit_fn, time.time(), [0]
+        if extra == "wall_clock":
+            exit_fn = lambda s: inner(s) or time.time() - t0 > 36000.0   # noqa: E731
+        elif extra == "np_random":             # consumes the global stream the host-drawn randoms come from: once per pass, or the rows differ
+            exit_fn = lambda s: inner(s) or np.random.random() > 2.0   # noqa: E731
+        else:
+            def exit_fn(s):
+                calls[0] += 1
+                return inner(s) or calls[0] > 10 ** 9
     kw = {} if steps_per_launch == "default" else {"steps_per_launch": steps_per_launch}     # "default": the constructor's own
     sim = phys.Simulation(cl_on=True, rng=cfg["rng"], seed=cfg["seed"], fuse=fuse, exit=exit_fn, **kw, **sim_kw)
     rs = np.random.RandomState(cfg["seed"])
@@ -182,6 +198,7 @@ def assert_same(a, b, what):
 
 SEEN = {}
 AUTO = {}
+EXTRA = {}
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("PCL_RANDOM_SEEDS", "60"))))
@@ -200,9 +217,14 @@ def test_random_simulation_does_not_depend_on_the_schedule(seed):
     plannable = cfg["exit_kind"] == "clock" or (cfg["exit_kind"] == "count" and not any(g[0] == "delete" for g in cfg["groups"])) \
         or (cfg["exit_kind"] == "closure_rows" and not has_measures)
     went_multi = any(k.endswith("_multi") for k in auto["schedule"])
-    if went_multi and not plannable and len(base["ts"]) > 3:
+    if went_multi and not plannable and len(base["ts"]) > 3 and cfg["exit_extra"] == "none":
         # a launch may carry the passes planned before the guard tripped; after that, one launch per light step -- and a note
         assert auto["note"] and "one launch per light step" in auto["note"], (cfg, auto["schedule"], auto["note"])
+    if cfg["exit_extra"] != "none":            # never planned ahead, and the note says what the function reaches
+        plannable = False
+        # (a loop that is not eligible for K passes per launch anyway -- host plugins, host-drawn randoms -- never asks the guard)
+        assert not went_multi and (auto["note"] is None or "one launch per light step: exit" in auto["note"]), (cfg, auto["schedule"], auto["note"])
+        EXTRA[cfg["exit_extra"]] = EXTRA.get(cfg["exit_extra"], 0) + int(auto["note"] is not None)
     if cfg["exit_kind"] == "closure_rows" and has_measures:
         assert not went_multi and (auto["note"] is None or "closes over" in auto["note"]), (cfg, auto["schedule"], auto["note"])
     for k, v in list(fused["schedule"].items()) + list(multi["schedule"].items()) + list(auto["schedule"].items()):
@@ -217,3 +239,4 @@ def test_the_random_simulations_reached_every_schedule():
     assert {"fused", "fused_delete", "fused_multi", "fused_delete_multi", "mixed_multi"} <= set(SEEN), SEEN
     # the default constructor took the K-pass path where the exit test allows it, and every kind of exit was drawn
     assert AUTO.get("clock", 0) > 0 and {"clock", "closure_rows", "sim_hits", "count"} <= set(AUTO), AUTO
+    assert all(EXTRA.get(k, 0) > 0 for k in ("wall_clock", "np_random", "counting")), EXTRA      # the guard refused each kind at least once

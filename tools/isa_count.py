@@ -144,7 +144,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("expr", nargs="?", default="0.000000001 * exp(r0[gid] - 5)")
     ap.add_argument("--json", default=None, help="merge the result into this file under the expression's text")
-    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1")
+    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1,pcl_rtc_multi2s_e1")
     ap.add_argument("--extra", default="", help="comma separated PCL_RTC_EXTRA names")
     ap.add_argument("--keep", default=None, help="directory to keep tu.hip / tu.s in")
     a = ap.parse_args()

@@ -97,7 +97,7 @@ def main():
          "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
          "|---|---|---|---|---|---|---|---|---|"]
     # the K-step pass has two forms (128 / 256 photons per wave: pcl_rtc_multi_e1 / pcl_rtc_multi2_e1), picked per launch
-    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multis_e1")
+    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multis_e1", "pcl_rtc_multi2s_e1")
     seq = sorted(((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                   for r in rows if short(r["Kernel_Name"]) in kms))
     f_seq = read_counter_seq(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"), kms)
@@ -151,7 +151,7 @@ def main():
     forms = []
     for i, (_, kname, d) in enumerate(seq[:len(ks) + 2]):
         K = ks[i] if i < len(ks) else None
-        forms.append("256" if kname.endswith("multi2_e1") else ("128 probe" if kname.endswith("multis_e1") else "128"))
+        forms.append({"pcl_rtc_multi2_e1": "256", "pcl_rtc_multis_e1": "128 probe", "pcl_rtc_multi2s_e1": "256 probe"}.get(kname, "128"))
         fb = f_seq[i][1].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(f_seq) else 0
         wb = w_seq[i][1].get("WRITE_SIZE", 0) * 1024 if i < len(w_seq) else 0
         c = s_seq[i][1] if i < len(s_seq) else {}
@@ -263,7 +263,7 @@ def main():
     kern_t = allt.setdefault("kernels", {})
     src_md = "profiles/%s_pmc.md" % tag
     for i, (K, d, b_hbm, busy, util, per_ps) in enumerate(multi_rows[1:1 + R]):
-        kern_t[{"256": "pcl_rtc_multi2_e1", "128 probe": "pcl_rtc_multis_e1"}.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
+        kern_t[{"256": "pcl_rtc_multi2_e1", "128 probe": "pcl_rtc_multis_e1", "256 probe": "pcl_rtc_multi2s_e1"}.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
             "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
     if single:
         kern_t["pcl_rtc_fast_e1"] = {"bytes_per_unit": round(tot / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
