@@ -16,6 +16,7 @@ computed ahead, exactly), the object count (unchanged by scatter steps; for dele
 """
 import builtins
 import dis
+import functools
 import types
 
 import numpy as np
@@ -148,6 +149,13 @@ def _plain(v, live, depth):
     return False
 
 
+@functools.lru_cache(maxsize=256)
+def _instrs(code):
+    """(opname, argval, arg) of a code object's instructions, decoded once per code object (both analyses below read them;
+    a script's exit lambda is judged again for every Simulation it creates)."""
+    return tuple((i.opname, i.argval, i.arg) for i in dis.get_instructions(code))
+
+
 def _codes(code):
     """The code object and every code object nested in it (lambdas, comprehensions, inner functions)."""
     yield code
@@ -169,13 +177,13 @@ def _writes_state(code):
     object, a variable of an enclosing scope), or of a disallowed ``import``; None if there is none.  Locals -- and cell
     variables the code object owns -- are the function's own business."""
     for c in _codes(code):
-        for ins in dis.get_instructions(c):
-            if ins.opname in _WRITES:
-                return "%s %s" % (ins.opname, ins.argval if isinstance(ins.argval, str) else "")
-            if ins.opname == "STORE_DEREF" and ins.argval in c.co_freevars:
-                return "STORE_DEREF %s" % ins.argval
-            if ins.opname == "IMPORT_NAME" and not _module_ok(ins.argval):
-                return "import %s" % ins.argval
+        for opname, argval, _ in _instrs(c):
+            if opname in _WRITES:
+                return "%s %s" % (opname, argval if isinstance(argval, str) else "")
+            if opname == "STORE_DEREF" and argval in c.co_freevars:
+                return "STORE_DEREF %s" % argval
+            if opname == "IMPORT_NAME" and not _module_ok(argval):
+                return "import %s" % argval
     return None
 
 
@@ -250,26 +258,25 @@ def _count_use_code(fn, code):
     (``not s.objects``, ``if s.objects``, ``bool(s.objects)``) or by ``len(s.objects) <op> <const>`` that only asks
     whether the list is empty (``== 0``, ``< 1``, ``> 0`` ...).  Recognised on the bytecode; anything else -- another
     comparison, arithmetic on the length, passing the list on -- is 'other'."""
-    ins = [i for i in dis.get_instructions(code) if i.opname not in ("PRECALL", "CACHE", "PUSH_NULL", "RESUME", "EXTENDED_ARG")]
+    ins = [i for i in _instrs(code) if i[0] not in ("PRECALL", "CACHE", "PUSH_NULL", "RESUME", "EXTENDED_ARG")]
     use = "none"
-    for k, i in enumerate(ins):
-        if i.argval != "objects" or i.opname not in ("LOAD_ATTR", "LOAD_METHOD", "STORE_ATTR", "DELETE_ATTR"):
-            if i.argval == "objects" and i.opname in ("LOAD_GLOBAL", "LOAD_NAME", "LOAD_DEREF", "LOAD_FAST"):
-                continue                         # a variable that happens to be called ``objects``: judged as a value elsewhere
-            continue
-        if i.opname != "LOAD_ATTR":
+    for k, (opname, argval, arg) in enumerate(ins):
+        if argval != "objects" or opname not in ("LOAD_ATTR", "LOAD_METHOD", "STORE_ATTR", "DELETE_ATTR"):
+            continue                             # (a variable that happens to be called ``objects`` is judged as a value elsewhere)
+        if opname != "LOAD_ATTR":
             return "other"
         nxt = ins[k + 1] if k + 1 < len(ins) else None
-        if nxt is not None and nxt.opname in _TRUTH_OPS:
+        if nxt is not None and nxt[0] in _TRUTH_OPS:
             use = "emptiness"
             continue
-        call = nxt is not None and nxt.opname in ("CALL_FUNCTION", "CALL") and nxt.arg == 1
-        if call and k >= 2 and ins[k - 1].opname in _LOADS and ins[k - 2].opname in ("LOAD_GLOBAL", "LOAD_NAME"):
-            callee = ins[k - 2].argval
+        call = nxt is not None and nxt[0] in ("CALL_FUNCTION", "CALL") and nxt[2] == 1
+        if call and k >= 2 and ins[k - 1][0] in _LOADS and ins[k - 2][0] in ("LOAD_GLOBAL", "LOAD_NAME"):
+            callee = ins[k - 2][1]
             if _is_builtin(fn, callee, bool):
                 use = "emptiness"
                 continue
-            if _is_builtin(fn, callee, len) and k + 3 < len(ins) and ins[k + 2].opname == "LOAD_CONST" and                     type(ins[k + 2].argval) is int and ins[k + 3].opname == "COMPARE_OP" and                     (ins[k + 3].argval, ins[k + 2].argval) in _EMPTY_TESTS:
+            if _is_builtin(fn, callee, len) and k + 3 < len(ins) and ins[k + 2][0] == "LOAD_CONST" and \
+                    type(ins[k + 2][1]) is int and ins[k + 3][0] == "COMPARE_OP" and (ins[k + 3][1], ins[k + 2][1]) in _EMPTY_TESTS:
                 use = "emptiness"
                 continue
         return "other"

@@ -1099,9 +1099,11 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
 }
 
 // the state after ``j`` of the bodies k_delete_ahead worked out, made real: alive bits (masks_out), the alive bits before
-// the j-th body (masks_prev: pcl_store_last_delete_flags), alive counts per tile, and r with the pending moves and the j
-// moves of those bodies applied (newton.py:15-16, one rounded multiply and one rounded add per move, in order)
-template <typename T>
+// the j-th body (masks_prev: pcl_store_last_delete_flags), alive counts per tile, and -- WRITE_R, small stores -- r with the
+// pending moves and the j moves of those bodies applied (newton.py:15-16, one rounded multiply and one rounded add per
+// move, in order).  Big stores leave r where it is: the j moves join the list of pending ones (a sweep of r and v is the
+// price of a whole body there), and the compaction that is usually due next applies them on the way.
+template <typename T, bool WRITE_R>
 __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
     typedef pcl_rt<T> R;
     typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
@@ -1125,6 +1127,7 @@ __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
                 a.masks_prev[tile * kTileRows + row + 1] = spread_bits((uint32_t)(p0 >> 32)) | (spread_bits((uint32_t)(p1 >> 32)) << 1);
             }
             kept += (uint32_t)(__popcll(b0) + __popcll(b1));
+            if constexpr (!WRITE_R) continue; // big stores: r stays behind, the host adds the j moves to its list of pending ones
             if ((p0 | p1) == 0ull) continue; // nobody was alive before that body: r of these slots is never read again
             const int64_t ti = pcl_tix(i, a.ts);
 #pragma unroll
@@ -2491,6 +2494,7 @@ struct pcl_ctx {
         uint32_t step0 = 0;
         int64_t before0 = 0, slots = 0;
         bool fresh = false;
+        bool big = false;  // extent above PCL_AHEAD_MAX_SLOTS: few bodies per launch, r is not rewritten at the commit
     } ahead, ahead_last;
     bool ahead_last_valid = false;
     uint8_t *ahead_death = nullptr;          // one byte per slot
@@ -4327,7 +4331,7 @@ int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 
 // ---- delete loop bodies ahead of their calls (k_delete_ahead) ---------------------------------------------------------
 // PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 16, at most kAheadMax); extents up to
-// PCL_AHEAD_MAX_SLOTS (default 2^20: a sweep of that many slots takes about as long as a launch's way to the host and back)
+// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 4, 0 or 1 = none)
 int ahead_k() {
     static knob k_on("PCL_AHEAD"), k_k("PCL_AHEAD_K");
     if (k_on.off()) return 0;
@@ -4336,8 +4340,13 @@ int ahead_k() {
 }
 int64_t ahead_max_slots() {
     static knob k("PCL_AHEAD_MAX_SLOTS");
-    const double v = k.value(1048576.0);
+    const double v = k.value(4194304.0);
     return (int64_t)(v > 0 ? v : 0);
+}
+int ahead_k_big() {
+    static knob k("PCL_AHEAD_K_BIG");
+    const int v = (int)k.value(4.0);
+    return v < 0 ? 0 : (v > kPendMax ? kPendMax : v);
 }
 
 bool ahead_same_call(const pcl_ctx::ahead_state &s, double dt, double A, double n, uint64_t seed, const double *planes_host, int n_planes) {
@@ -4382,20 +4391,27 @@ int ahead_launch_t(pcl_ctx *ctx) {
     ahead_args<T> a{};
     fill_ahead_args<T>(ctx, a);
     a.seq = ++ctx->ahead_seq;
-    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile);
+    // (workgroups walk the tiles with the grid's stride, every one of them the same number of tiles, as in delete_alive_t:
+    // a workgroup's sums reach the grid totals with K x (4 + planes) atomics)
+    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * 64;
+    const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_AHEAD);
-    hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, a);
+    hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     prof_end(ctx, ps);
     return launch_check("k_delete_ahead");
 }
 
 template <typename T>
-int ahead_commit_t(pcl_ctx *ctx) {
+int ahead_commit_t(pcl_ctx *ctx, bool write_r) {
     ahead_args<T> a{};
     fill_ahead_args<T>(ctx, a);
     a.j = ctx->ahead.used;
-    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile);
-    hipLaunchKernelGGL(k_ahead_commit<T>, dim3((unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, a);
+    const int64_t n_tiles = div_up(ctx->ahead.slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * 64;
+    const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
+    if (write_r)
+        hipLaunchKernelGGL((k_ahead_commit<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_ahead_commit<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     return launch_check("k_ahead_commit");
 }
 
@@ -4410,13 +4426,26 @@ int ahead_commit(pcl_ctx *ctx) {
     } else {
         ctx->ahead_backoff = 0;
     }
-    PCL_TRY(PCL_DISPATCH(ctx, ahead_commit_t<double>(ctx), ahead_commit_t<float>(ctx)));
+    const bool write_r = !s.big;
+    PCL_TRY(PCL_DISPATCH(ctx, ahead_commit_t<double>(ctx, write_r), ahead_commit_t<float>(ctx, write_r)));
     s.active = false;
     ctx->holes = true;
     ctx->slots = s.slots;
-    ctx->pend_n = 0; // the kernel wrote r with every move applied
+    if (write_r) {
+        ctx->pend_n = 0; // the kernel wrote r with every move applied
+    } else {
+        for (int q = 0; q < s.used; ++q) ctx->pend_dt[ctx->pend_n++] = s.dt; // (room was checked when the bodies were launched)
+    }
     ctx->last_delete_masked = true;
     ctx->last_delete_slots = s.slots;
+    // A big store whose alive photons have fallen below the compaction threshold is compacted NOW, from the masks just
+    // written: the compacting body's own flag pass (a sweep of v over the whole extent) has already been made by
+    // k_delete_ahead.  The survivors' r catches up with every pending move on the way (densify).
+    if (s.big && ctx->count > 0 && s.slots > alive_min_slots() && (double)ctx->count < alive_ratio() * (double)s.slots) {
+        const int64_t last_n = ctx->last_delete_n;
+        PCL_TRY(densify(ctx));
+        ctx->last_delete_n = last_n;
+    }
     return PCL_OK;
 }
 
@@ -4555,11 +4584,33 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     }
     int64_t alive = 0;
     if (ctx->ahead_wait > 0) --ctx->ahead_wait;
-    if (!compact_now && repeat && ahead_k() > 0 && slots <= ahead_max_slots() && ctx->ahead_wait == 0) {
-        // small store, predictable caller: this body and the next K - 1 in one launch that leaves the store as it is
+    // How many bodies ahead?  Small stores (extent <= PCL_AHEAD_MAX_SLOTS): PCL_AHEAD_K, their sweeps cost next to nothing.
+    // Big stores: the bodies up to AND INCLUDING the one that would compact, going by the survival rate of the previous body
+    // -- the compaction then runs from the masks at the commit, without that body's own flag sweep -- and no more than the
+    // list of pending moves has room for (r is not rewritten at a big store's commit); PCL_AHEAD_K_BIG caps it (default 4).
+    int k_ahead = 0;
+    bool big = false;
+    if (!compact_now && repeat && ahead_k() > 0 && ctx->ahead_wait == 0) {
+        if (slots <= ahead_max_slots()) {
+            k_ahead = ahead_k();
+        } else if (ahead_k_big() > 1 && ctx->last_delete_n > before && before > 0) {
+            const double surv = (double)before / (double)ctx->last_delete_n, floor_alive = alive_ratio() * (double)slots;
+            double a = (double)before;
+            int kb = 0;
+            while (kb < ahead_k_big() && a >= floor_alive) a *= surv, ++kb; // bodies that start above the threshold ...
+            if (kb < ahead_k_big()) ++kb;                                   // ... and the one that would compact
+            const int room = kPendMax - ctx->pend_n;
+            k_ahead = kb < room ? kb : room;
+            big = true;
+            if (k_ahead < 2) k_ahead = 0;
+        }
+    }
+    if (k_ahead > 0) {
+        // predictable caller: this body and the next K - 1 in one launch that leaves the store as it is
         PCL_TRY(ahead_resources(ctx, slots));
         sp = ctx->ahead_last;
-        sp.K = ahead_k();
+        sp.K = k_ahead;
+        sp.big = big;
         sp.used = 0;
         sp.before0 = before;
         sp.slots = slots;

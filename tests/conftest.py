@@ -42,7 +42,10 @@ DELETE_KNOBS = [
     ("alive_off", {"PCL_ALIVE": "0"}),                                                         # the round-2 pipeline
 ]
 # bodies worked out ahead (k_delete_ahead) only exist on the one-call-per-body path: the files that take it
-AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"})]
+AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"}),
+               # every store takes the big stores' form: few bodies per launch, r left behind at the commit, compaction from the
+               # committed masks
+               ("ahead_big_form", {"PCL_AHEAD_MAX_SLOTS": "0", "PCL_ALIVE_MIN_SLOTS": "0"})]
 AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py"}
 KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
                # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's

