@@ -787,32 +787,48 @@ class Simulation(threading.Thread):
         flat[:, 2:5] = raw[:, 1:4]
         flat[:, 5:5 + have] = raw[:, 4:4 + have]
         glob = self._global(flat.reshape(-1)).reshape(k * P, 5 + npl) if self.comm is not None else flat
-        rows = glob.tolist()                          # Python ints: the replay below touches every element
         ts = self.ts
-        for i, (t, dt) in enumerate(times):
-            self.t, self.dt = t, dt                   # each row carries its own pass's time ...
+        # How many of the k passes does the loop keep?  Without a delete step all of them (the exit tests were planned).  With
+        # one, the planned tests were made for a store that is not empty (the functions ask for emptiness only:
+        # _count_known_ahead); a pass that empties it gets its test -- the one the outer loop would make there -- again, on
+        # the simulation as it stood after that pass.  The later passes of the launch ran on an empty store: if the loop
+        # stops, their times are dropped.
+        done = [0]
+
+        def flush(upto):
+            """Passes [done, upto) become history: the state the last of them leaves behind, and their rows (each row carries
+            its own pass's time)."""
+            lo = done[0]
+            if upto <= lo:
+                return
+            self.t, self.dt = times[upto - 1]
             for j, g in enumerate(groups):
-                row = rows[i * P + j]
+                last = glob[(upto - 1) * P + j]
                 if phases[j] == "iso":
-                    self.hits = row[1]
+                    self.hits = int(last[1])
                     self._scattered = True
                 else:
-                    self._alive, lights[j].removed = row[0], row[1]
+                    self._alive, lights[j].removed = int(last[0]), int(last[1])
                 at = 5 + span[j][0]
                 for m in g[2:]:
                     n_m = m._n_planes()
-                    m._record(self, row[0], row[2:5], row[at:at + n_m])
+                    m._record_rows(self, [times[i][0] for i in range(lo, upto)], glob[lo * P + j:upto * P:P, 0],
+                                   glob[lo * P + j:upto * P:P, 2:5], glob[lo * P + j:upto * P:P, at:at + n_m])
                     at += n_m
-            if has_delete and i + 1 < k and self._alive == 0:
-                # The planned exit tests were made for a store that is not empty (the functions ask for emptiness only:
-                # _count_known_ahead); this pass emptied it, so its test -- the one the outer loop would make here -- is made
-                # again, on the simulation as it stood after this pass.  The later passes of the launch ran on an empty store:
-                # if the loop stops here their times are dropped.
+            done[0] = upto
+
+        keep = k
+        if has_delete:
+            jd = phases.index("delete")
+            for i in np.flatnonzero(glob[jd:(k - 1) * P:P, 0] == 0).tolist():
+                flush(i + 1)
                 later = ts[n_ts + i + 1:]
                 del ts[n_ts + i + 1:]
                 if self.exit(self):
+                    keep = i + 1
                     break
                 ts.extend(later)
+        flush(keep)
         return True
 
     def _run_fused(self, group):

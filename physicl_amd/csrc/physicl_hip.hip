@@ -4585,22 +4585,17 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     int64_t alive = 0;
     if (ctx->ahead_wait > 0) --ctx->ahead_wait;
     // How many bodies ahead?  Small stores (extent <= PCL_AHEAD_MAX_SLOTS): PCL_AHEAD_K, their sweeps cost next to nothing.
-    // Big stores: the bodies up to AND INCLUDING the one that would compact, going by the survival rate of the previous body
-    // -- the compaction then runs from the masks at the commit, without that body's own flag sweep -- and no more than the
-    // list of pending moves has room for (r is not rewritten at a big store's commit); PCL_AHEAD_K_BIG caps it (default 4).
+    // Big stores: PCL_AHEAD_K_BIG (default 4; measured 3 .. 8 at 1e8 photons), and no more than the list
+    // of pending moves has room for (r is not rewritten at a big store's commit).  One sweep of the extent then serves all
+    // of them, and the compaction that has become due meanwhile runs from the committed masks, without a flag sweep of its own.
     int k_ahead = 0;
     bool big = false;
     if (!compact_now && repeat && ahead_k() > 0 && ctx->ahead_wait == 0) {
         if (slots <= ahead_max_slots()) {
             k_ahead = ahead_k();
-        } else if (ahead_k_big() > 1 && ctx->last_delete_n > before && before > 0) {
-            const double surv = (double)before / (double)ctx->last_delete_n, floor_alive = alive_ratio() * (double)slots;
-            double a = (double)before;
-            int kb = 0;
-            while (kb < ahead_k_big() && a >= floor_alive) a *= surv, ++kb; // bodies that start above the threshold ...
-            if (kb < ahead_k_big()) ++kb;                                   // ... and the one that would compact
+        } else if (ahead_k_big() > 1) {
             const int room = kPendMax - ctx->pend_n;
-            k_ahead = kb < room ? kb : room;
+            k_ahead = ahead_k_big() < room ? ahead_k_big() : room;
             big = true;
             if (k_ahead < 2) k_ahead = 0;
         }

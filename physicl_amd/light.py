@@ -252,6 +252,27 @@ class _CountingMeasure(DeviceStep, MeasureStep):
         g = sim._global(cnt)
         self._record(sim, int(g[0]), g[1:4], g[4:])
 
+    def _record_rows(self, sim, ts, n, sign, planes):
+        """The rows of several passes at once (a K-pass launch): what ``_record`` appends pass by pass.  With a plain-number
+        clock the rows are cut from ONE float array (``np.array([t, N, ...])`` of a float and integers is a float64 array:
+        same values, same dtype); a clock with units takes the row-by-row way."""
+        if not all(type(t) in (float, np.float64) for t in ts):
+            t_keep = sim.t
+            for i, t in enumerate(ts):
+                sim.t = t
+                self._record(sim, int(n[i]), sign[i], planes[i])
+            sim.t = t_keep
+            return
+        cols = self._row_columns(n, sign, planes)
+        block = np.empty((len(ts), 1 + len(cols)), dtype=np.float64)
+        block[:, 0] = ts
+        for c, col in enumerate(cols):
+            block[:, 1 + c] = col
+        self.data.extend(list(block))
+
+    def _row_columns(self, n, sign, planes):
+        raise NotImplementedError
+
 
 class ScatterMeasureStep(_CountingMeasure):
     """Row per step: ``[t, N, crossings of plane 0, ...]`` (physicl/light.py:361-404).  A plane is a
@@ -299,6 +320,9 @@ class ScatterMeasureStep(_CountingMeasure):
         row.extend(int(x) for x in planes)
         self.data.append(np.array(row))
 
+    def _row_columns(self, n, sign, planes):
+        return ([n] if self.measure_n else []) + [planes[:, p] for p in range(planes.shape[1])]
+
 
 class ScatterSignMeasureStep(_CountingMeasure):
     """Row per step: ``[t, N, #v_x>0, #v_y>0, #v_z>0]`` (physicl/light.py:406-431)."""
@@ -313,6 +337,9 @@ class ScatterSignMeasureStep(_CountingMeasure):
             row.append(n)
         row.extend(int(x) for x in sign)
         self.data.append(np.array(row))
+
+    def _row_columns(self, n, sign, planes):
+        return ([n] if self.measure_n else []) + [sign[:, k] for k in range(3)]
 
 
 class TracePathMeasureStep(MeasureStep):
