@@ -238,13 +238,16 @@ int pcl_store_count(pcl_ctx *ctx, int64_t *count_out);         /* host mirror, n
  * count when it is dense); *pending_moves_out (may be NULL) = Newton moves r has not been given yet.  Every other entry
  * point sees the dense store: it is compacted first, survivors in order, r up to date.                               */
 int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
-/* Small stores (extent <= PCL_AHEAD_MAX_SLOTS, default 2^20 slots): when a pcl_step_fused_delete call repeats the
- * previous one with ``step`` advanced by one -- a run's loop, physicl/__init__.py:512-516 -- the library works out that
- * body AND the next PCL_AHEAD_K - 1 (default 16) in one launch that leaves the store untouched, and answers the following
- * calls, if they are the predicted ones, from those rows without a launch (a loop body of a small store is a 20 us round
- * trip to the host, not bytes).  Any other call first makes the state after the bodies handed out so far real (one small
- * kernel), so nothing but timing ever shows.  Statistics since the context was created (host pointers, any may be NULL):
- * launches of the K-body kernel, bodies answered (the launching one included), launches whose rows were not all used. */
+/* Delete loop bodies ahead of their calls.  When a pcl_step_fused_delete call repeats the previous one with ``step``
+ * advanced by one -- a run's loop, physicl/__init__.py:512-516 -- the library works out that body AND the next ones in one
+ * launch that leaves the store untouched (PCL_AHEAD_K = 16 bodies for stores of up to PCL_AHEAD_MAX_SLOTS = 2^22 slots,
+ * PCL_AHEAD_K_BIG = 6 above: one sweep of the extent serves them all), and answers the following calls, if they are the
+ * predicted ones, from those rows without a launch (a loop body of a small store is a 20 us round trip to the host, not
+ * bytes; a big store's body is a sweep of its extent).  Any other call first makes the state after the bodies handed out so
+ * far real (one kernel; a big store whose alive photons have fallen below the compaction threshold is compacted from those
+ * masks), so nothing but timing ever shows; a caller whose loop keeps looking at the store between bodies makes the library
+ * pause (exponentially) before it tries again.  Statistics since the context was created (host pointers, any may be NULL):
+ * launches of the K-body kernel, bodies answered (the launching one included), launches whose rows were not all used.  */
 int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_out, int64_t *missed_out);
 /* Allocate now what the first compaction of the store would allocate on demand (the second slab -- chosen among a few
  * candidates like the first, tens of ms for a big store --, the id arrays, the mask scratch), so that a run whose step

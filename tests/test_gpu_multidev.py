@@ -2,7 +2,8 @@
 counters summed on the host (physicl_amd/multidev.py).  The reference is one process with one simulation thread
 (physicl/__init__.py:400-432, 501-524); this is how a script written against it uses a node's GPUs without a launcher.
 
-On the one-GPU test box the contexts share device 0 (``devices=[0, 0]``, ``[0, 0, 0]``): the sharding, the fan-out and
+On a one-GPU test box the contexts share device 0 (``devices=[0, 0]``, ``[0, 0, 0]``; with more GPUs visible they go to
+distinct devices, ``_device_lists``): the sharding, the fan-out and
 the host-side reduction are exactly those of N GPUs.  Everything observable must equal the single-context run: ``ts``,
 every measure row, ``hits``, what host plugins saw, ``len(sim.objects)``, the position of the global ``np.random``
 stream, and the final state of every object bit for bit -- for the randomly drawn simulations of
@@ -20,16 +21,27 @@ from test_gpu_random_simulations import assert_same, build_and_run, draw_config
 pytestmark = pytest.mark.gpu
 
 
+def _device_lists():
+    """The contexts of these tests go to DISTINCT devices as soon as the box has them ([0, 1], [0, 1, 2]); on a one-GPU box
+    they share device 0.  Counting devices does not initialise the GPU (pcl_device_count -> hipGetDeviceCount)."""
+    from physicl_amd import _hip
+    n = max(1, _hip.device_count())
+    return [i % n for i in range(2)], [i % n for i in range(3)]
+
+
+DEV2, DEV3 = _device_lists()
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_sharded_in_process_equals_one_context(seed):
     cfg = draw_config(np.random.RandomState(500 + seed))
     one = build_and_run(cfg, "default", True)
-    two = build_and_run(cfg, "default", True, devices=[0, 0])
-    assert_same(one, two, ("devices=[0, 0]", cfg))
+    two = build_and_run(cfg, "default", True, devices=DEV2)
+    assert_same(one, two, ("devices=%s" % DEV2, cfg))
     assert one["schedule"] == two["schedule"]                  # the same launch formulations were chosen
     if seed % 3 == 0:
-        three = build_and_run(cfg, 1, True, devices=[0, 0, 0])
-        assert_same(one, three, ("devices=[0, 0, 0], one launch per light step", cfg))
+        three = build_and_run(cfg, 1, True, devices=DEV3)
+        assert_same(one, three, ("devices=%s, one launch per light step" % DEV3, cfg))
 
 
 def test_bulk_run_on_two_contexts_rows_counts_and_state():
@@ -65,7 +77,7 @@ def test_bulk_run_on_two_contexts_rows_counts_and_state():
         out["del"] = ([list(map(float, r)) for r in m.data], len(sim.ts), len(sim.objects), dict(sim.schedule))
         sim.close(download=False)
         return out
-    a, b = run(), run(devices=[0, 0])
+    a, b = run(), run(devices=DEV2)
     assert a["iso"][:4] == b["iso"][:4] and a["iso"][3] == {"fused_multi": 2}
     for f in a["iso"][4]:
         assert np.array_equal(a["iso"][4][f], b["iso"][4][f]), f
@@ -75,7 +87,7 @@ def test_bulk_run_on_two_contexts_rows_counts_and_state():
 def test_devices_and_comm_exclude_each_other():
     from physicl_amd.dist import CounterComm
     with pytest.raises(ValueError):
-        phys.Simulation(devices=[0, 0], comm=CounterComm(0, 1, "gloo"))
+        phys.Simulation(devices=DEV2, comm=CounterComm(0, 1, "gloo"))
 
 
 def test_device_group_of_the_c_abi_equals_multidevice_and_one_device():
@@ -87,7 +99,7 @@ def test_device_group_of_the_c_abi_equals_multidevice_and_one_device():
     C, H = 299792458.0, 6.62607015e-34
     sc = dict(A=1e-3, n=1e-3, flags=0, c=C, h=H, seed=seed, step=3)
     res = {}
-    for name, make in (("one", lambda: hip.Device(0)), ("multidev", lambda: MultiDevice([0, 0, 0])), ("group", lambda: hip.DeviceGroup([0, 0, 0]))):
+    for name, make in (("one", lambda: hip.Device(0)), ("multidev", lambda: MultiDevice(DEV3)), ("group", lambda: hip.DeviceGroup(DEV3))):
         with make() as d:
             d.store_alloc(N)
             d.fill_photons(N, 50, C, 2.8e-19, 9.9e-19, seed)
@@ -113,7 +125,7 @@ def test_device_group_of_the_c_abi_equals_multidevice_and_one_device():
 
 
 def test_cl_off_semantics_on_two_contexts_equal_one_context():
-    """``Simulation(cl_on=False, devices=[0, 0])``: the reference's CPU-path semantics (data-dependent np.random order of
+    """``Simulation(cl_on=False, devices=DEV2)``: the reference's CPU-path semantics (data-dependent np.random order of
     ScatterIsotropicStep.__run_py, physicl/light.py:335-350; the skip-after-removal iteration of
     ScatterDeleteStepReference.__run_py, light.py:216-223) on a store sharded over two contexts: same decisions, same
     state, same position of the np.random stream as on one context."""
@@ -145,6 +157,6 @@ def test_cl_off_semantics_on_two_contexts_equal_one_context():
                float(np.random.random_sample()))
         sim.close()
         return out
-    a, b = run(), run(devices=[0, 0])
+    a, b = run(), run(devices=DEV2)
     assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4] and 0 < len(a[1]) < 3001
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
