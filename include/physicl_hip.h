@@ -369,6 +369,10 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
  * without the probe; the library picks per launch, PCL_MULTI_SAT = 1 / 0 forces).                                    */
 int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out,
                               int64_t *saturated_wave_steps_out);
+/* Debug builds of the K-step kernels only (environment PCL_RTC_EXTRA=PCL_HIT_HIST, knob PCL_MULTI_HIST=1): the last
+ * launch's histogram of hits queued per wave and step (per round in the 256-photon form), bins 0 .. 127 and ">= 128"
+ * (host pointer, 129 elements).  tools/hit_hist.py; PCL_ERR_STATE otherwise.                                          */
+int pcl_store_last_multi_hist(pcl_ctx *ctx, int64_t *hist129_out);
 
 /* Counters of the OLDEST not-yet-read pcl_step_fused that was called with out_host == NULL and counters on
  * (same layout, same n_planes).  Up to two such steps may be outstanding: enqueue step k+1, then read step k --

@@ -57,6 +57,7 @@ _PROTOTYPES = {
     "pcl_comm_info": [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
     "pcl_comm_destroy": [_vp],
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
+    "pcl_store_last_multi_hist": [_vp, _vp],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
@@ -428,6 +429,12 @@ class Device:
         a, b, c, e = c_int64(), c_int64(), c_int(), c_int64()
         check(self.lib.pcl_store_last_multi_work(self.ctx, byref(a), byref(b), byref(c), byref(e)))
         return a.value, b.value, c.value, e.value
+
+    def last_multi_hist(self):
+        """Hits queued per wave and step in the last step_fused_multi launch, 129 bins (debug builds: pcl_store_last_multi_hist)."""
+        out = np.zeros(129, dtype=np.int64)
+        check(self.lib.pcl_store_last_multi_hist(self.ctx, out.ctypes.data))
+        return out
 
     def ahead_stats(self):
         """(launches, bodies answered, launches not used up) of the delete bodies worked out ahead (pcl_store_ahead_stats)."""

@@ -1056,6 +1056,9 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             const pcl_u32 n_hit = qbase + w_hits;
             w_passes += (w_hits + 63u) >> 6;
             asm volatile("" : "+v"(w_passes)); // lives in a VGPR (one is free, the scalar file is not): no lane spill for a tally
+#ifdef PCL_HIT_HIST /* debug build (PCL_RTC_EXTRA=PCL_HIT_HIST): how many hits did this wave queue in this step?  129 bins */
+            if (lane0) atomicAdd(&a.cnt[nslots * a.K + 2 + (w_hits < 128u ? w_hits : 128u)], (pcl_u64)1);
+#endif
             // the scatter itself, densely: item j by lane j                                light.py:309-311
             for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
                 const pcl_u32 o = s_q.owner[j];
@@ -1290,6 +1293,9 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 __builtin_amdgcn_wave_barrier();
                 w_passes += (wbase - qbase + 63u) >> 6;
                 asm volatile("" : "+v"(w_passes));
+#ifdef PCL_HIT_HIST /* (256-photon form: hits of the round -- all of the wave's, or one group's) */
+                if (lane0) atomicAdd(&a.cnt[nslots * a.K + 2 + ((wbase - qbase) < 128u ? (wbase - qbase) : 128u)], (pcl_u64)1);
+#endif
                 // the scatter itself, densely: item j by lane j                                light.py:309-311
                 for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
                     const pcl_u32 o = s_q.owner[j];

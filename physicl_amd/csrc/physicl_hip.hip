@@ -2471,6 +2471,7 @@ struct pcl_ctx {
     // again first (densify, through need_store / ensure_scratch).
     int64_t multi_work[4] = {0, 0, 0, 0}; // last pcl_step_fused_multi launch: dense passes, wave-steps, photons per wave, wave-steps that took
                                           // the saturation shortcut (-1: the launch did not probe) (pcl_store_last_multi_work)
+    int multi_hist_at = -1;          // where the last launch's hit histogram lies in h_multi (debug builds; -1: none)
     int64_t multi_launches = 0;      // pcl_step_fused_multi launches on this population
     bool multi_sat_on = false, multi_sat_used = false; // the probing variant paid on its last launch / the current launch uses it
     int multi_sat_next = 0;          // launches until the probing variant is tried again
@@ -4959,6 +4960,13 @@ int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *
     return PCL_OK;
 }
 
+int pcl_store_last_multi_hist(pcl_ctx *ctx, int64_t *hist129_out) {
+    if (!ctx || !hist129_out) return fail(PCL_ERR_ARG, "NULL argument");
+    if (ctx->multi_hist_at < 0) return fail(PCL_ERR_STATE, "no histogram: it needs a debug build of the K-step kernels (PCL_RTC_EXTRA=PCL_HIT_HIST) and PCL_MULTI_HIST=1");
+    for (int b = 0; b < 129; ++b) hist129_out[b] = (int64_t)ctx->h_multi[ctx->multi_hist_at + b];
+    return PCL_OK;
+}
+
 int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_out, int64_t *missed_out) {
     if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
     if (launches_out) *launches_out = ctx->ahead_launches;
@@ -5915,7 +5923,10 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
         }
     if (N == 0) return PCL_OK;
     // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
-    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + 2) * sizeof(uint64_t), ctx->stream)); // rows + the two work tallies
+    // rows + the two work tallies (+ the 129 bins of a PCL_HIT_HIST debug build's histogram, knob PCL_MULTI_HIST)
+    static knob k_hist("PCL_MULTI_HIST");
+    const int n_extra = 2 + ((k_hist.set() && !k_hist.off() && nslots * k_steps + 131 <= kMultiSlots) ? 129 : 0);
+    PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + n_extra) * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
     PCL_TRY(PCL_DISPATCH(ctx, step_multi_t<double>(ctx, dt, k_steps, A, n, use_e, var_n, ent, c, h, seed, step0, planes_host, np),
@@ -5928,13 +5939,14 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     PCL_HIP(hipMemcpyAsync(ctx->d_cnt, ctx->d_multi + nslots * (k_steps - 1), sizeof(uint64_t), hipMemcpyDeviceToDevice,
                            ctx->stream));
     if (out_host) {
-        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)(nslots * k_steps + 2) * sizeof(uint64_t), hipMemcpyDeviceToHost,
+        PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)(nslots * k_steps + n_extra) * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                ctx->stream));
         PCL_HIP(hipStreamSynchronize(ctx->stream));
         for (int k = 0; k < k_steps; ++k) {
             for (int j = 0; j < 3 + np; ++j) out_host[(5 + np) * k + 1 + j] = (int64_t)ctx->h_multi[nslots * k + 1 + j];
             out_host[(5 + np) * k + 4 + np] = (int64_t)ctx->h_multi[nslots * k];
         }
+        ctx->multi_hist_at = n_extra > 2 ? nslots * k_steps + 2 : -1;
         ctx->multi_work[0] = (int64_t)ctx->h_multi[nslots * k_steps];                                  // dense passes
         ctx->multi_work[1] = div_up(N, (int64_t)ctx->multi_work[2]) * (int64_t)k_steps;                // wave-steps
         ctx->multi_work[3] = ctx->multi_sat_used ? (int64_t)ctx->h_multi[nslots * k_steps + 1] : -1;
