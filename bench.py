@@ -614,7 +614,9 @@ def run_rank(args):
 def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     """Delete-until-empty at each size, two formulations: "per_step" = one call per loop body (pcl_step_fused_delete: the
     body runs on the store's alive mask -- ONE kernel, k_delete_alive, nothing moves -- and the store is compacted, flag
-    kernel -> scan -> k_compact_*, only in the bodies that start with fewer than half of the slots alive); "multi" = K
+    kernel -> scan -> k_compact_*, only in the bodies that start with fewer than half of the slots alive; from the second
+    call of the loop on the library works the next bodies out in one sweep, k_delete_ahead, and answers the calls from
+    those rows -- "bodies_answered_by" says how many launches the run really took); "multi" = K
     loop bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation runs by itself when the exit
     test allows it.  A "particle-step" is one photon alive at the start of one loop body.  The roofline records count the
     bytes of the SLOTS a kernel sweeps, dead ones included (fp64): k_delete_alive reads v (24) and, for the plane
@@ -714,20 +716,24 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 g3 = b3 / (p3_ms * 1e-3) / 1e9 if p3_ms else 0.0
                 answered = {h: how.count(h) for h in ("kernel", "ahead_launch", "ahead")}
                 r["bodies_answered_by"] = dict(answered, note="kernel: one k_delete_alive launch (or flag + scan + compaction); ahead_launch: "
-                                               "one k_delete_ahead launch worked out this body and the next ones of a small store; ahead: "
-                                               "answered from those rows, no launch")
+                                               "one k_delete_ahead launch worked out this body and the next ones; ahead: answered from those "
+                                               "rows, no launch (the commit behind the last of them also runs the compaction that has become due)")
                 r["roofline"] = {"bound": "hbm", "kernel": "k_delete_alive (one loop body on the alive mask: Newton + delete flag + counters, nothing moves)",
                                  "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
                                  "traffic": pmc_traffic("k_delete_alive<double, true>", slots_swept),
                                  "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
                                  "bytes_per_alive_particle_step": (b1 + b2 + b3) / tot if tot else 0.0}
-                r["ahead"] = {"kernel": "k_delete_ahead (K = 16 loop bodies of a store of <= 2^20 slots in one launch; the store is not written)",
+                r["ahead"] = {"kernel": "k_delete_ahead (the next loop bodies worked out in ONE sweep of the extent -- 16 for stores of <= 2^22 slots, 6 "
+                                        "above --, answered call by call from the rows; the store is only written at the commit)",
                               "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
                               "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"]}
                 r["roofline_compaction"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction of the survivors, %d of %d bodies)"
                                                                       % (compactions, r["loop_bodies"]),
                                             "achieved": g3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS,
-                                            "traffic": pmc_traffic("k_compact_lds<double, unsigned long, 7>", sum(c["slots"] for c in big)) if big else None,
+                                            # (since round 4 the compactions of big extents start from the masks of six bodies worked
+                                            # out ahead: ~8 % survivors, which the scan hands to the direct kernel)
+                                            "traffic": pmc_traffic("k_compact_count<double, unsigned long, 7>", sum(c["slots"] for c in big if c["slots"] >= 90_000_000))
+                                                       if any(c["slots"] >= 90_000_000 for c in big) else None,
                                             "algorithmic_bytes": b3, "total_ms": p3_ms, "compactions": compactions,
                                             # the bytes HBM cannot avoid serving: survivors are scattered at random, so every 128-byte
                                             # line of the seven source rows holds one (P(16 neighbours all removed) < 0.2 % at 34 %

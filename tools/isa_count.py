@@ -85,7 +85,8 @@ def analyse(asm, name):
     kloop = max(inner1, key=lambda lp: lp[1] - lp[0])
     inner2 = [lp for lp in loops if lp != kloop and kloop[0] <= lp[0] and lp[1] <= kloop[1]]
     # the dense pass: the inner loop that holds the direction block's Philox multiplies and the sincos polynomials
-    dense = max(inner2, key=lambda lp: count(lp[0], lp[1], valu))
+    innermost = [lp for lp in inner2 if not any(o != lp and lp[0] <= o[0] and o[1] <= lp[1] for o in inner2)]
+    dense = max(innermost, key=lambda lp: count(lp[0], lp[1], valu))     # (the 256-photon form wraps it in its loop over queue rounds)
     others = [lp for lp in inner2 if lp != dense and not (dense[0] <= lp[0] and lp[1] <= dense[1])]
     # basic blocks of the K loop outside its inner loops, with what they hold
     starts = sorted({kloop[0]} | {v for v in labels.values() if kloop[0] <= v <= kloop[1]} |

@@ -137,7 +137,9 @@ def main():
         if regime == "_mixed":
             continue
         # launches of the block length only (the short warm-up launch carries its prologue over fewer steps)
-        full = [a for st, a in vals if st == max(st2 for st2, _ in vals)]
+        full = [a for st, a in vals if st == max(st2 for st2, _ in vals) and st >= 16]
+        if not full:                     # only a short warm-up launch of this form in the run: no calibration from it
+            continue
         a_fit = sum(full) / len(full)
         W.append("")
         W.append("`%s`%s, `%s`: decision instructions per wave-step = **%.1f** (mean of %d launches of %d steps, min %.1f, max %.1f)"
@@ -211,7 +213,7 @@ def main():
             g = (fb + wb) / (d * 1e-9) / 1e9
             L.append("| %d | %s | %.1f | %.1f | %.0f | %.3f |" % (i, rows[j]["Grid_Size_X"], d * 1e-3, (fb + wb) / 1e6, g, g / HBM_PEAK))
     # ---- the compactions of >= 1e7 slots, dispatch by dispatch
-    kc = [k for k in disp if k.startswith("k_compact_lds<double")]
+    kc = [k for k in disp if k.startswith("k_compact_lds<double") or k.startswith("k_compact_count<double")]
     comp_rows = []
     for k in kc:
         js = [j for j, r in enumerate(rows) if short(r["Kernel_Name"]) == k]
@@ -224,19 +226,37 @@ def main():
             wb = write[k][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(k, [])) else 0
             comp_rows.append((k, slots, d, fb, wb))
     if comp_rows:
-        L += ["", "## `k_compact_lds` (stable compaction, pass 3): the dispatches of >= 1e7 slots of the `delete` leg", "",
-              "slots = grid x 8 (one 256-thread workgroup per 2048-slot tile).  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  The kernel "
-              "reads every 128-byte line of its seven source rows (56 B per SLOT: at a third of the photons surviving at random every line "
-              "holds a survivor) and writes 64 B per survivor.", "",
+        L += ["", "## `k_compact_lds` / `k_compact_count` (stable compaction, pass 3): the dispatches of >= 1e7 slots", "",
+              "slots = grid x 8 (one 256-thread workgroup per 2048-slot tile).  HBM bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  `<..., 7>` = the "
+              "`delete` leg (r, v, E move; dv known to be zero): the staged kernel reads every 128-byte line of its seven source rows (56 B per "
+              "SLOT: at a third of the photons surviving at random every line holds a survivor) and writes 64 B per survivor; the direct one "
+              "(chosen by the scan below 15 % survivors -- where the compactions of the bodies worked out ahead land) reads 8 B per surviving "
+              "lane.  `<..., 10>` = the `mixed` leg (the dv / vprev rows travel too).", "",
               "| kernel | slots | duration us | FETCH x2 MB | WRITE MB | HBM B / slot | HBM GB/s | frac of 8 TB/s |", "|---|---|---|---|---|---|---|---|"]
-        for k, slots, d, fb, wb in comp_rows[:12]:
+        for k, slots, d, fb, wb in comp_rows[:24]:
             L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.0f | %.3f |" % (k, slots, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / slots,
                                                                                (fb + wb) / (d * 1e-9) / 1e9, (fb + wb) / (d * 1e-9) / 1e9 / HBM_PEAK))
+    kah = [k for k in disp if k.startswith("k_delete_ahead<double")]
+    if kah:
+        kah = kah[0]
+        js = [j for j, r in enumerate(rows) if short(r["Kernel_Name"]) == kah]
+        L += ["", "## `k_delete_ahead<double>` (K delete loop bodies worked out in one launch): the dispatches with the capped grid (extents of >= 3.4e7 slots)", "",
+              "| dispatch | grid (threads) | duration us | FETCH x2 MB | WRITE MB | HBM GB/s |", "|---|---|---|---|---|---|"]
+        shown = 0
+        for i, j in enumerate(js):
+            g = int(rows[j]["Grid_Size_X"])
+            if g < 4_000_000 or shown >= 8:
+                continue
+            d = int(rows[j]["End_Timestamp"]) - int(rows[j]["Start_Timestamp"])
+            fb = fetch[kah][i].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(fetch.get(kah, [])) else 0
+            wb = write[kah][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(kah, [])) else 0
+            L.append("| %d | %d | %.1f | %.1f | %.1f | %.0f |" % (i, g, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / (d * 1e-9) / 1e9))
+            shown += 1
     L += ["", "## Delete legs (`delete` record): kernel totals over the whole run (warm-up repetition included; of the two pass-3 "
           "kernels enqueued per compaction the one the scan did not choose returns at once)", "",
           "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
     for k in sorted(disp):
-        if any(t in k for t in ("k_delete_alive", "k_apply_pending", "k_newton_mask", "k_flag_mask2", "k_compact_count", "k_compact_lds", "k_tile_scan",
+        if any(t in k for t in ("k_delete_alive", "k_delete_ahead", "k_ahead_commit", "k_apply_pending", "k_newton_mask", "k_flag_mask2", "k_compact_count", "k_compact_lds", "k_tile_scan",
                                 "k_mixed", "k_any_nonzero", "k_delete_onepass")):
             fb = sum(x.get("FETCH_SIZE", 0) for x in fetch.get(k, [])) * 2 * 1024 / 1e9
             wb = sum(x.get("WRITE_SIZE", 0) for x in write.get(k, [])) * 1024 / 1e9
@@ -272,14 +292,15 @@ def main():
         for j in big[:8]:
             i = idx_of[j]
             if i < len(fetch.get(ka, [])) and i < len(write.get(ka, [])):
-                per.append((fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 + write[ka][i].get("WRITE_SIZE", 0) * 1024) / (int(rows[j]["Grid_Size_X"]) / 256 * 2048))
+                # (the kernel's grid is capped and strides over the tiles: a grid of >= 4e6 threads is the 1e8-slot extent)
+                per.append((fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 + write[ka][i].get("WRITE_SIZE", 0) * 1024) / 1e8)
         if per:
             kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit}
-    if comp_rows:
-        first = [r for r in comp_rows if r[1] >= 90_000_000]
+    for kname in sorted({r[0] for r in comp_rows if ", 7>" in r[0]}):
+        first = [r for r in comp_rows if r[0] == kname and r[1] >= 90_000_000]
         if first:
-            kern_t["k_compact_lds<double, unsigned long, 7>"] = {"bytes_per_unit": round(sum((r[3] + r[4]) / r[1] for r in first) / len(first), 2),
-                                                                  "unit": "slot (a third of the slots survive)", "source": src_md, "commit": commit}
+            kern_t[kname] = {"bytes_per_unit": round(sum((r[3] + r[4]) / r[1] for r in first) / len(first), 2),
+                             "unit": "slot (the compactions of the 1e8-slot extent in the delete leg)", "source": src_md, "commit": commit}
     if timed:
         t_ok = [r for r in timed if r[0]]
         ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps),
