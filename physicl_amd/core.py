@@ -875,6 +875,14 @@ class Simulation(threading.Thread):
                 k += npl
 
     def run(self):
+        # HIP's current device is per thread and a thread's first HIP call sets its runtime state up (tenths of a millisecond):
+        # the simulation thread makes that call here, before the run's clock starts -- the reference creates its OpenCL context
+        # and queue before the thread exists (physicl/__init__.py:427-429) and pays nothing comparable inside run()
+        if self._dev is not None and os.environ.get("PCL_SIM_PREBIND", "1") != "0":
+            try:
+                self._dev.sync()
+            except Exception:                   # noqa: BLE001 -- the first real call will report it
+                pass
         self.start_time = time.time()
         self.t = 0
         self.dt = 0
