@@ -366,7 +366,8 @@ def pmc_traffic(kernel, units):
 def valu_roofline(work, kern_ms, expr, f32):
     """VALU-issue roofline of the K-step pass over a set of launches.  ``work``: per launch (steps, hits, dense passes,
     wave-steps, photons per wave) as the kernel tallied them; ``kern_ms``: the sum of those launches' durations (HIP
-    events).  Wave-instructions = decision instructions x wave-steps + dense-pass instructions x dense passes, the two
+    events).  Wave-instructions = decision instructions x wave-steps (+ the launch's fixed work per wave and grid-stride
+    trip) + dense-pass instructions x dense passes, the
     counts per code object from profiles/isa_counts.json (tools/isa_count.py: the hipRTC translation unit's gfx950
     assembly; the decision count is the dynamic one, calibrated against SQ_INSTS_VALU of the committed PMC run, the
     dense pass is a straight-line loop body).  Peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
@@ -380,8 +381,14 @@ def valu_roofline(work, kern_ms, expr, f32):
         if c is None:
             return None
         A, B = c["decision_valu_per_wave_step"], c["dense_pass_valu"]
+        trips = wsteps / float(steps)                  # waves x grid-stride trips: the launch's fixed work per wave
         # the variant with the saturation probe: wave-steps on exp's shortcut run the shorter decision part
-        dec = A * wsteps if sat < 0 else c.get("decision_valu_per_wave_step_shortcut", A) * sat + A * (wsteps - sat)
+        if sat < 0:
+            dec = A * wsteps + c.get("decision_valu_per_wave_trip", 0.0) * trips
+        else:
+            f = sat / float(wsteps)
+            dec = (c.get("decision_valu_per_wave_step_shortcut", A) * sat + A * (wsteps - sat) +
+                   (c.get("decision_valu_per_wave_trip_shortcut", 0.0) * f + c.get("decision_valu_per_wave_trip", 0.0) * (1.0 - f)) * trips)
         instr += dec + B * passes
         useful += dec + B * hits / 64.0
         forms[name] = forms.get(name, 0) + 1
@@ -393,6 +400,7 @@ def valu_roofline(work, kern_ms, expr, f32):
             "wave_steps": sum(w[3] for w in work), "dense_passes_per_wave_step": sum(w[2] for w in work) / float(sum(w[3] for w in work)),
             "saturated_wave_steps": sum(max(w[5], 0) for w in work),
             "kernel_forms": forms, "instruction_counts": {k: {key: table[k][key] for key in ("decision_valu_per_wave_step", "decision_valu_per_wave_step_shortcut",
+                                                                                           "decision_valu_per_wave_trip", "decision_valu_per_wave_trip_shortcut",
                                                                                            "dense_pass_valu") if key in table[k]} for k in forms},
             "instruction_counts_source": "profiles/isa_counts.json (tools/isa_count.py)",
             "peak_note": "%d SIMDs x %.1f GHz / 4 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ)}

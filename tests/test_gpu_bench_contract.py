@@ -44,9 +44,11 @@ def test_bench_line_has_the_contract_keys(extra):
         assert 0 < r["lane_util"] <= 1 and r["wave_steps"] in (-(-300000 // 128) * 6, -(-300000 // 256) * 6) and r["dense_passes"] > 0
         (form, ic), = r["instruction_counts"].items()      # the median block's one launch: one code object
         assert form in ("pcl_rtc_multi_e1", "pcl_rtc_multis_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multi2s_e1") and r["kernel_forms"] == {form: 1}
-        sat = r["saturated_wave_steps"]                    # wave-steps on exp's saturation shortcut run a shorter decision part
-        dec = ic["decision_valu_per_wave_step"] * (r["wave_steps"] - sat) + ic.get("decision_valu_per_wave_step_shortcut", ic["decision_valu_per_wave_step"]) * sat
-        assert abs(r["wave_instructions"] - (dec + ic["dense_pass_valu"] * r["dense_passes"])) < 1 and 0 <= sat <= r["wave_steps"]
+        sat, ws, trips = r["saturated_wave_steps"], r["wave_steps"], r["wave_steps"] / 6.0   # (6 steps per launch in this run)
+        A, As = ic["decision_valu_per_wave_step"], ic.get("decision_valu_per_wave_step_shortcut", ic["decision_valu_per_wave_step"])
+        T, Ts = ic.get("decision_valu_per_wave_trip", 0.0), ic.get("decision_valu_per_wave_trip_shortcut", 0.0)
+        dec = (A * (ws - sat) + As * sat + (Ts * sat / ws + T * (1 - sat / ws)) * trips) if sat >= 0 and form.endswith("s_e1") else A * ws + T * trips
+        assert abs(r["wave_instructions"] - (dec + ic["dense_pass_valu"] * r["dense_passes"])) < 2 and 0 <= sat <= ws
         assert r["hbm"]["peak"] == 8000.0 and r["hbm"]["algorithmic_bytes_per_particle"] == 128.0 and len(r["per_block"]) == 3
         assert r["traffic"]["source"].startswith("profiles/") and abs(r["traffic"]["bytes"] / 300000 - 128) < 2
         h = d["roofline_hbm"]                                # the north_star kernel's own record, in the line and not in an extra key

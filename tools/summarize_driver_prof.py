@@ -108,7 +108,9 @@ def main():
     sq_line = json.loads([ln for ln in open(os.path.join(src, "pmc_sq.json")) if ln.strip()][-1])
     work = sq_line.get("k_step_launch_work", [])
     isa = json.load(open(os.path.join(dst, "isa_counts.json"))) if os.path.exists(os.path.join(dst, "isa_counts.json")) else {}
-    exprs = [line["config"]["variable_n_fn"]] * (1 + R) + ["2.5E+25 * exp(r2[gid] / 8600.0)"] * (1 + R)
+    per_block = -(-steps // S)                       # launches per timed block
+    n_main = -(-warmup // S) + R * per_block
+    exprs = [line["config"]["variable_n_fn"]] * n_main + (["2.5E+25 * exp(r2[gid] / 8600.0)"] * n_main if "tame" in sq_line else [])
     calib = collections.defaultdict(list)
     W = ["", "### The same dispatches against the kernel's own work tally (SQ pass): wave-instructions = SQ_INSTS_VALU", "",
          "model = decision instructions x wave-steps + dense-pass instructions x dense passes (profiles/isa_counts.json; the dense "
@@ -117,10 +119,10 @@ def main():
          "| # | expression | form | K | hit fraction | wave-steps | dense passes | passes / wave-step | SQ_INSTS_VALU | (INSTS - dense x passes) / wave-steps | static upper estimate |",
          "|---|---|---|---|---|---|---|---|---|---|---|"]
     for i, wk in enumerate(work):
-        if i >= len(s_seq):
+        if i >= len(s_seq) or i >= len(exprs):
             break
         kname, c = s_seq[i]
-        e = exprs[i] if i < len(exprs) else "?"
+        e = exprs[i]
         cnt = isa.get(e, {}).get("kernels", {}).get(kname)
         if not cnt or not c.get("SQ_INSTS_VALU"):
             continue
@@ -133,20 +135,35 @@ def main():
                                                                                           steps_i, hits_i / float(N * steps_i), ws_i, passes_i,
                                                                                           passes_i / float(ws_i), c["SQ_INSTS_VALU"], a_dyn,
                                                                                           cnt.get("decision_valu_per_wave_step_static", 0)))
+    # The decision part's count per wave-step carries the launch's fixed work (a grid-stride trip's loads, stores and
+    # restores) spread over its K steps: A(K) = a + c / K.  Every profiled run adds its (K, A) points to the table; with
+    # two different K the fit gives a (per wave-step) and c (per wave and trip), which is what bench.py multiplies out.
     for (e, kname, regime), vals in sorted(calib.items()):
         if regime == "_mixed":
             continue
-        # launches of the block length only (the short warm-up launch carries its prologue over fewer steps)
-        full = [a for st, a in vals if st == max(st2 for st2, _ in vals) and st >= 16]
-        if not full:                     # only a short warm-up launch of this form in the run: no calibration from it
+        ent = isa[e]["kernels"][kname]
+        pts = ent.setdefault("decision_calibration_points" + regime, {})
+        for st in sorted({st for st, _ in vals if st >= 16}):
+            same = [a for st2, a in vals if st2 == st]
+            pts[str(st)] = {"mean": round(sum(same) / len(same), 2), "min": round(min(same), 2), "max": round(max(same), 2), "launches": len(same),
+                            "source": "profiles/%s_pmc.md" % tag}
+        if not pts:
             continue
-        a_fit = sum(full) / len(full)
+        ks = sorted(int(k) for k in pts)
+        if len(ks) >= 2:
+            x = [1.0 / k for k in ks]
+            y = [pts[str(k)]["mean"] for k in ks]
+            mx, my = sum(x) / len(x), sum(y) / len(y)
+            c_fit = sum((xi - mx) * (yi - my) for xi, yi in zip(x, y)) / sum((xi - mx) ** 2 for xi in x)
+            a_fit = my - c_fit * mx
+        else:
+            a_fit, c_fit = pts[str(ks[0])]["mean"], 0.0
+        ent["decision_valu_per_wave_step" + regime] = round(a_fit, 1)
+        ent["decision_valu_per_wave_trip" + regime] = round(c_fit, 1)
         W.append("")
-        W.append("`%s`%s, `%s`: decision instructions per wave-step = **%.1f** (mean of %d launches of %d steps, min %.1f, max %.1f)"
-                 % (kname, " on exp's saturation shortcut" if regime else "", e, a_fit, len(full), max(st for st, _ in vals), min(full), max(full)))
-        isa[e]["kernels"][kname]["decision_valu_per_wave_step" + regime] = round(a_fit, 1)
-        isa[e]["kernels"][kname]["decision_valu_calibration" + regime] = {"source": "profiles/%s_pmc.md" % tag, "launches": len(full),
-                                                                            "min": round(min(full), 1), "max": round(max(full), 1)}
+        W.append("`%s`%s, `%s`: decision instructions per wave-step at the launch lengths profiled so far %s -> **%.1f per wave-step + %.1f per "
+                 "wave and trip**" % (kname, " on exp's saturation shortcut" if regime else "", e,
+                                      ", ".join("K = %d: %.1f" % (k, pts[str(k)]["mean"]) for k in ks), a_fit, c_fit))
     if calib:
         json.dump(isa, open(os.path.join(dst, "isa_counts.json"), "w"), indent=1, sort_keys=True)
     multi_rows = []
