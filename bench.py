@@ -638,7 +638,10 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     for N in sizes:
         dev.store_alloc(N)
         rec = {}
-        for mode in ("per_step", "multi"):
+        for mode in ("per_step", "per_step_no_ahead", "multi"):
+            # per_step_no_ahead: the same calls with PCL_AHEAD=0 -- every body is its own launch (round 3's path + this round's
+            # narrower reads): what the bodies worked out ahead of their calls are worth, in the same line
+            hip.set_knob("PCL_AHEAD", "0" if mode == "per_step_no_ahead" else None)
             runs = []
             # rep 0 = warm-up (allocations of the second slab, first touch); reps 1..repeats are timed WITHOUT the HIP-event
             # pairs around the kernels (a loop body of a small store is a 10 us kernel: the two event records per kernel
@@ -650,7 +653,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 t0 = time.perf_counter()
                 work, per_step, k = 0, [], 0
                 nb = sb = N                                   # alive photons / slots of the store (dense after the fill)
-                track = rep == repeats + 1 and mode == "per_step"       # the instrumented run also notes how each body was answered
+                track = rep == repeats + 1 and mode.startswith("per_step")   # the instrumented run also notes how each body was answered
                 if track:
                     how, st_prev = [], dev.ahead_stats()
                 while nb > 0 and k < 4096:
@@ -692,7 +695,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                            % (len(runs), instrumented_ms),
                  "kernels_total_ms": {kname: round(v["total_ms"], 4) for kname, v in kern.items() if v["launches"]},
                  "kernel_launches": {kname: v["launches"] for kname, v in kern.items() if v["launches"]}}
-            if mode == "per_step":
+            if mode.startswith("per_step"):
                 b1 = b2 = b3 = 0.0
                 slots_swept = slots_ahead = compactions = 0
                 explicit_ids = False
@@ -740,7 +743,8 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                             "achieved": g3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS,
                                             # (since round 4 the compactions of big extents start from the masks of six bodies worked
                                             # out ahead: ~8 % survivors, which the scan hands to the direct kernel)
-                                            "traffic": pmc_traffic("k_compact_count<double, unsigned long, 7>", sum(c["slots"] for c in big if c["slots"] >= 90_000_000))
+                                            "traffic": pmc_traffic("k_compact_count<double, unsigned long, 7>" if mode == "per_step" else
+                                                                   "k_compact_lds<double, unsigned long, 7>", sum(c["slots"] for c in big if c["slots"] >= 90_000_000))
                                                        if any(c["slots"] >= 90_000_000 for c in big) else None,
                                             "algorithmic_bytes": b3, "total_ms": p3_ms, "compactions": compactions,
                                             # the bytes HBM cannot avoid serving: survivors are scattered at random, so every 128-byte
@@ -750,6 +754,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
             else:
                 r["steps_per_launch"] = K
             rec[mode] = r
+        hip.set_knob("PCL_AHEAD", None)
         out["sizes"]["%.0e" % N] = rec
         dev.store_free()
     return out

@@ -1023,25 +1023,14 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                             if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
                     }
                 }
-                pcl_u32 wodd[2][2] = {{0u, 0u}, {0u, 0u}}; // the decision block's second half, waiting for the odd step
-                for (int b = 0; b < a.K; ++b) {
-                    if (__ballot(al[0] || al[1]) == 0ull) break; // nobody of these 128 slots is left (wave-uniform)
-                    const uint32_t st = a.step0 + (uint32_t)b;
-                    const bool new_block = (st & 1u) == 0u || b == 0; // (uniform) one Philox block decides steps 2m and 2m + 1
+                // one body on the lane's two slots, with the bodies' uniforms in hand
+                auto body = [&](int b, const T (&rnd)[2]) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
                             if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], dd[k][e]);                                  // newton.py:16
-                        T rand;
-                        if (new_block) { // what pcl_draw_rand computes, the odd step's half kept
-                            const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                            rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
-                            wodd[e][0] = w.z, wodd[e][1] = w.w;
-                        } else {
-                            rand = R::uniform(wodd[e][0], wodd[e][1]);
-                        }
-                        const bool kp = !(pcoll[e] >= rand);
+                        const bool kp = !(pcoll[e] >= rnd[e]);
                         if (al[e] && !kp) dth_e[e] = (uint32_t)(b + 1);
                         al[e] = al[e] && kp;
                     }
@@ -1068,6 +1057,29 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                             if (lane == 0 && np) atomicAdd(&row_cnt[4 + p], np);
                         }
                     }
+                };
+                // One Philox block decides the steps 2m and 2m + 1 (pcl_draw_rand): the bodies are taken in such pairs -- the
+                // block once, no selects between its halves -- after a leading body when the first step is odd.
+                auto block = [&](uint32_t st, T (&lo)[2], T (&hi)[2]) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                        lo[e] = R::uniform(w.x, w.y);
+                        hi[e] = R::uniform(w.z, w.w);
+                    }
+                };
+                int b = 0;
+                T r_lo[2], r_hi[2];
+                if ((a.step0 & 1u) && __ballot(al[0] || al[1]) != 0ull) {
+                    block(a.step0, r_lo, r_hi);
+                    body(0, r_hi);
+                    b = 1;
+                }
+                for (; b < a.K; b += 2) {
+                    if (__ballot(al[0] || al[1]) == 0ull) break; // nobody of these 128 slots is left (wave-uniform)
+                    block(a.step0 + (uint32_t)b, r_lo, r_hi);
+                    body(b, r_lo);
+                    if (b + 1 < a.K && __ballot(al[0] || al[1]) != 0ull) body(b + 1, r_hi);
                 }
                 dth.x = (unsigned char)dth_e[0], dth.y = (unsigned char)dth_e[1];
             }
@@ -6745,16 +6757,20 @@ int pcl_comm_create(pcl_ctx *ctx, const void *id_host, int rank, int world, pcl_
     }
     // the proof that the collective is up and sees every rank: sum of ones == world (what dist.py's start-up probe does)
     c->h_buf[0] = 1;
-    PCL_HIP(hipMemcpyAsync(c->d_buf, c->h_buf, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PCL_RCCL(rccl().AllReduce(c->d_buf, c->d_buf, 1, 4 /* ncclInt64 */, 0 /* ncclSum */, c->nccl, ctx->stream));
-    PCL_HIP(hipMemcpyAsync(c->h_buf, c->d_buf, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
-    if (c->h_buf[0] != world) {
-        const long long seen = (long long)c->h_buf[0];
+    auto probe = [&]() -> int {
+        PCL_HIP(hipMemcpyAsync(c->d_buf, c->h_buf, sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        PCL_RCCL(rccl().AllReduce(c->d_buf, c->d_buf, 1, 4 /* ncclInt64 */, 0 /* ncclSum */, c->nccl, ctx->stream));
+        PCL_HIP(hipMemcpyAsync(c->h_buf, c->d_buf, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        if (c->h_buf[0] != world) return fail(PCL_ERR_HIP, "the start-up all-reduce saw %lld of %d ranks", (long long)c->h_buf[0], world);
+        return PCL_OK;
+    };
+    const int rc = probe();
+    if (rc != PCL_OK) { // (the message of the failing call stays in pcl_last_error)
         (void)rccl().CommDestroy(c->nccl);
         (void)hipFree(c->d_buf);
         (void)hipHostFree(c->h_buf);
-        return fail(PCL_ERR_HIP, "the start-up all-reduce saw %lld of %d ranks", seen, world);
+        return rc;
     }
     *comm_out = c.release();
     return PCL_OK;
