@@ -42,6 +42,7 @@
 #include <thread>
 #include <memory>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -3716,8 +3717,38 @@ int scan_tiles(pcl_ctx *ctx, int64_t n) {
 }
 
 // survivor count of the scan most recently enqueued by scan_tiles
+// Waiting for the stream (or an event on it) where the wait is usually SHORT -- a K-pass launch on a 1e7-photon store is a
+// few hundred microseconds, and a host thread that blocks pays the wake-up on top, with a jitter as large as the kernel:
+// poll for up to 1.5 ms, then block (PCL_SPIN_US changes the limit, 0 = always block).
+int64_t spin_limit_us() {
+    static knob k("PCL_SPIN_US");
+    const double v = k.value(1500.0);
+    return (int64_t)(v > 0 ? v : 0);
+}
+template <typename Query, typename Block>
+int spin_then_block(Query query, Block block, const char *what) {
+    const int64_t limit = spin_limit_us();
+    if (limit > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1;; ++spins) {
+            const hipError_t e = query();
+            if (e == hipSuccess) return PCL_OK;
+            if (e != hipErrorNotReady) return fail(PCL_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+            if ((spins & 15u) == 0 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit)
+                break;
+        }
+    }
+    const hipError_t e = block();
+    return e == hipSuccess ? PCL_OK : fail(PCL_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+}
+int stream_wait(pcl_ctx *ctx) {
+    return spin_then_block([&] { return hipStreamQuery(ctx->stream); }, [&] { return hipStreamSynchronize(ctx->stream); }, "waiting for the stream");
+}
+
 int wait_count(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
-    PCL_HIP(hipEventSynchronize(ctx->ev_count));
+    PCL_TRY(spin_then_block([&] { return hipEventQuery(ctx->ev_count); }, [&] { return hipEventSynchronize(ctx->ev_count); },
+                            "waiting for the survivor count"));
     const int64_t alive = (int64_t)ctx->h_cnt[kCounterSlots - 1];
     if (alive < 0 || alive > before)
         return fail(PCL_ERR_HIP, "compaction produced an impossible count %lld of %lld", (long long)alive, (long long)before);
@@ -6167,7 +6198,7 @@ int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, 
     // one wait; the count event fires before pass 3
     PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)k_steps * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    PCL_TRY(stream_wait(ctx));
     int64_t alive = 0;
     PCL_TRY(wait_count(ctx, N, &alive));
     if (alive != (int64_t)ctx->h_multi[(k_steps - 1) * nslots])
@@ -6260,7 +6291,7 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
         PCL_TRY(PCL_DISPATCH(ctx, compact_after_pass_t<double>(ctx, dt, has_dr, dv_mode),
                              compact_after_pass_t<float>(ctx, dt, has_dr, dv_mode)));
     }
-    PCL_HIP(hipStreamSynchronize(ctx->stream));
+    PCL_TRY(stream_wait(ctx));
     if (has_delete) {
         int64_t alive = 0;
         PCL_TRY(wait_count(ctx, N, &alive));
