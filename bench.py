@@ -737,7 +737,11 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 r["ahead"] = {"kernel": "k_delete_ahead (the next loop bodies worked out in ONE sweep of the extent -- 16 for stores of <= 2^22 slots, 6 "
                                         "above --, answered call by call from the rows; the store is only written at the commit)",
                               "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
-                              "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"]}
+                              "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"],
+                              # its HBM rate on the slots it sweeps: well below the streaming kernels' -- the K bodies' Philox blocks,
+                              # compares and ballots bind it (~135 VALU + ~130 SALU instructions per body and 128 slots), not bytes
+                              "achieved_GBps": b2 / (p2_ms * 1e-3) / 1e9 if p2_ms else 0.0,
+                              "frac_of_hbm_peak": b2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if p2_ms else 0.0, "bound": "valu"}
                 r["roofline_compaction"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction of the survivors, %d of %d bodies)"
                                                                       % (compactions, r["loop_bodies"]),
                                             "achieved": g3, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g3 / HBM_PEAK_GBPS,

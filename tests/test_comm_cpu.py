@@ -73,3 +73,13 @@ def test_allreduce_max_is_built_from_the_sum():
             return np.asarray(values, dtype=np.int64) + self.others
     c = Fake(1, 3, np.array([2_500_000, 0, 1_000_000]))
     assert abs(c.allreduce_max(1.75) - 2.5) < 1e-9
+
+
+def test_knobs_are_named_pcl_and_settable_without_a_gpu():
+    """pcl_set_knob only records a value (read at the next call of the path it belongs to): no device needed."""
+    lib = _hip.load()
+    assert lib.pcl_set_knob(b"LD_PRELOAD", b"x") == -2 and lib.pcl_set_knob(None, b"1") == -2
+    _hip.set_knob("PCL_AHEAD_K", 5)
+    _hip.set_knob("PCL_AHEAD_K", None)
+    with pytest.raises(_hip.HipError):
+        _hip.set_knob("NOT_A_KNOB", "1")
