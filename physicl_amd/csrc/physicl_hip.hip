@@ -6758,6 +6758,9 @@ extern "C" {
 
 int pcl_comm_unique_id(void *id_out_host) {
     if (!id_out_host) return fail(PCL_ERR_ARG, "NULL argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1)
+        return fail(PCL_ERR_STATE, "the RCCL collective needs a GPU: no HIP device is visible to this process (librccl is not asked)");
     PCL_TRY(need_rccl());
     rccl_id id;
     memset(&id, 0, sizeof id);

@@ -23,7 +23,7 @@ def test_without_a_gpu_the_id_request_fails_loudly_and_names_rccl():
         assert any(buf.raw)
         return
     msg = lib.pcl_last_error().decode()
-    assert rc < 0 and ("RCCL" in msg or "librccl" in msg), msg
+    assert rc == -3 and "RCCL" in msg and "no HIP device" in msg, msg      # PCL_ERR_STATE, said before librccl is even loaded
     with pytest.raises(_hip.HipError):
         _hip.check(rc)
 

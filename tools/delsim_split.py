@@ -7,7 +7,8 @@ import physicl as phys, physicl.light as light, physicl.newton as newton
 from physicl_amd import core
 n = 10_000_000
 for rep in range(4):
-    sim = phys.Simulation(cl_on=True, seed=7)
+    kw = {"steps_per_launch": int(sys.argv[sys.argv.index("--k") + 1])} if "--k" in sys.argv else {}
+    sim = phys.Simulation(cl_on=True, seed=7, **kw)
     sim.add_objs(light.generate_photons_bulk(n, min=1.0, max=1.0, seed=7))
     sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
     sim.add_step(1, newton.NewtonianKinematicsStep())
