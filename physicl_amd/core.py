@@ -230,7 +230,8 @@ class Simulation(threading.Thread):
                How many passes of the loop one launch may carry.  Default (None): automatic -- when every pass is exactly
                [UpdateTimeStep] followed by one or two groups [NewtonianKinematicsStep][ScatterIsotropicStep |
                ScatterDeleteStep][counting measures], rng is "philox", and ``exit`` / the time-step function look at
-               nothing but the clock (``t``, ``dt``, ``ts``) and the object count, up to 32 passes run as ONE pass over the
+               nothing but the clock (``t``, ``dt``, ``ts``) and the object count, up to 32 passes (64 in a loop whose only
+               light step is a ScatterDeleteStep) run as ONE pass over the
                device store (photons do not interact; state, ``hits`` and every measure row are bit-identical to one
                launch per step).  The host side of those passes -- the time update and ``exit(sim)`` -- is evaluated
                ahead of the launch on a view of the simulation that exposes exactly those things; a function that
@@ -748,10 +749,15 @@ class Simulation(threading.Thread):
         phases = ["iso" if s._fuse_role == "scatter_iso" else "delete" for s in lights]
         has_delete = "delete" in phases
         n_ts = len(self.ts)
-        # PCL_MULTI_MAX = 64 rows per launch (a delete-only loop with all 64 in one launch was measured no faster than two
-        # launches of 32: 0.96 vs 0.85 ms for the 1e7-photon run of test/test_light.py:52-59 -- the planning of the passes
-        # is serial host work in front of the launch)
-        times, dt0 = self._plan_passes(upd, max(1, min(self._k_wanted(), 64 // P)), has_delete)
+        # PCL_MULTI_MAX = 64 rows per launch.  A delete-only loop takes all 64 when the pass count is automatic: the first
+        # launch of such a run costs the same whatever it carries (0.37 ms at 1e7 photons with 16, 32 or 64 bodies -- the
+        # photons die off inside it), so the 49-53 passes of test/test_light.py:52-59's run are ONE launch instead of two with
+        # a replay and a planning round in between: 0.63 -> 0.54 ms (tools/delsim_split.py; round 3 measured the opposite,
+        # when planning and replay cost three times as much)
+        k_max = self._k_wanted()
+        if self.steps_per_launch is None and phases == ["delete"]:
+            k_max = 64                                # (automatic, delete-only loop: see above)
+        times, dt0 = self._plan_passes(upd, max(1, min(k_max, 64 // P)), has_delete)
         k = len(times)
         if k == 0:
             return False                              # nothing could be planned ahead: this pass runs the plain way
