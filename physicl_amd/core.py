@@ -280,6 +280,8 @@ class Simulation(threading.Thread):
         self.steps = {}
         self._state_lock = threading.Lock()
         self.running = False
+        self.ts = []                  # (the reference creates ``ts`` in run(), physicl/__init__.py:510: a script that polls it right after
+                                      #  start() would race the simulation thread for the attribute)
         self.start_time = 0
         self.error = None
         # device-side state
