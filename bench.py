@@ -622,8 +622,8 @@ def run_rank(args):
 def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
     """Delete-until-empty at each size, two formulations: "per_step" = one call per loop body (pcl_step_fused_delete: the
     body runs on the store's alive mask -- ONE kernel, k_delete_alive, nothing moves -- and the store is compacted, flag
-    kernel -> scan -> k_compact_*, only in the bodies that start with fewer than half of the slots alive; from the second
-    call of the loop on the library works the next bodies out in one sweep, k_delete_ahead, and answers the calls from
+    kernel -> scan -> k_compact_*, only in the bodies that start with fewer than half of the slots alive; from a population's
+    first delete body on the library works the next bodies out in one sweep, k_delete_ahead, and answers the calls from
     those rows -- "bodies_answered_by" says how many launches the run really took); "multi" = K
     loop bodies per pass and ONE compaction (pcl_step_fused_delete_multi), the form Simulation runs by itself when the exit
     test allows it.  A "particle-step" is one photon alive at the start of one loop body.  The roofline records count the

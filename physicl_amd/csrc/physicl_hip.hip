@@ -4617,9 +4617,12 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     const int np = n_planes > 0 ? n_planes : 0;
     PCL_TRY(ensure_scratch(ctx, slots, true));
     const bool compact_now = slots > alive_min_slots() && (double)before < alive_ratio() * (double)slots;
-    // the same call as last time with the launch number advanced by one: a run's loop
-    const bool repeat = ctx->ahead_last_valid && ahead_same_call(ctx->ahead_last, dt, A, n, seed, planes_host, n_planes) &&
-                        step == ctx->ahead_last.step0 + 1u;
+    // the same call as last time with the launch number advanced by one: a run's loop.  The FIRST delete body of a
+    // population (no call to compare with: drop_holes forgets the last one whenever the particles are replaced) is taken for
+    // the start of such a loop -- delete bodies come in loops (physicl/__init__.py:512-516) --; if the next call is not its
+    // continuation the library has lost part of one sweep, pauses (ahead_commit), and goes by evidence from then on.
+    const bool repeat = !ctx->ahead_last_valid ||
+                        (ahead_same_call(ctx->ahead_last, dt, A, n, seed, planes_host, n_planes) && step == ctx->ahead_last.step0 + 1u);
     {
         pcl_ctx::ahead_state &l = ctx->ahead_last;
         l.dt = dt, l.A = A, l.n = n, l.seed = seed, l.n_planes = n_planes, l.step0 = step;
@@ -5561,6 +5564,8 @@ int pcl_store_set_count(pcl_ctx *ctx, int64_t count, int64_t id_base) {
     ctx->ids_iota = true;
     ctx->last_delete_n = -1;
     ctx->lam4_valid = false;
+    ctx->ahead_last_valid = false; // (a new population: its first delete body is taken for the start of a loop again)
+    ctx->ahead_wait = ctx->ahead_backoff = 0;
     set_dv_zero(ctx, 0);
     ctx->alt_dv_zero_n = 0;
     // a new population: every particle is a photon again until pcl_store_upload_kind says otherwise (a kind array left
