@@ -149,21 +149,21 @@ def main():
                             "source": "profiles/%s_pmc.md" % tag}
         if not pts:
             continue
-        ks = sorted(int(k) for k in pts)
-        if len(ks) >= 2:
-            x = [1.0 / k for k in ks]
-            y = [pts[str(k)]["mean"] for k in ks]
+        kpts = sorted(int(k) for k in pts)
+        if len(kpts) >= 2:
+            x = [1.0 / k for k in kpts]
+            y = [pts[str(k)]["mean"] for k in kpts]
             mx, my = sum(x) / len(x), sum(y) / len(y)
             c_fit = sum((xi - mx) * (yi - my) for xi, yi in zip(x, y)) / sum((xi - mx) ** 2 for xi in x)
             a_fit = my - c_fit * mx
         else:
-            a_fit, c_fit = pts[str(ks[0])]["mean"], 0.0
+            a_fit, c_fit = pts[str(kpts[0])]["mean"], 0.0
         ent["decision_valu_per_wave_step" + regime] = round(a_fit, 1)
         ent["decision_valu_per_wave_trip" + regime] = round(c_fit, 1)
         W.append("")
         W.append("`%s`%s, `%s`: decision instructions per wave-step at the launch lengths profiled so far %s -> **%.1f per wave-step + %.1f per "
                  "wave and trip**" % (kname, " on exp's saturation shortcut" if regime else "", e,
-                                      ", ".join("K = %d: %.1f" % (k, pts[str(k)]["mean"]) for k in ks), a_fit, c_fit))
+                                      ", ".join("K = %d: %.1f" % (k, pts[str(k)]["mean"]) for k in kpts), a_fit, c_fit))
     if calib:
         json.dump(isa, open(os.path.join(dst, "isa_counts.json"), "w"), indent=1, sort_keys=True)
     multi_rows = []
