@@ -974,6 +974,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
     const bool hi = lane >= 32;
     const int bit = 2 * (lane & 31);
     const int64_t n_tiles = (a.slots + kTile - 1) / kTile;
+    uint32_t t_kept = 0, t_s[3] = {0, 0, 0}, t_p0 = 0; // lane b: this wave's sums of body b (alive, sign counts, first plane)
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll 1
         for (int pp = 0; pp < kTileRows / 8; ++pp) {
@@ -1024,68 +1025,107 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                             if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
                     }
                 }
-                // one body on the lane's two slots, with the bodies' uniforms in hand
-                auto body = [&](int b, const T (&rnd)[2]) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-                            if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], dd[k][e]);                                  // newton.py:16
-                        const bool kp = !(pcoll[e] >= rnd[e]);
-                        if (al[e] && !kp) dth_e[e] = (uint32_t)(b + 1);
-                        al[e] = al[e] && kp;
-                    }
-                    const uint64_t b0 = __ballot(al[0]), b1 = __ballot(al[1]);
-                    uint32_t *row_cnt = s_cnt + b * kAheadRow;
-                    const uint32_t kept = (uint32_t)(__popcll(b0) + __popcll(b1));
-                    if (lane == 0 && kept) atomicAdd(&row_cnt[0], kept);
-                    if (a.n_planes >= 0) { // (uniform)
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {                                                                        // light.py:424-426
-                            const uint32_t w = (uint32_t)__popcll(__ballot(al[0] && vv[k][0] > (T)0)) + (uint32_t)__popcll(__ballot(al[1] && vv[k][1] > (T)0));
-                            if (lane == 0 && w) atomicAdd(&row_cnt[1 + k], w);
-                        }
-                        for (int p = 0; p < a.n_planes; ++p) {                                                               // light.py:385-399
-                            const int ax = a.plane_ax[p];
-                            const T L = a.plane_L[p];
-                            uint32_t np = 0;
-#pragma unroll
-                            for (int e = 0; e < 2; ++e) {
-                                const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
-                                const T prev = R::sub(x, pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]));
-                                np += (uint32_t)__popcll(__ballot(al[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
-                            }
-                            if (lane == 0 && np) atomicAdd(&row_cnt[4 + p], np);
-                        }
-                    }
-                };
-                // One Philox block decides the steps 2m and 2m + 1 (pcl_draw_rand): the bodies are taken in such pairs -- the
-                // block once, no selects between its halves -- after a leading body when the first step is odd.
-                auto block = [&](uint32_t st, T (&lo)[2], T (&hi)[2]) {
+                // Phase 1, lane by lane: the body each slot is removed in.  One Philox block decides the steps 2m and 2m + 1
+                // (pcl_draw_rand): the bodies are taken in such pairs -- the block once, no selects between its halves --
+                // after a leading body when the first step is odd.  Nothing here crosses lanes but the "all decided" test.
+                auto block = [&](uint32_t st, T (&lo)[2], T (&hi2)[2]) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
                         lo[e] = R::uniform(w.x, w.y);
-                        hi[e] = R::uniform(w.z, w.w);
+                        hi2[e] = R::uniform(w.z, w.w);
                     }
                 };
-                int b = 0;
-                T r_lo[2], r_hi[2];
-                if ((a.step0 & 1u) && __ballot(al[0] || al[1]) != 0ull) {
-                    block(a.step0, r_lo, r_hi);
-                    body(0, r_hi);
-                    b = 1;
+                {
+                    int b = 0;
+                    T r_lo[2], r_hi[2];
+                    if (a.step0 & 1u) {
+                        block(a.step0, r_lo, r_hi);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+                            if (dth_e[e] == 255u && pcoll[e] >= r_hi[e]) dth_e[e] = 1u;
+                        b = 1;
+                    }
+                    for (; b < a.K; b += 2) {
+                        if (__ballot(dth_e[0] == 255u || dth_e[1] == 255u) == 0ull) break; // every slot of the wave has its body
+                        block(a.step0 + (uint32_t)b, r_lo, r_hi);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            if (dth_e[e] == 255u && pcoll[e] >= r_lo[e]) dth_e[e] = (uint32_t)(b + 1);
+                            if (b + 1 < a.K && dth_e[e] == 255u && pcoll[e] >= r_hi[e]) dth_e[e] = (uint32_t)(b + 2);
+                        }
+                    }
                 }
-                for (; b < a.K; b += 2) {
-                    if (__ballot(al[0] || al[1]) == 0ull) break; // nobody of these 128 slots is left (wave-uniform)
-                    block(a.step0 + (uint32_t)b, r_lo, r_hi);
-                    body(b, r_lo);
-                    if (b + 1 < a.K && __ballot(al[0] || al[1]) != 0ull) body(b + 1, r_hi);
+                // Phase 2, body by body: the counter rows of the survivors (light.py:385-399, 414-431).  Alive after body b =
+                // removed later or never; the velocity signs are ballots taken once (a delete run never changes a velocity), so
+                // the sign counts are scalar work; the first plane's coordinate lives in two registers per slot (its axis is
+                // picked once), further planes take the general way; the sums go to lane b's accumulators.
+                uint64_t sg[3][2] = {{0ull, 0ull}, {0ull, 0ull}, {0ull, 0ull}};
+                if (a.n_planes >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) sg[k][0] = __ballot(vv[k][0] > (T)0), sg[k][1] = __ballot(vv[k][1] > (T)0);
+                }
+                T xp[2] = {(T)0, (T)0}, dp[2] = {(T)0, (T)0};
+                const T L0 = a.n_planes > 0 ? a.plane_L[0] : (T)0;
+                if (a.n_planes > 0) {
+                    const int ax = a.plane_ax[0];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) xp[e] = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]), dp[e] = pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]);
+                }
+                uint64_t cur0 = __ballot(al[0]), cur1 = __ballot(al[1]);
+                for (int b = 0; b < a.K; ++b) {
+                    if ((cur0 | cur1) == 0ull) break; // nobody of these 128 slots was left before this body (wave-uniform)
+                    const uint64_t a0 = __ballot(dth_e[0] > (uint32_t)(b + 1)), a1 = __ballot(dth_e[1] > (uint32_t)(b + 1));
+                    const bool mine = lane == b;
+                    t_kept += mine ? (uint32_t)(__popcll(a0) + __popcll(a1)) : 0u;
+                    if (a.n_planes >= 0) { // (uniform)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)                                                                          // light.py:424-426
+                            t_s[k] += mine ? (uint32_t)(__popcll(a0 & sg[k][0]) + __popcll(a1 & sg[k][1])) : 0u;
+                        if (a.n_planes > 0) {                                                                                // light.py:385-399
+                            uint64_t c[2];
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                xp[e] = R::add(xp[e], dp[e]);                                                                // newton.py:16
+                                const T prev = R::sub(xp[e], dp[e]);
+                                c[e] = __ballot((prev <= L0 && L0 <= xp[e]) || (prev >= L0 && L0 >= xp[e]));
+                            }
+                            t_p0 += mine ? (uint32_t)(__popcll(a0 & c[0]) + __popcll(a1 & c[1])) : 0u;
+                        }
+                        if (a.n_planes > 1) { // the other planes: every needed component of r moves, the plane picks its own
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                                for (int k = 0; k < 3; ++k)
+                                    if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], dd[k][e]);
+                            }
+                            for (int p = 1; p < a.n_planes; ++p) {
+                                const int ax = a.plane_ax[p];
+                                const T L = a.plane_L[p];
+                                uint32_t np = 0;
+#pragma unroll
+                                for (int e = 0; e < 2; ++e) {
+                                    const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
+                                    const T prev = R::sub(x, pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]));
+                                    np += (uint32_t)__popcll((e ? a1 : a0) & __ballot((prev <= L && L <= x) || (prev >= L && L >= x)));
+                                }
+                                if (lane == 0 && np) atomicAdd(&s_cnt[b * kAheadRow + 4 + p], np);
+                            }
+                        }
+                    }
+                    cur0 = a0, cur1 = a1;
                 }
                 dth.x = (unsigned char)dth_e[0], dth.y = (unsigned char)dth_e[1];
             }
             *reinterpret_cast<uchar2 *>(a.death + i) = dth; // (whole tiles exist in the buffer)
         }
+    }
+    if (lane < a.K) { // the wave's sums join the workgroup's
+        if (t_kept) atomicAdd(&s_cnt[lane * kAheadRow + 0], t_kept);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (t_s[k]) atomicAdd(&s_cnt[lane * kAheadRow + 1 + k], t_s[k]);
+        if (t_p0) atomicAdd(&s_cnt[lane * kAheadRow + 4], t_p0);
     }
     __syncthreads();
     // grid totals as in k_delete_alive: returning agent-scope atomics, the last workgroup reports
@@ -1163,6 +1203,40 @@ __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
         __syncthreads();
         if (threadIdx.x == 0) a.tile_keep[tile] = (int32_t)(s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3]);
         __syncthreads();
+    }
+}
+
+// k_ahead_commit for big stores (r stays behind): only the alive bits, the alive bits before the last body and the tile
+// counts come out of the death bytes.  A lane takes 16 consecutive slots (one 16-byte load; 1 KiB per wave and load
+// instruction -- the two-byte loads of the general kernel made this sweep pure latency: 210 us for 1e8 slots), four lanes
+// put their 16-bit pieces together into a mask word, a wave (half a tile) adds its alive count to the tile's.
+__global__ void __launch_bounds__(kBlock) k_ahead_masks(const uint8_t *__restrict__ death, int j, uint64_t *__restrict__ masks_out,
+                                                        uint64_t *__restrict__ masks_prev, int32_t *__restrict__ tile_keep, int64_t n_groups) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t g0 = (int64_t)blockIdx.x * kBlock; g0 < n_groups; g0 += (int64_t)gridDim.x * kBlock) {
+        const int64_t g = g0 + threadIdx.x; // (n_groups is a multiple of 64 * 2: whole tiles, so a wave is all in or all out)
+        if (g0 + (threadIdx.x & ~63) >= n_groups) continue;
+        const uint4 q = *reinterpret_cast<const uint4 *>(death + 16 * g);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        uint32_t alive = 0, prev = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const uint32_t d = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+            alive |= (d > (uint32_t)j ? 1u : 0u) << t;
+            prev |= ((d >= (uint32_t)j && d != 0u) ? 1u : 0u) << t;
+        }
+        // lanes 4m .. 4m + 3 hold the four 16-bit quarters of mask word m of the wave's 16 words
+        const uint64_t a1 = (uint64_t)__shfl_down(alive, 1), a2 = (uint64_t)__shfl_down(alive, 2), a3 = (uint64_t)__shfl_down(alive, 3);
+        const uint64_t p1 = (uint64_t)__shfl_down(prev, 1), p2 = (uint64_t)__shfl_down(prev, 2), p3 = (uint64_t)__shfl_down(prev, 3);
+        if ((lane & 3) == 0) {
+            const int64_t word = g >> 2;
+            masks_out[word] = (uint64_t)alive | (a1 << 16) | (a2 << 32) | (a3 << 48);
+            masks_prev[word] = (uint64_t)prev | (p1 << 16) | (p2 << 32) | (p3 << 48);
+        }
+        uint32_t cnt = (uint32_t)__popc(alive);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_down(cnt, off);
+        if (lane == 0) atomicAdd(&tile_keep[g / (kTile / 16)], (int32_t)cnt);
     }
 }
 
@@ -4452,10 +4526,16 @@ int ahead_commit_t(pcl_ctx *ctx, bool write_r) {
     a.j = ctx->ahead.used;
     const int64_t n_tiles = div_up(ctx->ahead.slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * 64;
     const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
-    if (write_r)
+    if (write_r) {
         hipLaunchKernelGGL((k_ahead_commit<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((k_ahead_commit<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    } else { // big stores: masks and tile counts only, 16 slots per lane
+        PCL_HIP(hipMemsetAsync(ctx->tile_keep, 0, (size_t)n_tiles * sizeof(int32_t), ctx->stream));
+        const int64_t n_groups = n_tiles * (kTile / 16);
+        const int64_t blocks = div_up(n_groups, kBlock);
+        const int64_t g2 = blocks < cap ? blocks : cap;
+        hipLaunchKernelGGL(k_ahead_masks, dim3((unsigned)g2), dim3(kBlock), 0, ctx->stream, ctx->ahead_death, a.j, ctx->masks, ctx->masks_prev,
+                           ctx->tile_keep, n_groups);
+    }
     return launch_check("k_ahead_commit");
 }
 
