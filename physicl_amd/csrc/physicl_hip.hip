@@ -6775,8 +6775,10 @@ rccl_api &rccl() {
     static rccl_api api = [] {
         rccl_api a;
         std::vector<std::string> names;
-        if (const char *e = getenv("PCL_RCCL_LIB")) names.push_back(e);
+        const char *forced = getenv("PCL_RCCL_LIB"); // (says which file to load: no other copy is looked for)
+        if (forced) names.push_back(forced);
         for (const char *n : {"librccl.so.1", "librccl.so"}) { // a copy the process already holds (torch ships one) comes first
+            if (forced) break;
             if (void *h = dlopen(n, RTLD_NOW | RTLD_NOLOAD)) {
                 a.lib = h;
                 a.path = n;
@@ -6784,9 +6786,11 @@ rccl_api &rccl() {
             }
         }
         if (!a.lib) {
-            names.insert(names.end(), {"librccl.so.1", "librccl.so"});
-            if (const char *r = getenv("ROCM_PATH")) names.push_back(std::string(r) + "/lib/librccl.so.1");
-            names.push_back("/opt/rocm/lib/librccl.so.1");
+            if (!forced) {
+                names.insert(names.end(), {"librccl.so.1", "librccl.so"});
+                if (const char *r = getenv("ROCM_PATH")) names.push_back(std::string(r) + "/lib/librccl.so.1");
+                names.push_back("/opt/rocm/lib/librccl.so.1");
+            }
             for (const std::string &n : names) {
                 if (void *h = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL)) {
                     a.lib = h;
