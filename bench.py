@@ -738,6 +738,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                         "above --, answered call by call from the rows; the store is only written at the commit)",
                               "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
                               "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"],
+                              "traffic": pmc_traffic("k_delete_ahead<double>", slots_ahead),
                               # its HBM rate on the slots it sweeps: well below the streaming kernels' -- the K bodies' Philox blocks,
                               # compares and ballots bind it (~135 VALU + ~130 SALU instructions per body and 128 slots), not bytes
                               "achieved_GBps": b2 / (p2_ms * 1e-3) / 1e9 if p2_ms else 0.0,

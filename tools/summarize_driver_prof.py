@@ -254,6 +254,7 @@ def main():
             L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.0f | %.3f |" % (k, slots, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / slots,
                                                                                (fb + wb) / (d * 1e-9) / 1e9, (fb + wb) / (d * 1e-9) / 1e9 / HBM_PEAK))
     kah = [k for k in disp if k.startswith("k_delete_ahead<double")]
+    ahead_bytes = []
     if kah:
         kah = kah[0]
         js = [j for j, r in enumerate(rows) if short(r["Kernel_Name"]) == kah]
@@ -269,6 +270,8 @@ def main():
             wb = write[kah][i].get("WRITE_SIZE", 0) * 1024 if i < len(write.get(kah, [])) else 0
             L.append("| %d | %d | %.1f | %.1f | %.1f | %.0f |" % (i, g, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / (d * 1e-9) / 1e9))
             shown += 1
+            if fb > 3.0e9:                   # (the 1e8-slot extent: reads of ~32 B per slot)
+                ahead_bytes.append((fb + wb) / 1e8)
     L += ["", "## Delete legs (`delete` record): kernel totals over the whole run (warm-up repetition included; of the two pass-3 "
           "kernels enqueued per compaction the one the scan did not choose returns at once)", "",
           "| kernel | dispatches | total ms | FETCH x2 (GB) | WRITE (GB) |", "|---|---|---|---|---|"]
@@ -313,6 +316,9 @@ def main():
                 per.append((fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 + write[ka][i].get("WRITE_SIZE", 0) * 1024) / 1e8)
         if per:
             kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit}
+    if ahead_bytes:
+        kern_t["k_delete_ahead<double>"] = {"bytes_per_unit": round(sum(ahead_bytes) / len(ahead_bytes), 2), "unit": "slot (per launch, whatever K)",
+                                            "source": src_md, "commit": commit}
     for kname in sorted({r[0] for r in comp_rows if ", 7>" in r[0]}):
         first = [r for r in comp_rows if r[0] == kname and r[1] >= 90_000_000]
         if first:
