@@ -734,7 +734,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                  "traffic": pmc_traffic("k_delete_alive<double, true>", slots_swept),
                                  "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
                                  "bytes_per_alive_particle_step": (b1 + b2 + b3) / tot if tot else 0.0}
-                r["ahead"] = {"kernel": "k_delete_ahead (the next loop bodies worked out in ONE sweep of the extent -- 16 for stores of <= 2^22 slots, 6 "
+                r["ahead"] = {"kernel": "k_delete_ahead (the next loop bodies worked out in ONE sweep of the extent -- 16 for stores of <= 2^22 slots, 8 "
                                         "above --, answered call by call from the rows; the store is only written at the commit)",
                               "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
                               "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"],

@@ -242,7 +242,7 @@ int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
  * advanced by one -- a run's loop, physicl/__init__.py:512-516 --, or is the first delete body of a population (taken for
  * the start of such a loop), the library works out that body AND the next ones in one
  * launch that leaves the store untouched (PCL_AHEAD_K = 16 bodies for stores of up to PCL_AHEAD_MAX_SLOTS = 2^22 slots,
- * PCL_AHEAD_K_BIG = 6 above: one sweep of the extent serves them all), and answers the following calls, if they are the
+ * PCL_AHEAD_K_BIG = 8 above: one sweep of the extent serves them all), and answers the following calls, if they are the
  * predicted ones, from those rows without a launch (a loop body of a small store is a 20 us round trip to the host, not
  * bytes; a big store's body is a sweep of its extent).  Any other call first makes the state after the bodies handed out so
  * far real (one kernel; a big store whose alive photons have fallen below the compaction threshold is compacted from those

@@ -4449,7 +4449,7 @@ int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 
 // ---- delete loop bodies ahead of their calls (k_delete_ahead) ---------------------------------------------------------
 // PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 16, at most kAheadMax); extents up to
-// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 6, 0 or 1 = none)
+// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 8, 0 or 1 = none)
 int ahead_k() {
     static knob k_on("PCL_AHEAD"), k_k("PCL_AHEAD_K");
     if (k_on.off()) return 0;
@@ -4463,7 +4463,7 @@ int64_t ahead_max_slots() {
 }
 int ahead_k_big() {
     static knob k("PCL_AHEAD_K_BIG");
-    const int v = (int)k.value(6.0);
+    const int v = (int)k.value(8.0);
     return v < 0 ? 0 : (v > kPendMax ? kPendMax : v);
 }
 
@@ -4712,7 +4712,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     int64_t alive = 0;
     if (ctx->ahead_wait > 0) --ctx->ahead_wait;
     // How many bodies ahead?  Small stores (extent <= PCL_AHEAD_MAX_SLOTS): PCL_AHEAD_K, their sweeps cost next to nothing.
-    // Big stores: PCL_AHEAD_K_BIG (default 6; measured 3 .. 8 at 1e7 and 1e8 photons), and no more than the list
+    // Big stores: PCL_AHEAD_K_BIG (default 8 = all the list of pending moves holds; measured 3 .. 8 at 1e7 and 1e8 photons), and no more than the list
     // of pending moves has room for (r is not rewritten at a big store's commit).  One sweep of the extent then serves all
     // of them, and the compaction that has become due meanwhile runs from the committed masks, without a flag sweep of its own.
     int k_ahead = 0;
