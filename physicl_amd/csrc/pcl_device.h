@@ -750,7 +750,8 @@ struct pcl_fast_args {
     // pend_dt[]): they are applied first, with the velocity the photon had all along -- this step may change it.
     const pcl_u64 *alive;
     int n_pend;
-    T pend_dt[PCL_PEND_MAX];
+    T pend_dt[PCL_PEND_MAX];   // run-length: pend_rep[p] moves of pend_dt[p]
+    int pend_rep[PCL_PEND_MAX];
     pcl_nprof<T> np;          // ahead-of-time VAR_N kernels only
 };
 
@@ -826,9 +827,12 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
             if constexpr (GEN) {
                 live = live && ((cur.AL >> (i & 63)) & 1ull);
                 for (int p = 0; p < a.n_pend; ++p) { // moves of earlier delete bodies that r has not seen yet
-                    cur.R[0][e] = R::add(cur.R[0][e], R::mul(cur.V[0][e], a.pend_dt[p]));
-                    cur.R[1][e] = R::add(cur.R[1][e], R::mul(cur.V[1][e], a.pend_dt[p]));
-                    cur.R[2][e] = R::add(cur.R[2][e], R::mul(cur.V[2][e], a.pend_dt[p]));
+                    const T p0 = R::mul(cur.V[0][e], a.pend_dt[p]), p1 = R::mul(cur.V[1][e], a.pend_dt[p]), p2 = R::mul(cur.V[2][e], a.pend_dt[p]);
+                    for (int w = 0; w < a.pend_rep[p]; ++w) {
+                        cur.R[0][e] = R::add(cur.R[0][e], p0);
+                        cur.R[1][e] = R::add(cur.R[1][e], p1);
+                        cur.R[2][e] = R::add(cur.R[2][e], p2);
+                    }
                 }
             }
             // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16

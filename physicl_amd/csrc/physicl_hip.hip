@@ -701,7 +701,8 @@ struct alive_args {
     int64_t id_base, slots;     // slots: extent of the store (alive + dead)
     int64_t ts;
     T dt, An;
-    T pend_dt[kPendMax];
+    T pend_dt[kPendMax];        // moves r has not seen yet, oldest first, run-length: pend_rep[q] moves of pend_dt[q]
+    int pend_rep[kPendMax];
     int n_pend;
     uint64_t seed;
     uint32_t step;
@@ -806,7 +807,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                         for (int q = 0; q < a.n_pend; ++q) {
 #pragma unroll
                             for (int k = 0; k < 3; ++k)
-                                if ((a.r_axes >> k) & 1) xx[u][k][e] = R::add(xx[u][k][e], R::mul(vv[u][k][e], a.pend_dt[q]));
+                                if ((a.r_axes >> k) & 1) {
+                                    const T dq = R::mul(vv[u][k][e], a.pend_dt[q]); // (the same product every time: formed once)
+                                    for (int t = 0; t < a.pend_rep[q]; ++t) xx[u][k][e] = R::add(xx[u][k][e], dq);
+                                }
                         }
                         xx[u][0][e] = R::add(xx[u][0][e], d0);                                                                // newton.py:16
                         xx[u][1][e] = R::add(xx[u][1][e], d1);
@@ -914,8 +918,11 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
             const T2 v = *reinterpret_cast<const T2 *>(a.v[k] + ti);
             T2 x = *reinterpret_cast<const T2 *>(a.r[k] + ti);
             for (int q = 0; q < a.n_pend; ++q) {
-                x.x = R::add(x.x, R::mul(v.x, a.pend_dt[q]));
-                x.y = R::add(x.y, R::mul(v.y, a.pend_dt[q]));
+                const T dx = R::mul(v.x, a.pend_dt[q]), dy = R::mul(v.y, a.pend_dt[q]);
+                for (int t = 0; t < a.pend_rep[q]; ++t) {
+                    x.x = R::add(x.x, dx);
+                    x.y = R::add(x.y, dy);
+                }
             }
             *reinterpret_cast<T2 *>(a.r[k] + ti) = x;
         }
@@ -947,6 +954,7 @@ struct ahead_args {
     int64_t id_base, slots, ts;
     T dt, An;
     T pend_dt[kPendMax];
+    int pend_rep[kPendMax];
     int n_pend;
     uint64_t seed;
     uint32_t step0;
@@ -1022,7 +1030,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                     for (int q = 0; q < a.n_pend; ++q) {
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
-                            if ((a.r_axes >> k) & 1) xx[k][e] = R::add(xx[k][e], R::mul(vv[k][e], a.pend_dt[q]));
+                            if ((a.r_axes >> k) & 1) {
+                                const T dq = R::mul(vv[k][e], a.pend_dt[q]);
+                                for (int t = 0; t < a.pend_rep[q]; ++t) xx[k][e] = R::add(xx[k][e], dq);
+                            }
                     }
                 }
                 // Phase 1, lane by lane: the body each slot is removed in.  One Philox block decides the steps 2m and 2m + 1
@@ -1188,8 +1199,11 @@ __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
                 const T2 v = *reinterpret_cast<const T2 *>(a.v[k] + ti);
                 T2 x = *reinterpret_cast<const T2 *>(a.r[k] + ti);
                 for (int q = 0; q < a.n_pend; ++q) {
-                    x.x = R::add(x.x, R::mul(v.x, a.pend_dt[q]));
-                    x.y = R::add(x.y, R::mul(v.y, a.pend_dt[q]));
+                    const T px = R::mul(v.x, a.pend_dt[q]), py = R::mul(v.y, a.pend_dt[q]);
+                    for (int t = 0; t < a.pend_rep[q]; ++t) {
+                        x.x = R::add(x.x, px);
+                        x.y = R::add(x.y, py);
+                    }
                 }
                 const T dx = R::mul(v.x, a.dt), dy = R::mul(v.y, a.dt);
                 for (int q = 0; q < a.j; ++q) {
@@ -1701,7 +1715,8 @@ struct compact_counter_args {
     T dt;          // dr = v*dt when it is implicit
     int move;      // 1: pass 1 only flagged; the survivors' Newton move r = r + v*dt (newton.py:15-16) happens here
     int n_pend;    // alive-mask stores: moves of earlier loop bodies that r has not seen yet, applied first, in order
-    T pend_dt[kPendMax];
+    T pend_dt[kPendMax];       // (run-length: pend_rep[q] moves of pend_dt[q])
+    int pend_rep[kPendMax];
 };
 
 template <typename T, typename W> __device__ __forceinline__ T word_as(W w);
@@ -1742,7 +1757,10 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
                 for (int k = 0; k < 3; ++k) {
                     T rn = word_as<T, W>(val[k]);
                     const T vk = word_as<T, W>(val[3 + k]);
-                    for (int q = 0; q < c.n_pend; ++q) rn = R::add(rn, R::mul(vk, c.pend_dt[q]));
+                    for (int q = 0; q < c.n_pend; ++q) {
+                        const T dq = R::mul(vk, c.pend_dt[q]);
+                        for (int t = 0; t < c.pend_rep[q]; ++t) rn = R::add(rn, dq);
+                    }
                     if (c.move) rn = R::add(rn, R::mul(vk, c.dt));
                     __builtin_memcpy(&val[k], &rn, sizeof(W));
                 }
@@ -1897,8 +1915,11 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
                 T x0 = word_as<T, W>(x.x), x1 = word_as<T, W>(x.y);
                 const T d0 = R::mul(vkeep[ax][t][0], c.dt), d1 = R::mul(vkeep[ax][t][1], c.dt); // newton.py:15
                 for (int q = 0; q < c.n_pend; ++q) { // moves of earlier loop bodies r has not seen yet (alive-mask stores)
-                    x0 = R::add(x0, R::mul(vkeep[ax][t][0], c.pend_dt[q]));
-                    x1 = R::add(x1, R::mul(vkeep[ax][t][1], c.pend_dt[q]));
+                    const T p0 = R::mul(vkeep[ax][t][0], c.pend_dt[q]), p1 = R::mul(vkeep[ax][t][1], c.pend_dt[q]);
+                    for (int w = 0; w < c.pend_rep[q]; ++w) {
+                        x0 = R::add(x0, p0);
+                        x1 = R::add(x1, p1);
+                    }
                 }
                 if (c.move) {
                     x0 = R::add(x0, d0);                                                              // newton.py:16
@@ -2566,8 +2587,9 @@ struct pcl_ctx {
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
     int64_t slots = 0;
-    int pend_n = 0;
+    int pend_n = 0;                  // runs of equal moves r has not seen yet: pend_rep[q] moves of pend_dt[q], oldest first
     double pend_dt[kPendMax] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int pend_rep[kPendMax] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t *masks_prev = nullptr;  // alive bits before the last body of the alive path (last_delete_flags)
     bool last_delete_masked = false; // the last delete was such a body: flags come from masks_prev / masks
     int64_t last_delete_slots = 0;
@@ -3984,7 +4006,7 @@ int step_fast_t(pcl_ctx *ctx, double dt, double A, double n, bool use_e, bool va
     if (ctx->holes) { // the store keeps removed photons' slots: the kernel reads the alive bits, and r catches up first
         f.alive = reinterpret_cast<const pcl_u64 *>(ctx->masks);
         f.n_pend = ctx->pend_n;
-        for (int q = 0; q < ctx->pend_n; ++q) f.pend_dt[q] = (T)ctx->pend_dt[q];
+        for (int q = 0; q < ctx->pend_n; ++q) f.pend_dt[q] = (T)ctx->pend_dt[q], f.pend_rep[q] = ctx->pend_rep[q];
     }
     const bool gen = f.ids || f.kind || f.alive;
     const int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
@@ -4317,6 +4339,26 @@ int64_t alive_min_slots() {
     return (int64_t)(v >= 0 ? v : 65536);
 }
 
+// The list of moves r has not seen yet is run-length coded: a run's loop repeats one dt, so however many bodies r lags
+// behind the list holds one entry; only kPendMax CHANGES of dt fill it (then a body's kernel writes r back).
+bool pend_has_room(const pcl_ctx *ctx, double dt) {
+    return ctx->pend_n < kPendMax || ctx->pend_dt[ctx->pend_n - 1] == dt;
+}
+void pend_push(pcl_ctx *ctx, double dt, int count) {
+    if (count <= 0) return;
+    if (ctx->pend_n > 0 && ctx->pend_dt[ctx->pend_n - 1] == dt) {
+        ctx->pend_rep[ctx->pend_n - 1] += count;
+        return;
+    }
+    ctx->pend_dt[ctx->pend_n] = dt;
+    ctx->pend_rep[ctx->pend_n++] = count;
+}
+int pend_moves(const pcl_ctx *ctx) {
+    int n = 0;
+    for (int q = 0; q < ctx->pend_n; ++q) n += ctx->pend_rep[q];
+    return n;
+}
+
 template <typename T>
 void fill_alive_args(pcl_ctx *ctx, alive_args<T> &a, int64_t slots) {
     for (int k = 0; k < 3; ++k) {
@@ -4333,7 +4375,7 @@ void fill_alive_args(pcl_ctx *ctx, alive_args<T> &a, int64_t slots) {
     a.slots = slots;
     a.ts = tile_stride(ctx);
     a.n_pend = ctx->pend_n;
-    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q];
+    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q], a.pend_rep[q] = ctx->pend_rep[q];
 }
 
 // r catches up with the moves it has not seen (the list is full and no compaction is due)
@@ -4399,7 +4441,7 @@ int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const doubl
     cc.dt = (T)dt;
     cc.move = move ? 1 : 0;
     cc.n_pend = ctx->pend_n;
-    for (int q = 0; q < ctx->pend_n; ++q) cc.pend_dt[q] = (T)ctx->pend_dt[q];
+    for (int q = 0; q < ctx->pend_n; ++q) cc.pend_dt[q] = (T)ctx->pend_dt[q], cc.pend_rep[q] = ctx->pend_rep[q];
     plane_table<T>(planes_host, n_planes, cc.plane_ax, cc.plane_L);
     return launch_compact_count<T>(ctx, false, dv_mode, cc);
 }
@@ -4464,7 +4506,7 @@ int64_t ahead_max_slots() {
 int ahead_k_big() {
     static knob k("PCL_AHEAD_K_BIG");
     const int v = (int)k.value(8.0);
-    return v < 0 ? 0 : (v > kPendMax ? kPendMax : v);
+    return v < 0 ? 0 : (v > kAheadMax ? kAheadMax : v);
 }
 
 bool ahead_same_call(const pcl_ctx::ahead_state &s, double dt, double A, double n, uint64_t seed, const double *planes_host, int n_planes) {
@@ -4490,7 +4532,7 @@ void fill_ahead_args(pcl_ctx *ctx, ahead_args<T> &a) {
     a.dt = (T)s.dt;
     a.An = (T)s.A * (T)s.n;
     a.n_pend = ctx->pend_n;
-    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q];
+    for (int q = 0; q < ctx->pend_n; ++q) a.pend_dt[q] = (T)ctx->pend_dt[q], a.pend_rep[q] = ctx->pend_rep[q];
     a.seed = s.seed;
     a.step0 = s.step0;
     a.K = s.K;
@@ -4558,7 +4600,7 @@ int ahead_commit(pcl_ctx *ctx) {
     if (write_r) {
         ctx->pend_n = 0; // the kernel wrote r with every move applied
     } else {
-        for (int q = 0; q < s.used; ++q) ctx->pend_dt[ctx->pend_n++] = s.dt; // (room was checked when the bodies were launched)
+        pend_push(ctx, s.dt, s.used); // (room for the run was checked when the bodies were launched)
     }
     ctx->last_delete_masked = true;
     ctx->last_delete_slots = s.slots;
@@ -4720,11 +4762,9 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     if (!compact_now && repeat && ahead_k() > 0 && ctx->ahead_wait == 0) {
         if (slots <= ahead_max_slots()) {
             k_ahead = ahead_k();
-        } else if (ahead_k_big() > 1) {
-            const int room = kPendMax - ctx->pend_n;
-            k_ahead = ahead_k_big() < room ? ahead_k_big() : room;
+        } else if (ahead_k_big() > 1 && pend_has_room(ctx, dt)) {
+            k_ahead = ahead_k_big();
             big = true;
-            if (k_ahead < 2) k_ahead = 0;
         }
     }
     if (k_ahead > 0) {
@@ -4748,7 +4788,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         // (PCL_ALIVE_FLUSH_KERNEL: a separate k_apply_pending launch first, for A/B)
         static knob k_flush("PCL_ALIVE_FLUSH_KERNEL");
         const bool flush_kernel = k_flush.set();
-        bool write_r = ctx->pend_n == kPendMax;
+        bool write_r = !pend_has_room(ctx, dt);
         if (write_r && flush_kernel) {
             ctx->slots = slots;
             PCL_TRY(PCL_DISPATCH(ctx, apply_pending_t<double>(ctx), apply_pending_t<float>(ctx)));
@@ -4762,7 +4802,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         if (write_r)
             ctx->pend_n = 0;
         else
-            ctx->pend_dt[ctx->pend_n++] = dt;
+            pend_push(ctx, dt, 1);
         ctx->count = alive;
         ctx->last_delete_n = before;
     } else {
@@ -5628,11 +5668,11 @@ int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out) {
     if (!ctx || !slots_out) return fail(PCL_ERR_ARG, "NULL argument");
     if (ctx->ahead.active) { // (bodies worked out ahead: the extent they swept; r is owed the moves of those handed out)
         *slots_out = ctx->ahead.slots;
-        if (pending_moves_out) *pending_moves_out = ctx->pend_n + ctx->ahead.used;
+        if (pending_moves_out) *pending_moves_out = pend_moves(ctx) + ctx->ahead.used;
         return PCL_OK;
     }
     *slots_out = ctx->holes ? ctx->slots : ctx->count;
-    if (pending_moves_out) *pending_moves_out = ctx->holes ? ctx->pend_n : 0;
+    if (pending_moves_out) *pending_moves_out = ctx->holes ? pend_moves(ctx) : 0;
     return PCL_OK;
 }
 

@@ -102,6 +102,37 @@ def test_delete_bodies_on_the_alive_mask_vs_oracle(N, pdel, dtype, look):
             assert extents[0] == N and extents[1] < N                         # the second body already does
 
 
+@pytest.mark.parametrize("pattern", ["every_body", "runs_of_three"])
+def test_changing_time_steps_and_the_run_length_list_of_pending_moves_vs_oracle(pattern):
+    """r lags behind the bodies of an alive-mask store; the moves it is owed are kept as runs of equal dt (a loop repeats one
+    dt: one entry however long the run).  A time step that changes with every body opens a run per body -- the list of eight
+    fills and a body's kernel writes r back --, runs of three merge; positions, flags and rows must be the oracle's either way
+    (low removal rate: the path never compacts by itself, so everything rides on the pending moves)."""
+    from physicl_amd import _hip as hip
+    N, n_k, seed = 150_000, 1e-3, 23
+    rs = np.random.RandomState(7)
+    direction = rs.normal(size=(N, 3))
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    init = {"r": rs.normal(size=(N, 3)) * 1e5, "v": direction * C_LIT, "E": rs.uniform(1, 2, N)}
+    planes = [[np.nan, 1e5, np.nan], [-2e5, np.nan, np.nan]]
+    st = {"r": cols(init["r"]), "v": cols(init["v"]), "dr": [np.zeros(N)] * 3, "dv": [np.zeros(N)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64)}
+    dts = [1e-3 * (1.0 + 0.125 * ((k if pattern == "every_body" else k // 3) % 5)) for k in range(24)]
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        d.upload_state(dict(init, id_base=0))
+        for step, dt in enumerate(dts):
+            before = d.count
+            A_k = 0.03 / (n_k * C_LIT * dt)
+            flags, row = oracle_body(st, dt, A_k, n_k, seed, step, planes)
+            o = d.step_fused_delete(dt, A_k, n_k, hip.RNG_PHILOX, seed, step, planes, lazy=True)
+            assert device_row(o) == row, (step, device_row(o), row)
+            if step % 7 == 6:
+                assert np.array_equal(d.last_delete_flags(before), flags), step
+            if step in (10, 23):
+                assert_state(d, st, hip, (pattern, step))
+
+
 def test_alive_mask_chain_without_looking_equals_chain_with_looking():
     """Same bodies on two stores: one is downloaded after every body (dense every time), the other never until the end.
     Rows and final state must agree bit for bit; so must a third store on the round-2 pipeline (PCL_ALIVE=0)."""
