@@ -4754,8 +4754,8 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     int64_t alive = 0;
     if (ctx->ahead_wait > 0) --ctx->ahead_wait;
     // How many bodies ahead?  Small stores (extent <= PCL_AHEAD_MAX_SLOTS): PCL_AHEAD_K, their sweeps cost next to nothing.
-    // Big stores: PCL_AHEAD_K_BIG (default 8 = all the list of pending moves holds; measured 3 .. 8 at 1e7 and 1e8 photons), and no more than the list
-    // of pending moves has room for (r is not rewritten at a big store's commit).  One sweep of the extent then serves all
+    // Big stores: PCL_AHEAD_K_BIG (default 8; measured 3 .. 16 at 1e7 and 1e8 photons), if the list of
+    // pending moves can take their run (r is not rewritten at a big store's commit).  One sweep of the extent then serves all
     // of them, and the compaction that has become due meanwhile runs from the committed masks, without a flag sweep of its own.
     int k_ahead = 0;
     bool big = false;
