@@ -160,3 +160,25 @@ def test_cl_off_semantics_on_two_contexts_equal_one_context():
     a, b = run(), run(devices=DEV2)
     assert a[0] == b[0] and a[1] == b[1] and a[4] == b[4] and 0 < len(a[1]) < 3001
     assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+def test_group_downloads_in_the_stores_own_precision_and_windows_that_start_in_a_later_shard():
+    """``DeviceGroup.download`` allocated float64 whatever the store held; a window that starts beyond the first
+    shard's capacity used to hand that shard an offset it refuses (Python MultiDevice); shards are sized for any count up to
+    the capacity."""
+    from physicl_amd import _hip as hip
+    from physicl_amd.multidev import MultiDevice
+    N = 90_001
+    with hip.DeviceGroup(DEV3) as g:
+        g.store_alloc(N, "f32")
+        g.fill_photons(N, 0, 299792458.0, 1.0, 2.0, 3)
+        e = g.download(hip.E)
+        assert e.dtype == np.float32 and len(e) == N and np.all((e >= 1.0) & (e <= 2.0))
+        assert g.download(hip.E, dtype=np.float32).dtype == np.float32
+    with MultiDevice(DEV3) as md:
+        md.store_alloc(N)
+        md.fill_photons(N, 10, 299792458.0, 1.0, 2.0, 3)
+        tail = md.download_ids(100, N - 100)                       # the window lies in the last shard only
+        assert np.array_equal(tail, np.arange(N - 100 + 10, N + 10))
+        md.fill_photons(N - 7, 10, 299792458.0, 1.0, 2.0, 3)      # fewer photons into the same store: every shard has room
+        assert md.count == N - 7 and md.capacity >= N
