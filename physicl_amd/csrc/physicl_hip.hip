@@ -503,6 +503,7 @@ struct compact_args {
     int64_t ts; // tile stride of BOTH slabs (elements)
     int dense_dst; // 1: dst[] are plain dense arrays (pcl_step_plane_energies), not rows of a slab
     const int *choice; // non-NULL: which of the two pass-3 kernels the scan picked (k_tile_scan)
+    uint32_t sparse_max; // k_compact_count: a wave with at most this many survivors (of 512 slots) takes them survivor by survivor
 };
 
 template <typename W, int NF>
@@ -1738,17 +1739,29 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
     for (int r = 0; r < wave * (kTileRows / 4); ++r) dest += __popcll(tm[r]);
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t w_s[3] = {0, 0, 0};
-#pragma unroll 2
-    for (int rr = 0; rr < kTileRows / 4; ++rr) {
-        const int row = wave * (kTileRows / 4) + rr;
-        const uint64_t m = tm[row];
-        const int64_t i = tile * kTile + (int64_t)row * 64 + lane;
-        const bool keep = (m >> lane) & 1ull;
+    // How many of the wave's 512 slots survive?  With few of them (a store compacted after several bodies: 6 - 12 %) a
+    // row-by-row sweep keeps a handful of lanes busy per row -- eight rows, eight rounds of loads with next to nothing in
+    // flight.  Then the survivors' slots are first listed in order (two bytes each, the wave's own part of an LDS array: no
+    // barrier), and lane j takes the j-th survivor: every lane loads, the stores are consecutive.  Same order, same values.
+    __shared__ uint16_t s_list[kBlock / 64][64 * (kTileRows / 4)];
+    uint32_t total = 0;
+    for (int rr = 0; rr < kTileRows / 4; ++rr) total += (uint32_t)__popcll(tm[wave * (kTileRows / 4) + rr]);
+    const bool sparse = total <= a.sparse_max; // (wave-uniform) PCL_COMPACT_SPARSE, default: at most half of the slots
+    if (sparse) {
+        uint32_t at = 0;
+        for (int rr = 0; rr < kTileRows / 4; ++rr) {
+            const uint64_t m = tm[wave * (kTileRows / 4) + rr];
+            if ((m >> lane) & 1ull) s_list[wave][at + (uint32_t)__popcll(m & below)] = (uint16_t)(rr * 64 + lane);
+            at += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto item = [&](const bool keep, const int64_t i, const int64_t o) {
         W val[NF];
 #pragma unroll
         for (int f = 0; f < NF; ++f) val[f] = 0;
         if (keep) {
-            const int64_t o = dest + __popcll(m & below);
             const int64_t ti = pcl_tix(i, a.ts), to = pcl_tix(o, a.ts);
 #pragma unroll
             for (int f = 0; f < NF; ++f) val[f] = static_cast<const W *>(a.src[f])[ti];
@@ -1792,7 +1805,21 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
                 if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
             }
         }
-        dest += __popcll(m);
+    };
+    if (sparse) {
+        for (uint32_t j = (uint32_t)lane; j < ((total + 63u) & ~63u); j += 64u) {
+            const bool keep = j < total;
+            const uint32_t loc = keep ? (uint32_t)s_list[wave][j] : 0u;
+            item(keep, tile * kTile + (int64_t)wave * (64 * (kTileRows / 4)) + (int64_t)loc, dest + (int64_t)j);
+        }
+    } else {
+#pragma unroll 2
+        for (int rr = 0; rr < kTileRows / 4; ++rr) {
+            const int row = wave * (kTileRows / 4) + rr;
+            const uint64_t m = tm[row];
+            item((m >> lane) & 1ull, tile * kTile + (int64_t)row * 64 + lane, dest + __popcll(m & below));
+            dest += __popcll(m);
+        }
     }
     if (c.n_planes >= 0) {
         if (lane == 0)
@@ -4250,6 +4277,14 @@ void plane_table(const double *planes_host, int n_planes, int *ax_out, T *L_out)
 
 // pass 3 of a delete pipeline: stable compaction of the store into the other slab (+ the measure counters when
 // cc.n_planes >= 0); has_dr says whether the dr rows travel (13 fields) or stay implicit (10)
+// PCL_COMPACT_SPARSE: waves of k_compact_count with at most this many survivors among their 512 slots take them survivor
+// by survivor (default 256; 0 = always row by row, the round-3 form)
+uint32_t compact_sparse_max() {
+    static knob k("PCL_COMPACT_SPARSE");
+    const double v = k.value(256.0);
+    return v < 0 ? 0u : (v > 512.0 ? 512u : (uint32_t)v);
+}
+
 template <typename T>
 int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter_args<T> &cc) {
     const int tiles = (int)div_up(ctx->count, kTile);
@@ -4268,6 +4303,7 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter
     static const bool direct_only = getenv("PCL_COMPACT_DIRECT") != nullptr; // perf-experiment hook
     const bool both = !ctx->kind && !direct_only && ctx->count >= ((int64_t)1 << 22); // (the scan's rule needs >= 4M particles)
     ca.choice = both ? reinterpret_cast<const int *>(ctx->d_cnt + kCounterSlots - 2) : nullptr;
+    ca.sparse_max = compact_sparse_max();
     if (has_dr)
         hipLaunchKernelGGL((k_compact_count<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
     else if (dv_mode == kDvSkip)

@@ -40,6 +40,8 @@ DELETE_KNOBS = [
     ("any_size-flush_kernel-no_poll", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_FLUSH_KERNEL": "1", "PCL_ALIVE_POLL": "0"}),
     ("any_size-ratio_0.95", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}),         # nearly every body compacts
     ("alive_off", {"PCL_ALIVE": "0"}),                                                         # the round-2 pipeline
+    # k_compact_count takes every wave's survivors one by one (its form for sparse waves), whatever their number
+    ("any_size-compact_survivor_major", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_COMPACT_SPARSE": "512"}),
 ]
 # bodies worked out ahead (k_delete_ahead) only exist on the one-call-per-body path: the files that take it
 AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"}),
