@@ -734,13 +734,14 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                  "traffic": pmc_traffic("k_delete_alive<double, true>", slots_swept),
                                  "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
                                  "bytes_per_alive_particle_step": (b1 + b2 + b3) / tot if tot else 0.0}
-                r["ahead"] = {"kernel": "k_delete_ahead (the next loop bodies worked out in ONE sweep of the extent -- 16 for stores of <= 2^22 slots, 8 "
-                                        "above --, answered call by call from the rows; the store is only written at the commit)",
+                r["ahead"] = {"kernel": "k_delete_ahead_live (the next loop bodies worked out in ONE sweep of the extent -- 24 for stores of <= 2^22 "
+                                        "slots, 16 up to 2^25, 12 above --, answered call by call from the rows; the store is only written at the "
+                                        "commit; the kernel lists the photons still alive per 256 slots, so a body costs what they cost)",
                               "launches": kern["k_delete_ahead"]["launches"], "total_ms": p2_ms, "slots_swept": slots_ahead,
                               "algorithmic_bytes": b2, "bodies": answered["ahead_launch"] + answered["ahead"],
-                              "traffic": pmc_traffic("k_delete_ahead<double>", slots_ahead),
-                              # its HBM rate on the slots it sweeps: well below the streaming kernels' -- the K bodies' Philox blocks,
-                              # compares and ballots bind it (~135 VALU + ~130 SALU instructions per body and 128 slots), not bytes
+                              "traffic": pmc_traffic("k_delete_ahead_live<double>", slots_ahead),
+                              # its HBM rate on the slots it sweeps: well below the streaming kernels' -- the bodies' Philox blocks
+                              # (twenty quarter-rate 32 x 32 -> 64 multiplies each), compares and ballots bind it, not bytes
                               "achieved_GBps": b2 / (p2_ms * 1e-3) / 1e9 if p2_ms else 0.0,
                               "frac_of_hbm_peak": b2 / (p2_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if p2_ms else 0.0, "bound": "valu"}
                 r["roofline_compaction"] = {"bound": "hbm", "kernel": "k_compact_* (stable compaction of the survivors, %d of %d bodies)"

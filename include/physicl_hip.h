@@ -241,8 +241,8 @@ int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
 /* Delete loop bodies ahead of their calls.  When a pcl_step_fused_delete call repeats the previous one with ``step``
  * advanced by one -- a run's loop, physicl/__init__.py:512-516 --, or is the first delete body of a population (taken for
  * the start of such a loop), the library works out that body AND the next ones in one
- * launch that leaves the store untouched (PCL_AHEAD_K = 16 bodies for stores of up to PCL_AHEAD_MAX_SLOTS = 2^22 slots,
- * PCL_AHEAD_K_BIG = 8 above: one sweep of the extent serves them all), and answers the following calls, if they are the
+ * launch that leaves the store untouched (PCL_AHEAD_K = 24 bodies for stores of up to PCL_AHEAD_MAX_SLOTS = 2^22 slots,
+ * PCL_AHEAD_K_BIG = 16, 12 beyond 2^25 slots, above: one sweep of the extent serves them all), and answers the following calls, if they are the
  * predicted ones, from those rows without a launch (a loop body of a small store is a 20 us round trip to the host, not
  * bytes; a big store's body is a sweep of its extent).  Any other call first makes the state after the bodies handed out so
  * far real (one kernel; a big store whose alive photons have fallen below the compaction threshold is compacted from those

@@ -1163,6 +1163,214 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
     }
 }
 
+// ---- the same, for at most one plane: a body costs what the photons still ALIVE cost -----------------------------------
+//   k_delete_ahead decides every slot's bodies with the slot's own lane: after four bodies three quarters of the lanes
+//   work for photons that are gone, and the counter rows are ballots over all slots once more.  Here a wave takes 256
+//   slots at a time and lists the alive photons in LDS (id, collision probability, coordinate and move along the plane's
+//   axis, place and velocity signs); each pass over the list decides one Philox block's two bodies for 64 listed photons
+//   per round -- all lanes busy --, counts the round's survivors into those bodies' rows right there and writes them back
+//   to the front of the list (in place: a round writes no further than it has read).  Same operations per photon, same
+//   rows, same death bytes (tests run both kernels: PCL_AHEAD_LIVE).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
+    typedef pcl_rt<T> R;
+    typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    constexpr int kGroups = 2; // groups of 128 slots (two per lane) a wave takes together
+    constexpr int kBatch = kGroups * 128;
+    __shared__ uint32_t s_cnt[kAheadMax * kAheadRow];
+    __shared__ int s_last;
+    __shared__ uint64_t s_id[kBlock / 64][kBatch];
+    __shared__ T s_pc[kBlock / 64][kBatch], s_xp[kBlock / 64][kBatch], s_dp[kBlock / 64][kBatch];
+    __shared__ uint16_t s_ix[kBlock / 64][kBatch]; // place in the batch (8 bits), velocity signs (bits 8-10)
+    __shared__ uint8_t s_death[kBlock / 64][kBatch];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < kAheadMax * kAheadRow; q += kBlock) s_cnt[q] = 0;
+    __syncthreads();
+    const bool hi = lane >= 32;
+    const int bit = 2 * (lane & 31);
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int64_t n_tiles = (a.slots + kTile - 1) / kTile;
+    const bool has_plane = a.n_planes > 0, has_signs = a.n_planes >= 0;
+    const int ax0 = has_plane ? a.plane_ax[0] : 0;
+    const T L0 = has_plane ? a.plane_L[0] : (T)0;
+    uint32_t t_kept = 0, t_s[3] = {0, 0, 0}, t_p0 = 0; // lane b: this wave's sums of body b (alive, sign counts, the plane)
+    // one body's row from the photons of a round that it leaves alive (``s``): into lane b's accumulators
+    auto tally = [&](int b, bool s, uint32_t ix, bool cross) {
+        const bool mine = lane == b;
+        const uint64_t bs = __ballot(s);
+        t_kept += mine ? (uint32_t)__popcll(bs) : 0u;
+        if (has_signs) {                                                                                                 // light.py:424-426
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const uint64_t bk = __ballot(s && ((ix >> (8 + k)) & 1u)); // (every lane votes: not inside the select)
+                t_s[k] += mine ? (uint32_t)__popcll(bk) : 0u;
+            }
+            if (has_plane) {                                                                                             // light.py:385-399
+                const uint64_t bp = __ballot(s && cross);
+                t_p0 += mine ? (uint32_t)__popcll(bp) : 0u;
+            }
+        }
+    };
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#pragma unroll 1
+        for (int bt = 0; bt < kTileRows / (8 * kGroups); ++bt) {
+            // ---- the batch's alive photons join the list ----------------------------------------------------------------------
+            uint32_t n_list = 0;
+            const int row0 = (wave * (kTileRows / 8) + bt * kGroups) * 2;
+            const int64_t i0 = tile * kTile + (int64_t)row0 * 64; // the batch's first slot
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                const int row = row0 + 2 * g;
+                const int64_t i = i0 + g * 128 + 2 * lane; // the lane's two slots: i, i + 1
+                uint64_t m_lo, m_hi;
+                if (a.fresh) {
+                    const int64_t left = a.slots - (i0 + g * 128);
+                    m_lo = left >= 64 ? ~0ull : (left > 0 ? (1ull << left) - 1ull : 0ull);
+                    m_hi = left >= 128 ? ~0ull : (left > 64 ? (1ull << (left - 64)) - 1ull : 0ull);
+                } else {
+                    m_lo = a.masks[tile * kTileRows + row];
+                    m_hi = a.masks[tile * kTileRows + row + 1];
+                }
+                uchar2 d0;
+                d0.x = d0.y = 0;
+                if ((m_lo | m_hi) != 0ull) { // (wave-uniform)
+                    const uint64_t mm = hi ? m_hi : m_lo;
+                    const bool al[2] = {(bool)((mm >> bit) & 1ull), (bool)((mm >> (bit + 1)) & 1ull)};
+                    const int64_t ti = pcl_tix(i, a.ts);
+                    T vv[3][2], x0[2] = {(T)0, (T)0};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const T2 q = *reinterpret_cast<const T2 *>(a.v[k] + ti);
+                        vv[k][0] = q.x, vv[k][1] = q.y;
+                    }
+                    if (has_plane) {
+                        const T2 x = *reinterpret_cast<const T2 *>(a.r[ax0] + ti);
+                        x0[0] = x.x, x0[1] = x.y;
+                    }
+                    uint64_t id[2];
+                    if (a.ids) {
+                        const longlong2 q = *reinterpret_cast<const longlong2 *>(a.ids + (i < a.slots ? i : 0));
+                        id[0] = (uint64_t)q.x, id[1] = (uint64_t)q.y;
+                    } else {
+                        id[0] = (uint64_t)(a.id_base + i), id[1] = id[0] + 1;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        T dd[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) dd[k] = R::mul(vv[k][e], a.dt);                                          // newton.py:15
+                        const T pcoll = R::mul(a.An, pcl_step_norm<T>(dd[0], dd[1], dd[2]));                                 // light.py:241-247
+                        const T va = pcl_pick<T>(ax0, vv[0][e], vv[1][e], vv[2][e]);
+                        T x = x0[e];
+                        if (has_plane)
+                            for (int q = 0; q < a.n_pend; ++q) { // the moves the store still owes its r
+                                const T dq = R::mul(va, a.pend_dt[q]);
+                                for (int t = 0; t < a.pend_rep[q]; ++t) x = R::add(x, dq);
+                            }
+                        const uint64_t bal = __ballot(al[e]);
+                        if (al[e]) {
+                            const uint32_t pos = n_list + (uint32_t)__popcll(bal & below);
+                            s_id[wave][pos] = id[e];
+                            s_pc[wave][pos] = pcoll;
+                            s_xp[wave][pos] = x;
+                            s_dp[wave][pos] = pcl_pick<T>(ax0, dd[0], dd[1], dd[2]);
+                            s_ix[wave][pos] = (uint16_t)((g * 128 + 2 * lane + e) | (vv[0][e] > (T)0 ? 0x100 : 0) | (vv[1][e] > (T)0 ? 0x200 : 0) |
+                                                         (vv[2][e] > (T)0 ? 0x400 : 0));
+                        }
+                        n_list += (uint32_t)__popcll(bal);
+                    }
+                    d0.x = al[0] ? 255 : 0, d0.y = al[1] ? 255 : 0;
+                }
+                *reinterpret_cast<uchar2 *>(&s_death[wave][g * 128 + 2 * lane]) = d0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // ---- the bodies, one Philox block at a time: it decides the steps 2m and 2m + 1 (pcl_draw_rand), so the bodies are
+            // taken in such pairs, after a single one when the first step is odd ------------------------------------------------
+            for (int b = 0; b < a.K && n_list > 0;) {
+                const uint32_t st = a.step0 + (uint32_t)b;
+                const bool single = (st & 1u) != 0u;          // only the block's second half is a body of this launch
+                const bool two = !single && b + 1 < a.K;
+                uint32_t w = 0;
+                for (uint32_t r0 = 0; r0 < n_list; r0 += 64) {
+                    const uint32_t j = r0 + (uint32_t)lane;
+                    const bool on = j < n_list;
+                    const uint64_t id = on ? s_id[wave][j] : 0ull;
+                    const T pc = on ? s_pc[wave][j] : (T)0;
+                    T xp = on ? s_xp[wave][j] : (T)0;
+                    const T dp = on ? s_dp[wave][j] : (T)0;
+                    const uint32_t ix = on ? (uint32_t)s_ix[wave][j] : 0u;
+                    const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+                    const T r_first = single ? R::uniform(wd.z, wd.w) : R::uniform(wd.x, wd.y);
+                    const bool s0 = on && !(pc >= r_first); // alive after body b
+                    xp = R::add(xp, dp);                                                                                     // newton.py:16
+                    T prev = R::sub(xp, dp);
+                    tally(b, s0, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+                    bool left = s0;
+                    uint32_t d = s0 ? 255u : (uint32_t)(b + 1);
+                    if (two) { // (uniform)
+                        const T r_second = R::uniform(wd.z, wd.w);
+                        left = s0 && !(pc >= r_second);
+                        if (s0 && !left) d = (uint32_t)(b + 2);
+                        xp = R::add(xp, dp);
+                        prev = R::sub(xp, dp);
+                        tally(b + 1, left, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+                    }
+                    if (on && d != 255u) s_death[wave][ix & 0xFFu] = (uint8_t)d;
+                    const uint64_t bal = __ballot(left);
+                    if (left) {
+                        const uint32_t pos = w + (uint32_t)__popcll(bal & below);
+                        s_id[wave][pos] = id;
+                        s_pc[wave][pos] = pc;
+                        s_xp[wave][pos] = xp;
+                        s_dp[wave][pos] = dp;
+                        s_ix[wave][pos] = (uint16_t)ix;
+                    }
+                    w += (uint32_t)__popcll(bal);
+                }
+                n_list = w;
+                b += two ? 2 : 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            // the batch's death bytes: four consecutive slots per lane (whole tiles exist in the buffer)
+            *reinterpret_cast<uint32_t *>(a.death + i0 + 4 * lane) = *reinterpret_cast<const uint32_t *>(&s_death[wave][4 * lane]);
+        }
+    }
+    if (lane < a.K) { // the wave's sums join the workgroup's
+        if (t_kept) atomicAdd(&s_cnt[lane * kAheadRow + 0], t_kept);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (t_s[k]) atomicAdd(&s_cnt[lane * kAheadRow + 1 + k], t_s[k]);
+        if (t_p0) atomicAdd(&s_cnt[lane * kAheadRow + 4], t_p0);
+    }
+    __syncthreads();
+    // grid totals as in k_delete_alive: returning agent-scope atomics, the last workgroup reports
+    const int nrow = 4 + (a.n_planes > 0 ? a.n_planes : 0);
+    unsigned long long seen = 0;
+    for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
+        if ((q % kAheadRow) < nrow && s_cnt[q])
+            seen += __hip_atomic_fetch_add(&a.acc[1 + q], (unsigned long long)s_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(seen) : "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        s_last = __hip_atomic_fetch_add(&a.acc[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1ull;
+    __syncthreads();
+    if (!s_last) return;
+    volatile uint64_t *h = a.host;
+    for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
+        h[q] = (q % kAheadRow) < nrow ? __hip_atomic_exchange(&a.acc[1 + q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_exchange(&a.acc[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.host[kAheadMax * kAheadRow], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+
 // the state after ``j`` of the bodies k_delete_ahead worked out, made real: alive bits (masks_out), the alive bits before
 // the j-th body (masks_prev: pcl_store_last_delete_flags), alive counts per tile, and -- WRITE_R, small stores -- r with the
 // pending moves and the j moves of those bodies applied (newton.py:15-16, one rounded multiply and one rounded add per
@@ -4526,12 +4734,12 @@ int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 }
 
 // ---- delete loop bodies ahead of their calls (k_delete_ahead) ---------------------------------------------------------
-// PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 16, at most kAheadMax); extents up to
-// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 8, 0 or 1 = none)
+// PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 24, at most kAheadMax); extents up to
+// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 16 up to 2^25 slots, 12 above; 0 or 1 = none)
 int ahead_k() {
     static knob k_on("PCL_AHEAD"), k_k("PCL_AHEAD_K");
     if (k_on.off()) return 0;
-    const int k = (int)k_k.value(16.0);
+    const int k = (int)k_k.value(24.0);
     return k < 2 ? 0 : (k > kAheadMax ? kAheadMax : k);
 }
 int64_t ahead_max_slots() {
@@ -4539,9 +4747,12 @@ int64_t ahead_max_slots() {
     const double v = k.value(4194304.0);
     return (int64_t)(v > 0 ? v : 0);
 }
-int ahead_k_big() {
+int ahead_k_big(int64_t slots) {
     static knob k("PCL_AHEAD_K_BIG");
-    const int v = (int)k.value(8.0);
+    // (with k_delete_ahead_live a body costs what the photons still alive cost, but every pass over a 256-slot batch is at
+    // least one round: measured 8 / 10 / 12 / 14 / 16 / 20 bodies, 1e8 photons: 2.85 / 2.55 / 2.48 / 2.55 / 2.6 / 2.65 ms per run,
+    // 1e7: 0.70 / 0.66 / 0.66 / 0.65 / 0.62 / 0.61)
+    const int v = (int)k.value(slots > ((int64_t)1 << 25) ? 12.0 : 16.0);
     return v < 0 ? 0 : (v > kAheadMax ? kAheadMax : v);
 }
 
@@ -4592,7 +4803,11 @@ int ahead_launch_t(pcl_ctx *ctx) {
     const int64_t n_tiles = div_up(ctx->ahead.slots, kTile), cap = (int64_t)ctx->prop.multiProcessorCount * 64;
     const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_AHEAD);
-    hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    static knob k_live("PCL_AHEAD_LIVE"); // 0: always the slot-per-lane kernel
+    if (a.n_planes <= 1 && !k_live.off())
+        hipLaunchKernelGGL(k_delete_ahead_live<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     prof_end(ctx, ps);
     return launch_check("k_delete_ahead");
 }
@@ -4798,8 +5013,8 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     if (!compact_now && repeat && ahead_k() > 0 && ctx->ahead_wait == 0) {
         if (slots <= ahead_max_slots()) {
             k_ahead = ahead_k();
-        } else if (ahead_k_big() > 1 && pend_has_room(ctx, dt)) {
-            k_ahead = ahead_k_big();
+        } else if (ahead_k_big(slots) > 1 && pend_has_room(ctx, dt)) {
+            k_ahead = ahead_k_big(slots);
             big = true;
         }
     }

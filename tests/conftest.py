@@ -45,6 +45,8 @@ DELETE_KNOBS = [
 ]
 # bodies worked out ahead (k_delete_ahead) only exist on the one-call-per-body path: the files that take it
 AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "3"}),
+               # the kernel that gives every slot its own lane, also where the one that lists the alive photons would run
+               ("ahead_slot_per_lane", {"PCL_AHEAD_LIVE": "0"}),
                # every store takes the big stores' form: few bodies per launch, r left behind at the commit, compaction from the
                # committed masks
                ("ahead_big_form", {"PCL_AHEAD_MAX_SLOTS": "0", "PCL_ALIVE_MIN_SLOTS": "0"})]

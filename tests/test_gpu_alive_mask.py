@@ -264,12 +264,17 @@ def test_bodies_worked_out_ahead_change_nothing_but_the_number_of_launches(name,
         hip.set_knob("PCL_AHEAD_MAX_SLOTS", "0")
         hip.set_knob("PCL_ALIVE_MIN_SLOTS", "0")
         rows2, s2, st2 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
+        # ... and with the kernel that gives every slot its own lane also where the one that lists the alive photons would run
+        hip.set_knob("PCL_AHEAD_MAX_SLOTS", None)
+        hip.set_knob("PCL_ALIVE_MIN_SLOTS", None)
+        hip.set_knob("PCL_AHEAD_LIVE", "0")
+        rows3, s3, st3 = _ahead_run(hip, N, dtype, AHEAD_SCRIPTS[name])
     finally:
-        for k in ("PCL_AHEAD", "PCL_AHEAD_K", "PCL_AHEAD_MAX_SLOTS", "PCL_ALIVE_MIN_SLOTS"):
+        for k in ("PCL_AHEAD", "PCL_AHEAD_K", "PCL_AHEAD_MAX_SLOTS", "PCL_ALIVE_MIN_SLOTS", "PCL_AHEAD_LIVE"):
             hip.set_knob(k, None)
-    assert st0 == (0, 0, 0) and st1[0] >= 1 and st1[1] > st1[0] and st2[0] >= 1 and st2[1] > st2[0], (st0, st1, st2)
-    assert rows0 == rows1 == rows2
-    for sx in (s1, s2):
+    assert st0 == (0, 0, 0) and st1[0] >= 1 and st1[1] > st1[0] and st2[0] >= 1 and st2[1] > st2[0] and st3 == st1, (st0, st1, st2, st3)
+    assert rows0 == rows1 == rows2 == rows3
+    for sx in (s1, s2, s3):
         assert np.array_equal(s0["id"], sx["id"]) and np.array_equal(s0["E"], sx["E"])
         for f in ("r", "v", "dr", "dv"):
             for k in range(3):

@@ -253,12 +253,13 @@ def main():
         for k, slots, d, fb, wb in comp_rows[:24]:
             L.append("| `%s` | %d | %.1f | %.1f | %.1f | %.1f | %.0f | %.3f |" % (k, slots, d * 1e-3, fb / 1e6, wb / 1e6, (fb + wb) / slots,
                                                                                (fb + wb) / (d * 1e-9) / 1e9, (fb + wb) / (d * 1e-9) / 1e9 / HBM_PEAK))
-    kah = [k for k in disp if k.startswith("k_delete_ahead<double")]
+    # (runs with at most one plane take k_delete_ahead_live: the bench's delete legs do)
+    kah = [k for k in disp if k.startswith("k_delete_ahead_live<double")] or [k for k in disp if k.startswith("k_delete_ahead<double")]
     ahead_bytes = []
     if kah:
         kah = kah[0]
         js = [j for j, r in enumerate(rows) if short(r["Kernel_Name"]) == kah]
-        L += ["", "## `k_delete_ahead<double>` (K delete loop bodies worked out in one launch): the dispatches with the capped grid (extents of >= 3.4e7 slots)", "",
+        L += ["", "## `%s` (K delete loop bodies worked out in one launch): the dispatches with the capped grid (extents of >= 3.4e7 slots)" % kah, "",
               "| dispatch | grid (threads) | duration us | FETCH x2 MB | WRITE MB | HBM GB/s |", "|---|---|---|---|---|---|"]
         shown = 0
         for i, j in enumerate(js):
@@ -317,7 +318,7 @@ def main():
         if per:
             kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit}
     if ahead_bytes:
-        kern_t["k_delete_ahead<double>"] = {"bytes_per_unit": round(sum(ahead_bytes) / len(ahead_bytes), 2), "unit": "slot (per launch, whatever K)",
+        kern_t[kah] = {"bytes_per_unit": round(sum(ahead_bytes) / len(ahead_bytes), 2), "unit": "slot (per launch, whatever K)",
                                             "source": src_md, "commit": commit}
     for kname in sorted({r[0] for r in comp_rows if ", 7>" in r[0]}):
         first = [r for r in comp_rows if r[0] == kname and r[1] >= 90_000_000]
