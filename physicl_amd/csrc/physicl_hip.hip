@@ -1163,6 +1163,29 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
     }
 }
 
+// ``pcoll >= uniform`` without building the uniform: R::uniform is an integer m of 53 (fp32: 24) random bits times 2^-53
+// (2^-24), both exact, so  pcoll >= m * 2^-53  <=>  m <= floor(pcoll * 2^53)  (the scaling is exact too; a pcoll of 1 or
+// more removes whatever m, a NaN or a negative one never does: threshold -1).  The threshold is worked out once per photon.
+template <typename T> struct ahead_draw;
+template <> struct ahead_draw<double> {
+    typedef int64_t thr_t;
+    static __device__ __forceinline__ thr_t threshold(double pc) {
+        if (!(pc >= 0.0)) return -1;
+        const double y = pc * 9007199254740992.0;
+        return y >= 9007199254740992.0 ? (thr_t)9007199254740992ll : (thr_t)y; // (truncation = floor: y >= 0)
+    }
+    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { return (thr_t)(((pcl_u64)(a >> 5) << 26) | (pcl_u64)(b >> 6)); } // pcl_u53
+};
+template <> struct ahead_draw<float> {
+    typedef int32_t thr_t;
+    static __device__ __forceinline__ thr_t threshold(float pc) {
+        if (!(pc >= 0.0f)) return -1;
+        const float y = pc * 16777216.0f;
+        return y >= 16777216.0f ? (thr_t)16777216 : (thr_t)y;
+    }
+    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { (void)b; return (thr_t)(a >> 8); } // pcl_rt<float>::uniform
+};
+
 // ---- the same, for at most one plane: a body costs what the photons still ALIVE cost -----------------------------------
 //   k_delete_ahead decides every slot's bodies with the slot's own lane: after four bodies three quarters of the lanes
 //   work for photons that are gone, and the counter rows are ballots over all slots once more.  Here a wave takes 256
@@ -1175,12 +1198,15 @@ template <typename T>
 __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     typedef pcl_rt<T> R;
     typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
+    typedef ahead_draw<T> D;
+    typedef typename D::thr_t thr_t;
     constexpr int kGroups = 2; // groups of 128 slots (two per lane) a wave takes together
     constexpr int kBatch = kGroups * 128;
     __shared__ uint32_t s_cnt[kAheadMax * kAheadRow];
     __shared__ int s_last;
     __shared__ uint64_t s_id[kBlock / 64][kBatch];
-    __shared__ T s_pc[kBlock / 64][kBatch], s_xp[kBlock / 64][kBatch], s_dp[kBlock / 64][kBatch];
+    __shared__ thr_t s_pc[kBlock / 64][kBatch]; // the collision probability as the largest draw that removes (ahead_draw)
+    __shared__ T s_xp[kBlock / 64][kBatch], s_dp[kBlock / 64][kBatch];
     __shared__ uint16_t s_ix[kBlock / 64][kBatch]; // place in the batch (8 bits), velocity signs (bits 8-10)
     __shared__ uint8_t s_death[kBlock / 64][kBatch];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1271,7 +1297,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                         if (al[e]) {
                             const uint32_t pos = n_list + (uint32_t)__popcll(bal & below);
                             s_id[wave][pos] = id[e];
-                            s_pc[wave][pos] = pcoll;
+                            s_pc[wave][pos] = D::threshold(pcoll);
                             s_xp[wave][pos] = x;
                             s_dp[wave][pos] = pcl_pick<T>(ax0, dd[0], dd[1], dd[2]);
                             s_ix[wave][pos] = (uint16_t)((g * 128 + 2 * lane + e) | (vv[0][e] > (T)0 ? 0x100 : 0) | (vv[1][e] > (T)0 ? 0x200 : 0) |
@@ -1296,21 +1322,20 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                     const uint32_t j = r0 + (uint32_t)lane;
                     const bool on = j < n_list;
                     const uint64_t id = on ? s_id[wave][j] : 0ull;
-                    const T pc = on ? s_pc[wave][j] : (T)0;
+                    const thr_t pc = on ? s_pc[wave][j] : (thr_t)-1;
                     T xp = on ? s_xp[wave][j] : (T)0;
                     const T dp = on ? s_dp[wave][j] : (T)0;
                     const uint32_t ix = on ? (uint32_t)s_ix[wave][j] : 0u;
                     const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                    const T r_first = single ? R::uniform(wd.z, wd.w) : R::uniform(wd.x, wd.y);
-                    const bool s0 = on && !(pc >= r_first); // alive after body b
+                    const thr_t m_first = single ? D::draw(wd.z, wd.w) : D::draw(wd.x, wd.y);
+                    const bool s0 = on && !(m_first <= pc); // alive after body b                                                  light.py:243
                     xp = R::add(xp, dp);                                                                                     // newton.py:16
                     T prev = R::sub(xp, dp);
                     tally(b, s0, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
                     bool left = s0;
                     uint32_t d = s0 ? 255u : (uint32_t)(b + 1);
                     if (two) { // (uniform)
-                        const T r_second = R::uniform(wd.z, wd.w);
-                        left = s0 && !(pc >= r_second);
+                        left = s0 && !(D::draw(wd.z, wd.w) <= pc);
                         if (s0 && !left) d = (uint32_t)(b + 2);
                         xp = R::add(xp, dp);
                         prev = R::sub(xp, dp);
@@ -4974,8 +4999,10 @@ int densify(pcl_ctx *ctx) {
 
 // pcl_step_fused_delete on the alive mask (lazy, all photons, device RNG).  Returns the alive count in *alive_out; the
 // measure counters are in h_cnt[1..] when n_planes >= 0.
+// ``known``: how many bodies of this run the caller is certain to ask for, this one included (pcl_step_fused_delete_multi
+// knows; 0 = a single call, the library goes by the pattern of the calls).
 int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t seed, uint32_t step, const double *planes_host,
-                       int n_planes, int64_t *alive_out) {
+                       int n_planes, int64_t *alive_out, int known = 0) {
     const int64_t before = ctx->count;
     pcl_ctx::ahead_state &sp = ctx->ahead;
     if (sp.active) { // bodies were worked out ahead: is this the call they are waiting for?
@@ -4994,8 +5021,9 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     // population (no call to compare with: drop_holes forgets the last one whenever the particles are replaced) is taken for
     // the start of such a loop -- delete bodies come in loops (physicl/__init__.py:512-516) --; if the next call is not its
     // continuation the library has lost part of one sweep, pauses (ahead_commit), and goes by evidence from then on.
-    const bool repeat = !ctx->ahead_last_valid ||
-                        (ahead_same_call(ctx->ahead_last, dt, A, n, seed, planes_host, n_planes) && step == ctx->ahead_last.step0 + 1u);
+    const bool pattern = !ctx->ahead_last_valid ||
+                         (ahead_same_call(ctx->ahead_last, dt, A, n, seed, planes_host, n_planes) && step == ctx->ahead_last.step0 + 1u);
+    const bool repeat = pattern || known > 1;
     {
         pcl_ctx::ahead_state &l = ctx->ahead_last;
         l.dt = dt, l.A = A, l.n = n, l.seed = seed, l.n_planes = n_planes, l.step0 = step;
@@ -5010,12 +5038,16 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
     // of them, and the compaction that has become due meanwhile runs from the committed masks, without a flag sweep of its own.
     int k_ahead = 0;
     bool big = false;
-    if (!compact_now && repeat && ahead_k() > 0 && ctx->ahead_wait == 0) {
+    if (!compact_now && repeat && ahead_k() > 0 && (ctx->ahead_wait == 0 || known > 1)) {
+        // (a caller that has said how many bodies it wants gets those -- and the usual number when the pattern of the calls
+        // promises more --, never fewer than two, never more than a launch holds or a big store's sweep is worth)
+        const int by_pattern = pattern && ctx->ahead_wait == 0;
         if (slots <= ahead_max_slots()) {
-            k_ahead = ahead_k();
+            k_ahead = by_pattern ? ahead_k() : 0;
+            if (known > 1 && known > k_ahead) k_ahead = known < kAheadMax ? known : kAheadMax;
         } else if (ahead_k_big(slots) > 1 && pend_has_room(ctx, dt)) {
-            k_ahead = ahead_k_big(slots);
-            big = true;
+            k_ahead = by_pattern || known >= ahead_k_big(slots) ? ahead_k_big(slots) : (known > 1 ? known : 0);
+            big = k_ahead > 0;
         }
     }
     if (k_ahead > 0) {
@@ -6551,11 +6583,39 @@ int pcl_step_fused_delete(pcl_ctx *ctx, double dt, double A, double n, int flags
 
 int pcl_step_fused_delete_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double n, uint64_t seed, uint32_t step0,
                                 const double *planes_host, int n_planes, int64_t *out_host) {
-    PCL_TRY(need_store_raw(ctx));
+    PCL_TRY(need_store_raw(ctx, true)); // (bodies worked out ahead stay: they may be this call's)
     if (k_steps < 1 || k_steps > PCL_MULTI_MAX) return fail(PCL_ERR_ARG, "k_steps outside [1, %d]", PCL_MULTI_MAX);
     if (n_planes < -1 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [-1, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
+    // An all-photon store takes the path of the single calls, body by body, with the number of bodies still to come as a
+    // promise: one k_delete_ahead(_live) launch works out as many as a launch holds and the rest of them are answered from
+    // its rows -- the same sweeps a loop of pcl_step_fused_delete calls gets, without the calls.  (PCL_MULTI_AHEAD=0: the
+    // K-step flag kernel + compaction below, which stores with kind bytes always take.)
+    static knob k_via("PCL_MULTI_AHEAD");
+    static const bool onepass = getenv("PCL_ONEPASS") != nullptr;
+    if (!ctx->kind && alive_enabled() && ahead_k() > 0 && !k_via.off() && !onepass) {
+        const int np = n_planes > 0 ? n_planes : 0;
+        if (out_host)
+            for (int k = 0; k < k_steps * (5 + np); ++k) out_host[k] = 0;
+        for (int k = 0; k < k_steps && ctx->count > 0; ++k) {
+            const int64_t before = ctx->count;
+            int64_t alive = 0;
+            ctx->lazy_dr = ctx->lazy_dr_vprev = false; // an implicit dr is superseded by this body's move
+            PCL_TRY(fused_delete_alive(ctx, dt, A, n, seed, step0 + (uint32_t)k, planes_host, n_planes, &alive, k_steps - k));
+            ctx->lazy_dr = true; // dr = v*dt with the (unchanged) velocities of the survivors
+            ctx->lazy_dt = dt;
+            if (out_host) {
+                int64_t *o = out_host + (int64_t)k * (5 + np);
+                o[0] = alive;
+                if (n_planes >= 0)
+                    for (int j = 0; j < 3 + np; ++j) o[1 + j] = (int64_t)ctx->h_cnt[1 + j];
+                o[4 + np] = before - alive;
+            }
+        }
+        return PCL_OK;
+    }
+    PCL_TRY(ahead_commit(ctx));
     PCL_TRY(densify(ctx));
     const int64_t N = ctx->count;
     const int np = n_planes > 0 ? n_planes : 0, nslots = 4 + np;

@@ -40,6 +40,7 @@ DELETE_KNOBS = [
     ("any_size-flush_kernel-no_poll", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_FLUSH_KERNEL": "1", "PCL_ALIVE_POLL": "0"}),
     ("any_size-ratio_0.95", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}),         # nearly every body compacts
     ("alive_off", {"PCL_ALIVE": "0"}),                                                         # the round-2 pipeline
+    ("multi_flag_kernel", {"PCL_MULTI_AHEAD": "0"}),            # K-body calls: the K-step flag kernel + compaction, as stores with kinds
     # k_compact_count takes every wave's survivors one by one (its form for sparse waves), whatever their number
     ("any_size-compact_survivor_major", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_COMPACT_SPARSE": "512"}),
 ]
@@ -50,7 +51,7 @@ AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "
                # every store takes the big stores' form: few bodies per launch, r left behind at the commit, compaction from the
                # committed masks
                ("ahead_big_form", {"PCL_AHEAD_MAX_SLOTS": "0", "PCL_ALIVE_MIN_SLOTS": "0"})]
-AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py"}
+AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py", "test_gpu_multi.py"}
 KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
                # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's
                # photons start at the origin and fly out of exp's range), never

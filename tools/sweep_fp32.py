@@ -24,13 +24,18 @@ def run(dev, N, dtype, K, sample, per_launch):
     """per_launch > 1: that many whole iterations per pass over the store and one compaction (pcl_step_mixed_multi);
     1: one launch per light step (pcl_step_fused + pcl_step_fused_delete, dr/dv implicit).  Same photons, same rows."""
     dev.store_alloc(N, dtype)
+    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=_hip.RNG_PHILOX, seed=11)
+    # one untimed iteration first: the store's second slab (the compaction's destination) is allocated on first use, and
+    # after a change of precision that is a multi-GB hipMalloc (0.19 s in some runs) -- set-up, not the path; then the
+    # photons are created again
+    dev.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, 11)
+    dev.step_mixed_multi(1e-3, 1, ("iso", "delete"), sc, (2e-5, 1e-3), (), 11, 2)
     dev.fill_photons(N, 0, C_LIT, 2.84e-19, 9.93e-19, 11)
     out = {}
     dev.sync()
     t0 = time.perf_counter()
     hits = deleted = work = 0
     alive = N
-    sc = dict(A=1e-3, n=1e-3, flags=0, c=C_LIT, h=H_LIT, rng_mode=_hip.RNG_PHILOX, seed=11)
     k = 0
     for stop in (1, 10, 100, K):
         while k < min(stop, K):
