@@ -40,7 +40,6 @@ DELETE_KNOBS = [
     ("any_size-flush_kernel-no_poll", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_FLUSH_KERNEL": "1", "PCL_ALIVE_POLL": "0"}),
     ("any_size-ratio_0.95", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_ALIVE_RATIO": "0.95"}),         # nearly every body compacts
     ("alive_off", {"PCL_ALIVE": "0"}),                                                         # the round-2 pipeline
-    ("multi_flag_kernel", {"PCL_MULTI_AHEAD": "0"}),            # K-body calls: the K-step flag kernel + compaction, as stores with kinds
     # k_compact_count takes every wave's survivors one by one (its form for sparse waves), whatever their number
     ("any_size-compact_survivor_major", {"PCL_ALIVE_MIN_SLOTS": "0", "PCL_COMPACT_SPARSE": "512"}),
 ]
@@ -51,6 +50,9 @@ AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "
                # every store takes the big stores' form: few bodies per launch, r left behind at the commit, compaction from the
                # committed masks
                ("ahead_big_form", {"PCL_AHEAD_MAX_SLOTS": "0", "PCL_ALIVE_MIN_SLOTS": "0"})]
+# K-body calls on the K-step flag kernel + compaction (what stores with kinds always take): the files with such calls
+MULTI_AHEAD_KNOBS = [("multi_flag_kernel", {"PCL_MULTI_AHEAD": "0"})]
+MULTI_AHEAD_FILES = {"test_gpu_multi.py", "test_gpu_simulation.py", "test_gpu_random_programs.py"}
 AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py", "test_gpu_multi.py"}
 KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
                # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's
@@ -68,7 +70,9 @@ def pytest_generate_tests(metafunc):
     node = (fname + "::" + metafunc.function.__name__).lower()
     sets = []
     if fname in DELETE_FILES and re.search("delete|random|mixed|program", node):
-        sets += DELETE_KNOBS + (AHEAD_KNOBS if fname in AHEAD_FILES else [])
+        # (the mixed K-pass kernel has its own delete phase: of the single calls' knobs it only meets the compaction's)
+        sets += [k for k in DELETE_KNOBS if fname != "test_gpu_mixed.py" or "flush_kernel" not in k[0]]
+        sets += (AHEAD_KNOBS if fname in AHEAD_FILES else []) + (MULTI_AHEAD_KNOBS if fname in MULTI_AHEAD_FILES else [])
     if fname in KSTEP_FILES and "photons_per_wave" not in node:
         sets += KSTEP_KNOBS
     if sets:
