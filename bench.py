@@ -363,6 +363,28 @@ def pmc_traffic(kernel, units):
             "source": rec["source"], "measured_at_commit": rec.get("commit"), "note": "committed rocprofv3 --pmc run, not this process"}
 
 
+def ahead_valu_roofline(work, kern_ms):
+    """VALU-issue roofline of k_delete_ahead_live over the launches of one run: wave-instructions = the kernel's own tally
+    (groups of 128 slots loaded, rounds of 64 listed photons deciding two bodies / one body: pcl_store_ahead_work) x the
+    three instruction counts of profiles/isa_counts.json ("k_delete_ahead_live<double>": least squares of SQ_INSTS_VALU on
+    that tally over eight launches, residuals < 0.5 %, profiles/r04_calib_ahead.md) / the launches' duration (HIP events)."""
+    c = _json_file("isa_counts.json").get("k_delete_ahead_live<double>")
+    if not c or not kern_ms or not sum(work):
+        return None
+    groups, r2, r1 = work
+    instr = c["valu_per_group_loaded"] * groups + c["valu_per_round_two_bodies"] * r2 + c["valu_per_round_one_body"] * r1
+    ach = instr / (kern_ms * 1e-3)
+    return {"bound": "valu", "kernel": "k_delete_ahead_live (the run's loop bodies worked out a launch at a time for the photons still alive)",
+            "achieved": ach, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": ach / VALU_PEAK, "wave_instructions": instr,
+            "work": {"groups_of_128_slots_loaded": groups, "rounds_two_bodies": r2, "rounds_one_body": r1},
+            "instruction_counts": {k: c[k] for k in ("valu_per_group_loaded", "valu_per_round_two_bodies", "valu_per_round_one_body")},
+            "instruction_counts_source": c["source"], "total_ms": kern_ms,
+            "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+            "traffic": pmc_traffic("k_delete_ahead_live<double>", groups * 128),
+            "hbm": {"achieved": 33.0 * groups * 128 / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": 33.0 * groups * 128 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_slot": 33.0}}
+
+
 def valu_roofline(work, kern_ms, expr, f32):
     """VALU-issue roofline of the K-step pass over a set of launches.  ``work``: per launch (steps, hits, dense passes,
     wave-steps, photons per wave) as the kernel tallied them; ``kern_ms``: the sum of those launches' durations (HIP
@@ -650,6 +672,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 dev.fill_photons(N, 0, C_LIT, 1.0, 1.0, seed)
                 dev.prof_enable(rep == repeats + 1)
                 dev.sync()
+                aw0 = dev.ahead_work()
                 t0 = time.perf_counter()
                 work, per_step, k = 0, [], 0
                 nb = sb = N                                   # alive photons / slots of the store (dense after the fill)
@@ -680,6 +703,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                     how = []
                 if rep == repeats + 1:
                     kern = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
+                    ahead_work = [b - a for a, b in zip(aw0, dev.ahead_work())]
                     instrumented_ms = el * 1e3
                     dev.prof_enable(False)
                 elif rep:
@@ -729,11 +753,19 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 r["bodies_answered_by"] = dict(answered, note="kernel: one k_delete_alive launch (or flag + scan + compaction); ahead_launch: "
                                                "one k_delete_ahead launch worked out this body and the next ones; ahead: answered from those "
                                                "rows, no launch (the commit behind the last of them also runs the compaction that has become due)")
-                r["roofline"] = {"bound": "hbm", "kernel": "k_delete_alive (one loop body on the alive mask: Newton + delete flag + counters, nothing moves)",
+                alive_rec = {"bound": "hbm", "kernel": "k_delete_alive (one loop body on the alive mask: Newton + delete flag + counters, nothing moves)",
                                  "achieved": g1, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": g1 / HBM_PEAK_GBPS,
                                  "traffic": pmc_traffic("k_delete_alive<double, true>", slots_swept),
                                  "algorithmic_bytes": b1, "total_ms": p1_ms, "slots_swept": slots_swept, "alive_particle_steps": tot,
                                  "bytes_per_alive_particle_step": (b1 + b2 + b3) / tot if tot else 0.0}
+                # the record of the kernel that does the run's work: k_delete_ahead_live when the bodies are worked out ahead (its
+                # VALU roofline, from the kernel's own tally; k_delete_alive then sweeps next to nothing and keeps its figures as
+                # "roofline_alive"), k_delete_alive otherwise
+                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"])
+                if va:
+                    r["roofline"], r["roofline_alive"] = va, alive_rec
+                else:
+                    r["roofline"] = alive_rec
                 r["ahead"] = {"kernel": "k_delete_ahead_live (the next loop bodies worked out in ONE sweep of the extent -- 24 for stores of <= 2^22 "
                                         "slots, 16 up to 2^25, 12 above --, answered call by call from the rows; the store is only written at the "
                                         "commit; the kernel lists the photons still alive per 256 slots, so a body costs what they cost)",
@@ -759,6 +791,9 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                             "compactions_of_1e7_slots_or_more": big}
             else:
                 r["steps_per_launch"] = K
+                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"])   # (K-body calls on an all-photon store
+                if va:                                                                      # take the single calls' path)
+                    r["roofline"] = va
             rec[mode] = r
         hip.set_knob("PCL_AHEAD", None)
         out["sizes"]["%.0e" % N] = rec

@@ -59,6 +59,7 @@ _PROTOTYPES = {
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
     "pcl_store_last_multi_hist": [_vp, _vp],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
+    "pcl_store_ahead_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
     "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
@@ -440,6 +441,13 @@ class Device:
         """(launches, bodies answered, launches not used up) of the delete bodies worked out ahead (pcl_store_ahead_stats)."""
         a, b, c = c_int64(), c_int64(), c_int64()
         check(self.lib.pcl_store_ahead_stats(self.ctx, byref(a), byref(b), byref(c)))
+        return a.value, b.value, c.value
+
+    def ahead_work(self):
+        """(groups of 128 slots loaded, rounds deciding two bodies, rounds deciding one) summed over the k_delete_ahead_live
+        launches of this context, as the kernel tallied them (pcl_store_ahead_work)."""
+        a, b, c = c_int64(), c_int64(), c_int64()
+        check(self.lib.pcl_store_ahead_work(self.ctx, byref(a), byref(b), byref(c)))
         return a.value, b.value, c.value
 
     def reserve_compaction(self):

@@ -943,6 +943,8 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
 //   the ordinary way.  Same operations per photon as k_delete_alive (tests/test_gpu_alive_mask.py runs both).
 constexpr int kAheadMax = 32;                       // bodies per launch, at most
 constexpr int kAheadRow = 4 + PCL_MAX_PLANES;       // counters per body: alive, sign x 3, planes
+constexpr int kAheadWork = 3;                       // k_delete_ahead_live's own work tally: groups loaded, rounds of two bodies, of one
+constexpr int kAheadAcc = 1 + kAheadMax * kAheadRow + kAheadWork; // device accumulators: ticket, rows, work; pinned block: rows, sequence word, work
 template <typename T>
 struct ahead_args {
     const T *v[3];
@@ -950,8 +952,8 @@ struct ahead_args {
     const int64_t *ids;
     const uint64_t *masks;      // alive bits before the first body (unless fresh)
     uint8_t *death;
-    unsigned long long *acc;    // device accumulators: [0] ticket, [1 + k * kAheadRow + c]
-    uint64_t *host;             // pinned: [k * kAheadRow + c]; [kAheadMax * kAheadRow] = the launch's sequence number
+    unsigned long long *acc;    // device accumulators: [0] ticket, [1 + k * kAheadRow + c], [1 + kAheadMax * kAheadRow + i] work tally
+    uint64_t *host;             // pinned: [k * kAheadRow + c]; [kAheadMax * kAheadRow] = the launch's sequence number, then the work tally
     int64_t id_base, slots, ts;
     T dt, An;
     T pend_dt[kPendMax];
@@ -1204,6 +1206,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     constexpr int kBatch = kGroups * 128;
     __shared__ uint32_t s_cnt[kAheadMax * kAheadRow];
     __shared__ int s_last;
+    __shared__ uint32_t s_work[kAheadWork];
     __shared__ uint64_t s_id[kBlock / 64][kBatch];
     __shared__ thr_t s_pc[kBlock / 64][kBatch]; // the collision probability as the largest draw that removes (ahead_draw)
     __shared__ T s_xp[kBlock / 64][kBatch], s_dp[kBlock / 64][kBatch];
@@ -1211,6 +1214,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     __shared__ uint8_t s_death[kBlock / 64][kBatch];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int q = threadIdx.x; q < kAheadMax * kAheadRow; q += kBlock) s_cnt[q] = 0;
+    if (threadIdx.x < kAheadWork) s_work[threadIdx.x] = 0;
     __syncthreads();
     const bool hi = lane >= 32;
     const int bit = 2 * (lane & 31);
@@ -1220,6 +1224,9 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     const int ax0 = has_plane ? a.plane_ax[0] : 0;
     const T L0 = has_plane ? a.plane_L[0] : (T)0;
     uint32_t t_kept = 0, t_s[3] = {0, 0, 0}, t_p0 = 0; // lane b: this wave's sums of body b (alive, sign counts, the plane)
+    // what this wave did, for the VALU roofline of the launch (wave-uniform: scalar adds): groups of 128 slots it loaded, rounds
+    // of 64 listed photons deciding two bodies, rounds deciding one (pcl_store_ahead_work)
+    uint32_t w_groups = 0, w_rounds2 = 0, w_rounds1 = 0;
     // one body's row from the photons of a round that it leaves alive (``s``): into lane b's accumulators
     auto tally = [&](int b, bool s, uint32_t ix, bool cross) {
         const bool mine = lane == b;
@@ -1260,6 +1267,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                 uchar2 d0;
                 d0.x = d0.y = 0;
                 if ((m_lo | m_hi) != 0ull) { // (wave-uniform)
+                    ++w_groups;
                     const uint64_t mm = hi ? m_hi : m_lo;
                     const bool al[2] = {(bool)((mm >> bit) & 1ull), (bool)((mm >> (bit + 1)) & 1ull)};
                     const int64_t ti = pcl_tix(i, a.ts);
@@ -1319,6 +1327,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                 const bool two = !single && b + 1 < a.K;
                 uint32_t w = 0;
                 for (uint32_t r0 = 0; r0 < n_list; r0 += 64) {
+                    if (two) ++w_rounds2; else ++w_rounds1;
                     const uint32_t j = r0 + (uint32_t)lane;
                     const bool on = j < n_list;
                     const uint64_t id = on ? s_id[wave][j] : 0ull;
@@ -1364,6 +1373,11 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
             *reinterpret_cast<uint32_t *>(a.death + i0 + 4 * lane) = *reinterpret_cast<const uint32_t *>(&s_death[wave][4 * lane]);
         }
     }
+    if (lane == 0) {
+        atomicAdd(&s_work[0], w_groups);
+        atomicAdd(&s_work[1], w_rounds2);
+        atomicAdd(&s_work[2], w_rounds1);
+    }
     if (lane < a.K) { // the wave's sums join the workgroup's
         if (t_kept) atomicAdd(&s_cnt[lane * kAheadRow + 0], t_kept);
 #pragma unroll
@@ -1378,6 +1392,9 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
         if ((q % kAheadRow) < nrow && s_cnt[q])
             seen += __hip_atomic_fetch_add(&a.acc[1 + q], (unsigned long long)s_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < kAheadWork && s_work[threadIdx.x])
+        seen += __hip_atomic_fetch_add(&a.acc[1 + kAheadMax * kAheadRow + threadIdx.x], (unsigned long long)s_work[threadIdx.x], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("" ::"v"(seen) : "memory");
     __syncthreads();
     if (threadIdx.x == 0)
@@ -1387,6 +1404,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     volatile uint64_t *h = a.host;
     for (int q = threadIdx.x; q < a.K * kAheadRow; q += kBlock)
         h[q] = (q % kAheadRow) < nrow ? __hip_atomic_exchange(&a.acc[1 + q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    if (threadIdx.x < kAheadWork)
+        h[kAheadMax * kAheadRow + 1 + threadIdx.x] = __hip_atomic_exchange(&a.acc[1 + kAheadMax * kAheadRow + threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2873,6 +2892,7 @@ struct pcl_ctx {
     uint64_t *ahead_host = nullptr;          // pinned rows + sequence word
     uint64_t ahead_seq = 0;
     int64_t ahead_launches = 0, ahead_served = 0, ahead_missed = 0; // statistics (pcl_store_ahead_stats)
+    int64_t ahead_work[3] = {0, 0, 0};       // k_delete_ahead_live's own tally, summed over its launches (pcl_store_ahead_work)
     int ahead_wait = 0, ahead_backoff = 0;   // bodies to run the plain way before the next attempt / the last such pause (doubles per
                                              // launch that was cut short: a loop that looks at the store between its bodies)
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
@@ -4722,7 +4742,7 @@ int compact_alive_t(pcl_ctx *ctx, int dv_mode, bool move, double dt, const doubl
 // after a failed launch: ticket and sums of k_delete_alive / k_delete_ahead back to zero (best effort, on the stream)
 void reset_alive_acc(pcl_ctx *ctx) {
     (void)hipMemsetAsync(ctx->d_cnt + kCounterSlots, 0, (size_t)kAccSlots * sizeof(uint64_t), ctx->stream);
-    if (ctx->ahead_acc) (void)hipMemsetAsync(ctx->ahead_acc, 0, (size_t)(1 + kAheadMax * kAheadRow) * sizeof(unsigned long long), ctx->stream);
+    if (ctx->ahead_acc) (void)hipMemsetAsync(ctx->ahead_acc, 0, (size_t)kAheadAcc * sizeof(unsigned long long), ctx->stream);
 }
 
 int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out);
@@ -4829,6 +4849,7 @@ int ahead_launch_t(pcl_ctx *ctx) {
     const int64_t grid = div_up(n_tiles, div_up(n_tiles, cap));
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_AHEAD);
     static knob k_live("PCL_AHEAD_LIVE"); // 0: always the slot-per-lane kernel
+    for (int i = 0; i < kAheadWork; ++i) ctx->ahead_host[kAheadMax * kAheadRow + 1 + i] = 0; // (only the live kernel tallies its work)
     if (a.n_planes <= 1 && !k_live.off())
         hipLaunchKernelGGL(k_delete_ahead_live<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     else
@@ -4932,7 +4953,7 @@ int ahead_serve(pcl_ctx *ctx, int64_t *alive_out) {
 
 int ahead_resources(pcl_ctx *ctx, int64_t slots) {
     if (!ctx->ahead_acc) {
-        const size_t n = (size_t)(1 + kAheadMax * kAheadRow);
+        const size_t n = (size_t)kAheadAcc;
         PCL_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->ahead_acc), n * sizeof(unsigned long long)));
         PCL_HIP(hipMemsetAsync(ctx->ahead_acc, 0, n * sizeof(unsigned long long), ctx->stream));
         PCL_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->ahead_host), n * sizeof(uint64_t)));
@@ -5062,6 +5083,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         sp.fresh = fresh;
         PCL_TRY(PCL_DISPATCH(ctx, ahead_launch_t<double>(ctx), ahead_launch_t<float>(ctx)));
         PCL_TRY(ahead_wait(ctx));
+        for (int i = 0; i < kAheadWork; ++i) ctx->ahead_work[i] += (int64_t)ctx->ahead_host[kAheadMax * kAheadRow + 1 + i];
         sp.active = true;
         ++ctx->ahead_launches;
         return ahead_serve(ctx, alive_out);
@@ -5421,6 +5443,14 @@ int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_o
     if (launches_out) *launches_out = ctx->ahead_launches;
     if (served_out) *served_out = ctx->ahead_served;
     if (missed_out) *missed_out = ctx->ahead_missed;
+    return PCL_OK;
+}
+
+int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_out, int64_t *rounds_two_out, int64_t *rounds_one_out) {
+    if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
+    if (groups_out) *groups_out = ctx->ahead_work[0];
+    if (rounds_two_out) *rounds_two_out = ctx->ahead_work[1];
+    if (rounds_one_out) *rounds_one_out = ctx->ahead_work[2];
     return PCL_OK;
 }
 

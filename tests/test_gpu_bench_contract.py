@@ -78,6 +78,16 @@ def test_bench_line_has_the_contract_keys(extra):
             assert rec["per_step"]["ahead"]["launches"] >= 1 and rec["per_step"]["ahead"]["achieved_GBps"] > 0
             by = rec["per_step"]["bodies_answered_by"]
             assert by["kernel"] + by["ahead_launch"] + by["ahead"] == rec["per_step"]["loop_bodies"] and by["ahead"] > by["ahead_launch"] >= 1
+            # the run's own record is the kernel that did its work: k_delete_ahead_live, priced by its own tally
+            for mode in ("per_step", "multi"):
+                v = rec[mode]["roofline"]
+                assert v["bound"] == "valu" and v["unit"] == "wave-instr/s" and v["peak"] == 1024 * 2.4e9 / 4 and 0 < v["frac"] < 1.2
+                w, c = v["work"], v["instruction_counts"]
+                instr = (c["valu_per_group_loaded"] * w["groups_of_128_slots_loaded"] + c["valu_per_round_two_bodies"] * w["rounds_two_bodies"]
+                         + c["valu_per_round_one_body"] * w["rounds_one_body"])
+                assert abs(instr - v["wave_instructions"]) <= 1e-9 * instr and abs(v["achieved"] - instr / (v["total_ms"] * 1e-3)) <= 1e-6 * v["achieved"]
+                assert w["groups_of_128_slots_loaded"] >= 30000 // 128 and w["rounds_two_bodies"] >= w["groups_of_128_slots_loaded"] // 2
+            assert rec["per_step"]["roofline_alive"]["bound"] == "hbm"
         assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
         # the constructor as a reference script calls it takes the K-pass launches by itself
         assert d["api"]["default"]["steps"] == 6 and d["api"]["default"]["schedule"] == {"fused_multi": 1} and d["api"]["default"]["note"] is None

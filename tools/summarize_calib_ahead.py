@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Fit of k_delete_ahead_live's VALU instruction counts to its own work tally: SQ_INSTS_VALU of each launch of
+tools/calib_ahead.py (gpurun_out/prof_calib_ahead, tools/prof_calib_ahead.sh) = a x groups + b x rounds_two + c x rounds_one
+(least squares over the cases).  Writes the three counts and the fit's residuals into profiles/isa_counts.json under
+"k_delete_ahead_live<double>" and prints the table (profiles/r04_calib_ahead.md)."""
+import csv
+import glob
+import json
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    cases = [json.loads(ln) for ln in open(os.path.join(ROOT, "gpurun_out", "calib_ahead.jsonl")) if ln.strip().startswith("{")]
+    f = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_calib_ahead", "**", "pmc_counter_collection.csv"), recursive=True)[0]
+    per = {}
+    for r in csv.DictReader(open(f)):
+        if "k_delete_ahead_live" not in r["Kernel_Name"] or int(r["Grid_Size"]) < 4_000_000:
+            continue
+        d = per.setdefault(int(r["Dispatch_Id"]), {})
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    disp = [per[k] for k in sorted(per)]
+    assert len(disp) == len(cases), (len(disp), len(cases))
+    A = np.array([[c["groups"], c["rounds_two"], c["rounds_one"]] for c in cases], dtype=np.float64)
+    y = np.array([d["SQ_INSTS_VALU"] for d in disp])
+    coef, *_ = np.linalg.lstsq(A, y, rcond=None)
+    fit = A @ coef
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    L = ["# `k_delete_ahead_live<double>`: VALU wave-instructions against the kernel's own work tally", "",
+         "One launch per case on a fresh store of 1e8 photons (`tools/calib_ahead.py` under `rocprofv3 --pmc SQ_INSTS_VALU`, commit %s)." % commit,
+         "Model: SQ_INSTS_VALU = a x groups of 128 slots loaded + b x rounds of 64 listed photons deciding two bodies + c x rounds deciding one;",
+         "least squares over the cases: **a = %.1f, b = %.1f, c = %.1f** wave-instructions." % tuple(coef), "",
+         "| K | first step | groups | rounds (two bodies) | rounds (one body) | SQ_INSTS_VALU | model | model / measured | SQ_INSTS_SALU | duration ms (GRBM / 8 / 2.4 GHz) |",
+         "|---|---|---|---|---|---|---|---|---|---|"]
+    for c, d, m in zip(cases, disp, fit):
+        L.append("| %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f |" % (
+            c["K"], c["step0"], c["groups"], c["rounds_two"], c["rounds_one"], d["SQ_INSTS_VALU"], m, m / d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0),
+            d.get("GRBM_GUI_ACTIVE", 0) / 8 / 2.4e9 * 1e3))
+    L += ["", "VALU issue peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 6.144e11 wave-instructions/s; the twelve-body launch: "
+          "%.3g / %.3f ms = %.3g = %.2f of it." % (y[3], disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9 * 1e3, y[3] / (disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9),
+                                                   y[3] / (disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9) / 6.144e11)]
+    open(os.path.join(ROOT, "profiles", "r04_calib_ahead.md"), "w").write("\n".join(L) + "\n")
+    print("\n".join(L))
+    p = os.path.join(ROOT, "profiles", "isa_counts.json")
+    j = json.load(open(p))
+    j["k_delete_ahead_live<double>"] = {"valu_per_group_loaded": round(float(coef[0]), 1), "valu_per_round_two_bodies": round(float(coef[1]), 1),
+                                        "valu_per_round_one_body": round(float(coef[2]), 1), "max_relative_residual": round(float(np.max(np.abs(fit / y - 1))), 4),
+                                        "source": "profiles/r04_calib_ahead.md (SQ_INSTS_VALU of 8 launches, least squares on the kernel's own tally)", "commit": commit}
+    json.dump(j, open(p, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
