@@ -286,12 +286,18 @@ def main():
     for size, rec in dl.items():
         p = rec["per_step"]
         L.append("")
+        pa = p.get("roofline_alive", p["roofline"])        # (k_delete_alive's record; "roofline" is k_delete_ahead_live's when it ran)
         L.append("`delete` %s photons under the profiler, per_step: %.4g particle-steps/s in %d loop bodies (%d of them compact); "
                  "`k_delete_alive` %.0f GB/s on the slots it sweeps = %.3f of peak, the compactions %.0f GB/s = %.3f; %.1f B per alive "
                  "particle-step; multi (K = %d): %.4g particle-steps/s."
-                 % (size, p["value"], p["loop_bodies"], p["roofline_compaction"]["compactions"], p["roofline"]["achieved"], p["roofline"]["frac"],
-                    p["roofline_compaction"]["achieved"], p["roofline_compaction"]["frac"], p["roofline"]["bytes_per_alive_particle_step"],
+                 % (size, p["value"], p["loop_bodies"], p["roofline_compaction"]["compactions"], pa["achieved"], pa["frac"],
+                    p["roofline_compaction"]["achieved"], p["roofline_compaction"]["frac"], pa["bytes_per_alive_particle_step"],
                     rec["multi"]["steps_per_launch"], rec["multi"]["value"]))
+        for mode in ("per_step", "multi"):
+            v = rec[mode].get("roofline") or {}
+            if v.get("bound") == "valu":
+                L.append("  `%s`: `k_delete_ahead_live` %.4g wave-instructions (its own tally x profiles/isa_counts.json) in %.3f ms = %.3g / s = **%.3f** of "
+                         "the VALU issue peak; 33 B per slot = %.0f GB/s." % (mode, v["wave_instructions"], v["total_ms"], v["achieved"], v["frac"], v["hbm"]["achieved"]))
     L += ["", "## All kernels of the trace pass (count, total ms)", "", "| kernel | dispatches | total ms | avg ms |", "|---|---|---|---|"]
     for k in sorted(disp, key=lambda k: -sum(disp[k])):
         L.append("| `%s` | %d | %.3f | %.4f |" % (k, len(disp[k]), sum(disp[k]) * 1e-6, sum(disp[k]) / len(disp[k]) * 1e-6))
