@@ -281,3 +281,59 @@ def test_bodies_worked_out_ahead_change_nothing_but_the_number_of_launches(name,
                 assert np.array_equal(s0[f][k], sx[f][k]), (f, k)
     if name == "until_empty":
         assert rows1[-1][0] == 0 and len(s1["id"]) == 0
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("K,planes", [(5, PL1), (40, PL1), (64, None), (17, PL3)])
+def test_a_k_body_call_takes_the_single_calls_path_with_k_as_a_promise(K, planes, dtype):
+    """pcl_step_fused_delete_multi on an all-photon store: the bodies one by one through pcl_step_fused_delete's code, the
+    number still to come handed to it as a promise -- one k_delete_ahead(_live) launch per as many bodies as a launch holds
+    (never a launch per body, never a pause), the rest answered from its rows.  Rows and final state equal K single calls
+    with the bodies-ahead path off, and the K-step flag kernel (PCL_MULTI_AHEAD=0) -- bit for bit; two such calls in a row
+    continue each other; the kernel's work tally (pcl_store_ahead_work) covers every alive slot once per launch."""
+    from physicl_amd import _hip as hip
+    N, dt, pdel, seed = 200_003, 1e-3, 0.2, 33
+    A = pdel / (1e-3 * C_LIT * dt)
+
+    def run(how):
+        with hip.Device(0) as d:
+            d.store_alloc(N, dtype)
+            d.fill_photons(N, 5, C_LIT, 1.0, 2.0, seed)
+            rows = []
+            if how == "single":
+                for k in range(2 * K):
+                    o = d.step_fused_delete(dt, A, 1e-3, hip.RNG_PHILOX, seed, 3 + k, planes, lazy=True)   # (odd first step)
+                    rows.append(device_row(o) if planes is not None else [o["N"], o["removed"]])
+            else:
+                for call in range(2):
+                    for o in d.step_fused_delete_multi(dt, K, A, 1e-3, seed, 3 + call * K, planes):
+                        rows.append(device_row(o) if planes is not None else [o["N"], o["removed"]])
+            stats, work = d.ahead_stats(), d.ahead_work()
+            return rows, d.download_state(), stats, work
+
+    try:
+        hip.set_knob("PCL_AHEAD", "0")
+        rows0, s0, st0, _ = run("single")
+        hip.set_knob("PCL_AHEAD", None)
+        rows1, s1, st1, w1 = run("multi")
+        hip.set_knob("PCL_MULTI_AHEAD", "0")
+        rows2, s2, st2, _ = run("multi")
+    finally:
+        hip.set_knob("PCL_AHEAD", None)
+        hip.set_knob("PCL_MULTI_AHEAD", None)
+    assert rows0 == rows1 == rows2
+    for sx in (s1, s2):
+        assert np.array_equal(s0["id"], sx["id"]) and np.array_equal(s0["E"], sx["E"])
+        for f in ("r", "v", "dr", "dv"):
+            for k in range(3):
+                assert np.array_equal(s0[f][k], sx[f][k]), (f, k)
+    bodies = len([r for r in rows1 if r[0] + r[1] > 0])                     # bodies that found photons
+    launches, served, missed = st1
+    assert st0 == (0, 0, 0) and st2 == (0, 0, 0)
+    # (a body that finds the store sparse enough to compact runs the plain way: at most a few of a run)
+    assert bodies - 3 <= served <= bodies and 1 <= launches <= -(-bodies // min(K, 24)) + 2, (st1, bodies)
+    if planes is None or len(planes) <= 1:                                  # (more planes: k_delete_ahead, which keeps no tally)
+        groups, r2, r1 = w1
+        assert groups >= -(-N // 128) and r2 + r1 >= groups // 2 and r1 >= 1   # first launch: every slot; the odd first step: rounds of one body
+    else:
+        assert w1 == (0, 0, 0)
