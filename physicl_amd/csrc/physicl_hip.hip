@@ -1196,7 +1196,9 @@ template <> struct ahead_draw<float> {
 //   per round -- all lanes busy --, counts the round's survivors into those bodies' rows right there and writes them back
 //   to the front of the list (in place: a round writes no further than it has read).  Same operations per photon, same
 //   rows, same death bytes (tests run both kernels: PCL_AHEAD_LIVE).
-template <typename T>
+// IDS: the store's ids are an array (a listed photon's id travels in LDS); false: implicit, id = id_base + slot -- no id
+// array in LDS, and a fifth workgroup per CU (a population's first launches, the ones that sweep the whole extent)
+template <typename T, bool IDS>
 __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     typedef pcl_rt<T> R;
     typedef typename std::conditional<sizeof(T) == 8, double2, float2>::type T2;
@@ -1207,7 +1209,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     __shared__ uint32_t s_cnt[kAheadMax * kAheadRow];
     __shared__ int s_last;
     __shared__ uint32_t s_work[kAheadWork];
-    __shared__ uint64_t s_id[kBlock / 64][kBatch];
+    __shared__ uint64_t s_id[kBlock / 64][IDS ? kBatch : 1];
     __shared__ thr_t s_pc[kBlock / 64][kBatch]; // the collision probability as the largest draw that removes (ahead_draw)
     __shared__ T s_xp[kBlock / 64][kBatch], s_dp[kBlock / 64][kBatch];
     __shared__ uint16_t s_ix[kBlock / 64][kBatch]; // place in the batch (8 bits), velocity signs (bits 8-10)
@@ -1304,7 +1306,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                         const uint64_t bal = __ballot(al[e]);
                         if (al[e]) {
                             const uint32_t pos = n_list + (uint32_t)__popcll(bal & below);
-                            s_id[wave][pos] = id[e];
+                            if constexpr (IDS) s_id[wave][pos] = id[e];
                             s_pc[wave][pos] = D::threshold(pcoll);
                             s_xp[wave][pos] = x;
                             s_dp[wave][pos] = pcl_pick<T>(ax0, dd[0], dd[1], dd[2]);
@@ -1330,11 +1332,15 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                     if (two) ++w_rounds2; else ++w_rounds1;
                     const uint32_t j = r0 + (uint32_t)lane;
                     const bool on = j < n_list;
-                    const uint64_t id = on ? s_id[wave][j] : 0ull;
                     const thr_t pc = on ? s_pc[wave][j] : (thr_t)-1;
                     T xp = on ? s_xp[wave][j] : (T)0;
                     const T dp = on ? s_dp[wave][j] : (T)0;
                     const uint32_t ix = on ? (uint32_t)s_ix[wave][j] : 0u;
+                    uint64_t id;
+                    if constexpr (IDS)
+                        id = on ? s_id[wave][j] : 0ull;
+                    else
+                        id = (uint64_t)(a.id_base + i0 + (int64_t)(ix & 0xFFu));
                     const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
                     const thr_t m_first = single ? D::draw(wd.z, wd.w) : D::draw(wd.x, wd.y);
                     const bool s0 = on && !(m_first <= pc); // alive after body b                                                  light.py:243
@@ -1354,7 +1360,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                     const uint64_t bal = __ballot(left);
                     if (left) {
                         const uint32_t pos = w + (uint32_t)__popcll(bal & below);
-                        s_id[wave][pos] = id;
+                        if constexpr (IDS) s_id[wave][pos] = id;
                         s_pc[wave][pos] = pc;
                         s_xp[wave][pos] = xp;
                         s_dp[wave][pos] = dp;
@@ -4850,8 +4856,10 @@ int ahead_launch_t(pcl_ctx *ctx) {
     const int ps = prof_begin(ctx, PCL_PROF_DELETE_AHEAD);
     static knob k_live("PCL_AHEAD_LIVE"); // 0: always the slot-per-lane kernel
     for (int i = 0; i < kAheadWork; ++i) ctx->ahead_host[kAheadMax * kAheadRow + 1 + i] = 0; // (only the live kernel tallies its work)
-    if (a.n_planes <= 1 && !k_live.off())
-        hipLaunchKernelGGL(k_delete_ahead_live<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    if (a.n_planes <= 1 && !k_live.off() && a.ids)
+        hipLaunchKernelGGL((k_delete_ahead_live<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
+    else if (a.n_planes <= 1 && !k_live.off())
+        hipLaunchKernelGGL((k_delete_ahead_live<T, false>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     else
         hipLaunchKernelGGL(k_delete_ahead<T>, dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     prof_end(ctx, ps);
