@@ -1330,15 +1330,15 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                 uint32_t w = 0;
                 for (uint32_t r0 = 0; r0 < n_list; r0 += 64) {
                     if (two) ++w_rounds2; else ++w_rounds1;
-                    const uint32_t j = r0 + (uint32_t)lane;
+                    const uint32_t j = r0 + (uint32_t)lane;   // (< 256: beyond n_list a stale entry is read -- ``on`` gates every effect)
                     const bool on = j < n_list;
-                    const thr_t pc = on ? s_pc[wave][j] : (thr_t)-1;
-                    T xp = on ? s_xp[wave][j] : (T)0;
-                    const T dp = on ? s_dp[wave][j] : (T)0;
-                    const uint32_t ix = on ? (uint32_t)s_ix[wave][j] : 0u;
+                    const thr_t pc = s_pc[wave][j];
+                    T xp = s_xp[wave][j];
+                    const T dp = s_dp[wave][j];
+                    const uint32_t ix = s_ix[wave][j];
                     uint64_t id;
                     if constexpr (IDS)
-                        id = on ? s_id[wave][j] : 0ull;
+                        id = s_id[wave][j];
                     else
                         id = (uint64_t)(a.id_base + i0 + (int64_t)(ix & 0xFFu));
                     const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));

@@ -23,6 +23,10 @@ def main():
             continue
         d = per.setdefault(int(r["Dispatch_Id"]), {})
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    tr = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_calib_ahead", "**", "pmc_kernel_trace.csv"), recursive=True)[0]
+    for r in csv.DictReader(open(tr)):                 # the launch's duration: the trace's own timestamps (ns)
+        if int(r["Dispatch_Id"]) in per:
+            per[int(r["Dispatch_Id"])]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     disp = [per[k] for k in sorted(per)]
     assert len(disp) == len(cases), (len(disp), len(cases))
     A = np.array([[c["groups"], c["rounds_two"], c["rounds_one"]] for c in cases], dtype=np.float64)
@@ -34,15 +38,14 @@ def main():
          "One launch per case on a fresh store of 1e8 photons (`tools/calib_ahead.py` under `rocprofv3 --pmc SQ_INSTS_VALU`, commit %s)." % commit,
          "Model: SQ_INSTS_VALU = a x groups of 128 slots loaded + b x rounds of 64 listed photons deciding two bodies + c x rounds deciding one;",
          "least squares over the cases: **a = %.1f, b = %.1f, c = %.1f** wave-instructions." % tuple(coef), "",
-         "| K | first step | groups | rounds (two bodies) | rounds (one body) | SQ_INSTS_VALU | model | model / measured | SQ_INSTS_SALU | duration ms (GRBM / 8 / 2.4 GHz) |",
-         "|---|---|---|---|---|---|---|---|---|---|"]
+         "| K | first step | groups | rounds (two bodies) | rounds (one body) | SQ_INSTS_VALU | model | model / measured | SQ_INSTS_SALU | duration ms (trace) | GRBM_GUI_ACTIVE / 8 / duration (GHz) |",
+         "|---|---|---|---|---|---|---|---|---|---|---|"]
     for c, d, m in zip(cases, disp, fit):
-        L.append("| %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f |" % (
+        L.append("| %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f | %.2f |" % (
             c["K"], c["step0"], c["groups"], c["rounds_two"], c["rounds_one"], d["SQ_INSTS_VALU"], m, m / d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0),
-            d.get("GRBM_GUI_ACTIVE", 0) / 8 / 2.4e9 * 1e3))
+            d["ms"], d.get("GRBM_GUI_ACTIVE", 0) / 8 / (d["ms"] * 1e-3) / 1e9))
     L += ["", "VALU issue peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 6.144e11 wave-instructions/s; the twelve-body launch: "
-          "%.3g / %.3f ms = %.3g = %.2f of it." % (y[3], disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9 * 1e3, y[3] / (disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9),
-                                                   y[3] / (disp[3]["GRBM_GUI_ACTIVE"] / 8 / 2.4e9) / 6.144e11)]
+          "%.3g / %.3f ms = %.3g = %.2f of it." % (y[3], disp[3]["ms"], y[3] / (disp[3]["ms"] * 1e-3), y[3] / (disp[3]["ms"] * 1e-3) / 6.144e11)]
     open(os.path.join(ROOT, "profiles", "r04_calib_ahead.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
