@@ -5982,6 +5982,8 @@ int pcl_store_reserve_compaction(pcl_ctx *ctx) {
     PCL_TRY(need_store_raw(ctx));
     if (ctx->holes) return PCL_OK; // (only a store that has already deleted is behind a mask: everything exists)
     PCL_TRY(ensure_scratch(ctx, ctx->capacity));
+    // (... and what the bodies worked out ahead need: a byte per slot, the accumulators, the pinned rows)
+    if (!ctx->kind && alive_enabled() && ahead_k() > 0) PCL_TRY(ahead_resources(ctx, ctx->capacity));
     return ensure_alt(ctx);
 }
 
