@@ -365,19 +365,22 @@ def pmc_traffic(kernel, units):
 
 def ahead_valu_roofline(work, kern_ms):
     """VALU-issue roofline of k_delete_ahead_live over the launches of one run: wave-instructions = the kernel's own tally
-    (groups of 128 slots loaded, rounds of 64 listed photons deciding two bodies / one body: pcl_store_ahead_work) x the
-    three instruction counts of profiles/isa_counts.json ("k_delete_ahead_live<double>": least squares of SQ_INSTS_VALU on
+    (groups of 128 slots loaded -- their first pass decided on the spot, two bodies or one --, rounds of 64 listed photons deciding
+    two bodies / one body: pcl_store_ahead_work) x the four instruction counts of profiles/isa_counts.json ("k_delete_ahead_live<double>": least squares of SQ_INSTS_VALU on
     that tally over eight launches, residuals < 0.5 %, profiles/r04_calib_ahead.md) / the launches' duration (HIP events)."""
     c = _json_file("isa_counts.json").get("k_delete_ahead_live<double>")
     if not c or not kern_ms or not sum(work):
         return None
-    groups, r2, r1 = work
-    instr = c["valu_per_group_loaded"] * groups + c["valu_per_round_two_bodies"] * r2 + c["valu_per_round_one_body"] * r1
+    g2, g1, r2, r1 = work
+    groups = g2 + g1
+    names = ("valu_per_group_first_pass_two_bodies", "valu_per_group_first_pass_one_body", "valu_per_round_two_bodies", "valu_per_round_one_body")
+    instr = sum(c[nm] * w for nm, w in zip(names, work))
     ach = instr / (kern_ms * 1e-3)
     return {"bound": "valu", "kernel": "k_delete_ahead_live (the run's loop bodies worked out a launch at a time for the photons still alive)",
             "achieved": ach, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": ach / VALU_PEAK, "wave_instructions": instr,
-            "work": {"groups_of_128_slots_loaded": groups, "rounds_two_bodies": r2, "rounds_one_body": r1},
-            "instruction_counts": {k: c[k] for k in ("valu_per_group_loaded", "valu_per_round_two_bodies", "valu_per_round_one_body")},
+            "work": {"groups_of_128_slots_first_pass_two_bodies": g2, "groups_of_128_slots_first_pass_one_body": g1, "rounds_two_bodies": r2,
+                     "rounds_one_body": r1},
+            "instruction_counts": {nm: c[nm] for nm in names},
             "instruction_counts_source": c["source"], "total_ms": kern_ms,
             "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
             "traffic": pmc_traffic("k_delete_ahead_live<double>", groups * 128),

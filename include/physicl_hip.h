@@ -251,10 +251,11 @@ int pcl_store_slots(pcl_ctx *ctx, int64_t *slots_out, int *pending_moves_out);
  * launches of the K-body kernel, bodies answered (the launching one included), launches whose rows were not all used.  */
 int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_out, int64_t *missed_out);
 /* What k_delete_ahead_live did in its launches since the context was created, as the kernel itself tallied it (host
- * pointers, any may be NULL): groups of 128 slots loaded (groups without an alive photon are skipped), rounds of 64 listed
+ * pointers, any may be NULL): groups of 128 slots loaded (groups without an alive photon are skipped; the photons' first
+ * Philox block is decided where they are loaded) whose first pass decided two bodies / one body, rounds of 64 listed
  * photons that decided two bodies, rounds that decided one.  bench.py prices them with the kernel's instruction counts
- * (profiles/isa_counts.json, "k_delete_ahead_live") for the VALU roofline of the delete legs. */
-int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_out, int64_t *rounds_two_out, int64_t *rounds_one_out);
+ * (profiles/isa_counts.json, "k_delete_ahead_live<double>") for the VALU roofline of the delete legs. */
+int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_two_out, int64_t *groups_one_out, int64_t *rounds_two_out, int64_t *rounds_one_out);
 /* Allocate now what the first compaction of the store would allocate on demand (the second slab -- chosen among a few
  * candidates like the first, tens of ms for a big store --, the id arrays, the mask scratch), so that a run whose step
  * list holds a delete step pays for it at set-up and not inside its third loop body.  Optional.                        */

@@ -59,7 +59,7 @@ _PROTOTYPES = {
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
     "pcl_store_last_multi_hist": [_vp, _vp],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
-    "pcl_store_ahead_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
+    "pcl_store_ahead_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_alloc_info": [_vp, POINTER(c_int), POINTER(c_double), c_int, POINTER(c_double)],
     "pcl_ctx_set_rtc_background": [_vp, c_int],
     "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
@@ -444,11 +444,12 @@ class Device:
         return a.value, b.value, c.value
 
     def ahead_work(self):
-        """(groups of 128 slots loaded, rounds deciding two bodies, rounds deciding one) summed over the k_delete_ahead_live
-        launches of this context, as the kernel tallied them (pcl_store_ahead_work)."""
-        a, b, c = c_int64(), c_int64(), c_int64()
-        check(self.lib.pcl_store_ahead_work(self.ctx, byref(a), byref(b), byref(c)))
-        return a.value, b.value, c.value
+        """(groups of 128 slots loaded with a first pass of two bodies, ... of one body, rounds deciding two bodies, rounds
+        deciding one) summed over the k_delete_ahead_live launches of this context, as the kernel tallied them
+        (pcl_store_ahead_work)."""
+        a, b, c, d = c_int64(), c_int64(), c_int64(), c_int64()
+        check(self.lib.pcl_store_ahead_work(self.ctx, byref(a), byref(b), byref(c), byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def reserve_compaction(self):
         """Allocate the second slab, id arrays and mask scratch of the delete path now (pcl_store_reserve_compaction)."""

@@ -943,7 +943,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
 //   the ordinary way.  Same operations per photon as k_delete_alive (tests/test_gpu_alive_mask.py runs both).
 constexpr int kAheadMax = 32;                       // bodies per launch, at most
 constexpr int kAheadRow = 4 + PCL_MAX_PLANES;       // counters per body: alive, sign x 3, planes
-constexpr int kAheadWork = 3;                       // k_delete_ahead_live's own work tally: groups loaded, rounds of two bodies, of one
+constexpr int kAheadWork = 4;                       // k_delete_ahead_live's own work tally: groups loaded (first pass of two bodies, of one), rounds of two bodies, of one
 constexpr int kAheadAcc = 1 + kAheadMax * kAheadRow + kAheadWork; // device accumulators: ticket, rows, work; pinned block: rows, sequence word, work
 template <typename T>
 struct ahead_args {
@@ -1226,9 +1226,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     const int ax0 = has_plane ? a.plane_ax[0] : 0;
     const T L0 = has_plane ? a.plane_L[0] : (T)0;
     uint32_t t_kept = 0, t_s[3] = {0, 0, 0}, t_p0 = 0; // lane b: this wave's sums of body b (alive, sign counts, the plane)
-    // what this wave did, for the VALU roofline of the launch (wave-uniform: scalar adds): groups of 128 slots it loaded, rounds
-    // of 64 listed photons deciding two bodies, rounds deciding one (pcl_store_ahead_work)
-    uint32_t w_groups = 0, w_rounds2 = 0, w_rounds1 = 0;
+    // what this wave did, for the VALU roofline of the launch (wave-uniform: scalar adds): groups of 128 slots it loaded (their
+    // photons' first Philox block decided on the spot: two bodies, or one), rounds of 64 listed photons deciding two bodies,
+    // rounds deciding one (pcl_store_ahead_work)
+    uint32_t w_groups2 = 0, w_groups1 = 0, w_rounds2 = 0, w_rounds1 = 0;
     // one body's row from the photons of a round that it leaves alive (``s``): into lane b's accumulators
     auto tally = [&](int b, bool s, uint32_t ix, bool cross) {
         const bool mine = lane == b;
@@ -1246,6 +1247,31 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
             }
         }
     };
+    // One Philox block of one photon: the body (or the two bodies) it decides, starting with body ``b`` -- ``single``: only the
+    // block's second half is a body of this launch; ``two``: both halves are.  Counts the photon into the rows of the bodies
+    // that leave it alive, advances its coordinate along the plane's axis, returns whether it is still alive afterwards and,
+    // if not, the body that removed it (counted from 1).  Called by all lanes together (ballots inside).
+    auto decide = [&](int b, bool single, bool two, uint32_t step, bool on, uint64_t id, thr_t pc, T &xp, T dp, uint32_t ix, uint32_t &d) -> bool {
+        const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), step >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
+        const thr_t m_first = single ? D::draw(wd.z, wd.w) : D::draw(wd.x, wd.y);
+        const bool s0 = on && !(m_first <= pc); // alive after body b                                                              light.py:243
+        xp = R::add(xp, dp);                                                                                                 // newton.py:16
+        T prev = R::sub(xp, dp);
+        tally(b, s0, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+        bool left = s0;
+        d = s0 ? 255u : (uint32_t)(b + 1);
+        if (two) { // (uniform)
+            left = s0 && !(D::draw(wd.z, wd.w) <= pc);
+            if (s0 && !left) d = (uint32_t)(b + 2);
+            xp = R::add(xp, dp);
+            prev = R::sub(xp, dp);
+            tally(b + 1, left, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+        }
+        return left;
+    };
+    // the launch's first pass is the same for every photon: decided where the photon is loaded, before it is listed
+    const bool single0 = (a.step0 & 1u) != 0u, two0 = !single0 && a.K > 1;
+    const int b_first = two0 ? 2 : 1;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
 #pragma unroll 1
         for (int bt = 0; bt < kTileRows / (8 * kGroups); ++bt) {
@@ -1269,7 +1295,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                 uchar2 d0;
                 d0.x = d0.y = 0;
                 if ((m_lo | m_hi) != 0ull) { // (wave-uniform)
-                    ++w_groups;
+                    if (two0) ++w_groups2; else ++w_groups1;
                     const uint64_t mm = hi ? m_hi : m_lo;
                     const bool al[2] = {(bool)((mm >> bit) & 1ull), (bool)((mm >> (bit + 1)) & 1ull)};
                     const int64_t ti = pcl_tix(i, a.ts);
@@ -1303,19 +1329,24 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                                 const T dq = R::mul(va, a.pend_dt[q]);
                                 for (int t = 0; t < a.pend_rep[q]; ++t) x = R::add(x, dq);
                             }
-                        const uint64_t bal = __ballot(al[e]);
-                        if (al[e]) {
+                        const uint32_t ix = (uint32_t)(g * 128 + 2 * lane + e) | (vv[0][e] > (T)0 ? 0x100u : 0u) | (vv[1][e] > (T)0 ? 0x200u : 0u) |
+                                            (vv[2][e] > (T)0 ? 0x400u : 0u);
+                        const thr_t thr = D::threshold(pcoll);
+                        const T dpe = pcl_pick<T>(ax0, dd[0], dd[1], dd[2]);
+                        uint32_t d;
+                        const bool left = decide(0, single0, two0, a.step0, al[e], id[e], thr, x, dpe, ix, d);
+                        if (e == 0) d0.x = (unsigned char)(al[e] ? d : 0u); else d0.y = (unsigned char)(al[e] ? d : 0u);
+                        const uint64_t bal = __ballot(left);
+                        if (left) { // still alive after the first pass: listed for the next ones
                             const uint32_t pos = n_list + (uint32_t)__popcll(bal & below);
                             if constexpr (IDS) s_id[wave][pos] = id[e];
-                            s_pc[wave][pos] = D::threshold(pcoll);
+                            s_pc[wave][pos] = thr;
                             s_xp[wave][pos] = x;
-                            s_dp[wave][pos] = pcl_pick<T>(ax0, dd[0], dd[1], dd[2]);
-                            s_ix[wave][pos] = (uint16_t)((g * 128 + 2 * lane + e) | (vv[0][e] > (T)0 ? 0x100 : 0) | (vv[1][e] > (T)0 ? 0x200 : 0) |
-                                                         (vv[2][e] > (T)0 ? 0x400 : 0));
+                            s_dp[wave][pos] = dpe;
+                            s_ix[wave][pos] = (uint16_t)ix;
                         }
                         n_list += (uint32_t)__popcll(bal);
                     }
-                    d0.x = al[0] ? 255 : 0, d0.y = al[1] ? 255 : 0;
                 }
                 *reinterpret_cast<uchar2 *>(&s_death[wave][g * 128 + 2 * lane]) = d0;
             }
@@ -1323,7 +1354,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
             __builtin_amdgcn_wave_barrier();
             // ---- the bodies, one Philox block at a time: it decides the steps 2m and 2m + 1 (pcl_draw_rand), so the bodies are
             // taken in such pairs, after a single one when the first step is odd ------------------------------------------------
-            for (int b = 0; b < a.K && n_list > 0;) {
+            for (int b = b_first; b < a.K && n_list > 0;) {
                 const uint32_t st = a.step0 + (uint32_t)b;
                 const bool single = (st & 1u) != 0u;          // only the block's second half is a body of this launch
                 const bool two = !single && b + 1 < a.K;
@@ -1341,21 +1372,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                         id = s_id[wave][j];
                     else
                         id = (uint64_t)(a.id_base + i0 + (int64_t)(ix & 0xFFu));
-                    const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
-                    const thr_t m_first = single ? D::draw(wd.z, wd.w) : D::draw(wd.x, wd.y);
-                    const bool s0 = on && !(m_first <= pc); // alive after body b                                                  light.py:243
-                    xp = R::add(xp, dp);                                                                                     // newton.py:16
-                    T prev = R::sub(xp, dp);
-                    tally(b, s0, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
-                    bool left = s0;
-                    uint32_t d = s0 ? 255u : (uint32_t)(b + 1);
-                    if (two) { // (uniform)
-                        left = s0 && !(D::draw(wd.z, wd.w) <= pc);
-                        if (s0 && !left) d = (uint32_t)(b + 2);
-                        xp = R::add(xp, dp);
-                        prev = R::sub(xp, dp);
-                        tally(b + 1, left, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
-                    }
+                    uint32_t d;
+                    const bool left = decide(b, single, two, st, on, id, pc, xp, dp, ix, d);
                     if (on && d != 255u) s_death[wave][ix & 0xFFu] = (uint8_t)d;
                     const uint64_t bal = __ballot(left);
                     if (left) {
@@ -1380,9 +1398,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
         }
     }
     if (lane == 0) {
-        atomicAdd(&s_work[0], w_groups);
-        atomicAdd(&s_work[1], w_rounds2);
-        atomicAdd(&s_work[2], w_rounds1);
+        atomicAdd(&s_work[0], w_groups2);
+        atomicAdd(&s_work[1], w_groups1);
+        atomicAdd(&s_work[2], w_rounds2);
+        atomicAdd(&s_work[3], w_rounds1);
     }
     if (lane < a.K) { // the wave's sums join the workgroup's
         if (t_kept) atomicAdd(&s_cnt[lane * kAheadRow + 0], t_kept);
@@ -2898,7 +2917,7 @@ struct pcl_ctx {
     uint64_t *ahead_host = nullptr;          // pinned rows + sequence word
     uint64_t ahead_seq = 0;
     int64_t ahead_launches = 0, ahead_served = 0, ahead_missed = 0; // statistics (pcl_store_ahead_stats)
-    int64_t ahead_work[3] = {0, 0, 0};       // k_delete_ahead_live's own tally, summed over its launches (pcl_store_ahead_work)
+    int64_t ahead_work[kAheadWork] = {0, 0, 0, 0}; // k_delete_ahead_live's own tally, summed over its launches (pcl_store_ahead_work)
     int ahead_wait = 0, ahead_backoff = 0;   // bodies to run the plain way before the next attempt / the last such pause (doubles per
                                              // launch that was cut short: a loop that looks at the store between its bodies)
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
@@ -5454,11 +5473,12 @@ int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_o
     return PCL_OK;
 }
 
-int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_out, int64_t *rounds_two_out, int64_t *rounds_one_out) {
+int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_two_out, int64_t *groups_one_out, int64_t *rounds_two_out, int64_t *rounds_one_out) {
     if (!ctx) return fail(PCL_ERR_ARG, "NULL argument");
-    if (groups_out) *groups_out = ctx->ahead_work[0];
-    if (rounds_two_out) *rounds_two_out = ctx->ahead_work[1];
-    if (rounds_one_out) *rounds_one_out = ctx->ahead_work[2];
+    if (groups_two_out) *groups_two_out = ctx->ahead_work[0];
+    if (groups_one_out) *groups_one_out = ctx->ahead_work[1];
+    if (rounds_two_out) *rounds_two_out = ctx->ahead_work[2];
+    if (rounds_one_out) *rounds_one_out = ctx->ahead_work[3];
     return PCL_OK;
 }
 

@@ -333,7 +333,8 @@ def test_a_k_body_call_takes_the_single_calls_path_with_k_as_a_promise(K, planes
     # (a body that finds the store sparse enough to compact runs the plain way: at most a few of a run)
     assert bodies - 3 <= served <= bodies and 1 <= launches <= -(-bodies // min(K, 24)) + 2, (st1, bodies)
     if planes is None or len(planes) <= 1:                                  # (more planes: k_delete_ahead, which keeps no tally)
-        groups, r2, r1 = w1
-        assert groups >= -(-N // 128) and r2 + r1 >= groups // 2 and r1 >= 1   # first launch: every slot; the odd first step: rounds of one body
+        g2, g1, r2, r1 = w1
+        # the first launch loads every slot, and its first step is odd: a first pass of one body; later launches, later passes
+        assert g1 >= -(-N // 128) and g2 + g1 > g1 - 1 and r2 >= 1
     else:
-        assert w1 == (0, 0, 0)
+        assert w1 == (0, 0, 0, 0)

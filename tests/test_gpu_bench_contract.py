@@ -83,10 +83,11 @@ def test_bench_line_has_the_contract_keys(extra):
                 v = rec[mode]["roofline"]
                 assert v["bound"] == "valu" and v["unit"] == "wave-instr/s" and v["peak"] == 1024 * 2.4e9 / 4 and 0 < v["frac"] < 1.2
                 w, c = v["work"], v["instruction_counts"]
-                instr = (c["valu_per_group_loaded"] * w["groups_of_128_slots_loaded"] + c["valu_per_round_two_bodies"] * w["rounds_two_bodies"]
-                         + c["valu_per_round_one_body"] * w["rounds_one_body"])
+                instr = (c["valu_per_group_first_pass_two_bodies"] * w["groups_of_128_slots_first_pass_two_bodies"]
+                         + c["valu_per_group_first_pass_one_body"] * w["groups_of_128_slots_first_pass_one_body"]
+                         + c["valu_per_round_two_bodies"] * w["rounds_two_bodies"] + c["valu_per_round_one_body"] * w["rounds_one_body"])
                 assert abs(instr - v["wave_instructions"]) <= 1e-9 * instr and abs(v["achieved"] - instr / (v["total_ms"] * 1e-3)) <= 1e-6 * v["achieved"]
-                assert w["groups_of_128_slots_loaded"] >= 30000 // 128 and w["rounds_two_bodies"] >= w["groups_of_128_slots_loaded"] // 2
+                assert w["groups_of_128_slots_first_pass_two_bodies"] >= 30000 // 128 and w["rounds_two_bodies"] >= 1
             assert rec["per_step"]["roofline_alive"]["bound"] == "hbm"
         assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
         # the constructor as a reference script calls it takes the K-pass launches by itself

@@ -29,20 +29,21 @@ def main():
             per[int(r["Dispatch_Id"])]["ms"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     disp = [per[k] for k in sorted(per)]
     assert len(disp) == len(cases), (len(disp), len(cases))
-    A = np.array([[c["groups"], c["rounds_two"], c["rounds_one"]] for c in cases], dtype=np.float64)
+    A = np.array([[c["groups_two"], c["groups_one"], c["rounds_two"], c["rounds_one"]] for c in cases], dtype=np.float64)
     y = np.array([d["SQ_INSTS_VALU"] for d in disp])
     coef, *_ = np.linalg.lstsq(A, y, rcond=None)
     fit = A @ coef
     commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     L = ["# `k_delete_ahead_live<double>`: VALU wave-instructions against the kernel's own work tally", "",
          "One launch per case on a fresh store of 1e8 photons (`tools/calib_ahead.py` under `rocprofv3 --pmc SQ_INSTS_VALU`, commit %s)." % commit,
-         "Model: SQ_INSTS_VALU = a x groups of 128 slots loaded + b x rounds of 64 listed photons deciding two bodies + c x rounds deciding one;",
-         "least squares over the cases: **a = %.1f, b = %.1f, c = %.1f** wave-instructions." % tuple(coef), "",
-         "| K | first step | groups | rounds (two bodies) | rounds (one body) | SQ_INSTS_VALU | model | model / measured | SQ_INSTS_SALU | duration ms (trace) | GRBM_GUI_ACTIVE / 8 / duration (GHz) |",
-         "|---|---|---|---|---|---|---|---|---|---|---|"]
+         "Model: SQ_INSTS_VALU = a2 x groups of 128 slots loaded whose first pass (decided where the photons are loaded) takes two bodies + a1 x groups whose",
+         "first pass takes one + b x rounds of 64 listed photons deciding two bodies + c x rounds deciding one;",
+         "least squares over the cases: **a2 = %.1f, a1 = %.1f, b = %.1f, c = %.1f** wave-instructions." % tuple(coef), "",
+         "| K | first step | groups (first pass: two) | groups (first pass: one) | rounds (two bodies) | rounds (one body) | SQ_INSTS_VALU | model | model / measured | SQ_INSTS_SALU | duration ms (trace) | GRBM_GUI_ACTIVE / 8 / duration (GHz) |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for c, d, m in zip(cases, disp, fit):
-        L.append("| %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f | %.2f |" % (
-            c["K"], c["step0"], c["groups"], c["rounds_two"], c["rounds_one"], d["SQ_INSTS_VALU"], m, m / d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0),
+        L.append("| %d | %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f | %.2f |" % (
+            c["K"], c["step0"], c["groups_two"], c["groups_one"], c["rounds_two"], c["rounds_one"], d["SQ_INSTS_VALU"], m, m / d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0),
             d["ms"], d.get("GRBM_GUI_ACTIVE", 0) / 8 / (d["ms"] * 1e-3) / 1e9))
     L += ["", "VALU issue peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 6.144e11 wave-instructions/s; the twelve-body launch: "
           "%.3g / %.3f ms = %.3g = %.2f of it." % (y[3], disp[3]["ms"], y[3] / (disp[3]["ms"] * 1e-3), y[3] / (disp[3]["ms"] * 1e-3) / 6.144e11)]
@@ -50,9 +51,9 @@ def main():
     print("\n".join(L))
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
     j = json.load(open(p))
-    j["k_delete_ahead_live<double>"] = {"valu_per_group_loaded": round(float(coef[0]), 1), "valu_per_round_two_bodies": round(float(coef[1]), 1),
-                                        "valu_per_round_one_body": round(float(coef[2]), 1), "max_relative_residual": round(float(np.max(np.abs(fit / y - 1))), 4),
-                                        "source": "profiles/r04_calib_ahead.md (SQ_INSTS_VALU of 8 launches, least squares on the kernel's own tally)", "commit": commit}
+    j["k_delete_ahead_live<double>"] = {"valu_per_group_first_pass_two_bodies": round(float(coef[0]), 1), "valu_per_group_first_pass_one_body": round(float(coef[1]), 1),
+                                        "valu_per_round_two_bodies": round(float(coef[2]), 1), "valu_per_round_one_body": round(float(coef[3]), 1), "max_relative_residual": round(float(np.max(np.abs(fit / y - 1))), 4),
+                                        "source": "profiles/r04_calib_ahead.md (SQ_INSTS_VALU of %d launches, least squares on the kernel's own tally)" % len(cases) + "", "commit": commit}
     json.dump(j, open(p, "w"), indent=1, sort_keys=True)
 
 
