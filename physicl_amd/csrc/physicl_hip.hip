@@ -258,8 +258,11 @@ template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
     pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC, true>(a);
 }
+// (constant n, fp64: 133 VGPRs left three waves per SIMD, and the K-pass loop is arithmetic -- with four, what 128 registers
+// allow without a spill, configs[4]'s 100 iterations at 1e8 photons take 0.089 instead of 0.095 s; the wavelength-term and
+// variable-n forms would spill to scratch under that bound and keep theirs)
 template <typename T, bool USE_E, int VAR_N>
-__global__ void __launch_bounds__(kBlock) k_mixed(pcl_mixed_args<T> a) {
+__global__ void __launch_bounds__(kBlock, (VAR_N == 0 && !USE_E && sizeof(T) == 8) ? 4 : 1) k_mixed(pcl_mixed_args<T> a) {
     pcl_mixed_body<T, USE_E, VAR_N>(a);
 }
 
