@@ -691,7 +691,8 @@ class Device:
                                             int(rng_mode), int(seed), int(step) & 0xFFFFFFFF, pp, npl, out.ctypes.data)
         if rc != 0:
             check(rc)
-        return {"N": int(out[0]), "sign": out[1:4].copy(), "planes": out[4:4 + k].copy(), "removed": int(out[4 + k])}
+        # (``out`` is this call's own array: the slices need no copy)
+        return {"N": int(out[0]), "sign": out[1:4], "planes": out[4:4 + k], "removed": int(out[4 + k])}
 
     def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None, raw=False):
         """``k_steps`` delete loop bodies (Newton + ScatterDelete + counters on the survivors) in one pass and one
