@@ -1507,31 +1507,41 @@ __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
 // put their 16-bit pieces together into a mask word, a wave (half a tile) adds its alive count to the tile's.
 __global__ void __launch_bounds__(kBlock) k_ahead_masks(const uint8_t *__restrict__ death, int j, uint64_t *__restrict__ masks_out,
                                                         uint64_t *__restrict__ masks_prev, int32_t *__restrict__ tile_keep, int64_t n_groups) {
-    const int lane = threadIdx.x & 63;
+    // (a workgroup's 256 lanes x 16 slots are two whole tiles -- n_groups is a multiple of a tile's 128 --: each tile's count is
+    // WRITTEN by the one workgroup that sees all of it, waves 0-1 the first tile, waves 2-3 the second; nothing to zero first)
+    __shared__ uint32_t s_c[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t g0 = (int64_t)blockIdx.x * kBlock; g0 < n_groups; g0 += (int64_t)gridDim.x * kBlock) {
-        const int64_t g = g0 + threadIdx.x; // (n_groups is a multiple of 64 * 2: whole tiles, so a wave is all in or all out)
-        if (g0 + (threadIdx.x & ~63) >= n_groups) continue;
-        const uint4 q = *reinterpret_cast<const uint4 *>(death + 16 * g);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-        uint32_t alive = 0, prev = 0;
+        const int64_t g = g0 + threadIdx.x;
+        const bool in = g0 + (threadIdx.x & ~63) < n_groups; // (wave-uniform)
+        uint32_t cnt = 0;
+        if (in) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(death + 16 * g);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t alive = 0, prev = 0;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const uint32_t d = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
-            alive |= (d > (uint32_t)j ? 1u : 0u) << t;
-            prev |= ((d >= (uint32_t)j && d != 0u) ? 1u : 0u) << t;
-        }
-        // lanes 4m .. 4m + 3 hold the four 16-bit quarters of mask word m of the wave's 16 words
-        const uint64_t a1 = (uint64_t)__shfl_down(alive, 1), a2 = (uint64_t)__shfl_down(alive, 2), a3 = (uint64_t)__shfl_down(alive, 3);
-        const uint64_t p1 = (uint64_t)__shfl_down(prev, 1), p2 = (uint64_t)__shfl_down(prev, 2), p3 = (uint64_t)__shfl_down(prev, 3);
-        if ((lane & 3) == 0) {
-            const int64_t word = g >> 2;
-            masks_out[word] = (uint64_t)alive | (a1 << 16) | (a2 << 32) | (a3 << 48);
-            masks_prev[word] = (uint64_t)prev | (p1 << 16) | (p2 << 32) | (p3 << 48);
-        }
-        uint32_t cnt = (uint32_t)__popc(alive);
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t d = (w[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+                alive |= (d > (uint32_t)j ? 1u : 0u) << t;
+                prev |= ((d >= (uint32_t)j && d != 0u) ? 1u : 0u) << t;
+            }
+            // lanes 4m .. 4m + 3 hold the four 16-bit quarters of mask word m of the wave's 16 words
+            const uint64_t a1 = (uint64_t)__shfl_down(alive, 1), a2 = (uint64_t)__shfl_down(alive, 2), a3 = (uint64_t)__shfl_down(alive, 3);
+            const uint64_t p1 = (uint64_t)__shfl_down(prev, 1), p2 = (uint64_t)__shfl_down(prev, 2), p3 = (uint64_t)__shfl_down(prev, 3);
+            if ((lane & 3) == 0) {
+                const int64_t word = g >> 2;
+                masks_out[word] = (uint64_t)alive | (a1 << 16) | (a2 << 32) | (a3 << 48);
+                masks_prev[word] = (uint64_t)prev | (p1 << 16) | (p2 << 32) | (p3 << 48);
+            }
+            cnt = (uint32_t)__popc(alive);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_down(cnt, off);
-        if (lane == 0) atomicAdd(&tile_keep[g / (kTile / 16)], (int32_t)cnt);
+            for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_down(cnt, off);
+        }
+        if (lane == 0) s_c[wave] = cnt;
+        __syncthreads();
+        if (threadIdx.x < 2 && g0 + 128 * (int64_t)threadIdx.x < n_groups)
+            tile_keep[g0 / (kTile / 16) + threadIdx.x] = (int32_t)(s_c[2 * threadIdx.x] + s_c[2 * threadIdx.x + 1]);
+        __syncthreads();
     }
 }
 
@@ -2931,6 +2941,7 @@ struct pcl_ctx {
     int64_t dv_zero_n = 0;        // leading elements of THIS slab's dv rows known to be +0.0 (>= count while dv_zero == 1; a
                                   // high-water mark: whatever was zero beyond the live range stays zero until somebody writes dv)
     int64_t alt_dv_zero_n = 0;    // leading elements of the OTHER slab's dv rows known to be +0.0
+    int64_t compact_known_alive = -1; // >= 0: the caller of the compaction knows the survivor count (densify): the host picks the pass-3 kernel
     int compact_dv_mode = 0;      // how the last compaction launch treated dv (kDvMove / kDvVprev / kDvSkip), for adopt_compacted
 
     // counters: device slots + pinned host mirror
@@ -4103,12 +4114,17 @@ int launch_module(pcl_ctx *ctx, hipFunction_t fn, int grid, Args &args, const ch
 }
 
 // run pass 2 of the compaction pipeline on tile_keep already produced for n particles
-int scan_tiles(pcl_ctx *ctx, int64_t n) {
-    const int64_t tiles = div_up(n, kTile);
-    static const int lds_min_pct = [] { // perf-experiment hook: survivor percentage above which pass 3 is k_compact_lds
+int compact_lds_min_pct() { // perf-experiment hook: survivor percentage above which pass 3 is k_compact_lds
+    static const int pct = [] {
         const char *e = getenv("PCL_COMPACT_LDS_MIN_PCT");
         return e ? atoi(e) : 15; // (round 2: 35; re-measured with the alive path, whose compactions start at 34 % survivors)
     }();
+    return pct;
+}
+
+int scan_tiles(pcl_ctx *ctx, int64_t n) {
+    const int64_t tiles = div_up(n, kTile);
+    const int lds_min_pct = compact_lds_min_pct();
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_keep, tiles, ctx->tile_off,
                        reinterpret_cast<int64_t *>(ctx->d_cnt + kCounterSlots - 1), n,
                        reinterpret_cast<int *>(ctx->d_cnt + kCounterSlots - 2),
@@ -4582,17 +4598,27 @@ int launch_compact_count(pcl_ctx *ctx, bool has_dr, int dv_mode, compact_counter
     // Two formulations, both enqueued; the scan's verdict (d_cnt[kCounterSlots - 2]) lets exactly one of them work.
     // Stores with kind bytes (plain Objects) always take the direct kernel -- the staged one does not move them.
     static const bool direct_only = getenv("PCL_COMPACT_DIRECT") != nullptr; // perf-experiment hook
-    const bool both = !ctx->kind && !direct_only && ctx->count >= ((int64_t)1 << 22); // (the scan's rule needs >= 4M particles)
+    bool both = !ctx->kind && !direct_only && ctx->count >= ((int64_t)1 << 22); // (the scan's rule needs >= 4M particles)
+    // ... unless the host knows the survivor count already (the compaction behind bodies worked out ahead): the scan's rule,
+    // applied here, and ONE launch
+    bool direct = true, staged = both;
+    if (both && ctx->compact_known_alive >= 0) {
+        staged = ctx->compact_known_alive * 100 > ctx->count * (int64_t)compact_lds_min_pct();
+        direct = !staged;
+        both = false;
+    }
     ca.choice = both ? reinterpret_cast<const int *>(ctx->d_cnt + kCounterSlots - 2) : nullptr;
     ca.sparse_max = compact_sparse_max();
-    if (has_dr)
-        hipLaunchKernelGGL((k_compact_count<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    else if (dv_mode == kDvSkip)
-        hipLaunchKernelGGL((k_compact_count<T, W, 7>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    else
-        hipLaunchKernelGGL((k_compact_count<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
-    if (both) {
+    if (direct) {
+        if (has_dr)
+            hipLaunchKernelGGL((k_compact_count<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        else if (dv_mode == kDvSkip)
+            hipLaunchKernelGGL((k_compact_count<T, W, 7>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
+        else
+            hipLaunchKernelGGL((k_compact_count<T, W, 10>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
         PCL_TRY(launch_check("k_compact_count"));
+    }
+    if (staged) {
         if (has_dr)
             hipLaunchKernelGGL((k_compact_lds<T, W, 13>), dim3(tiles), dim3(kBlock), 0, ctx->stream, ca, cc);
         else if (dv_mode == kDvSkip)
@@ -4898,7 +4924,6 @@ int ahead_commit_t(pcl_ctx *ctx, bool write_r) {
     if (write_r) {
         hipLaunchKernelGGL((k_ahead_commit<T, true>), dim3((unsigned)grid), dim3(kBlock), 0, ctx->stream, a);
     } else { // big stores: masks and tile counts only, 16 slots per lane
-        PCL_HIP(hipMemsetAsync(ctx->tile_keep, 0, (size_t)n_tiles * sizeof(int32_t), ctx->stream));
         const int64_t n_groups = n_tiles * (kTile / 16);
         const int64_t blocks = div_up(n_groups, kBlock);
         const int64_t g2 = blocks < cap ? blocks : cap;
@@ -5029,9 +5054,12 @@ int densify(pcl_ctx *ctx) {
     int rc = ensure_alt(ctx);
     int dv_mode = kDvMove;
     if (rc == PCL_OK) rc = decide_dv_mode(ctx, true, &dv_mode);
-    if (rc == PCL_OK)
+    if (rc == PCL_OK) {
+        ctx->compact_known_alive = alive;
         rc = PCL_DISPATCH(ctx, compact_alive_t<double>(ctx, dv_mode, false, 0.0, nullptr, -1),
                           compact_alive_t<float>(ctx, dv_mode, false, 0.0, nullptr, -1));
+        ctx->compact_known_alive = -1;
+    }
     int64_t got = 0;
     if (rc == PCL_OK) rc = wait_count(ctx, slots, &got);
     if (rc == PCL_OK && got != alive)
