@@ -160,7 +160,7 @@ int pcl_timer_stop(pcl_ctx *ctx, double *ms_out); /* synchronises */
 #define PCL_PROF_FUSED       5 /* k_fused / hipRTC specialisation  */
 #define PCL_PROF_MULTI       6 /* k_multi / k_mixed / hipRTC specialisations */
 #define PCL_PROF_ONEPASS     7 /* k_delete_onepass                 */
-#define PCL_PROF_DELETE_AHEAD 8 /* k_delete_ahead: K delete loop bodies of a small store worked out in one launch */
+#define PCL_PROF_DELETE_AHEAD 8 /* k_delete_ahead / k_delete_ahead_live: delete loop bodies worked out a launch at a time */
 int pcl_prof_enable(pcl_ctx *ctx, int on);
 int pcl_prof_read(pcl_ctx *ctx, int kernel_id, int64_t *launches_out, double *total_ms_out,
                   double *min_ms_out, double *max_ms_out);
