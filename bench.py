@@ -857,6 +857,20 @@ def iso_leg(dev, hip, N, seed, steps=100, repeats=3):
     return out
 
 
+def mixed_valu_record():
+    """What binds k_mixed (the K-pass kernel of configs[4]): VALU issue.  Its instruction count per launch depends on the
+    photons' histories, and the kernel keeps no tally of its own, so this record is NOT computed in this process: it is the
+    committed rocprofv3 run of the same command (profiles/pmc_traffic.json: SQ_INSTS_VALU of the fp64 16-iteration launches
+    over their durations in the trace pass, VALU busy and lane utilisation from the SQ counters)."""
+    rec = _json_file("pmc_traffic.json").get("kernels", {}).get("k_mixed valu f64")
+    if not rec:
+        return None
+    return {"bound": "valu", "kernel": "k_mixed<double> (16 iterations of [Newton, ScatterIsotropic, Newton, ScatterDelete] per launch)",
+            "achieved": rec["wave_instructions_per_s"], "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": rec["wave_instructions_per_s"] / VALU_PEAK,
+            "valu_busy": rec["valu_busy"], "lane_util": rec["lane_utilisation"], "launches": rec["launches"],
+            "source": rec["source"], "measured_at_commit": rec.get("commit"), "note": "committed rocprofv3 --pmc run, not this process"}
+
+
 def mixed_leg(dev, N, iterations=100, sample=2_000_000):
     """BASELINE configs[4], 1-GPU form: [Newton, ScatterIsotropic(A=n=1e-3), Newton, ScatterDelete] x 100 on ``N`` photons
     (1e8) in fp64 and in fp32, same Philox stream (tools/sweep_fp32.py): seconds per precision (16 iterations per launch,
@@ -872,6 +886,7 @@ def mixed_leg(dev, N, iterations=100, sample=2_000_000):
             "particle_steps": work, "value_f64": work / last["seconds_f64"], "value_f32": rep["particle_steps_f32"] / last["seconds_f32"],
             "unit": "particle-steps/s (a particle-step = one photon alive at the start of one Newton + light step)",
             "one_launch_per_light_step": {"seconds_f64": one["seconds_f64"], "seconds_f32": one["seconds_f32"]},
+            "roofline": mixed_valu_record(),
             "fp32_vs_fp64": {str(k): {key: v[key] for key in ("decision_mismatch_rate", "identical_history_fraction", "median_rel_err_r",
                                                                 "p99_rel_err_r", "p9999_rel_err_r", "max_rel_err_r", "fraction_above_1e-4",
                                                                 "compared")}

@@ -331,6 +331,21 @@ def main():
         if first:
             kern_t[kname] = {"bytes_per_unit": round(sum((r[3] + r[4]) / r[1] for r in first) / len(first), 2),
                              "unit": "slot (the compactions of the 1e8-slot extent in the delete leg)", "source": src_md, "commit": commit}
+    # k_mixed (configs[4]): VALU issue of its 16-iteration launches -- SQ_INSTS_VALU of the SQ pass over their durations in the
+    # trace pass (the run is deterministic: same dispatches, same order) -- for the bench line's ``mixed.roofline``
+    for kname, tag_t in (("k_mixed<double, false, 0>", "f64"), ("k_mixed<float, false, 0>", "f32")):
+        pairs = [(c, d) for c, d in zip(sq.get(kname, []), disp.get(kname, [])) if c.get("SQ_INSTS_VALU", 0) > 1e9 and c.get("GRBM_GUI_ACTIVE")]
+        if pairs:
+            insts, dur = sum(c["SQ_INSTS_VALU"] for c, _ in pairs), sum(d for _, d in pairs) * 1e-9
+            kern_t["k_mixed valu " + tag_t] = {
+                "wave_instructions_per_s": insts / dur, "launches": len(pairs), "wave_instructions": insts, "seconds": dur,
+                "valu_busy": round(sum(c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) for c, _ in pairs) / len(pairs), 4),
+                "lane_utilisation": round(sum(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) for c, _ in pairs) / len(pairs), 4),
+                "source": src_md, "commit": commit}
+            L += ["", "`%s`, the %d launches of 16 iterations: %.4g VALU wave-instructions in %.2f ms = %.3g / s = %.3f of the issue peak "
+                  "(1024 SIMDs x 2.4 GHz / 4); VALU busy %.3f, lane utilisation %.3f." % (
+                      kname, len(pairs), insts, dur * 1e3, insts / dur, insts / dur / 6.144e11, kern_t["k_mixed valu " + tag_t]["valu_busy"],
+                      kern_t["k_mixed valu " + tag_t]["lane_utilisation"])]
     if timed:
         t_ok = [r for r in timed if r[0]]
         ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps),
