@@ -636,8 +636,101 @@ def run_rank(args):
 
     comm.close()
     if rank == 0:
+        # The contract is ONE short JSON line, the last thing on stdout.  Everything the run measured goes to
+        # bench_detail.json next to this file (and, as one line, to stderr BEFORE the contract line is written).
+        detail_file = write_detail(out)
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        sys.stderr.write(json.dumps(out) + "\n")
+        sys.stderr.flush()
+        os.write(json_fd, (json.dumps(contract_line(out, detail_file)) + "\n").encode())
+
+
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+LINE_LIMIT = 4000              # characters: the driver keeps the last ~8 000 of stdout, the line must fit with room to spare
+
+
+def write_detail(out):
+    """Everything the run measured (per-block tables, every leg, the instruction-count dictionaries, the other CPU
+    legs) as indented JSON next to bench.py.  Returns the path relative to the repo root, or None when the directory
+    cannot be written (the contract line then says so: the line itself never depends on the file)."""
+    path = os.environ.get("PCL_BENCH_DETAIL", DETAIL_FILE)
+    try:
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        os.replace(tmp, path)
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
+        return None
+    return os.path.relpath(path, ROOT)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _traffic_number(t):
+    """The contract's ``traffic``: HBM bytes of one launch from the PMC counters, a number (or null).  Where the figure
+    comes from (profile file, commit) is in ``traffic_source`` beside it."""
+    return (None, None) if not t else (t["bytes"], "%s @ %s" % (t.get("source"), t.get("measured_at_commit")))
+
+
+def contract_line(out, detail_file):
+    """The one stdout line: the bench contract's keys and nothing else.  ``out`` is the full record of the run."""
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "repeats", "repeat_ms_per_step"))
+    line["config"] = _pick(out["config"], ("workload", "photons_per_gpu", "profile", "mode", "steps_per_launch_max",
+                                           "steps_per_timed_launch", "variable_n_fn", "dt", "rng", "parallelism"))
+    r = out["roofline"]
+    rl = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "valu_busy", "lane_util", "useful", "clock_GHz",
+                   "avg_launch_ms", "launches", "hit_fraction"))
+    rl["kernel"] = rl.get("kernel", "").split(":")[0].split(";")[0][:120]
+    rl["traffic"], rl["traffic_source"] = _traffic_number(r.get("traffic"))
+    line["roofline"] = rl
+    h = out.get("roofline_hbm")
+    if h is not None:
+        hl = _pick(h, ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "value", "ms_per_step"))
+        hl["traffic"], hl["traffic_source"] = _traffic_number(h.get("traffic"))
+        hl["algorithmic_bytes_per_particle"] = h.get("algorithmic_bytes_per_particle")
+        line["roofline_hbm"] = hl
+    else:
+        line["roofline_hbm"] = None
+    c = out.get("cpu_baseline")
+    line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "nproc", "kind", "sample")) if c else None
+    coll = out.get("collective")
+    if coll is not None:
+        line["collective"] = dict(_pick(coll, ("backend", "ranks_seen", "world", "rccl_version", "block_min_ms_per_step",
+                                               "block_max_ms_per_step")),
+                                  devices=[_pick(d, ("rank", "device", "pci")) for d in coll.get("devices", [])])
+    else:
+        line["collective"] = None
+    line["counters_last_step"] = out.get("counters_last_step")
+    # the other BASELINE configurations that rode along (N = 1): one figure each, particle-steps/s; the records are in the detail file
+    legs = {}
+    for name, path in (("iso_1e7_per_step", ("iso_1e7", "per_step", "value")), ("iso_1e7_multi", ("iso_1e7", "multi", "value")),
+                       ("mixed_f64", ("mixed", "value_f64")), ("mixed_f32", ("mixed", "value_f32")), ("tame", ("tame", "value")),
+                       ("api_default", ("api", "default", "value")), ("api_delete_default", ("api", "delete_default", "value"))):
+        v = out
+        for k in path:
+            v = v.get(k) if isinstance(v, dict) else None
+        if v is not None:
+            legs[name] = float("%.4g" % v)
+    for size, rec in (out.get("delete") or {}).get("sizes", {}).items():
+        for mode in ("per_step", "multi"):
+            if mode in rec:
+                legs["delete_%s_%s" % (size.replace("+", ""), mode)] = float("%.4g" % rec[mode]["value"])
+    if legs:
+        line["legs"] = legs
+    line["device"] = out.get("device")
+    line["detail_file"] = detail_file
+    s = json.dumps(line)
+    if len(s) >= LINE_LIMIT:                 # never let the line outgrow the driver's window: drop the optional parts first
+        for k in ("legs", "counters_last_step", "repeat_ms_per_step"):
+            line.pop(k, None)
+            if len(json.dumps(line)) < LINE_LIMIT:
+                break
+    return line
 
 
 # ---------------------------------------------------------------------------------------------------------------------

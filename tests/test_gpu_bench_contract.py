@@ -3,6 +3,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -10,14 +11,47 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "config", "roofline", "roofline_hbm", "cpu_baseline", "collective", "detail_file")
+
+
+def check_line(stdout, only_line=True):
+    """What the driver does with bench.py's stdout: it keeps the last ~8 000 characters and parses the last line.  The
+    line must survive that (round 4's grew to 31 kB and did not), carry the contract's keys and stay under 4 000 characters."""
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 or (lines and not only_line), lines
+    assert len(lines[-1]) < 4000, len(lines[-1])
+    line = json.loads(stdout.rstrip()[-8000:].splitlines()[-1])
+    for k in LINE_KEYS:
+        assert k in line, k
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    assert set(line["config"]) <= {"workload", "photons_per_gpu", "profile", "mode", "steps_per_launch_max", "steps_per_timed_launch",
+                                   "variable_n_fn", "dt", "rng", "parallelism"} and "workload" in line["config"]
+    assert line["roofline"]["traffic"] is None or isinstance(line["roofline"]["traffic"], (int, float))
+    return line
+
+
 def run_bench(*extra, photons="300000"):
-    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--photons", photons, "--steps", "6",
-                                   "--warmup", "3", "--repeats", "3", "--cpu-photons", "20000", "--cpu-seconds", "0.5",
-                                   "--delete-photons", "30000", "--iso-photons", "30000",
-                                   "--mixed-photons", "30000", *extra], cwd=ROOT)
-    lines = [ln for ln in out.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    """Runs bench.py, checks the stdout line as the driver would read it, and returns the run's FULL record (the detail
+    file bench.py writes beside the line) with the parsed line under "_line"."""
+    with tempfile.TemporaryDirectory() as tmp:
+        detail = os.path.join(tmp, "bench_detail.json")
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--photons", photons, "--steps", "6",
+                                       "--warmup", "3", "--repeats", "3", "--cpu-photons", "20000", "--cpu-seconds", "0.5",
+                                       "--delete-photons", "30000", "--iso-photons", "30000",
+                                       "--mixed-photons", "30000", *extra], cwd=ROOT, env=dict(os.environ, PCL_BENCH_DETAIL=detail),
+                                      stderr=subprocess.DEVNULL)
+        line = check_line(out.decode())
+        d = json.load(open(detail))
+    # the line is a projection of the detail record: same headline, same roofline figures
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "data"):
+        assert line[k] == d[k], k
+    for k in ("bound", "achieved", "peak", "unit", "frac"):
+        assert line["roofline"][k] == d["roofline"][k], k
+    assert line["detail_file"].endswith("bench_detail.json")
+    d["_line"] = line
+    return d
 
 
 @pytest.mark.parametrize("extra", [(), ("--steps-per-launch", "1"), ("--mode", "separate"), ("--dtype", "f32", "--steps-per-launch", "4")])
@@ -154,9 +188,7 @@ def test_two_ranks_started_by_torchrun_the_way_the_driver_documents_it():
                                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                                    "--gpus", "2", "--backend", "gloo", "--device", "0", "--photons", "150000", "--steps", "6",
                                    "--warmup", "3", "--repeats", "2"], cwd=ROOT, stderr=subprocess.DEVNULL, timeout=900)
-    lines = [ln for ln in out.decode().splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, out[-2000:]
-    d = json.loads(lines[0])
+    d = check_line(out.decode(), only_line=False)     # (torchrun may write lines of its own; the driver reads the last one)
     assert d["n_gpus"] == 2 and d["collective"]["backend"] == "gloo" and d["collective"]["ranks_seen"] == 2
     assert d["counters_last_step"]["N"] == 300000 and d["repeats"] == 2
 
