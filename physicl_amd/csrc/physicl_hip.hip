@@ -3124,12 +3124,35 @@ size_t big_min_bytes() {
 //   what alloc_slab's candidates are made of.  Blocks of >= 64 MB are built that way; PCL_VMM=0 goes back to hipMalloc
 //   and so does any failure of the virtual-memory calls.  hipMemcpy2DAsync refuses rows that reach from one handle into
 //   the next (tools/vmm_copy_test2.hip): handles hold whole tiles and copy_row cuts its strided copies at their ends.
+//   A virtual address range is mapped ONCE (round 5).  Measured on this runtime (tools/attic/debug_shard.py,
+//   profiles/r05_vmm_remap.log): after hipMemUnmap + hipMemAddressFree of a 109 GB range, hipMemAddressReserve hands the
+//   same addresses out again, and the first kernels that go through the new hipMemMap'ing there still hit translations of
+//   the old one -- of the 1e8 photons a fill kernel wrote, 10 % to 76 % were not in the new range afterwards (zeros where
+//   the candidate sweep or the driver had left zeros), with fresh handles and with re-used ones alike, whether or not the
+//   process slept in between; the store's second fill was intact, and so was everything with hipMalloc'ed blocks
+//   (PCL_VMM=0).  With the freed range's addresses out of circulation -- so that a new range never lies where an old one
+//   was -- the fill is intact (PCL_VMM_KEEP_VA=0 brings the fault back).  The runtime only lets go of a range's physical
+//   memory at hipMemAddressFree (keeping the reservation across the unmap kept 54 GB "in use" after every handle had been
+//   released, tools/attic/debug_trim.py), so raw_free frees the addresses and reserves the very same ones again at once,
+//   unmapped for good.  Address space is plentiful (a 13.6 GB store per range, 2^47 bytes to spend) and most stores
+//   never get here: they come out of the pool still mapped.
+//   The physical handles of an unmapped range wait in g_vmm_idle (per device, by length) and the next range is mapped
+//   from them before new ones are created; pcl_pool_trim, PCL_POOL_GB=0 or an allocation that runs out of memory hand
+//   them back to the driver.
 struct vmm_block {
     size_t bytes;
     size_t chunk; // bytes per physical handle (the last one may be shorter)
+    int device;
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
+struct vmm_idle_handle {
+    hipMemGenericAllocationHandle_t h;
+    size_t len;
+    int device;
+};
 std::unordered_map<void *, vmm_block> g_vmm; // guarded by g_vmm_mu
+std::vector<vmm_idle_handle> g_vmm_idle;     // physical handles of freed ranges, kept for the next ones; guarded by g_vmm_mu
+size_t g_vmm_idle_bytes = 0;
 std::mutex g_vmm_mu;
 std::unordered_map<void *, double> g_rate; // whole-block sweep rate (GB/s) of live and idle blocks (alloc_slab); guarded by g_vmm_mu
 
@@ -3184,6 +3207,44 @@ size_t vmm_chunk_bytes() {
     return c;
 }
 
+// an idle handle of exactly ``len`` bytes on ``device``, if there is one (the caller maps it)
+bool vmm_take_idle(size_t len, int device, hipMemGenericAllocationHandle_t *h) {
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    for (size_t k = g_vmm_idle.size(); k-- > 0;)
+        if (g_vmm_idle[k].len == len && g_vmm_idle[k].device == device) {
+            *h = g_vmm_idle[k].h;
+            g_vmm_idle_bytes -= len;
+            g_vmm_idle.erase(g_vmm_idle.begin() + (long)k);
+            return true;
+        }
+    return false;
+}
+
+void vmm_keep_idle(const std::vector<hipMemGenericAllocationHandle_t> &handles, size_t total, size_t chunk, int device) {
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    size_t off = 0;
+    for (auto h : handles) {
+        const size_t len = total - off < chunk ? total - off : chunk;
+        g_vmm_idle.push_back({h, len, device});
+        g_vmm_idle_bytes += len;
+        off += len;
+    }
+}
+
+// every idle handle back to the driver
+size_t vmm_release_idle() {
+    std::vector<vmm_idle_handle> drop;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        drop.swap(g_vmm_idle);
+        bytes = g_vmm_idle_bytes;
+        g_vmm_idle_bytes = 0;
+    }
+    for (const vmm_idle_handle &d : drop) (void)hipMemRelease(d.h);
+    return bytes;
+}
+
 hipError_t vmm_malloc(void **p, size_t bytes, int device) {
     const size_t chunk = vmm_chunk_bytes();
     hipMemAllocationProp prop = {};
@@ -3200,15 +3261,22 @@ hipError_t vmm_malloc(void **p, size_t bytes, int device) {
     vmm_block blk;
     blk.bytes = total;
     blk.chunk = chunk;
+    blk.device = device;
     size_t mapped = 0;
     while (e == hipSuccess && mapped < total) {
         const size_t len = total - mapped < chunk ? total - mapped : chunk;
         hipMemGenericAllocationHandle_t h;
-        e = hipMemCreate(&h, len, &prop, 0);
-        if (e != hipSuccess) break;
+        if (!vmm_take_idle(len, device, &h)) {
+            e = hipMemCreate(&h, len, &prop, 0);
+            if (e == hipErrorOutOfMemory && vmm_release_idle() > 0) { // idle handles of other lengths held the memory
+                (void)hipGetLastError();
+                e = hipMemCreate(&h, len, &prop, 0);
+            }
+            if (e != hipSuccess) break;
+        }
         e = hipMemMap(static_cast<char *>(va) + mapped, len, 0, h, 0);
         if (e != hipSuccess) {
-            (void)hipMemRelease(h);
+            vmm_keep_idle({h}, len, len, device);
             break;
         }
         blk.handles.push_back(h);
@@ -3223,8 +3291,8 @@ hipError_t vmm_malloc(void **p, size_t bytes, int device) {
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (mapped) (void)hipMemUnmap(va, mapped);
-        for (auto h : blk.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(va, total);
+        vmm_keep_idle(blk.handles, mapped, chunk, device); // (the handles stay with the process)
+        if (!mapped) (void)hipMemAddressFree(va, total);   // (a range that was mapped, even in part, stays reserved)
         return e;
     }
     {
@@ -3241,9 +3309,12 @@ hipError_t raw_malloc(void **p, size_t bytes, int device) {
     if (bytes >= kPoolMinBlock && vmm_enabled()) {
         const hipError_t e = vmm_malloc(p, bytes, device);
         if (e == hipSuccess || e == hipErrorOutOfMemory) return e;
+        (void)hipGetLastError();
     }
     return hipMalloc(p, bytes);
 }
+
+size_t pool_limit();
 
 void raw_free(void *p) {
     if (!p) return;
@@ -3265,8 +3336,18 @@ void raw_free(void *p) {
     }
     (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block
     (void)hipMemUnmap(p, blk.bytes);
-    for (auto h : blk.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(p, blk.bytes);
+    (void)hipMemAddressFree(p, blk.bytes); // (the runtime lets go of the physical memory only here, not at the unmap)
+    static const bool park = [] { const char *e = getenv("PCL_VMM_KEEP_VA"); return !(e && e[0] == '0'); }();
+    if (park) { // the addresses are reserved again at once, never to be mapped: nothing of this process lands where the range was
+        void *again = nullptr;
+        if (hipMemAddressReserve(&again, blk.bytes, (size_t)2 << 20, p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+        } else if (again != p) { // (somebody else's addresses: not ours to hold)
+            (void)hipMemAddressFree(again, blk.bytes);
+        }
+    }
+    vmm_keep_idle(blk.handles, blk.bytes, blk.chunk, blk.device); // the physical memory stays with the process (see vmm_block)
+    if (pool_limit() == 0) (void)vmm_release_idle();              // PCL_POOL_GB=0: nothing is kept
 }
 
 // hipMemcpy2DAsync refuses a copy that reaches from one physical handle of a mapped range into the next (measured:
@@ -3343,6 +3424,22 @@ hipError_t big_malloc(void **p, size_t bytes) {
         }
         (void)hipSetDevice(device);
         e = raw_malloc(p, bytes, device);
+        // Memory this process has just handed back (tens of GB of released handles, pcl_pool_trim) is the driver's for a
+        // while before it is anybody's again: hipMemCreate says "out of memory" where hipMalloc used to stall (measured:
+        // a 13.6 GB slab refused right after 218 GB had been released).  While the device reports more free memory from
+        // one look to the next, wait and try again -- 3 s at most; a real shortage is reported after the first look that
+        // shows no progress.
+        size_t free_prev = 0, total_b = 0;
+        if (e == hipErrorOutOfMemory && hipMemGetInfo(&free_prev, &total_b) != hipSuccess) free_prev = 0;
+        for (int k = 0; e == hipErrorOutOfMemory && k < 30; ++k) {
+            (void)hipGetLastError();
+            std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            size_t free_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+            e = raw_malloc(p, bytes, device);
+            if (e == hipErrorOutOfMemory && free_b <= free_prev && k >= 2) break; // nothing is coming back
+            free_prev = free_b;
+        }
     }
     if (e == hipSuccess && eligible) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -5532,19 +5629,29 @@ int pcl_ctx_rtc_wait(pcl_ctx *ctx, int *pending_out) {
 }
 
 int pcl_pool_trim(int64_t *released_out) {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (released_out) *released_out = (int64_t)g_pool_bytes;
-    int device = 0;
-    const bool had = hipGetDevice(&device) == hipSuccess;
-    pool_flush_locked();
-    if (had) (void)hipSetDevice(device);
+    size_t held = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        held = g_pool_bytes;
+        int device = 0;
+        const bool had = hipGetDevice(&device) == hipSuccess;
+        pool_flush_locked(); // (mapped ranges give their handles to the idle list ...)
+        if (had) (void)hipSetDevice(device);
+    }
+    const size_t idle = vmm_release_idle(); // (... which goes back to the driver here: the memory is the device's again)
+    if (released_out) *released_out = (int64_t)(idle > held ? idle : held);
     return PCL_OK;
 }
 
 int pcl_pool_bytes(int64_t *idle_out) {
     if (!idle_out) return fail(PCL_ERR_ARG, "idle_out is NULL");
+    size_t handles;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        handles = g_vmm_idle_bytes;
+    }
     std::lock_guard<std::mutex> lk(g_pool_mu);
-    *idle_out = (int64_t)g_pool_bytes;
+    *idle_out = (int64_t)(g_pool_bytes + handles); // idle blocks + idle physical handles of ranges that were unmapped
     return PCL_OK;
 }
 

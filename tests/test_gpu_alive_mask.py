@@ -338,3 +338,109 @@ def test_a_k_body_call_takes_the_single_calls_path_with_k_as_a_promise(K, planes
         assert g1 >= -(-N // 128) and g2 + g1 > g1 - 1 and r2 >= 1
     else:
         assert w1 == (0, 0, 0, 0)
+
+
+LIVE_PLANES = {"no_measure": None, "no_planes": [], "one_plane": [[2e5, np.nan, np.nan]], "three_planes": PL3}
+
+
+@pytest.mark.parametrize("ids", ["implicit_ids", "explicit_ids"])
+@pytest.mark.parametrize("first_step", [0, 1], ids=["even_first_step", "odd_first_step"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("planes_key", sorted(LIVE_PLANES))
+def test_delete_ahead_live_kernel_vs_oracle(planes_key, dtype, first_step, ids):
+    """k_delete_ahead_live -- the kernel that carries every delete leg of the bench -- directly against the oracle's
+    step-by-step chain (physicl/light.py:239-260, physicl/newton.py:15-16), in every shape ahead_launch_t picks it for:
+    no measure step at all (n_planes = -1), a measure step without planes, one plane; fp64 and fp32; a first body on an
+    even and on an odd launch index (an odd one starts in the middle of a Philox decision block); ids implicit (a fresh
+    store) and explicit (after an earlier compaction).  Nothing but the rows is looked at between the bodies, so the
+    bodies are answered from the launch's rows; flags once near the end, survivor ids / r / v / dr at the end -- bit for
+    bit.  ``pcl_store_ahead_work`` says which kernel ran: the live kernel tallies its groups and rounds, k_delete_ahead
+    (three planes: the shape the live kernel does not take) tallies nothing."""
+    from physicl_amd import _hip as hip
+    planes = LIVE_PLANES[planes_key]
+    np_t = np.float64 if dtype == "f64" else np.float32
+    N, dt, n_k, seed = 300_007, 1e-3, 1e-3, 29
+    rs = np.random.RandomState(11)
+    direction = rs.normal(size=(N, 3))
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    init = {"r": (rs.normal(size=(N, 3)) * 1e5).astype(np_t), "v": (direction * C_LIT).astype(np_t), "E": rs.uniform(1, 2, N).astype(np_t)}
+    st = {"r": cols(init["r"]), "v": cols(init["v"]), "dr": [np.zeros(N, np_t)] * 3, "dv": [np.zeros(N, np_t)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64) + 1000}
+    oplanes = planes or []
+
+    def body(d, step, pdel):
+        A_k = pdel / (n_k * C_LIT * dt)
+        before = d.count
+        flags, row = oracle_body(st, dt, A_k, n_k, seed, step, oplanes, dtype=np_t)
+        o = d.step_fused_delete(dt, A_k, n_k, hip.RNG_PHILOX, seed, step, planes, lazy=True)
+        got = device_row(o) if planes is not None else [o["N"], o["removed"]]
+        want = row if planes is not None else row[:2]
+        assert got == want, (step, got, want)
+        return before, flags
+
+    try:
+        with hip.Device(0) as d:
+            d.store_alloc(N, dtype)
+            d.upload_state(dict(init, id_base=1000))
+            step = first_step
+            if ids == "explicit_ids":
+                hip.set_knob("PCL_AHEAD", "0")                     # two plain bodies, then a download: the store is compacted, ids explicit
+                for _ in range(2):
+                    body(d, step, 0.45)
+                    step += 1
+                assert_state(d, st, hip, "after the compaction")
+                assert d.slots == d.count and not d.is_uniform()
+                hip.set_knob("PCL_AHEAD", None)
+            w0, (l0, s0, _) = d.ahead_work(), d.ahead_stats()
+            bodies = 11
+            for k in range(bodies):
+                before, flags = body(d, step, 0.2)
+                if k == bodies - 2:
+                    assert np.array_equal(d.last_delete_flags(before), flags), step
+                step += 1
+            w1, (l1, s1, _) = d.ahead_work(), d.ahead_stats()
+            assert_state(d, st, hip, "end")
+            work = [b - a for a, b in zip(w0, w1)]
+            assert l1 - l0 >= 1 and s1 - s0 > l1 - l0, (l0, s0, l1, s1)       # bodies were answered from rows worked out ahead
+            if planes_key == "three_planes":
+                assert work == [0, 0, 0, 0]                                    # k_delete_ahead ran (it keeps no tally)
+            else:
+                g2, g1, r2, r1 = work                                          # the live kernel ran: every slot loaded once per launch
+                assert g2 + g1 >= (l1 - l0) and g2 + g1 >= -(-before // 128), work
+                if ids == "implicit_ids":      # (after the download of the explicit case the library runs one plain body before it works ahead again)
+                    assert (g1 > 0) if first_step % 2 == 1 else (g2 > 0), (work, first_step)     # odd first step: a first pass of one body
+    finally:
+        hip.set_knob("PCL_AHEAD", None)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_delete_ahead_live_with_changing_time_steps_vs_oracle(dtype):
+    """The changing-dt chain of the test above with ONE plane, so that the live kernel is the one that works the bodies out:
+    runs of three equal time steps (every change of dt ends a launch's prediction: the rows handed out so far are committed,
+    r owes the run's moves, and a new launch starts from there).  Rows every body, flags now and then, the state twice."""
+    from physicl_amd import _hip as hip
+    np_t = np.float64 if dtype == "f64" else np.float32
+    N, n_k, seed = 150_000, 1e-3, 31
+    rs = np.random.RandomState(8)
+    direction = rs.normal(size=(N, 3))
+    direction /= np.linalg.norm(direction, axis=1)[:, None]
+    init = {"r": (rs.normal(size=(N, 3)) * 1e5).astype(np_t), "v": (direction * C_LIT).astype(np_t), "E": rs.uniform(1, 2, N).astype(np_t)}
+    planes = [[np.nan, 1e5, np.nan]]
+    st = {"r": cols(init["r"]), "v": cols(init["v"]), "dr": [np.zeros(N, np_t)] * 3, "dv": [np.zeros(N, np_t)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64)}
+    dts = [1e-3 * (1.0 + 0.125 * ((k // 3) % 5)) for k in range(24)]
+    with hip.Device(0) as d:
+        d.store_alloc(N, dtype)
+        d.upload_state(dict(init, id_base=0))
+        for step, dt in enumerate(dts):
+            before = d.count
+            A_k = 0.05 / (n_k * C_LIT * dt)
+            flags, row = oracle_body(st, dt, A_k, n_k, seed, step, planes, dtype=np_t)
+            o = d.step_fused_delete(dt, A_k, n_k, hip.RNG_PHILOX, seed, step, planes, lazy=True)
+            assert device_row(o) == row, (step, device_row(o), row)
+            if step % 7 == 6:
+                assert np.array_equal(d.last_delete_flags(before), flags), step
+            if step in (10, 23):
+                assert_state(d, st, hip, step)
+        launches, served, missed = d.ahead_stats()
+        assert launches >= 1 and sum(d.ahead_work()) > 0, (launches, served, missed, d.ahead_work())

@@ -123,3 +123,33 @@ def test_temporaries_of_big_stores_go_back_where_they_came_from():
             "d.close(); print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, PCL_BIG_MIN_MB="1"), timeout=300)
     assert out.decode().strip().endswith("ok")
+
+
+@pytest.mark.parametrize("trim", [False, True], ids=["handles_kept", "handles_released"])
+def test_a_store_created_after_a_much_bigger_one_was_freed_keeps_what_kernels_wrote(trim):
+    """Regression (round 5, profiles/r05_vmm_remap.log): after this process had unmapped and freed the address range of a
+    109 GB store, hipMemAddressReserve handed the same addresses out again and the first kernels through the new mapping
+    still hit translations of the old one -- 10 % to 76 % of what a fill kernel wrote was not in the new store.  A freed
+    range now keeps its addresses reserved (never mapped twice) and its physical handles serve the next range
+    (``handles_kept``) unless pcl_pool_trim handed them back to the driver in between (``handles_released``)."""
+    code = ("import numpy as np, sys\n"
+            "from physicl_amd import _hip as hip\n"
+            "C = 299792458.0\n"
+            "d = hip.Device(0)\n"
+            "f, t = d.mem_info()\n"
+            "BIG = 800_000_000 if t > 250 * 2**30 else 200_000_000\n"
+            "d.store_alloc(BIG); d.fill_photons(BIG, 0, C, 1.0, 2.0, 3); d.sync(); d.store_free()\n"
+            "held = hip.pool_bytes()\n"
+            "assert held >= BIG * 17 * 8\n"
+            "if sys.argv[1] == 'trim':\n"
+            "    assert hip.pool_trim() >= BIG * 17 * 8 and hip.pool_bytes() == 0\n"
+            "N = 100_000_000\n"
+            "d.store_alloc(N)\n"
+            "for g in range(2):\n"
+            "    d.fill_photons(N, g * N, C, 1.0, 2.0, 3)\n"
+            "    v0 = d.download(hip.V0); E = d.download(hip.E)\n"
+            "    assert int((v0 != C).sum()) == 0 and int(((E < 1.0) | (E > 2.0)).sum()) == 0, (g, int((v0 != C).sum()))\n"
+            "    assert d.step_counters([])[0] == N\n"
+            "d.close(); print('ok')\n")
+    out = subprocess.check_output([sys.executable, "-c", code, "trim" if trim else "keep"], cwd=ROOT, timeout=600)
+    assert out.decode().strip().endswith("ok")
