@@ -256,6 +256,9 @@ int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_o
  * photons that decided two bodies, rounds that decided one.  bench.py prices them with the kernel's instruction counts
  * (profiles/isa_counts.json, "k_delete_ahead_live<double>") for the VALU roofline of the delete legs. */
 int pcl_store_ahead_work(pcl_ctx *ctx, int64_t *groups_two_out, int64_t *groups_one_out, int64_t *rounds_two_out, int64_t *rounds_one_out);
+/* The clock (GHz) the chip held under the k_delete_ahead_live launches of this context (as pcl_store_last_multi_clock,
+ * over all of them); 0 before any launch. */
+int pcl_store_ahead_clock(pcl_ctx *ctx, double *ghz_out);
 /* Allocate now what the first compaction of the store would allocate on demand (the second slab -- chosen among a few
  * candidates like the first, tens of ms for a big store --, the id arrays, the mask scratch), so that a run whose step
  * list holds a delete step pays for it at set-up and not inside its third loop body.  Optional.                        */
@@ -376,6 +379,11 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
  * without the probe; the library picks per launch, PCL_MULTI_SAT = 1 / 0 forces).                                    */
 int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *wave_steps_out, int *photons_per_wave_out,
                               int64_t *saturated_wave_steps_out);
+/* The clock (GHz) the chip held under the last pcl_step_fused_multi launch: shader cycles (s_memtime) over 100 MHz ticks
+ * (s_memrealtime) between the start and the end of every workgroup, summed over the launch.  The ceiling of a kernel bound
+ * by VALU issue is 1024 SIMDs x THIS clock, in SIMD-cycles per second (bench.py's roofline record); 0 before any launch.
+ * No counterpart in the reference (instrumentation of this library).                                                    */
+int pcl_store_last_multi_clock(pcl_ctx *ctx, double *ghz_out);
 /* Debug builds of the K-step kernels only (environment PCL_RTC_EXTRA=PCL_HIT_HIST, knob PCL_MULTI_HIST=1): the last
  * launch's histogram of hits queued per wave and step (per round in the 256-photon form), bins 0 .. 127 and ">= 128"
  * (host pointer, 129 elements).  tools/hit_hist.py; PCL_ERR_STATE otherwise.                                          */

@@ -57,6 +57,8 @@ _PROTOTYPES = {
     "pcl_comm_info": [_vp, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int64)],
     "pcl_comm_destroy": [_vp],
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
+    "pcl_store_last_multi_clock": [_vp, POINTER(c_double)],
+    "pcl_store_ahead_clock": [_vp, POINTER(c_double)],
     "pcl_store_last_multi_hist": [_vp, _vp],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
     "pcl_store_ahead_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
@@ -430,6 +432,18 @@ class Device:
         a, b, c, e = c_int64(), c_int64(), c_int(), c_int64()
         check(self.lib.pcl_store_last_multi_work(self.ctx, byref(a), byref(b), byref(c), byref(e)))
         return a.value, b.value, c.value, e.value
+
+    def last_multi_clock(self):
+        """GHz the chip held under the last step_fused_multi launch (pcl_store_last_multi_clock); 0.0 before any."""
+        g = c_double()
+        check(self.lib.pcl_store_last_multi_clock(self.ctx, byref(g)))
+        return g.value
+
+    def ahead_clock(self):
+        """GHz the chip held under this context's k_delete_ahead_live launches (pcl_store_ahead_clock); 0.0 before any."""
+        g = c_double()
+        check(self.lib.pcl_store_ahead_clock(self.ctx, byref(g)))
+        return g.value
 
     def last_multi_hist(self):
         """Hits queued per wave and step in the last step_fused_multi launch, 129 bins (debug builds: pcl_store_last_multi_hist)."""

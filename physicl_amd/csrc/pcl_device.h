@@ -893,7 +893,31 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
 // cnt[(4 + n_planes)*k + {0: hits, 1..3: sign counts, 4..: plane crossings}] for k = 0..K-1.
 // cnt[(4 + n_planes)*K] = dense passes of the hit queues over the whole launch (the work tally of the VALU roofline record);
 // cnt[(4 + n_planes)*K + 1] = wave-steps that took the saturation shortcut (SATP variants).
+// cnt[(4 + n_planes)*K + 2], [.. + 3] = shader cycles and 100 MHz ticks between start and end, summed over the workgroups:
+// their quotient x 100 MHz is the clock the chip held under THIS launch (the VALU roofline's ceiling is in cycles).
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// What clock did the chip hold under this launch?  The kernels that are bound by VALU issue have their ceiling in
+// SIMD-cycles, and the chip lowers its clock under exactly such kernels (2.1 - 2.3 GHz instead of the 2.4 GHz of the data
+// sheet).  s_memtime counts shader cycles, s_memrealtime a constant 100 MHz (MI355X_MICROARCH.md, "DVFS give-back" item 6):
+// every workgroup notes both when it starts and adds the two differences to a pair of launch-wide sums when it ends --
+// two scalar reads at either end and two atomics per workgroup.  The start values wait in LDS, not in registers.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pcl_clock_begin(pcl_u64 *s_clk) {
+    if (threadIdx.x == 0) {
+        s_clk[1] = __builtin_amdgcn_s_memrealtime();
+        s_clk[0] = __builtin_amdgcn_s_memtime();
+    }
+}
+// (call after the workgroup's last barrier; sums[0] += shader cycles, sums[1] += 100 MHz ticks)
+__device__ __forceinline__ void pcl_clock_end(const pcl_u64 *s_clk, pcl_u64 *sums) {
+    if (threadIdx.x == 0) {
+        const pcl_u64 t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&sums[0], t1 - s_clk[0]);
+        atomicAdd(&sums[1], w1 - s_clk[1]);
+    }
+}
+
 #define PCL_MULTI_MAX 64
 template <typename T>
 struct pcl_multi_args {
@@ -936,8 +960,10 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
     __shared__ pcl_u32 s_pass, s_sat;
+    __shared__ pcl_u64 s_clk[2]; // the workgroup's start: shader cycles, 100 MHz ticks (pcl_clock_stamp)
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
     if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
+    pcl_clock_begin(s_clk);
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
@@ -1061,7 +1087,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
             w_passes += (w_hits + 63u) >> 6;
             asm volatile("" : "+v"(w_passes)); // lives in a VGPR (one is free, the scalar file is not): no lane spill for a tally
 #ifdef PCL_HIT_HIST /* debug build (PCL_RTC_EXTRA=PCL_HIT_HIST): how many hits did this wave queue in this step?  129 bins */
-            if (lane0) atomicAdd(&a.cnt[nslots * a.K + 2 + (w_hits < 128u ? w_hits : 128u)], (pcl_u64)1);
+            if (lane0) atomicAdd(&a.cnt[nslots * a.K + 4 + (w_hits < 128u ? w_hits : 128u)], (pcl_u64)1);
 #endif
             // the scatter itself, densely: item j by lane j                                light.py:309-311
             for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
@@ -1119,6 +1145,7 @@ __device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
     if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
     if (threadIdx.x == 0 && s_sat) atomicAdd(&a.cnt[nslots * a.K + 1], (pcl_u64)s_sat);
+    pcl_clock_end(s_clk, &a.cnt[nslots * a.K + 2]);
 }
 
 // NQ: VEC-wide groups per lane and trip (photons per lane = VEC * NQ).  The dense pass costs the same whether 5 or 64
@@ -1134,8 +1161,10 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
     const int nslots = 4 + a.n_planes;
     __shared__ pcl_hit_queue<T, VEC> s_q;
     __shared__ pcl_u32 s_pass, s_sat;
+    __shared__ pcl_u64 s_clk[2]; // the workgroup's start: shader cycles, 100 MHz ticks (pcl_clock_stamp)
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
     if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
+    pcl_clock_begin(s_clk);
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
     const bool lane0 = (threadIdx.x & 63) == 0;
@@ -1298,7 +1327,7 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 w_passes += (wbase - qbase + 63u) >> 6;
                 asm volatile("" : "+v"(w_passes));
 #ifdef PCL_HIT_HIST /* (256-photon form: hits of the round -- all of the wave's, or one group's) */
-                if (lane0) atomicAdd(&a.cnt[nslots * a.K + 2 + ((wbase - qbase) < 128u ? (wbase - qbase) : 128u)], (pcl_u64)1);
+                if (lane0) atomicAdd(&a.cnt[nslots * a.K + 4 + ((wbase - qbase) < 128u ? (wbase - qbase) : 128u)], (pcl_u64)1);
 #endif
                 // the scatter itself, densely: item j by lane j                                light.py:309-311
                 for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
@@ -1374,6 +1403,7 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
     if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
     if (threadIdx.x == 0 && s_sat) atomicAdd(&a.cnt[nslots * a.K + 1], (pcl_u64)s_sat);
+    pcl_clock_end(s_clk, &a.cnt[nslots * a.K + 2]);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -946,7 +946,8 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
 //   the ordinary way.  Same operations per photon as k_delete_alive (tests/test_gpu_alive_mask.py runs both).
 constexpr int kAheadMax = 32;                       // bodies per launch, at most
 constexpr int kAheadRow = 4 + PCL_MAX_PLANES;       // counters per body: alive, sign x 3, planes
-constexpr int kAheadWork = 4;                       // k_delete_ahead_live's own work tally: groups loaded (first pass of two bodies, of one), rounds of two bodies, of one
+constexpr int kAheadWork = 6;                       // k_delete_ahead_live's own work tally: groups loaded (first pass of two bodies, of one), rounds of two bodies, of one;
+                                                    // [4], [5]: shader cycles and 100 MHz ticks of the workgroups' lifetimes (the clock under the launch)
 constexpr int kAheadAcc = 1 + kAheadMax * kAheadRow + kAheadWork; // device accumulators: ticket, rows, work; pinned block: rows, sequence word, work
 template <typename T>
 struct ahead_args {
@@ -1220,6 +1221,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int q = threadIdx.x; q < kAheadMax * kAheadRow; q += kBlock) s_cnt[q] = 0;
     if (threadIdx.x < kAheadWork) s_work[threadIdx.x] = 0;
+    __shared__ pcl_u64 s_clk[2];
+    pcl_clock_begin(s_clk);
     __syncthreads();
     const bool hi = lane >= 32;
     const int bit = 2 * (lane & 31);
@@ -1405,6 +1408,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
         atomicAdd(&s_work[1], w_groups1);
         atomicAdd(&s_work[2], w_rounds2);
         atomicAdd(&s_work[3], w_rounds1);
+    }
+    if (threadIdx.x == 0) { // (this workgroup's lifetime so far: its rows are done)
+        s_work[4] = (uint32_t)(__builtin_amdgcn_s_memtime() - s_clk[0]);
+        s_work[5] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - s_clk[1]);
     }
     if (lane < a.K) { // the wave's sums join the workgroup's
         if (t_kept) atomicAdd(&s_cnt[lane * kAheadRow + 0], t_kept);
@@ -2897,6 +2904,8 @@ struct pcl_ctx {
     int64_t multi_work[4] = {0, 0, 0, 0}; // last pcl_step_fused_multi launch: dense passes, wave-steps, photons per wave, wave-steps that took
                                           // the saturation shortcut (-1: the launch did not probe) (pcl_store_last_multi_work)
     int multi_hist_at = -1;          // where the last launch's hit histogram lies in h_multi (debug builds; -1: none)
+    double multi_clock_ghz = 0.0;    // the clock the chip held under the last pcl_step_fused_multi launch (pcl_store_last_multi_clock)
+    double ahead_clock_cycles = 0.0, ahead_clock_ticks = 0.0; // k_delete_ahead_live launches of this context: shader cycles / 100 MHz ticks
     int64_t multi_launches = 0;      // pcl_step_fused_multi launches on this population
     bool multi_sat_on = false, multi_sat_used = false; // the probing variant paid on its last launch / the current launch uses it
     int multi_sat_next = 0;          // launches until the probing variant is tried again
@@ -2930,7 +2939,7 @@ struct pcl_ctx {
     uint64_t *ahead_host = nullptr;          // pinned rows + sequence word
     uint64_t ahead_seq = 0;
     int64_t ahead_launches = 0, ahead_served = 0, ahead_missed = 0; // statistics (pcl_store_ahead_stats)
-    int64_t ahead_work[kAheadWork] = {0, 0, 0, 0}; // k_delete_ahead_live's own tally, summed over its launches (pcl_store_ahead_work)
+    int64_t ahead_work[kAheadWork] = {0, 0, 0, 0, 0, 0}; // k_delete_ahead_live's own tally, summed over its launches (pcl_store_ahead_work)
     int ahead_wait = 0, ahead_backoff = 0;   // bodies to run the plain way before the next attempt / the last such pause (doubles per
                                              // launch that was cut short: a loop that looks at the store between its bodies)
     unsigned long long *lb_status = nullptr; // decoupled look-back words of k_delete_onepass, one per 1024-particle unit
@@ -5239,6 +5248,8 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
         PCL_TRY(PCL_DISPATCH(ctx, ahead_launch_t<double>(ctx), ahead_launch_t<float>(ctx)));
         PCL_TRY(ahead_wait(ctx));
         for (int i = 0; i < kAheadWork; ++i) ctx->ahead_work[i] += (int64_t)ctx->ahead_host[kAheadMax * kAheadRow + 1 + i];
+        ctx->ahead_clock_cycles += (double)ctx->ahead_host[kAheadMax * kAheadRow + 1 + 4];
+        ctx->ahead_clock_ticks += (double)ctx->ahead_host[kAheadMax * kAheadRow + 1 + 5];
         sp.active = true;
         ++ctx->ahead_launches;
         return ahead_serve(ctx, alive_out);
@@ -5598,6 +5609,18 @@ int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_o
     if (launches_out) *launches_out = ctx->ahead_launches;
     if (served_out) *served_out = ctx->ahead_served;
     if (missed_out) *missed_out = ctx->ahead_missed;
+    return PCL_OK;
+}
+
+int pcl_store_last_multi_clock(pcl_ctx *ctx, double *ghz_out) {
+    if (!ctx || !ghz_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *ghz_out = ctx->multi_clock_ghz;
+    return PCL_OK;
+}
+
+int pcl_store_ahead_clock(pcl_ctx *ctx, double *ghz_out) {
+    if (!ctx || !ghz_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *ghz_out = ctx->ahead_clock_ticks > 0.0 ? ctx->ahead_clock_cycles / ctx->ahead_clock_ticks * 0.1 : 0.0;
     return PCL_OK;
 }
 
@@ -6574,7 +6597,7 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     // the v rows must hold the current velocity; a pending implicit dv of an earlier step is simply superseded
     // rows + the two work tallies (+ the 129 bins of a PCL_HIT_HIST debug build's histogram, knob PCL_MULTI_HIST)
     static knob k_hist("PCL_MULTI_HIST");
-    const int n_extra = 2 + ((k_hist.set() && !k_hist.off() && nslots * k_steps + 131 <= kMultiSlots) ? 129 : 0);
+    const int n_extra = 4 + ((k_hist.set() && !k_hist.off() && nslots * k_steps + 133 <= kMultiSlots) ? 129 : 0);
     PCL_HIP(hipMemsetAsync(ctx->d_multi, 0, (size_t)(nslots * k_steps + n_extra) * sizeof(uint64_t), ctx->stream));
     ctx->hits_on_host = false;
     ctx->last_async_bank = -1;
@@ -6595,7 +6618,11 @@ int pcl_step_fused_multi(pcl_ctx *ctx, double dt, int k_steps, double A, double 
             for (int j = 0; j < 3 + np; ++j) out_host[(5 + np) * k + 1 + j] = (int64_t)ctx->h_multi[nslots * k + 1 + j];
             out_host[(5 + np) * k + 4 + np] = (int64_t)ctx->h_multi[nslots * k];
         }
-        ctx->multi_hist_at = n_extra > 2 ? nslots * k_steps + 2 : -1;
+        ctx->multi_hist_at = n_extra > 4 ? nslots * k_steps + 4 : -1;
+        {   // the clock the chip held under this launch: shader cycles / 100 MHz ticks, summed over the workgroups (pcl_clock_end)
+            const uint64_t cyc = ctx->h_multi[nslots * k_steps + 2], ticks = ctx->h_multi[nslots * k_steps + 3];
+            ctx->multi_clock_ghz = ticks ? (double)cyc / (double)ticks * 0.1 : 0.0;
+        }
         ctx->multi_work[0] = (int64_t)ctx->h_multi[nslots * k_steps];                                  // dense passes
         ctx->multi_work[1] = div_up(N, (int64_t)ctx->multi_work[2]) * (int64_t)k_steps;                // wave-steps
         ctx->multi_work[3] = ctx->multi_sat_used ? (int64_t)ctx->h_multi[nslots * k_steps + 1] : -1;
