@@ -55,8 +55,15 @@ sys.path.insert(0, ROOT)
 C_LIT = 299792458.0            # str(light.c)          physicl/light.py:14
 H_LIT = 6.62607015e-34         # str(light.h).upper()  physicl/light.py:15
 HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md)
-VALU_PEAK = N_SIMD * CLOCK_GHZ * 1e9 / 4.0     # a wave64 VALU instruction occupies its 16-lane SIMD for 4 cycles: 6.14e11 wave-instr/s
+N_SIMD, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMDs; the data sheet's engine clock (MI355X_MICROARCH.md) -- only where no launch measured its own
+
+
+def valu_peak(clock_ghz):
+    """The ceiling of a kernel bound by VALU issue: SIMD-cycles per second at the clock the chip HELD under the launch
+    (measured in the kernel: pcl_store_last_multi_clock / pcl_store_ahead_clock), not at the data sheet's 2.4 GHz.  What an
+    instruction costs of those cycles is a property of its class (2 / 4 / 8 / 16: tools/valu_issue_probe.hip,
+    profiles/r05_valu_issue_probe.txt; tools/isa_count.py prices a kernel's instruction mix)."""
+    return N_SIMD * (clock_ghz if clock_ghz and clock_ghz > 0 else CLOCK_GHZ) * 1e9
 
 PROFILES = {
     # examples/variable_n_scattering.ipynb:30,52-56.  User n=1e-15, A=1e-19; the reference swaps them
@@ -211,7 +218,8 @@ class Bench:
             rows = self.dev.step_fused_multi(self.prof["dt"], ks, self.sc(k))
             c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
             hits += int(c[:, 1].sum())
-            self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work())   # steps, hits, dense passes, wave-steps, photons per wave, wave-steps on exp's shortcut (-1: no probe)
+            # steps, hits, dense passes, wave-steps, photons per wave, wave-steps on exp's shortcut (-1: no probe), GHz held under the launch
+            self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work() + (round(self.dev.last_multi_clock(), 4),))
             self.totals = self.comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
             k += ks
         return hits
@@ -296,6 +304,7 @@ def tame_leg(b, args, R):
                "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el],
                "repeat_hit_fraction": [round(h / float(N * args.steps), 6) for h in hits],
                "roofline": (dict(valu, bound="valu", kernel="k_multi (hipRTC specialisation of the tame expression)",
+                                 valu_busy=static_valu("pcl_rtc_multi_e1 tame")[0],
                                  traffic=pmc_traffic("pcl_rtc_multi_e1", N), avg_launch_ms=kb["avg_ms"], launches=kb["launches"],
                                  hbm={"achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_particle": 128.0})
@@ -337,7 +346,7 @@ def static_profile(profile, mode, dtype, N, S, steps):
         return None
     for key in ("%s:%s%s:%d:K%d:steps%d" % (profile, mode, "-f32" if dtype == "f32" else "", N, S, steps),
                 "%s:%s%s:%d" % (profile, mode, "-f32" if dtype == "f32" else "", N)):
-        if key in table:
+        if key in table and table[key].get("csrc_sha") == csrc_sha():          # (a run of other device sources is not quoted)
             return dict(table[key], key=key, file="profiles/pmc_traffic.json",
                         note="from a committed rocprofv3 --pmc run of this configuration, not from this process")
     return None
@@ -351,38 +360,69 @@ def _json_file(name):
         return {}
 
 
+_CSRC_SHA = None
+
+
+def csrc_sha():
+    global _CSRC_SHA
+    if _CSRC_SHA is None:
+        from physicl_amd import build
+        _CSRC_SHA = build.csrc_sha()
+    return _CSRC_SHA
+
+
+def pmc_record(kernel):
+    """The committed rocprofv3 --pmc record of one kernel (profiles/pmc_traffic.json, section "kernels"), or None when there is
+    none OR when it was measured on other device sources than the ones this process runs (``csrc_sha``): a counter figure
+    of a kernel that has changed since is not quoted."""
+    rec = _json_file("pmc_traffic.json").get("kernels", {}).get(kernel)
+    if not rec or rec.get("csrc_sha") != csrc_sha():
+        return None
+    return rec
+
+
 def pmc_traffic(kernel, units):
     """HBM bytes of one launch of ``kernel`` from the COMMITTED rocprofv3 --pmc run (profiles/pmc_traffic.json, section
     "kernels": bytes per photon or per slot = FETCH_SIZE x 2 + WRITE_SIZE per MI355X_MICROARCH.md, separate passes, and
     the commit / profile file they were measured at) x the units this launch processed.  PMC counters cannot be read
     from inside the process: the record says where the figure comes from."""
-    rec = _json_file("pmc_traffic.json").get("kernels", {}).get(kernel)
-    if not rec:
+    rec = pmc_record(kernel)
+    if not rec or "bytes_per_unit" not in rec:
         return None
     return {"bytes": rec["bytes_per_unit"] * units, "bytes_per_unit": rec["bytes_per_unit"], "unit": rec["unit"],
-            "source": rec["source"], "measured_at_commit": rec.get("commit"), "note": "committed rocprofv3 --pmc run, not this process"}
+            "source": rec["source"], "measured_at_commit": rec.get("commit"), "csrc_sha": rec.get("csrc_sha"),
+            "note": "committed rocprofv3 --pmc run, not this process"}
 
 
-def ahead_valu_roofline(work, kern_ms):
-    """VALU-issue roofline of k_delete_ahead_live over the launches of one run: wave-instructions = the kernel's own tally
-    (groups of 128 slots loaded -- their first pass decided on the spot, two bodies or one --, rounds of 64 listed photons deciding
-    two bodies / one body: pcl_store_ahead_work) x the four instruction counts of profiles/isa_counts.json ("k_delete_ahead_live<double>": least squares of SQ_INSTS_VALU on
-    that tally over eight launches, residuals < 0.5 %, profiles/r04_calib_ahead.md) / the launches' duration (HIP events)."""
-    c = _json_file("isa_counts.json").get("k_delete_ahead_live<double>")
-    if not c or not kern_ms or not sum(work):
+def ahead_valu_roofline(work, kern_ms, clock_ghz=0.0, ids=False):
+    """VALU-issue roofline of k_delete_ahead_live over the launches of one run.  Issue work = the kernel's own tally (groups
+    of 128 slots loaded -- their first pass decided on the spot, two bodies or one --, rounds of 64 listed photons deciding
+    two bodies / one body: pcl_store_ahead_work) x the four instruction counts of profiles/isa_counts.json (least squares of
+    SQ_INSTS_VALU on that tally, profiles/r04_calib_ahead.md) x the mean price of an instruction of the kernel's mix
+    (tools/isa_count.py --aot; classes priced by tools/valu_issue_probe.hip) = SIMD-cycles; ceiling = 1024 SIMDs x the clock
+    the launches held (pcl_store_ahead_clock)."""
+    tab = _json_file("isa_counts.json")
+    c = tab.get("k_delete_ahead_live<double>")
+    mix = tab.get("aot", {}).get("k_delete_ahead_live<double, %s>" % ("true" if ids else "false"))
+    if not c or not mix or not kern_ms or not sum(work[:4]):
         return None
-    g2, g1, r2, r1 = work
+    g2, g1, r2, r1 = work[:4]
     groups = g2 + g1
     names = ("valu_per_group_first_pass_two_bodies", "valu_per_group_first_pass_one_body", "valu_per_round_two_bodies", "valu_per_round_one_body")
     instr = sum(c[nm] * w for nm, w in zip(names, work))
-    ach = instr / (kern_ms * 1e-3)
+    peak = valu_peak(clock_ghz)
+    ach = instr * mix["cycles_per_valu"] / (kern_ms * 1e-3)
+    rec = pmc_record("k_delete_ahead_live<double>") or {}
     return {"bound": "valu", "kernel": "k_delete_ahead_live (the run's loop bodies worked out a launch at a time for the photons still alive)",
-            "achieved": ach, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": ach / VALU_PEAK, "wave_instructions": instr,
+            "achieved": ach, "peak": peak, "unit": "SIMD-cycles/s", "frac": ach / peak,
+            "frac_at_4_waves_per_simd": instr * mix["cycles_per_valu_at_4_waves"] / (kern_ms * 1e-3) / peak,
+            "clock_GHz": clock_ghz if clock_ghz > 0 else None, "valu_busy": rec.get("valu_busy"), "wave_instructions": instr,
+            "cycles_per_wave_instruction": mix["cycles_per_valu"],
             "work": {"groups_of_128_slots_first_pass_two_bodies": g2, "groups_of_128_slots_first_pass_one_body": g1, "rounds_two_bodies": r2,
                      "rounds_one_body": r1},
             "instruction_counts": {nm: c[nm] for nm in names},
             "instruction_counts_source": c["source"], "total_ms": kern_ms,
-            "peak_note": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction",
+            "peak_note": "1024 SIMDs x the clock measured in the kernel (s_memtime / s_memrealtime); an instruction costs 2 / 4 / 8 / 16 cycles by class",
             "traffic": pmc_traffic("k_delete_ahead_live<double>", groups * 128),
             "hbm": {"achieved": 33.0 * groups * 128 / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": 33.0 * groups * 128 / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_slot": 33.0}}
@@ -390,20 +430,25 @@ def ahead_valu_roofline(work, kern_ms):
 
 def valu_roofline(work, kern_ms, expr, f32):
     """VALU-issue roofline of the K-step pass over a set of launches.  ``work``: per launch (steps, hits, dense passes,
-    wave-steps, photons per wave) as the kernel tallied them; ``kern_ms``: the sum of those launches' durations (HIP
-    events).  Wave-instructions = decision instructions x wave-steps (+ the launch's fixed work per wave and grid-stride
-    trip) + dense-pass instructions x dense passes, the
-    counts per code object from profiles/isa_counts.json (tools/isa_count.py: the hipRTC translation unit's gfx950
-    assembly; the decision count is the dynamic one, calibrated against SQ_INSTS_VALU of the committed PMC run, the
-    dense pass is a straight-line loop body).  Peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction."""
+    wave-steps, photons per wave, wave-steps on exp's shortcut, GHz the chip held) as the kernel tallied them; ``kern_ms``: the
+    sum of those launches' durations (HIP events).
+    Issue work in SIMD-cycles = decision instructions x wave-steps (+ the launch's fixed work per wave and grid-stride trip)
+    x the mean price of the decision part's instruction mix + the dense pass's cycles x dense passes -- counts and prices per
+    code object from profiles/isa_counts.json (tools/isa_count.py: the hipRTC translation unit's gfx950 assembly; the decision
+    count is the dynamic one, calibrated against SQ_INSTS_VALU of the committed PMC run; the dense pass is a straight-line loop
+    body; an instruction costs 2 / 4 / 8 / 16 cycles by class, tools/valu_issue_probe.hip).
+    Ceiling = 1024 SIMDs x the clock the launches held.  ``frac`` prices instructions at what a SIMD with many waves pays (a
+    true ceiling); ``frac_at_4_waves_per_simd`` at what the probe measured with the four waves these kernels keep per SIMD."""
     table = _json_file("isa_counts.json").get(expr, {}).get("kernels", {})
-    instr = dec = 0.0
-    useful = 0.0
+    instr = cycles = cycles4 = useful = 0.0
+    clk_w = clk_n = 0.0
     forms = {}
-    for steps, hits, passes, wsteps, ppw, sat in work:
+    for w in work:
+        steps, hits, passes, wsteps, ppw, sat = w[:6]
+        ghz = w[6] if len(w) > 6 else 0.0
         name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi%s%s_e1" % ("2" if ppw == 256 else "", "s" if sat >= 0 else ""))
         c = table.get(name)
-        if c is None:
+        if c is None or "dense_pass_cycles" not in c:
             return None
         A, B = c["decision_valu_per_wave_step"], c["dense_pass_valu"]
         trips = wsteps / float(steps)                  # waves x grid-stride trips: the launch's fixed work per wave
@@ -415,20 +460,39 @@ def valu_roofline(work, kern_ms, expr, f32):
             dec = (c.get("decision_valu_per_wave_step_shortcut", A) * sat + A * (wsteps - sat) +
                    (c.get("decision_valu_per_wave_trip_shortcut", 0.0) * f + c.get("decision_valu_per_wave_trip", 0.0) * (1.0 - f)) * trips)
         instr += dec + B * passes
-        useful += dec + B * hits / 64.0
+        cycles += dec * c["decision_cycles_per_valu"] + c["dense_pass_cycles"] * passes
+        cycles4 += dec * c["decision_cycles_per_valu_at_4_waves"] + c["dense_pass_cycles_at_4_waves"] * passes
+        useful += dec * c["decision_cycles_per_valu"] + c["dense_pass_cycles"] * hits / 64.0
         forms[name] = forms.get(name, 0) + 1
-    if not instr or not kern_ms:
+        if ghz > 0:
+            clk_w += ghz * wsteps
+            clk_n += wsteps
+    if not cycles or not kern_ms:
         return None
-    achieved = instr / (kern_ms * 1e-3)
-    return {"achieved": achieved, "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": achieved / VALU_PEAK,
-            "lane_util": useful / instr, "wave_instructions": instr, "dense_passes": sum(w[2] for w in work),
+    clock = clk_w / clk_n if clk_n else 0.0
+    peak = valu_peak(clock)
+    achieved = cycles / (kern_ms * 1e-3)
+    return {"achieved": achieved, "peak": peak, "unit": "SIMD-cycles/s", "frac": achieved / peak,
+            "frac_at_4_waves_per_simd": cycles4 / (kern_ms * 1e-3) / peak, "clock_GHz": clock if clock > 0 else None,
+            "lane_util": useful / cycles, "wave_instructions": instr, "issue_cycles": cycles, "dense_passes": sum(w[2] for w in work),
             "wave_steps": sum(w[3] for w in work), "dense_passes_per_wave_step": sum(w[2] for w in work) / float(sum(w[3] for w in work)),
             "saturated_wave_steps": sum(max(w[5], 0) for w in work),
             "kernel_forms": forms, "instruction_counts": {k: {key: table[k][key] for key in ("decision_valu_per_wave_step", "decision_valu_per_wave_step_shortcut",
                                                                                            "decision_valu_per_wave_trip", "decision_valu_per_wave_trip_shortcut",
-                                                                                           "dense_pass_valu") if key in table[k]} for k in forms},
+                                                                                           "dense_pass_valu", "dense_pass_cycles", "decision_cycles_per_valu",
+                                                                                           "dense_pass_cycles_at_4_waves", "decision_cycles_per_valu_at_4_waves",
+                                                                                           "dense_pass_classes", "decision_classes_static") if key in table[k]} for k in forms},
             "instruction_counts_source": "profiles/isa_counts.json (tools/isa_count.py)",
-            "peak_note": "%d SIMDs x %.1f GHz / 4 cycles per wave64 VALU instruction" % (N_SIMD, CLOCK_GHZ)}
+            "peak_note": "%d SIMDs x the clock measured in the kernel (s_memtime / s_memrealtime; %.1f GHz where a launch has none); an instruction "
+                         "costs 2 / 4 / 8 / 16 cycles by class (profiles/r05_valu_issue_probe.txt)" % (N_SIMD, CLOCK_GHZ)}
+
+
+def static_valu(kernel):
+    """valu_busy / lane utilisation of ``kernel`` from the committed SQ-counter pass (None when the device sources changed since)."""
+    rec = pmc_record(kernel)
+    if not rec or "valu_busy" not in rec:
+        return None, None
+    return rec["valu_busy"], rec.get("source")
 
 
 def run_rank(args):
@@ -535,16 +599,23 @@ def run_rank(args):
     if valu is not None:
         # The K-step pass moves 128 B per photon per LAUNCH and is bound by VALU issue: the record
         # says so.  ``traffic`` (HBM bytes of one launch, committed PMC run) and the HBM form of the same launch ride along.
+        form = max(valu["kernel_forms"], key=valu["kernel_forms"].get)
+        busy, busy_src = static_valu(form)
         roofline = dict(valu, bound="valu",
-                        kernel="k_multi (pcl_rtc_multi_e1 / multi2_e1): %d x (Newton + ScatterIsotropic + counters) per pass over the "
-                               "store, dr/dv implicit; bound by VALU issue -- the HBM-bound formulation is roofline_hbm" % S,
+                        kernel="k_multi (%s): %d x (Newton + ScatterIsotropic + counters) per pass over the "
+                               "store, dr/dv implicit; bound by VALU issue -- the HBM-bound formulation is roofline_hbm" % (form, S),
+                        # what the SQ counters of the committed rocprofv3 run of this code object say (None: the device sources
+                        # have changed since that run): the share of SIMD-cycles with a vector instruction in flight, and that
+                        # share x the lanes that did useful work
+                        valu_busy=busy, valu_busy_source=busy_src, useful=(busy * valu["lane_util"] if busy else None),
                         traffic=hbm_rec["traffic"], hbm=hbm_rec,
                         # SURVEY 8(d)'s per-step form: what the same particle-steps would have had to move one launch per step
                         # (104 B each).  > peak is possible precisely because the pass does not move those bytes.
                         per_step_form={"bytes_per_particle_step": 104.0 * bscale,
                                        "GBps": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9,
                                        "frac_of_peak": N * 104.0 * bscale * steps_per_timed_launch / (kb["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS},
-                        per_block=[(lambda v: None if v is None else {"frac": round(v["frac"], 4), "lane_util": round(v["lane_util"], 4),
+                        per_block=[(lambda v: None if v is None else {"frac": round(v["frac"], 4), "frac_at_4_waves_per_simd": round(v["frac_at_4_waves_per_simd"], 4),
+                                                                         "clock_GHz": v["clock_GHz"], "lane_util": round(v["lane_util"], 4),
                                                                          "dense_passes_per_wave_step": round(v["dense_passes_per_wave_step"], 4),
                                                                          "forms": v["kernel_forms"]})(
                             valu_roofline(b.block_work_main[i], kern[i][dominant]["total_ms"], prof["expr"], f32)) for i in range(R)],
@@ -683,7 +754,7 @@ def contract_line(out, detail_file):
     line["config"] = _pick(out["config"], ("workload", "photons_per_gpu", "profile", "mode", "steps_per_launch_max",
                                            "steps_per_timed_launch", "variable_n_fn", "dt", "rng", "parallelism"))
     r = out["roofline"]
-    rl = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "valu_busy", "lane_util", "useful", "clock_GHz",
+    rl = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_at_4_waves_per_simd", "valu_busy", "lane_util", "useful", "clock_GHz",
                    "avg_launch_ms", "launches", "hit_fraction"))
     rl["kernel"] = rl.get("kernel", "").split(":")[0].split(";")[0][:120]
     rl["traffic"], rl["traffic_source"] = _traffic_number(r.get("traffic"))
@@ -800,6 +871,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 if rep == repeats + 1:
                     kern = {name: dev.prof_read(kid) for kid, name in hip.PROF_NAMES.items()}
                     ahead_work = [b - a for a, b in zip(aw0, dev.ahead_work())]
+                    ahead_clock = dev.ahead_clock()          # (GHz held under this context's k_delete_ahead_live launches so far)
                     instrumented_ms = el * 1e3
                     dev.prof_enable(False)
                 elif rep:
@@ -857,7 +929,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                 # the record of the kernel that does the run's work: k_delete_ahead_live when the bodies are worked out ahead (its
                 # VALU roofline, from the kernel's own tally; k_delete_alive then sweeps next to nothing and keeps its figures as
                 # "roofline_alive"), k_delete_alive otherwise
-                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"])
+                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"], ahead_clock)
                 if va:
                     r["roofline"], r["roofline_alive"] = va, alive_rec
                 else:
@@ -887,7 +959,7 @@ def delete_leg(dev, hip, sizes, seed, repeats=3, K=16):
                                             "compactions_of_1e7_slots_or_more": big}
             else:
                 r["steps_per_launch"] = K
-                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"])   # (K-body calls on an all-photon store
+                va = ahead_valu_roofline(ahead_work, kern["k_delete_ahead"]["total_ms"], ahead_clock)   # (K-body calls on an all-photon store
                 if va:                                                                      # take the single calls' path)
                     r["roofline"] = va
             rec[mode] = r
@@ -953,15 +1025,25 @@ def iso_leg(dev, hip, N, seed, steps=100, repeats=3):
 def mixed_valu_record():
     """What binds k_mixed (the K-pass kernel of configs[4]): VALU issue.  Its instruction count per launch depends on the
     photons' histories, and the kernel keeps no tally of its own, so this record is NOT computed in this process: it is the
-    committed rocprofv3 run of the same command (profiles/pmc_traffic.json: SQ_INSTS_VALU of the fp64 16-iteration launches
-    over their durations in the trace pass, VALU busy and lane utilisation from the SQ counters)."""
-    rec = _json_file("pmc_traffic.json").get("kernels", {}).get("k_mixed valu f64")
+    committed rocprofv3 run of the same command (profiles/pmc_traffic.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU and
+    GRBM_GUI_ACTIVE of the fp64 16-iteration launches, durations from the trace pass).  ``frac`` = the counters' own ratio
+    (VALU busy: SIMD-cycles with a vector instruction in flight / SIMD-cycles of the launches), which needs no clock and no
+    price list; the priced form (wave-instructions x the mean price of the kernel's instruction mix / (1024 SIMDs x the
+    clock GRBM_GUI_ACTIVE gives)) rides along.  None when the device sources have changed since that run."""
+    rec = pmc_record("k_mixed valu f64")
     if not rec:
         return None
+    mix = _json_file("isa_counts.json").get("aot", {}).get("k_mixed<double, false, 0>", {})
+    clock = rec.get("clock_GHz")
+    peak = valu_peak(clock)
+    priced = rec["wave_instructions"] * mix.get("cycles_per_valu", 4.0) / rec["seconds"]
     return {"bound": "valu", "kernel": "k_mixed<double> (16 iterations of [Newton, ScatterIsotropic, Newton, ScatterDelete] per launch)",
-            "achieved": rec["wave_instructions_per_s"], "peak": VALU_PEAK, "unit": "wave-instr/s", "frac": rec["wave_instructions_per_s"] / VALU_PEAK,
-            "valu_busy": rec["valu_busy"], "lane_util": rec["lane_utilisation"], "launches": rec["launches"],
-            "source": rec["source"], "measured_at_commit": rec.get("commit"), "note": "committed rocprofv3 --pmc run, not this process"}
+            "achieved": rec["valu_busy"] * peak, "peak": peak, "unit": "SIMD-cycles/s", "frac": rec["valu_busy"],
+            "frac_priced": priced / peak, "cycles_per_wave_instruction": mix.get("cycles_per_valu"), "clock_GHz": clock,
+            "valu_busy": rec["valu_busy"], "lane_util": rec["lane_utilisation"], "useful": rec["valu_busy"] * rec["lane_utilisation"],
+            "wave_instructions_per_s": rec["wave_instructions_per_s"], "launches": rec["launches"],
+            "source": rec["source"], "measured_at_commit": rec.get("commit"), "csrc_sha": rec.get("csrc_sha"),
+            "note": "committed rocprofv3 --pmc run, not this process"}
 
 
 def mixed_leg(dev, N, iterations=100, sample=2_000_000):

@@ -74,7 +74,10 @@ def test_bench_line_has_the_contract_keys(extra):
     if not extra:
         # the K-step pass says what binds it: VALU issue.  achieved = (decision instructions x wave-steps + dense-pass
         # instructions x dense passes, both tallied by the kernel itself) / launch time; the HBM form rides along
-        assert r["bound"] == "valu" and r["unit"] == "wave-instr/s" and r["peak"] == 1024 * 2.4e9 / 4
+        assert r["bound"] == "valu" and r["unit"] == "SIMD-cycles/s"
+        # the ceiling is in SIMD-cycles at the clock the launch HELD (measured in the kernel), not at the data sheet's 2.4 GHz
+        assert 1.0 < r["clock_GHz"] < 2.6 and abs(r["peak"] - 1024 * r["clock_GHz"] * 1e9) < 1e-3 * r["peak"]
+        assert 0 < r["frac"] <= 1.0 and r["frac"] <= r["frac_at_4_waves_per_simd"] <= 1.1        # priced issue work never exceeds the cycles there were
         assert 0 < r["lane_util"] <= 1 and r["wave_steps"] in (-(-300000 // 128) * 6, -(-300000 // 256) * 6) and r["dense_passes"] > 0
         (form, ic), = r["instruction_counts"].items()      # the median block's one launch: one code object
         assert form in ("pcl_rtc_multi_e1", "pcl_rtc_multis_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multi2s_e1") and r["kernel_forms"] == {form: 1}
@@ -83,11 +86,18 @@ def test_bench_line_has_the_contract_keys(extra):
         T, Ts = ic.get("decision_valu_per_wave_trip", 0.0), ic.get("decision_valu_per_wave_trip_shortcut", 0.0)
         dec = (A * (ws - sat) + As * sat + (Ts * sat / ws + T * (1 - sat / ws)) * trips) if sat >= 0 and form.endswith("s_e1") else A * ws + T * trips
         assert abs(r["wave_instructions"] - (dec + ic["dense_pass_valu"] * r["dense_passes"])) < 2 and 0 <= sat <= ws
+        # ... priced: the decision part at the mean price of its mix, the dense pass at its own cycles (2 / 4 / 8 / 16 per class)
+        cyc = dec * ic["decision_cycles_per_valu"] + ic["dense_pass_cycles"] * r["dense_passes"]
+        assert abs(r["issue_cycles"] - cyc) <= 1e-9 * cyc and abs(r["achieved"] - cyc / (r["avg_launch_ms"] * 1e-3)) <= 1e-6 * r["achieved"]
+        assert sum(ic["dense_pass_classes"].values()) == ic["dense_pass_valu"] and 2.0 < ic["decision_cycles_per_valu"] < 4.0
         assert r["hbm"]["peak"] == 8000.0 and r["hbm"]["algorithmic_bytes_per_particle"] == 128.0 and len(r["per_block"]) == 3
-        assert r["traffic"]["source"].startswith("profiles/") and abs(r["traffic"]["bytes"] / 300000 - 128) < 2
+        if r["traffic"] is not None:                        # (None: the kernels have changed since the committed counter run)
+            assert r["traffic"]["source"].startswith("profiles/") and abs(r["traffic"]["bytes"] / 300000 - 128) < 2
+            assert r["valu_busy"] is None or (0 < r["valu_busy"] <= 1 and abs(r["useful"] - r["valu_busy"] * r["lane_util"]) < 1e-12)
         h = d["roofline_hbm"]                                # the north_star kernel's own record, in the line and not in an extra key
         assert h["bound"] == "hbm" and h["peak"] == 8000.0 and h["algorithmic_bytes_per_particle"] == 104.0 and h["frac"] > 0
-        assert abs(h["traffic"]["bytes_per_unit"] - 104) < 1 and h == dict(d["single_step"]["roofline"], value=h["value"], ms_per_step=h["ms_per_step"])
+        assert h["traffic"] is None or abs(h["traffic"]["bytes_per_unit"] - 104) < 1
+        assert h == dict(d["single_step"]["roofline"], value=h["value"], ms_per_step=h["ms_per_step"])
         t = d["tame"]                                        # SURVEY 8(d) config 3's second profile
         assert t["roofline"]["bound"] == "valu" and "exp(r2[gid] / 8600.0)" in t["workload"] and len(t["repeat_hit_fraction"]) == 3
         assert 0 < min(t["repeat_hit_fraction"]) and max(t["repeat_hit_fraction"]) < 1 and t["value"] > 0
@@ -115,12 +125,14 @@ def test_bench_line_has_the_contract_keys(extra):
             # the run's own record is the kernel that did its work: k_delete_ahead_live, priced by its own tally
             for mode in ("per_step", "multi"):
                 v = rec[mode]["roofline"]
-                assert v["bound"] == "valu" and v["unit"] == "wave-instr/s" and v["peak"] == 1024 * 2.4e9 / 4 and 0 < v["frac"] < 1.2
+                assert v["bound"] == "valu" and v["unit"] == "SIMD-cycles/s" and 0 < v["frac"] <= 1.0 and 1.0 < v["clock_GHz"] < 2.6
+                assert abs(v["peak"] - 1024 * v["clock_GHz"] * 1e9) < 1e-3 * v["peak"]
                 w, c = v["work"], v["instruction_counts"]
                 instr = (c["valu_per_group_first_pass_two_bodies"] * w["groups_of_128_slots_first_pass_two_bodies"]
                          + c["valu_per_group_first_pass_one_body"] * w["groups_of_128_slots_first_pass_one_body"]
                          + c["valu_per_round_two_bodies"] * w["rounds_two_bodies"] + c["valu_per_round_one_body"] * w["rounds_one_body"])
-                assert abs(instr - v["wave_instructions"]) <= 1e-9 * instr and abs(v["achieved"] - instr / (v["total_ms"] * 1e-3)) <= 1e-6 * v["achieved"]
+                assert abs(instr - v["wave_instructions"]) <= 1e-9 * instr
+                assert abs(v["achieved"] - instr * v["cycles_per_wave_instruction"] / (v["total_ms"] * 1e-3)) <= 1e-6 * v["achieved"]
                 assert w["groups_of_128_slots_first_pass_two_bodies"] >= 30000 // 128 and w["rounds_two_bodies"] >= 1
             assert rec["per_step"]["roofline_alive"]["bound"] == "hbm"
         assert d["api"]["steps_per_launch_32"]["steps"] == 6 and d["api"]["steps_per_launch_1"]["rows"] == 6
@@ -134,7 +146,8 @@ def test_bench_line_has_the_contract_keys(extra):
         mx = d["mixed"]
         assert mx["iterations"] == 100 and mx["seconds_f64"] > 0 and mx["seconds_f32"] > 0 and set(mx["fp32_vs_fp64"]) == {"1", "10", "100"}
         # k_mixed keeps no tally of its own: its VALU record is the committed PMC run's, and says so
-        assert mx["roofline"]["bound"] == "valu" and 0 < mx["roofline"]["frac"] < 1.2 and "not this process" in mx["roofline"]["note"]
+        assert mx["roofline"] is None or (mx["roofline"]["bound"] == "valu" and 0 < mx["roofline"]["frac"] <= 1.0 and
+                                          mx["roofline"]["frac"] == mx["roofline"]["valu_busy"] and "not this process" in mx["roofline"]["note"])
         assert mx["fp32_vs_fp64"]["1"]["decision_mismatch_rate"] < 1e-3
     if not extra:
         assert d["config"]["steps_per_launch_max"] == 32 and d["config"]["steps_per_timed_launch"] == 6

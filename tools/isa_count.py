@@ -22,6 +22,81 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+# ---------------------------------------------------------------------------------------------------------------------
+# What a wave64 vector instruction costs its SIMD, in cycles of VALU issue, by class: measured on gfx950 by
+# tools/valu_issue_probe.hip (profiles/r05_valu_issue_probe.txt: every SIMD holding 1, 2, 4 and 8 waves of ONE opcode; the
+# figures below are the values the 8-wave streams approach -- 2.13-2.25, 4.05-4.17, 8.05, 16.08 -- so that cost x count
+# never overstates the issue work).  They confirm MI355X_MICROARCH.md:54 ("2 cycles" for 32-bit VALU on a busy SIMD, 4 for one
+# wave alone) and its constants table (:473 v_fma_f32 2 cyc, transcendentals 8) and add what the guide does not list: EVERY
+# fp64 arithmetic instruction, every integer multiply (v_mad_u64_u32, v_mul_lo/hi_u32: full "4-cycle" rate, not quarter
+# rate), every three-operand integer VOP3 (v_add3, v_lshl_or, v_alignbit, v_perm, v_mad_u32_u24, v_mbcnt), every compare,
+# carry, conversion, select and cross-lane read/write costs 4; fp64 rcp / rsq / sqrt cost 16.
+# ---------------------------------------------------------------------------------------------------------------------
+COST_CLASSES = {
+    "fp64 transcendental (16)": (16, ("v_rcp_f64", "v_rsq_f64", "v_sqrt_f64")),
+    "fp32 transcendental (8)": (8, ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32")),
+    "32-bit simple (2)": (2, ("v_mov_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32",
+                              "v_lshrrev_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32",
+                              "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_max_f32", "v_min_f32", "v_max_u32", "v_min_u32", "v_max_i32",
+                              "v_min_i32", "v_bitop3_b32", "v_accvgpr_read_b32", "v_accvgpr_write_b32")),
+}
+DEFAULT_CLASS = "fp64 / 64-bit / multiply / compare / select / convert / cross-lane (4)"
+
+
+def valu_class(op):
+    """(class name, cycles) of one vector opcode as it stands in the assembly (suffixes _e32 / _e64 / _sdwa / _dpp dropped;
+    an SDWA or DPP form of a 2-cycle opcode is priced at 4)."""
+    base = re.sub(r"_(e32|e64)$", "", op)
+    if base.endswith("_sdwa") or base.endswith("_dpp"):
+        return DEFAULT_CLASS, 4
+    for name, (cyc, ops) in COST_CLASSES.items():
+        if base in ops:
+            return name, cyc
+    return DEFAULT_CLASS, 4
+
+
+_PROBE = None
+
+
+def probed_cost(op, waves=4):
+    """Cycles per wave-instruction with ``waves`` waves on the SIMD as tools/valu_issue_probe.hip measured them
+    (profiles/r05_valu_issue_probe.json); opcodes the probe did not run take their class's nominal price x the mean
+    measured / nominal ratio of the probed opcodes of that class."""
+    global _PROBE
+    if _PROBE is None:
+        _PROBE = {"by_op": {}, "ratio": {}}
+        path = os.path.join(ROOT, "profiles", "r05_valu_issue_probe.json")
+        if os.path.exists(path):
+            acc = {}
+            for r in json.load(open(path))["rows"]:
+                if r["instruction"].startswith("v_") and " " not in r["instruction"] and r["instruction"] != "v_cndmask_b32":
+                    _PROBE["by_op"][(r["instruction"], r["waves_per_simd"])] = r["cycles_per_wave_instruction"]
+                    name, cyc = valu_class(r["instruction"])
+                    acc.setdefault((name, r["waves_per_simd"]), []).append(r["cycles_per_wave_instruction"] / cyc)
+            _PROBE["ratio"] = {k: sum(v) / len(v) for k, v in acc.items()}
+    base = re.sub(r"_(e32|e64)$", "", op)
+    hit = _PROBE["by_op"].get((base, waves))
+    if hit is not None:
+        return hit
+    name, cyc = valu_class(op)
+    return cyc * _PROBE["ratio"].get((name, waves), 1.0)
+
+
+def class_histogram(ops):
+    """{class: count}, total instructions, total cycles (nominal), total cycles at 4 waves per SIMD of a list of vector opcodes."""
+    hist, cycles, cycles4 = {}, 0, 0.0
+    for op in ops:
+        name, cyc = valu_class(op)
+        hist[name] = hist.get(name, 0) + 1
+        cycles += cyc
+        cycles4 += probed_cost(op, 4)
+    return hist, len(ops), cycles, cycles4
+
+
+def build_sha():
+    from physicl_amd import build
+    return build.csrc_sha()
+
 
 def rtc_source(expr, expr_f32=None, dt=0, use_e=1, extra=()):
     from physicl_amd import build
@@ -118,7 +193,17 @@ def analyse(asm, name):
         if mm:
             meta[key] = int(mm.group(1))
     lanes = lambda t: t.startswith("v_readlane") or t.startswith("v_writelane")   # noqa: E731
+    # cycle-weighted: the dense pass is a straight-line loop body (exact); the decision part by the mean price of its static
+    # instruction mix (its branches skip blocks of much the same make-up) x the dynamic count the PMC run calibrates
+    dense_ops = [ins[i].split()[0] for i in range(dense[0], dense[1] + 1) if valu(ins[i])]
+    dec_ops = [ins[i].split()[0] for i in range(kloop[0], kloop[1] + 1) if valu(ins[i]) and not any(a <= i <= b for a, b in inner2)]
+    dense_hist, dense_n, dense_cyc, dense_cyc4 = class_histogram(dense_ops)
+    dec_hist, dec_n, dec_cyc, dec_cyc4 = class_histogram(dec_ops)
     return {
+        "dense_pass_classes": dense_hist, "dense_pass_cycles": dense_cyc, "dense_pass_cycles_at_4_waves": round(dense_cyc4, 1),
+        "decision_classes_static": dec_hist, "decision_cycles_per_valu": round(dec_cyc / float(dec_n), 4) if dec_n else 0.0,
+        "decision_cycles_per_valu_at_4_waves": round(dec_cyc4 / float(dec_n), 4) if dec_n else 0.0,
+        "dense_pass_cycles_per_valu": round(dense_cyc / float(dense_n), 4) if dense_n else 0.0,
         "kernel": name,
         "k_loop": {"instructions": kloop[1] - kloop[0] + 1, "valu_total_static": count(kloop[0], kloop[1], valu)},
         "decision_blocks": blocks,
@@ -141,6 +226,39 @@ def analyse(asm, name):
     }
 
 
+def aot_kernels(names, workdir):
+    """Whole-kernel static instruction mix of ahead-of-time kernels of libphysicl_hip (demangled names as rocprofv3 prints
+    them, without the argument list): {name: {classes, valu, cycles_per_valu, registers}}.  For the kernels whose
+    instruction counts per unit of work are calibrated against SQ_INSTS_VALU (k_delete_ahead_live) or taken from the
+    counters of a committed run (k_mixed): the mean price of an instruction of theirs."""
+    from physicl_amd import build
+    build._generate_rtc_source()
+    asm_path = os.path.join(workdir, "aot.s")
+    if not (os.path.exists(asm_path) and all(os.path.getmtime(asm_path) > os.path.getmtime(f) for f in build.SOURCES)):
+        subprocess.check_call([build.HIPCC] + [f for f in build.FLAGS if f not in ("-shared", "-fPIC")] +
+                              ["--cuda-device-only", "-S", "-o", asm_path, build.SOURCES[0]], stderr=subprocess.DEVNULL)
+    asm = open(asm_path).read()
+    labels = re.findall(r"^(_Z[\w$.]+):", asm, re.M)
+    dem = subprocess.check_output(["c++filt"], input="\n".join(labels).encode()).decode().splitlines()
+    out = {}
+    for want in names:
+        hits = [m for m, d in zip(labels, dem) if d.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0] == want]
+        if not hits:
+            raise SystemExit("no kernel %r in the library's assembly" % want)
+        body = function_body(asm, hits[0])
+        ops = [t.strip().split(";")[0].split()[0] for t in body if t.strip().startswith("v_")]
+        hist, n, cyc, cyc4 = class_histogram(ops)
+        md = asm[asm.rindex(".name:           %s" % hits[0]):]
+        meta = {}
+        for key in ("sgpr_count", "sgpr_spill_count", "vgpr_count", "vgpr_spill_count", "private_segment_fixed_size"):
+            mm = re.search(r"\.%s:\s+(\d+)" % key, md)
+            if mm:
+                meta[key] = int(mm.group(1))
+        out[want] = {"classes_static": hist, "valu_static": n, "cycles_per_valu": round(cyc / float(n), 4),
+                     "cycles_per_valu_at_4_waves": round(cyc4 / float(n), 4), "registers": meta}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("expr", nargs="?", default="0.000000001 * exp(r0[gid] - 5)")
@@ -148,9 +266,20 @@ def main():
     ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1,pcl_rtc_multi2s_e1")
     ap.add_argument("--extra", default="", help="comma separated PCL_RTC_EXTRA names")
     ap.add_argument("--keep", default=None, help="directory to keep tu.hip / tu.s in")
+    ap.add_argument("--aot", default=None, help="comma separated ahead-of-time kernels (demangled, e.g. 'k_delete_ahead_live<double, false>'): "
+                                                "their static instruction mix, merged under \"aot\" of --json")
     a = ap.parse_args()
     work = a.keep or tempfile.mkdtemp(prefix="pcl_isa_")
     os.makedirs(work, exist_ok=True)
+    if a.aot:
+        rec = aot_kernels([x.strip() for x in a.aot.split(";") if x.strip()], work)
+        print(json.dumps(rec, indent=1))
+        if a.json:
+            table = json.load(open(a.json)) if os.path.exists(a.json) else {}
+            table.setdefault("aot", {}).update(rec)
+            table["csrc_sha"] = build_sha()
+            json.dump(table, open(a.json, "w"), indent=1, sort_keys=True)
+        return
     asm = compile_asm(rtc_source(a.expr, extra=[x for x in a.extra.split(",") if x]), work)
     out = {k: analyse(asm, k) for k in a.kernels.split(",")}
     hipcc = subprocess.check_output(["/opt/rocm/bin/hipcc", "--version"]).decode().splitlines()[0]
@@ -160,11 +289,13 @@ def main():
         table = json.load(open(a.json)) if os.path.exists(a.json) else {}
         old = table.get(a.expr, {}).get("kernels", {})
         for k, v in rec["kernels"].items():        # calibrated counts (tools/summarize_driver_prof.py) survive a re-count of the statics
+            calibrated = any("calibration" in key for key in old.get(k, {}))
             for key, val in old.get(k, {}).items():
-                if "calibration" in key or (key.startswith("decision_valu_per_wave_step") and not key.endswith("_static") and
-                                            ("decision_valu_calibration" + key[len("decision_valu_per_wave_step"):]) in old.get(k, {})):
+                if "calibration" in key or (calibrated and not key.endswith("_static") and
+                                            (key.startswith("decision_valu_per_wave_step") or key.startswith("decision_valu_per_wave_trip"))):
                     v[key] = val
         table[a.expr] = rec
+        table["csrc_sha"] = build_sha()
         json.dump(table, open(a.json, "w"), indent=1, sort_keys=True)
 
 

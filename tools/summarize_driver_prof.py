@@ -65,8 +65,18 @@ def main():
     os.makedirs(dst, exist_ok=True)
     args = open(os.path.join(src, "bench_args.txt")).read().strip()
     shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, tag + "_kernel_stats.csv"))
-    shutil.copy(os.path.join(src, "trace_bench.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
-    line = json.loads([ln for ln in open(os.path.join(src, "trace_bench.json")) if ln.strip()][-1])
+    def record(name):
+        """The run's full record of one pass: bench.py's detail file (round 5 on: stdout carries only the contract line)."""
+        detail = os.path.join(src, name + "_detail.json")
+        if os.path.exists(detail):
+            return json.load(open(detail))
+        return json.loads([ln for ln in open(os.path.join(src, name + ("_bench.json" if name == "trace" else ".json"))) if ln.strip()][-1])
+
+    line = record("trace")
+    json.dump(line, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"))
+    sys.path.insert(0, ROOT)
+    from physicl_amd import build
+    sha = build.csrc_sha()
     N, steps, warmup, R = line["config"]["photons_per_gpu"], line["steps"], line["warmup"], line["repeats"]
     S = line["config"].get("steps_per_launch_max", line["config"].get("steps_per_launch"))
     # ---- per-dispatch trace
@@ -105,13 +115,14 @@ def main():
     s_seq = read_counter_seq(os.path.join(src, "pmc_sq", "pmc_counter_collection.csv"), kms)
     ks = [min(S, warmup)] + [min(S, steps)] * R
     # the kernel's own work tallies of the SQ pass's process (bench line key k_step_launch_work), launch by launch
-    sq_line = json.loads([ln for ln in open(os.path.join(src, "pmc_sq.json")) if ln.strip()][-1])
+    sq_line = record("pmc_sq")
     work = sq_line.get("k_step_launch_work", [])
     isa = json.load(open(os.path.join(dst, "isa_counts.json"))) if os.path.exists(os.path.join(dst, "isa_counts.json")) else {}
     per_block = -(-steps // S)                       # launches per timed block
     n_main = -(-warmup // S) + R * per_block
     exprs = [line["config"]["variable_n_fn"]] * n_main + (["2.5E+25 * exp(r2[gid] / 8600.0)"] * n_main if "tame" in sq_line else [])
     calib = collections.defaultdict(list)
+    priced_rows = []
     W = ["", "### The same dispatches against the kernel's own work tally (SQ pass): wave-instructions = SQ_INSTS_VALU", "",
          "model = decision instructions x wave-steps + dense-pass instructions x dense passes (profiles/isa_counts.json; the dense "
          "pass is a straight-line loop body counted in the assembly, the decision count is what this table calibrates: "
@@ -135,6 +146,16 @@ def main():
                                                                                           steps_i, hits_i / float(N * steps_i), ws_i, passes_i,
                                                                                           passes_i / float(ws_i), c["SQ_INSTS_VALU"], a_dyn,
                                                                                           cnt.get("decision_valu_per_wave_step_static", 0)))
+        if "dense_pass_cycles" in cnt and c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+            # the same dispatch priced: every instruction at its class's cycles (tools/isa_count.py) against the counters' own cycles
+            dec_i = c["SQ_INSTS_VALU"] - cnt["dense_pass_valu"] * passes_i
+            priced = dec_i * cnt["decision_cycles_per_valu"] + cnt["dense_pass_cycles"] * passes_i
+            priced4 = dec_i * cnt["decision_cycles_per_valu_at_4_waves"] + cnt["dense_pass_cycles_at_4_waves"] * passes_i
+            busy_c, avail_c = c["SQ_ACTIVE_INST_VALU"] * 4.0, c["GRBM_GUI_ACTIVE"] / 8.0 * 1024
+            ghz_sq = (wk[6] if len(wk) > 6 else 0.0)
+            priced_rows.append("| %d | %s | %.4g | %.4g | %.4g | %.4g | %.3f | %.3f | %.3f | %.3f | %s |" % (
+                i, kname, priced, priced4, busy_c, avail_c, priced / avail_c, priced4 / avail_c, busy_c / avail_c, priced4 / busy_c,
+                ("%.3f" % ghz_sq) if ghz_sq else "-"))
     # The decision part's count per wave-step carries the launch's fixed work (a grid-stride trip's loads, stores and
     # restores) spread over its K steps: A(K) = a + c / K.  Every profiled run adds its (K, A) points to the table; with
     # two different K the fit gives a (per wave-step) and c (per wave and trip), which is what bench.py multiplies out.
@@ -164,6 +185,17 @@ def main():
         W.append("`%s`%s, `%s`: decision instructions per wave-step at the launch lengths profiled so far %s -> **%.1f per wave-step + %.1f per "
                  "wave and trip**" % (kname, " on exp's saturation shortcut" if regime else "", e,
                                       ", ".join("K = %d: %.1f" % (k, pts[str(k)]["mean"]) for k in kpts), a_fit, c_fit))
+    if priced_rows:
+        W += ["", "### The same dispatches priced in SIMD-cycles", "",
+              "priced = (SQ_INSTS_VALU - dense x passes) x the mean price of the decision part's instruction mix + dense-pass cycles x passes, an "
+              "instruction costing 2 / 4 / 8 / 16 cycles by class (tools/isa_count.py; tools/valu_issue_probe.hip: profiles/r05_valu_issue_probe.txt); "
+              "\"at 4 waves\" prices every opcode at what the probe measured with four waves on the SIMD (what these kernels keep).  busy = "
+              "SQ_ACTIVE_INST_VALU x 4 (the counter ticks every fourth cycle), available = GRBM_GUI_ACTIVE / 8 x 1024 SIMDs -- both of the SQ pass "
+              "itself, so no clock and no duration enters the ratios.  What separates priced-at-4-waves from busy is the time an instruction "
+              "stays in flight beyond its issue slots while no other wave of the SIMD has one ready (dependent chains: the probe's own Philox "
+              "round mix runs 1.35 x its priced cycles at four waves).  GHz = the clock the kernel measured in that pass (s_memtime / s_memrealtime).", "",
+              "| # | kernel | priced cycles | priced at 4 waves | busy cycles | available cycles | priced / available | at 4 waves / available | busy / available | at 4 waves / busy | GHz |",
+              "|---|---|---|---|---|---|---|---|---|---|---|"] + priced_rows
     if calib:
         json.dump(isa, open(os.path.join(dst, "isa_counts.json"), "w"), indent=1, sort_keys=True)
     multi_rows = []
@@ -305,15 +337,19 @@ def main():
     # ---- static_profile entry of bench.py
     tf = os.path.join(dst, "pmc_traffic.json")
     allt = json.load(open(tf)) if os.path.exists(tf) else {}
+    # records of other device sources than the ones profiled here are history (git has them): bench.py would not quote them
+    allt = {k: v for k, v in allt.items() if k == "kernels" or v.get("csrc_sha") == sha}
+    allt["kernels"] = {k: v for k, v in allt.get("kernels", {}).items() if v.get("csrc_sha") == sha}
     # per-kernel HBM bytes per unit of work: what bench.py's records carry as ``traffic`` (with this file and commit as source)
     commit = os.popen("git -C %s rev-parse --short HEAD" % ROOT).read().strip()
     kern_t = allt.setdefault("kernels", {})
     src_md = "profiles/%s_pmc.md" % tag
     for i, (K, d, b_hbm, busy, util, per_ps) in enumerate(multi_rows[1:1 + R]):
         kern_t[{"256": "pcl_rtc_multi2_e1", "128 probe": "pcl_rtc_multis_e1", "256 probe": "pcl_rtc_multi2s_e1"}.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
-            "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
+            "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "valu_busy": round(busy, 4), "lane_utilisation": round(util, 4),
+            "source": src_md, "commit": commit, "csrc_sha": sha}
     if single:
-        kern_t["pcl_rtc_fast_e1"] = {"bytes_per_unit": round(tot / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit}
+        kern_t["pcl_rtc_fast_e1"] = {"bytes_per_unit": round(tot / N, 2), "unit": "photon (per launch)", "source": src_md, "commit": commit, "csrc_sha": sha}
     if ka and big:
         per = []
         for j in big[:8]:
@@ -322,15 +358,20 @@ def main():
                 # (the kernel's grid is capped and strides over the tiles: a grid of >= 4e6 threads is the 1e8-slot extent)
                 per.append((fetch[ka][i].get("FETCH_SIZE", 0) * 2 * 1024 + write[ka][i].get("WRITE_SIZE", 0) * 1024) / 1e8)
         if per:
-            kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit}
+            kern_t["k_delete_alive<double, true>"] = {"bytes_per_unit": round(sum(per) / len(per), 2), "unit": "slot", "source": src_md, "commit": commit, "csrc_sha": sha}
     if ahead_bytes:
+        csq = [c for c in sq.get(kah, []) if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_INSTS_VALU", 0) > 1e8]
         kern_t[kah] = {"bytes_per_unit": round(sum(ahead_bytes) / len(ahead_bytes), 2), "unit": "slot (per launch, whatever K)",
-                                            "source": src_md, "commit": commit}
+                       "source": src_md, "commit": commit, "csrc_sha": sha}
+        if csq:
+            kern_t[kah]["valu_busy"] = round(sum(c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) for c in csq) / len(csq), 4)
+            kern_t[kah]["lane_utilisation"] = round(sum(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) for c in csq) / len(csq), 4)
+        kern_t["k_delete_ahead_live<double>"] = dict(kern_t[kah])    # (the name bench.py asks for: either template form)
     for kname in sorted({r[0] for r in comp_rows if ", 7>" in r[0]}):
         first = [r for r in comp_rows if r[0] == kname and r[1] >= 90_000_000]
         if first:
             kern_t[kname] = {"bytes_per_unit": round(sum((r[3] + r[4]) / r[1] for r in first) / len(first), 2),
-                             "unit": "slot (the compactions of the 1e8-slot extent in the delete leg)", "source": src_md, "commit": commit}
+                             "unit": "slot (the compactions of the 1e8-slot extent in the delete leg)", "source": src_md, "commit": commit, "csrc_sha": sha}
     # k_mixed (configs[4]): VALU issue of its 16-iteration launches -- SQ_INSTS_VALU of the SQ pass over their durations in the
     # trace pass (the run is deterministic: same dispatches, same order) -- for the bench line's ``mixed.roofline``
     for kname, tag_t in (("k_mixed<double, false, 0>", "f64"), ("k_mixed<float, false, 0>", "f32")):
@@ -341,14 +382,21 @@ def main():
                 "wave_instructions_per_s": insts / dur, "launches": len(pairs), "wave_instructions": insts, "seconds": dur,
                 "valu_busy": round(sum(c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024) for c, _ in pairs) / len(pairs), 4),
                 "lane_utilisation": round(sum(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) for c, _ in pairs) / len(pairs), 4),
-                "source": src_md, "commit": commit}
-            L += ["", "`%s`, the %d launches of 16 iterations: %.4g VALU wave-instructions in %.2f ms = %.3g / s = %.3f of the issue peak "
-                  "(1024 SIMDs x 2.4 GHz / 4); VALU busy %.3f, lane utilisation %.3f." % (
-                      kname, len(pairs), insts, dur * 1e3, insts / dur, insts / dur / 6.144e11, kern_t["k_mixed valu " + tag_t]["valu_busy"],
-                      kern_t["k_mixed valu " + tag_t]["lane_utilisation"])]
+                # (the SQ pass's own GRBM cycles over the trace pass's durations of the same dispatches)
+                "clock_GHz": round(sum(c["GRBM_GUI_ACTIVE"] for c, _ in pairs) / 8.0 / (sum(d for _, d in pairs)), 4),
+                "source": src_md, "commit": commit, "csrc_sha": sha}
+            mixk = isa.get("aot", {}).get(kname, {})
+            ghz = kern_t["k_mixed valu " + tag_t]["clock_GHz"]
+            L += ["", "`%s`, the %d launches of 16 iterations: %.4g VALU wave-instructions in %.2f ms at %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration); "
+                  "VALU busy %.3f (SQ_ACTIVE_INST_VALU x 4 / available SIMD-cycles), lane utilisation %.3f; priced at %.2f cycles per instruction "
+                  "(the kernel's static mix, tools/isa_count.py --aot): %.3f of the available cycles (%.3f at 4 waves per SIMD)." % (
+                      kname, len(pairs), insts, dur * 1e3, ghz, kern_t["k_mixed valu " + tag_t]["valu_busy"],
+                      kern_t["k_mixed valu " + tag_t]["lane_utilisation"], mixk.get("cycles_per_valu", 0.0),
+                      insts * mixk.get("cycles_per_valu", 0.0) / (dur * ghz * 1e9 * 1024),
+                      insts * mixk.get("cycles_per_valu_at_4_waves", 0.0) / (dur * ghz * 1e9 * 1024))]
     if timed:
         t_ok = [r for r in timed if r[0]]
-        ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps),
+        ent = {"source": "profiles/%s_pmc.md" % tag, "command": "bench.py " + args, "K": min(S, steps), "commit": commit, "csrc_sha": sha,
                "hit_fraction_of_timed_blocks": line["repeat_hit_fraction"],
                "k_multi_bytes_per_launch": sum(r[2] for r in t_ok) / len(t_ok),
                "k_multi_valu": {"busy": round(sum(r[3] for r in t_ok) / len(t_ok), 4),
