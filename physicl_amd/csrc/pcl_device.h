@@ -19,6 +19,11 @@ typedef unsigned int pcl_u32;
 #define PCL_SC_FN __device__ __forceinline__
 #include "pcl_sincos.h" /* build.py splices the file in here for the hipRTC copy of this text */
 
+// The wave's vote as the hardware gives it: the compare's own lane mask (ANDed with exec).  HIP's __ballot(int) first turns
+// the predicate into an integer and compares that with zero again -- a v_cndmask and a second v_cmp, 8 SIMD-cycles per
+// vote (tools/valu_issue_probe.hip) in kernels that vote four times per photon and step.
+__device__ __forceinline__ pcl_u64 pcl_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 #define PCL_PI 3.141592653589793 /* == numpy.pi */
 #define PCL_RNG_IN 0
 #define PCL_RNG_PHX 1
@@ -283,13 +288,13 @@ struct pcl_nprof {
 // exp never saturates -- the branch splits the two photons' dependency chains and costs registers -- so it is not on.
 __device__ __forceinline__ double pcl_exp_wave(double x) {
 #ifdef PCL_EXP_WAVE
-    if (__ballot(!(__builtin_fabs(x) > 750.0)) == 0ull) return x > 0.0 ? __builtin_inf() : 0.0;
+    if (pcl_ballot(!(__builtin_fabs(x) > 750.0)) == 0ull) return x > 0.0 ? __builtin_inf() : 0.0;
 #endif
     return exp(x);
 }
 __device__ __forceinline__ float pcl_exp_wave(float x) {
 #ifdef PCL_EXP_WAVE
-    if (__ballot(!(__builtin_fabsf(x) > 105.0f)) == 0ull) return x > 0.0f ? __builtin_inff() : 0.0f;
+    if (pcl_ballot(!(__builtin_fabsf(x) > 105.0f)) == 0ull) return x > 0.0f ? __builtin_inff() : 0.0f;
 #endif
     return expf(x);
 }
@@ -643,7 +648,7 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
                 }
                 all_photon = all_photon && photon[e];
                 all_hit = all_hit && hit[e];
-                w_hits += (pcl_u32)__popcll(__ballot(hit[e]));
+                w_hits += (pcl_u32)__popcll(pcl_ballot(hit[e]));
             }
             if (a.lazy) {
                 // v double buffer: every particle's (possibly new) velocity goes to the other buffer, whole
@@ -687,9 +692,9 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
         if (counters) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                w_sx += (pcl_u32)__popcll(__ballot(live[e] && V[0][e] > (T)0));
-                w_sy += (pcl_u32)__popcll(__ballot(live[e] && V[1][e] > (T)0));
-                w_sz += (pcl_u32)__popcll(__ballot(live[e] && V[2][e] > (T)0));
+                w_sx += (pcl_u32)__popcll(pcl_ballot(live[e] && V[0][e] > (T)0));
+                w_sy += (pcl_u32)__popcll(pcl_ballot(live[e] && V[1][e] > (T)0));
+                w_sz += (pcl_u32)__popcll(pcl_ballot(live[e] && V[2][e] > (T)0));
             }
             for (int p = 0; p < a.n_planes; ++p) { // rolled: planes are rare, keep their state out of registers
                 const int ax = a.plane_ax[p];
@@ -700,7 +705,7 @@ __device__ __forceinline__ void pcl_fused_body(const pcl_fused_args<T> &a) {
                     const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, D[0][e], D[1][e], D[2][e]));
                     const bool cross = live[e] && ((prev <= L && L <= x) || (prev >= L && L >= x));
-                    np += (pcl_u32)__popcll(__ballot(cross));
+                    np += (pcl_u32)__popcll(pcl_ballot(cross));
                 }
                 if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
             }
@@ -857,10 +862,10 @@ __device__ __forceinline__ void pcl_fast_body(const pcl_fast_args<T> &a) {
                 pcl_draw_angles<T>(id, a.step, k0, k1, rtheta, rphi);
                 pcl_new_velocity<T, true>(a.c, rtheta, rphi, cur.V[0][e], cur.V[1][e], cur.V[2][e]);
             }
-            w_hits += (pcl_u32)__popcll(__ballot(hit));
-            w_sx += (pcl_u32)__popcll(__ballot(live && cur.V[0][e] > (T)0));
-            w_sy += (pcl_u32)__popcll(__ballot(live && cur.V[1][e] > (T)0));
-            w_sz += (pcl_u32)__popcll(__ballot(live && cur.V[2][e] > (T)0));
+            w_hits += (pcl_u32)__popcll(pcl_ballot(hit));
+            w_sx += (pcl_u32)__popcll(pcl_ballot(live && cur.V[0][e] > (T)0));
+            w_sy += (pcl_u32)__popcll(pcl_ballot(live && cur.V[1][e] > (T)0));
+            w_sz += (pcl_u32)__popcll(pcl_ballot(live && cur.V[2][e] > (T)0));
         }
         if (live_q) {
             const pcl_i64 qs = pcl_tq<VEC>(q, a.ts);
@@ -939,343 +944,188 @@ struct pcl_multi_args {
     pcl_nprof<T> np;          // ahead-of-time VAR_N kernels only
 };
 
-// The scatter branch (second Philox block, two sincos, the new velocity) is ~half of a step's arithmetic but
-// only the hit photons need it; executed in place it costs every wave the full branch however few of its
-// lanes hit.  So each wave queues the hits of its 64*VEC photons in its own slice of an LDS queue (slots from
-// the ballots' prefix counts), processes them densely -- item j by lane j, ceil(hits/64) passes instead of VEC --
-// and hands the new velocities back through LDS.  Same operations on the same operands per photon, so nothing
-// changes in the results; only which lane executes them.  (A workgroup-wide queue packs better -- 0.75 instead
-// of 1.0 passes per wave at 26 % hits -- but its two barriers per step cost more than that: measured 7 % slower.)
-template <typename T, int VEC>
-struct pcl_hit_queue {
-    pcl_u32 owner[256 * VEC]; // thread * VEC + e of the photon that hit
-    T out[4][256 * VEC];      // the new velocity and its step length |v' * dt|
+// ------------------------------------------------------------------------------------------------
+// The K-step pass.  The scatter branch (second Philox block, two sincos, the new velocity: ~750 SIMD-cycles) is more than
+// half of a step's arithmetic but only the hit photons need it; executed in place it costs every wave the full branch
+// however few of its lanes hit.  So each wave queues the hits of its photons (slots from the ballots' prefix counts) and
+// processes them DENSELY -- item j by lane j, ceil(hits / 64) passes -- with the same operations on the same operands per
+// photon, so nothing changes in the results; only which lane executes them.  (A workgroup-wide queue packs better still,
+// but its two barriers per step cost more than that: measured 7 % slower.)  What a dense pass costs does not depend on
+// how many of its 64 lanes carry a hit, so a wave should own as many photons as it can: 256 (NQ = 2 in fp64, VEC = 4 in
+// fp32) fill a pass with 54 hits at a 21 % hit fraction where 128 fill it with 27.
+// Rounds 2-4 kept a lane's photons in registers (pcl_multi_body: 128 per wave; pcl_multi_body_nq: 256 per wave at 72 VGPRs
+// of state, 168 in all, 20 of them spilled to scratch, one wave per SIMD fewer) and handed the new velocities back through
+// eight selects per photon and step.  Here r (and lam4, and the odd step's random words) stay in registers; v and |v dt| of
+// every photon live in LDS ("home", 32 B per fp64 photon): a step READS them from there, the dense pass WRITES the new ones
+// straight into the owner's home, and nothing is handed back.  40 VGPRs of state per lane at four photons: 124 in all, four
+// waves per SIMD, nothing spilled (measured at 1e8 photons: 0.38 instead of 0.50 ms per step at a 21 % hit fraction, faster
+// than the 128-photon form at every hit fraction from 0.52 down).
+//   * per photon and step: 4 ds_read_b64 instead of 8 v_cndmask + 4 conditional ds_reads; the hit queue carries only the
+//     owners (2 B per entry, room for every photon of the wave: never more than one round);
+//   * the sign counts of step k are those of the velocities step k + 1 reads (Newton does not change v): they are tallied
+//     there, the last step's when the velocities are read for the final store -- no second look at v after the dense pass;
+//   * the velocity before the last step (vp rows) is copied from the homes when the last step begins.
+// Same operations on the same operands per photon, in the same order, as K launches of pcl_fast_body: bit-identical state and rows
+// (tests/test_gpu_multi.py runs every form against the single steps and the oracle).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NP>
+struct pcl_multi_home {
+    T c[4][NP][256];                   // v0, v1, v2, |v dt| of photon p of thread t (component-major: lanes read consecutive words)
+    unsigned short owner[4][NP * 64];  // per wave: the step's hits, p * 64 + lane
 };
 
-template <typename T, bool USE_E, int VAR_N, int VEC, bool SATP = false>
-__device__ __forceinline__ void pcl_multi_body(const pcl_multi_args<T> &a) {
-    typedef pcl_rt<T> R;
-    typedef pcl_vec<T, VEC> VV;
-    __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
-    const int nslots = 4 + a.n_planes;
-    __shared__ pcl_hit_queue<T, VEC> s_q;
-    __shared__ pcl_u32 s_pass, s_sat;
-    __shared__ pcl_u64 s_clk[2]; // the workgroup's start: shader cycles, 100 MHz ticks (pcl_clock_stamp)
-    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
-    if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
-    pcl_clock_begin(s_clk);
-    __syncthreads();
-    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
-    const bool lane0 = (threadIdx.x & 63) == 0;
-    const pcl_i64 nq = (a.N + VEC - 1) / VEC;
-    const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x;
-    pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform: a scalar add per step)
-    pcl_u32 w_sat = 0;    // SATP: wave-steps whose expression values came from the saturation shortcut
-    for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x; base < nq; base += stride) {
-        const pcl_i64 q = base + threadIdx.x;
-        const bool live_q = q < nq;
-        const pcl_i64 qs = pcl_tq<VEC>(live_q ? q : 0, a.ts);
-        T Rr[3][VEC], V[3][VEC], L4[VEC], Ev[VEC], NM[VEC];
-        pcl_u32 wodd0[VEC], wodd1[VEC]; // the decision block's second half, waiting for the odd step
-        VV::ld(a.r0, qs, Rr[0]);
-        VV::ld(a.r1, qs, Rr[1]);
-        VV::ld(a.r2, qs, Rr[2]);
-        VV::ld(a.v0, qs, V[0]);
-        VV::ld(a.v1, qs, V[1]);
-        VV::ld(a.v2, qs, V[2]);
-        if constexpr (USE_E) VV::ld(a.lam4, qs, L4);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-            Ev[e] = a.E[pcl_tix((live_q && q * VEC + e < a.N) ? q * VEC + e : 0, a.ts)];
-            // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
-            NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
-        }
-        for (int k = 0; k < a.K; ++k) {
-            const pcl_u32 st = a.step + (pcl_u32)k;
-            // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push
-            // other scalars into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler
-            // rebuild them per iteration on the otherwise idle scalar unit instead.
-            pcl_u32 kk0 = k0, kk1 = k1;
-            asm volatile("" : "+s"(kk0), "+s"(kk1));
-            pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
-            bool hit[VEC];
-            pcl_u32 slot[VEC];
-            const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
-            T nv[VEC], dd[3][VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const pcl_i64 i = q * VEC + e;
-                const bool live = live_q && i < a.N;
-                // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
-                const T d0 = R::mul(V[0][e], a.dt), d1 = R::mul(V[1][e], a.dt), d2 = R::mul(V[2][e], a.dt);
-                dd[0][e] = d0, dd[1][e] = d1, dd[2][e] = d2;
-                Rr[0][e] = R::add(Rr[0][e], d0);
-                Rr[1][e] = R::add(Rr[1][e], d1);
-                Rr[2][e] = R::add(Rr[2][e], d2);
-                // plane crossings of this step's move (r - dr, r)                        light.py:385-399
-                for (int p = 0; p < a.n_planes; ++p) {
-                    const int ax = a.plane_ax[p];
-                    const T L = a.plane_L[p];
-                    const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
-                    const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
-                    const pcl_u32 nc = (pcl_u32)__popcll(__ballot(live && ((prev <= L && L <= x) || (prev >= L && L >= x))));
-                    if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + p], nc);
-                }
-            }
-#ifdef PCL_N_EXPR
-            if constexpr (SATP && VAR_N != 0) { // the expression of all of the lane's photons by the saturation shortcut, if it holds wave-wide
-                bool unsat = false;
-#pragma unroll
-                for (int e = 0; e < VEC; ++e)
-                    nv[e] = pcl_n_expr_sat<T>(Rr[0][e], Rr[1][e], Rr[2][e], dd[0][e], dd[1][e], dd[2][e], Ev[e], unsat);
-                if (__ballot(unsat) != 0ull) { // (wave-uniform) some argument is in exp's working range: the ordinary way
-#pragma unroll
-                    for (int e = 0; e < VEC; ++e)
-                        nv[e] = pcl_n_expr_val<T, VAR_N>(a.np, Rr[0][e], Rr[1][e], Rr[2][e], dd[0][e], dd[1][e], dd[2][e], Ev[e]);
-                } else {
-                    ++w_sat;
-                    asm volatile("" : "+v"(w_sat));
-                }
-            }
-#endif
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const pcl_i64 i = q * VEC + e;
-                const bool live = live_q && i < a.N;
-                const T d0 = dd[0][e], d1 = dd[1][e], d2 = dd[2][e];
-                // scatter decision                                                       light.py:303-308
-                T pc;
-#ifdef PCL_N_EXPR
-                if constexpr (SATP && VAR_N != 0)
-                    pc = R::mul(R::mul(a.A, nv[e]), NM[e]); // pcl_pcoll_norm with the expression's value in hand
-                else
-#endif
-                    pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[e], d0, d1, d2, Rr[0][e], Rr[1][e], Rr[2][e], Ev[e]);
-                if constexpr (USE_E) pc = R::mul(pc, L4[e]);
-                const pcl_u64 id = (pcl_u64)(a.id_base + i);
-                T rand;
-                if (new_block) { // decision block of steps (st & ~1, st | 1): computed once for the pair
-                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
-                    rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
-                    wodd0[e] = w.z;
-                    wodd1[e] = w.w;
-                } else {
-                    rand = R::uniform(wodd0[e], wodd1[e]);
-                }
-                hit[e] = live && (pc >= rand);
-            }
-            // queue slots from the wave's own ballots
-            pcl_u64 ballot[VEC];
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                ballot[e] = __ballot(hit[e]);
-                w_hits += (pcl_u32)__popcll(ballot[e]);
-            }
-            const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
-            pcl_u32 wbase = qbase;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(ballot[e] >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)ballot[e], 0u));
-                wbase += (pcl_u32)__popcll(ballot[e]);
-                if (hit[e]) s_q.owner[slot[e]] = threadIdx.x * VEC + e;
-            }
-            // the queue is private to the wave: LDS executes a wave's accesses in order, so a compiler-level fence
-            // is all the hand-over needs -- no workgroup barrier anywhere in the K loop
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            const pcl_u32 n_hit = qbase + w_hits;
-            w_passes += (w_hits + 63u) >> 6;
-            asm volatile("" : "+v"(w_passes)); // lives in a VGPR (one is free, the scalar file is not): no lane spill for a tally
-#ifdef PCL_HIT_HIST /* debug build (PCL_RTC_EXTRA=PCL_HIT_HIST): how many hits did this wave queue in this step?  129 bins */
-            if (lane0) atomicAdd(&a.cnt[nslots * a.K + 4 + (w_hits < 128u ? w_hits : 128u)], (pcl_u64)1);
-#endif
-            // the scatter itself, densely: item j by lane j                                light.py:309-311
-            for (pcl_u32 j = qbase + (threadIdx.x & 63); j < n_hit; j += 64) {
-                const pcl_u32 o = s_q.owner[j];
-                const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(o / VEC)) * VEC + (pcl_i64)(o % VEC));
-                T rtheta, rphi;
-                pcl_draw_angles<T>(id, st, kk0, kk1, rtheta, rphi);
-                T o0, o1, o2;
-                pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
-                s_q.out[0][j] = o0;
-                s_q.out[1][j] = o1;
-                s_q.out[2][j] = o2;
-                s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            if (k + 1 == a.K && live_q) { // the velocity before the LAST step is what dv = v - v_prev needs: stored
-                VV::st(a.vp0, qs, V[0]);  // straight from the v registers (wave-uniform branch), no copy kept
-                VV::st(a.vp1, qs, V[1]);
-                VV::st(a.vp2, qs, V[2]);
-            }
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const bool live = live_q && q * VEC + e < a.N;
-                if (hit[e]) {
-                    V[0][e] = s_q.out[0][slot[e]];
-                    V[1][e] = s_q.out[1][slot[e]];
-                    V[2][e] = s_q.out[2][slot[e]];
-                    NM[e] = s_q.out[3][slot[e]];
-                }
-                w_sx += (pcl_u32)__popcll(__ballot(live && V[0][e] > (T)0));
-                w_sy += (pcl_u32)__popcll(__ballot(live && V[1][e] > (T)0));
-                w_sz += (pcl_u32)__popcll(__ballot(live && V[2][e] > (T)0));
-            }
-            if (lane0) {
-                if (w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
-                if (w_sx) atomicAdd(&s_cnt[nslots * k + 1], w_sx);
-                if (w_sy) atomicAdd(&s_cnt[nslots * k + 2], w_sy);
-                if (w_sz) atomicAdd(&s_cnt[nslots * k + 3], w_sz);
-            }
-        }
-        if (live_q) {
-            VV::st(a.r0, qs, Rr[0]);
-            VV::st(a.r1, qs, Rr[1]);
-            VV::st(a.r2, qs, Rr[2]);
-            VV::st(a.v0, qs, V[0]);
-            VV::st(a.v1, qs, V[1]);
-            VV::st(a.v2, qs, V[2]);
-        }
-    }
-    if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
-    if (lane0 && w_sat) atomicAdd(&s_sat, w_sat);
-    __syncthreads();
-    for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x)
-        if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
-    if (threadIdx.x == 0 && s_pass) atomicAdd(&a.cnt[nslots * a.K], (pcl_u64)s_pass);
-    if (threadIdx.x == 0 && s_sat) atomicAdd(&a.cnt[nslots * a.K + 1], (pcl_u64)s_sat);
-    pcl_clock_end(s_clk, &a.cnt[nslots * a.K + 2]);
-}
-
-// NQ: VEC-wide groups per lane and trip (photons per lane = VEC * NQ).  The dense pass costs the same whether 5 or 64
-// of its lanes carry a hit, so the more photons a wave queues per step the fuller its passes: with NQ = 2 a wave owns
-// 128 * NQ photons per trip and, while their hits fit the queue (<= 64 * VEC), handles them in ONE round of
-// ceil(hits / 64) passes; a busier step falls back to one round per group.  Same operations per photon either way.
 template <typename T, bool USE_E, int VAR_N, int VEC, int NQ, bool SATP = false>
-__device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
+__device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
     constexpr int NP = VEC * NQ; // photons per lane
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
-    __shared__ pcl_hit_queue<T, VEC> s_q;
+    __shared__ pcl_multi_home<T, NP> s_h;
     __shared__ pcl_u32 s_pass, s_sat;
-    __shared__ pcl_u64 s_clk[2]; // the workgroup's start: shader cycles, 100 MHz ticks (pcl_clock_stamp)
+    __shared__ pcl_u64 s_clk[2];
     for (int k = threadIdx.x; k < nslots * a.K; k += blockDim.x) s_cnt[k] = 0;
     if (threadIdx.x == 0) s_pass = 0, s_sat = 0;
     pcl_clock_begin(s_clk);
     __syncthreads();
     const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
-    const bool lane0 = (threadIdx.x & 63) == 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lane0 = lane == 0;
     const pcl_i64 nq = (a.N + VEC - 1) / VEC;
     const pcl_i64 stride = (pcl_i64)gridDim.x * blockDim.x * NQ;
     pcl_u32 w_passes = 0; // dense passes this wave made (wave-uniform)
     pcl_u32 w_sat = 0;    // SATP: wave-steps whose expression values came from the saturation shortcut
-    const pcl_u32 qbase = (threadIdx.x >> 6) * 64u * VEC; // this wave's part of the queue
-    constexpr pcl_u32 QCAP = 64u * VEC;
     for (pcl_i64 base = (pcl_i64)blockIdx.x * blockDim.x * NQ; base < nq; base += stride) {
-        pcl_i64 q[NQ], qs[NQ];
-        bool live_q[NQ];
-        T Rr[3][NP], V[3][NP], L4[NP], Ev[NP], NM[NP];
+        T Rr[3][NP], L4[NP], Ev[NP];
         pcl_u32 wodd0[NP], wodd1[NP]; // the decision block's second half, waiting for the odd step
+        bool live[NP];
+        // the wave's votes are taken on bare compares and masked with the photons' live masks in the scalar unit: a vote on a
+        // compound predicate makes the compiler turn it into an integer and compare again (v_cndmask + v_cmp, 8 cycles a vote)
+        pcl_u64 lm[NP];
 #pragma unroll
         for (int g = 0; g < NQ; ++g) {
-            q[g] = base + (pcl_i64)g * blockDim.x + threadIdx.x;
-            live_q[g] = q[g] < nq;
-            qs[g] = pcl_tq<VEC>(live_q[g] ? q[g] : 0, a.ts);
+            const pcl_i64 q = base + (pcl_i64)g * blockDim.x + tid;
+            const bool live_q = q < nq;
+            const pcl_i64 qs = pcl_tq<VEC>(live_q ? q : 0, a.ts);
             T t0[VEC], t1[VEC], t2[VEC], t3[VEC], t4[VEC], t5[VEC], t6[VEC];
-            VV::ld(a.r0, qs[g], t0);
-            VV::ld(a.r1, qs[g], t1);
-            VV::ld(a.r2, qs[g], t2);
-            VV::ld(a.v0, qs[g], t3);
-            VV::ld(a.v1, qs[g], t4);
-            VV::ld(a.v2, qs[g], t5);
-            if constexpr (USE_E) VV::ld(a.lam4, qs[g], t6);
+            VV::ld(a.r0, qs, t0);
+            VV::ld(a.r1, qs, t1);
+            VV::ld(a.r2, qs, t2);
+            VV::ld(a.v0, qs, t3);
+            VV::ld(a.v1, qs, t4);
+            VV::ld(a.v2, qs, t5);
+            if constexpr (USE_E) VV::ld(a.lam4, qs, t6);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const int p = g * VEC + e;
+                live[p] = live_q && q * VEC + e < a.N;
+                lm[p] = pcl_ballot(live[p]);
                 Rr[0][p] = t0[e];
                 Rr[1][p] = t1[e];
                 Rr[2][p] = t2[e];
-                V[0][p] = t3[e];
-                V[1][p] = t4[e];
-                V[2][p] = t5[e];
                 L4[p] = (T)1;
                 if constexpr (USE_E) L4[p] = t6[e];
-                Ev[p] = a.E[pcl_tix((live_q[g] && q[g] * VEC + e < a.N) ? q[g] * VEC + e : 0, a.ts)];
-                // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
-                NM[p] = pcl_step_norm<T>(R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt), R::mul(V[2][p], a.dt));
+                Ev[p] = a.E[pcl_tix(live[p] ? q * VEC + e : 0, a.ts)];
+                s_h.c[0][p][tid] = t3[e];
+                s_h.c[1][p][tid] = t4[e];
+                s_h.c[2][p][tid] = t5[e];
+                // |dr| = |v * dt| only changes when the photon scatters: kept beside v, recomputed with the new velocity
+                s_h.c[3][p][tid] = pcl_step_norm<T>(R::mul(t3[e], a.dt), R::mul(t4[e], a.dt), R::mul(t5[e], a.dt));
             }
         }
         for (int k = 0; k < a.K; ++k) {
             const pcl_u32 st = a.step + (pcl_u32)k;
-            // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push
-            // other scalars into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler
-            // rebuild them per iteration on the otherwise idle scalar unit instead.
+            // (see pcl_multi_body: opaque copies keep the 20 Philox round keys out of the scalar file's long-lived set)
             pcl_u32 kk0 = k0, kk1 = k1;
             asm volatile("" : "+s"(kk0), "+s"(kk1));
-            pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
-            bool hit[NP];
-            pcl_u32 slot[NP];
-            pcl_u64 ballot[NP];
             const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
-#ifdef PCL_N_EXPR
-            T nv[NP];
-            if constexpr (SATP && VAR_N != 0) { // Newton for all of the lane's photons first, then the expression by the saturation
-                bool unsat = false;             // shortcut if it holds wave-wide (pcl_n_expr_sat)
+            if (k + 1 == a.K) { // the velocity before the LAST step is what dv = v - v_prev needs: copied from the homes
+                int tid_here = tid; // (opaque: the addresses below are worked out HERE, once per trip, not hoisted out of the K loop
+                asm volatile("" : "+v"(tid_here)); // into registers that would have to live -- or spill -- through every step)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    Rr[0][p] = R::add(Rr[0][p], R::mul(V[0][p], a.dt));
-                    Rr[1][p] = R::add(Rr[1][p], R::mul(V[1][p], a.dt));
-                    Rr[2][p] = R::add(Rr[2][p], R::mul(V[2][p], a.dt));
-                    nv[p] = pcl_n_expr_sat<T>(Rr[0][p], Rr[1][p], Rr[2][p], R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt), R::mul(V[2][p], a.dt), Ev[p], unsat);
-                }
-                if (__ballot(unsat) != 0ull) {
+                for (int g = 0; g < NQ; ++g) {
+                    const pcl_i64 q = base + (pcl_i64)g * blockDim.x + tid_here;
+                    if (q < nq) {
+                        T t3[VEC], t4[VEC], t5[VEC];
 #pragma unroll
-                    for (int p = 0; p < NP; ++p)
-                        nv[p] = pcl_n_expr_val<T, VAR_N>(a.np, Rr[0][p], Rr[1][p], Rr[2][p], R::mul(V[0][p], a.dt), R::mul(V[1][p], a.dt),
-                                                         R::mul(V[2][p], a.dt), Ev[p]);
-                } else {
-                    ++w_sat;
-                    asm volatile("" : "+v"(w_sat));
+                        for (int e = 0; e < VEC; ++e) {
+                            t3[e] = s_h.c[0][g * VEC + e][tid];
+                            t4[e] = s_h.c[1][g * VEC + e][tid];
+                            t5[e] = s_h.c[2][g * VEC + e][tid];
+                        }
+                        const pcl_i64 qs = pcl_tq<VEC>(q, a.ts);
+                        VV::st(a.vp0, qs, t3);
+                        VV::st(a.vp1, qs, t4);
+                        VV::st(a.vp2, qs, t5);
+                    }
                 }
             }
-#endif
+            pcl_u32 w_hits = 0, w_sx = 0, w_sy = 0, w_sz = 0;
+            T pcn[NP], nmv[NP]; // per photon: the collision probability, or (SATP) the expression's value and |v dt|
+            bool unsat = false;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const int g = p / VEC, e = p % VEC;
-                const pcl_i64 i = q[g] * VEC + e;
-                const bool live = live_q[g] && i < a.N;
+                const T v0 = s_h.c[0][p][tid], v1 = s_h.c[1][p][tid], v2 = s_h.c[2][p][tid], nm = s_h.c[3][p][tid];
+                // sign counts of the state step k - 1 left behind (Newton does not touch v)                light.py:424-426
+                w_sx += (pcl_u32)__popcll(pcl_ballot(v0 > (T)0) & lm[p]);
+                w_sy += (pcl_u32)__popcll(pcl_ballot(v1 > (T)0) & lm[p]);
+                w_sz += (pcl_u32)__popcll(pcl_ballot(v2 > (T)0) & lm[p]);
                 // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
-                const T d0 = R::mul(V[0][p], a.dt), d1 = R::mul(V[1][p], a.dt), d2 = R::mul(V[2][p], a.dt);
-#ifdef PCL_N_EXPR
-                if constexpr (!(SATP && VAR_N != 0))
-#endif
-                {
-                    Rr[0][p] = R::add(Rr[0][p], d0);
-                    Rr[1][p] = R::add(Rr[1][p], d1);
-                    Rr[2][p] = R::add(Rr[2][p], d2);
-                }
+                const T d0 = R::mul(v0, a.dt), d1 = R::mul(v1, a.dt), d2 = R::mul(v2, a.dt);
+                Rr[0][p] = R::add(Rr[0][p], d0);
+                Rr[1][p] = R::add(Rr[1][p], d1);
+                Rr[2][p] = R::add(Rr[2][p], d2);
                 // plane crossings of this step's move (r - dr, r)                        light.py:385-399
                 for (int pl = 0; pl < a.n_planes; ++pl) {
                     const int ax = a.plane_ax[pl];
                     const T L = a.plane_L[pl];
                     const T x = pcl_pick<T>(ax, Rr[0][p], Rr[1][p], Rr[2][p]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
-                    const pcl_u32 nc = (pcl_u32)__popcll(__ballot(live && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    const pcl_u32 nc = (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & lm[p]);
                     if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
                 }
                 // scatter decision                                                       light.py:303-308
-                T pc;
 #ifdef PCL_N_EXPR
-                if constexpr (SATP && VAR_N != 0)
-                    pc = R::mul(R::mul(a.A, nv[p]), NM[p]); // pcl_pcoll_norm with the expression's value in hand
-                else
+                if constexpr (SATP && VAR_N != 0) { // by exp's saturation shortcut first (pcl_n_expr_sat): settled wave-wide below
+                    pcn[p] = pcl_n_expr_sat<T>(Rr[0][p], Rr[1][p], Rr[2][p], d0, d1, d2, Ev[p], unsat);
+                    nmv[p] = nm;
+                } else
 #endif
-                    pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, NM[p], d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p], Ev[p]);
-                if constexpr (USE_E) pc = R::mul(pc, L4[p]);
-                const pcl_u64 id = (pcl_u64)(a.id_base + i);
+                {
+                    T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, nm, d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p], Ev[p]);
+                    if constexpr (USE_E) pc = R::mul(pc, L4[p]);
+                    pcn[p] = pc;
+                }
+            }
+            if (k > 0 && lane0) { // (row k - 1)
+                if (w_sx) atomicAdd(&s_cnt[nslots * (k - 1) + 1], w_sx);
+                if (w_sy) atomicAdd(&s_cnt[nslots * (k - 1) + 2], w_sy);
+                if (w_sz) atomicAdd(&s_cnt[nslots * (k - 1) + 3], w_sz);
+            }
+#ifdef PCL_N_EXPR
+            if constexpr (SATP && VAR_N != 0) {
+                if (pcl_ballot(unsat) != 0ull) { // (wave-uniform) some argument is in exp's working range: the ordinary way
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const T d0 = R::mul(s_h.c[0][p][tid], a.dt), d1 = R::mul(s_h.c[1][p][tid], a.dt), d2 = R::mul(s_h.c[2][p][tid], a.dt);
+                        pcn[p] = pcl_n_expr_val<T, VAR_N>(a.np, Rr[0][p], Rr[1][p], Rr[2][p], d0, d1, d2, Ev[p]);
+                    }
+                } else {
+                    ++w_sat;
+                    asm volatile("" : "+v"(w_sat));
+                }
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { // pcl_pcoll_norm with the expression's value in hand
+                    T pc = R::mul(R::mul(a.A, pcn[p]), nmv[p]);
+                    if constexpr (USE_E) pc = R::mul(pc, L4[p]);
+                    pcn[p] = pc;
+                }
+            }
+#endif
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int g = p / VEC, e = p % VEC;
+                const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)g * blockDim.x + tid) * VEC + e);
                 T rand;
                 if (new_block) { // decision block of steps (st & ~1, st | 1): computed once for the pair
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
@@ -1285,116 +1135,72 @@ __device__ __forceinline__ void pcl_multi_body_nq(const pcl_multi_args<T> &a) {
                 } else {
                     rand = R::uniform(wodd0[p], wodd1[p]);
                 }
-                hit[p] = live && (pc >= rand);
-                ballot[p] = __ballot(hit[p]);
-                w_hits += (pcl_u32)__popcll(ballot[p]);
-#ifdef PCL_NQ_SCHED_BARRIER
-                __builtin_amdgcn_sched_barrier(0); // one photon's Philox / exp chain at a time: their temporaries do not pile up
+                const pcl_u64 bal = pcl_ballot(pcn[p] >= rand) & lm[p]; // (NaN compares false, +inf true: the reference's ``pcoll >= rand``)
+                const bool hit = (bal >> lane) & 1ull;
+                if (hit) s_h.owner[wave][w_hits + __builtin_amdgcn_mbcnt_hi((pcl_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)bal, 0u))] = (unsigned short)(p * 64 + lane);
+                w_hits += (pcl_u32)__popcll(bal);
+            }
+            // the queue and the homes of a wave's photons are private to the wave: LDS executes a wave's accesses in order, so
+            // a compiler-level fence is all the hand-over needs -- no workgroup barrier anywhere in the K loop
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            w_passes += (w_hits + 63u) >> 6;
+            asm volatile("" : "+v"(w_passes)); // lives in a VGPR: no lane spill for a tally
+#ifdef PCL_HIT_HIST /* debug build (PCL_RTC_EXTRA=PCL_HIT_HIST): how many hits did this wave queue in this step?  129 bins */
+            if (lane0) atomicAdd(&a.cnt[nslots * a.K + 4 + (w_hits < 128u ? w_hits : 128u)], (pcl_u64)1);
 #endif
+            // the scatter itself, densely: item j by lane j, the new velocity straight into its owner's home  light.py:309-311
+            for (pcl_u32 j = (pcl_u32)lane; j < w_hits; j += 64) {
+                const pcl_u32 o = s_h.owner[wave][j];
+                const pcl_u32 op = o >> 6, ot = (pcl_u32)wave * 64u + (o & 63u);
+                const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(op / VEC) * blockDim.x + (pcl_i64)ot) * VEC + (pcl_i64)(op % VEC));
+                T rtheta, rphi;
+                pcl_draw_angles<T>(id, st, kk0, kk1, rtheta, rphi);
+                T o0, o1, o2;
+                pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
+                s_h.c[0][op][ot] = o0;
+                s_h.c[1][op][ot] = o1;
+                s_h.c[2][op][ot] = o2;
+                s_h.c[3][op][ot] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
             }
-            if (k + 1 == a.K) { // the velocity before the LAST step is what dv = v - v_prev needs: stored straight
-#pragma unroll                  // from the v registers (wave-uniform branch), no copy kept
-                for (int g = 0; g < NQ; ++g)
-                    if (live_q[g]) {
-                        T t3[VEC], t4[VEC], t5[VEC];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (lane0 && w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
+        }
+        // the last step's sign counts, and the store
+        pcl_u32 w_sx = 0, w_sy = 0, w_sz = 0;
 #pragma unroll
-                        for (int e = 0; e < VEC; ++e) {
-                            t3[e] = V[0][g * VEC + e];
-                            t4[e] = V[1][g * VEC + e];
-                            t5[e] = V[2][g * VEC + e];
-                        }
-                        VV::st(a.vp0, qs[g], t3);
-                        VV::st(a.vp1, qs[g], t4);
-                        VV::st(a.vp2, qs[g], t5);
-                    }
+        for (int g = 0; g < NQ; ++g) {
+            const pcl_i64 q = base + (pcl_i64)g * blockDim.x + tid;
+            T t0[VEC], t1[VEC], t2[VEC], t3[VEC], t4[VEC], t5[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const int p = g * VEC + e;
+                t0[e] = Rr[0][p];
+                t1[e] = Rr[1][p];
+                t2[e] = Rr[2][p];
+                t3[e] = s_h.c[0][p][tid];
+                t4[e] = s_h.c[1][p][tid];
+                t5[e] = s_h.c[2][p][tid];
+                w_sx += (pcl_u32)__popcll(pcl_ballot(t3[e] > (T)0) & lm[p]);
+                w_sy += (pcl_u32)__popcll(pcl_ballot(t4[e] > (T)0) & lm[p]);
+                w_sz += (pcl_u32)__popcll(pcl_ballot(t5[e] > (T)0) & lm[p]);
             }
-            // One round for all of the wave's hits when they fit its queue, else one round per group.  The queue is
-            // private to the wave: LDS executes a wave's accesses in order, so a compiler-level fence is all the
-            // hand-over needs -- no workgroup barrier anywhere in the K loop.
-            const int rounds = (NQ == 1 || w_hits <= QCAP) ? 1 : NQ; // wave-uniform
-            for (int rd = 0; rd < rounds; ++rd) {
-                pcl_u32 wbase = qbase;
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    if (rounds == 1 || p / VEC == rd) {
-                        slot[p] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(ballot[p] >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)ballot[p], 0u));
-                        wbase += (pcl_u32)__popcll(ballot[p]);
-                        if (hit[p]) s_q.owner[slot[p]] = threadIdx.x * NP + p;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                w_passes += (wbase - qbase + 63u) >> 6;
-                asm volatile("" : "+v"(w_passes));
-#ifdef PCL_HIT_HIST /* (256-photon form: hits of the round -- all of the wave's, or one group's) */
-                if (lane0) atomicAdd(&a.cnt[nslots * a.K + 4 + ((wbase - qbase) < 128u ? (wbase - qbase) : 128u)], (pcl_u64)1);
-#endif
-                // the scatter itself, densely: item j by lane j                                light.py:309-311
-                for (pcl_u32 j = qbase + (threadIdx.x & 63); j < wbase; j += 64) {
-                    const pcl_u32 o = s_q.owner[j];
-                    const pcl_u32 ot = o / NP, op = o % NP;
-                    const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(op / VEC) * blockDim.x + (pcl_i64)ot) * VEC + (pcl_i64)(op % VEC));
-                    T rtheta, rphi;
-                    pcl_draw_angles<T>(id, st, kk0, kk1, rtheta, rphi);
-                    T o0, o1, o2;
-                    pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
-                    s_q.out[0][j] = o0;
-                    s_q.out[1][j] = o1;
-                    s_q.out[2][j] = o2;
-                    s_q.out[3][j] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    if ((rounds == 1 || p / VEC == rd) && hit[p]) {
-                        V[0][p] = s_q.out[0][slot[p]];
-                        V[1][p] = s_q.out[1][slot[p]];
-                        V[2][p] = s_q.out[2][slot[p]];
-                        NM[p] = s_q.out[3][slot[p]];
-                    }
-                }
-                if (NQ > 1) { // the next round reuses the queue: its reads above come first (same wave, in order)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int g = p / VEC, e = p % VEC;
-                const bool live = live_q[g] && q[g] * VEC + e < a.N;
-                w_sx += (pcl_u32)__popcll(__ballot(live && V[0][p] > (T)0));
-                w_sy += (pcl_u32)__popcll(__ballot(live && V[1][p] > (T)0));
-                w_sz += (pcl_u32)__popcll(__ballot(live && V[2][p] > (T)0));
-            }
-            if (lane0) {
-                if (w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
-                if (w_sx) atomicAdd(&s_cnt[nslots * k + 1], w_sx);
-                if (w_sy) atomicAdd(&s_cnt[nslots * k + 2], w_sy);
-                if (w_sz) atomicAdd(&s_cnt[nslots * k + 3], w_sz);
+            if (q < nq) {
+                const pcl_i64 qs = pcl_tq<VEC>(q, a.ts);
+                VV::st(a.r0, qs, t0);
+                VV::st(a.r1, qs, t1);
+                VV::st(a.r2, qs, t2);
+                VV::st(a.v0, qs, t3);
+                VV::st(a.v1, qs, t4);
+                VV::st(a.v2, qs, t5);
             }
         }
-#pragma unroll
-        for (int g = 0; g < NQ; ++g)
-            if (live_q[g]) {
-                T t0[VEC], t1[VEC], t2[VEC], t3[VEC], t4[VEC], t5[VEC];
-#pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    const int p = g * VEC + e;
-                    t0[e] = Rr[0][p];
-                    t1[e] = Rr[1][p];
-                    t2[e] = Rr[2][p];
-                    t3[e] = V[0][p];
-                    t4[e] = V[1][p];
-                    t5[e] = V[2][p];
-                }
-                VV::st(a.r0, qs[g], t0);
-                VV::st(a.r1, qs[g], t1);
-                VV::st(a.r2, qs[g], t2);
-                VV::st(a.v0, qs[g], t3);
-                VV::st(a.v1, qs[g], t4);
-                VV::st(a.v2, qs[g], t5);
-            }
+        if (lane0) {
+            if (w_sx) atomicAdd(&s_cnt[nslots * (a.K - 1) + 1], w_sx);
+            if (w_sy) atomicAdd(&s_cnt[nslots * (a.K - 1) + 2], w_sy);
+            if (w_sz) atomicAdd(&s_cnt[nslots * (a.K - 1) + 3], w_sz);
+        }
     }
     if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
     if (lane0 && w_sat) atomicAdd(&s_sat, w_sat);
@@ -1502,7 +1308,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
         }
         for (int ph = 0; ph < n_ph; ++ph) {
-            if (!(__ballot(alive[0]) | __ballot(alive[1]))) break; // nobody of these rows is left: their rows stay 0
+            if (!(pcl_ballot(alive[0]) | pcl_ballot(alive[1]))) break; // nobody of these rows is left: their rows stay 0
             const pcl_u32 st = a.step + (pcl_u32)ph;
             const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
             pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body: keeps the round keys off the VGPR spills
@@ -1534,7 +1340,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 for (int e = 0; e < NE; ++e) {
                     const T pc = R::mul(a.An_del, NM[e]);
                     const bool gone = alive[e] && photon[e] && (pc >= rand[e]);
-                    w_evt += (pcl_u32)__popcll(__ballot(gone));
+                    w_evt += (pcl_u32)__popcll(pcl_ballot(gone));
                     alive[e] = alive[e] && !gone;
                 }
             } else {
@@ -1548,7 +1354,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                                                            Rr[1][e], Rr[2][e], Ev[e]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                     hit[e] = alive[e] && photon[e] && (pc >= rand[e]);
-                    const pcl_u64 b = __ballot(hit[e]);
+                    const pcl_u64 b = pcl_ballot(hit[e]);
                     slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u));
                     wbase += (pcl_u32)__popcll(b);
                     if (hit[e]) s_q.id[slot[e]] = id[e];
@@ -1589,10 +1395,10 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             pcl_u32 w_n = 0, w_sx = 0, w_sy = 0, w_sz = 0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                w_n += (pcl_u32)__popcll(__ballot(alive[e]));
-                w_sx += (pcl_u32)__popcll(__ballot(alive[e] && V[0][e] > (T)0));
-                w_sy += (pcl_u32)__popcll(__ballot(alive[e] && V[1][e] > (T)0));
-                w_sz += (pcl_u32)__popcll(__ballot(alive[e] && V[2][e] > (T)0));
+                w_n += (pcl_u32)__popcll(pcl_ballot(alive[e]));
+                w_sx += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[0][e] > (T)0));
+                w_sy += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[1][e] > (T)0));
+                w_sz += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[2][e] > (T)0));
             }
             pcl_u32 *c = &s_cnt[nslots * ph];
             for (int p = 0; p < a.n_planes; ++p) {
@@ -1603,7 +1409,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 for (int e = 0; e < NE; ++e) {
                     const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
-                    nc += (pcl_u32)__popcll(__ballot(alive[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    nc += (pcl_u32)__popcll(pcl_ballot(alive[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                 }
                 if (lane0 && nc) atomicAdd(&c[5 + p], nc);
             }
@@ -1626,7 +1432,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 a.v2[ti[e]] = V[2][e];
             }
             if (a.has_delete) {
-                const pcl_u64 m = __ballot(alive[e]);
+                const pcl_u64 m = pcl_ballot(alive[e]);
                 if (lane0) a.masks[tile * 32 + row0 + e] = m;
                 kept += (int)__popcll(m);
             }
@@ -1727,55 +1533,55 @@ PCL_RTC_KERNEL(pcl_rtc_mixed_f_e1, pcl_mixed_args<float>, (pcl_mixed_body<float,
 #endif
 #if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e0(pcl_multi_args<double> a) {
-    pcl_multi_body<double, false, true, 2>(a);
+    pcl_multi_body_lds<double, false, true, 2, 1>(a);
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multi_e1(pcl_multi_args<double> a) {
-    pcl_multi_body<double, true, true, 2>(a);
+    pcl_multi_body_lds<double, true, true, 2, 1>(a);
 }
 #endif
 #if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multis_e0(pcl_multi_args<double> a) {
-    pcl_multi_body<double, false, true, 2, true>(a); // with the saturation probe (pcl_n_expr_sat)
+    pcl_multi_body_lds<double, false, true, 2, 1, true>(a); // with the saturation probe (pcl_n_expr_sat)
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI_ATTR pcl_rtc_multis_e1(pcl_multi_args<double> a) {
-    pcl_multi_body<double, true, true, 2, true>(a);
+    pcl_multi_body_lds<double, true, true, 2, 1, true>(a);
 }
 #endif
 #if PCL_RTC_WANT(1, 0)
-PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body<float, false, true, 4>))
+PCL_RTC_KERNEL(pcl_rtc_multi_f_e0, pcl_multi_args<float>, (pcl_multi_body_lds<float, false, true, 4, 1>))
 #endif
 #if PCL_RTC_WANT(1, 1)
-PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body<float, true, true, 4>))
+PCL_RTC_KERNEL(pcl_rtc_multi_f_e1, pcl_multi_args<float>, (pcl_multi_body_lds<float, true, true, 4, 1>))
 #endif
 // two VEC groups per lane and trip (256 photons per wave): the dense hit pass costs the same for 20 hits as for 64, so at
 // LOW hit fractions a wave that owns twice the photons fills its passes better (+5 .. +13 % below ~25 % hits) -- at the
 // price of the fourth wave per SIMD (-8 % above 27 %).  pcl_step_fused_multi picks per launch, by the hit fraction of the
 // launch before ("K steps per pass").
 #ifndef PCL_MULTI2_ATTR
-#define PCL_MULTI2_ATTR __attribute__((amdgpu_waves_per_eu(3, 3)))
+#define PCL_MULTI2_ATTR __attribute__((amdgpu_waves_per_eu(4, 4))) /* four waves per SIMD: 128 VGPRs (the variant without the probe would take 159) */
 #endif
 #if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e0(pcl_multi_args<double> a) {
-    pcl_multi_body_nq<double, false, true, 2, 2>(a);
+    pcl_multi_body_lds<double, false, true, 2, 2>(a);
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2_e1(pcl_multi_args<double> a) {
-    pcl_multi_body_nq<double, true, true, 2, 2>(a);
+    pcl_multi_body_lds<double, true, true, 2, 2>(a);
 }
 #endif
 #if PCL_RTC_WANT(0, 0)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2s_e0(pcl_multi_args<double> a) {
-    pcl_multi_body_nq<double, false, true, 2, 2, true>(a); // 256 photons per wave with the saturation probe
+    pcl_multi_body_lds<double, false, true, 2, 2, true>(a); // 256 photons per wave with the saturation probe
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2s_e1(pcl_multi_args<double> a) {
-    pcl_multi_body_nq<double, true, true, 2, 2, true>(a);
+    pcl_multi_body_lds<double, true, true, 2, 2, true>(a);
 }
 #endif
 #endif

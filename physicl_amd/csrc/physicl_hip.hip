@@ -23,7 +23,7 @@
 //   k_mixed<T,E>          K passes of [Newton, ScatterIsotropic] and/or [Newton, ScatterDelete] on any store (pcl_device.h)
 //   k_compact_count<T,W>  compaction with the measure counters folded in (pass 3, 8 B per surviving lane)
 //   k_compact_lds<T,W>    the same through LDS: aligned 16-B groups (chosen on the device when > 35 % survive)
-//   (opt-in experiments, measured and not adopted: k_delete_onepass, k_newton_mask_multi_p, pcl_multi_body_nq)
+//   (opt-in experiments, measured and not adopted: k_delete_onepass, k_newton_mask_multi_p)
 //   k_tile_scan           exclusive scan of per-tile survivor counts
 //   k_compact<W,NF>       stable compaction of the SoA state          physicl/light.py:258-260,
 //                                                                      physicl/__init__.py:455-459
@@ -250,9 +250,10 @@ template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fast(pcl_fast_args<T> a) {
     pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
 }
+template <typename T> constexpr int kMultiNQ = sizeof(T) == 8 ? 2 : 1; // VEC-wide groups per lane of the K-step pass
 template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
-    pcl_multi_body<T, USE_E, VAR_N, pcl_rt<T>::VEC>(a);
+    pcl_multi_body_lds<T, USE_E, VAR_N, pcl_rt<T>::VEC, kMultiNQ<T>>(a); // 256 photons per wave in either precision
 }
 template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
@@ -317,7 +318,7 @@ __global__ void __launch_bounds__(kBlock) k_any_nonzero(const W *__restrict__ a0
         const int64_t ti = pcl_tix(i, ts);
         any = any || a0[ti] != 0 || a1[ti] != 0 || a2[ti] != 0;
     }
-    if (__ballot(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+    if (pcl_ballot(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // per-photon wavelength factor pow((h*c)/E, -4) (light.py:301): E never changes during a run, so the
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_mask(delmask_args<T> a) {
                 keep = !(photon && (pcoll >= rand));
             }
         }
-        const uint64_t m = __ballot(keep);
+        const uint64_t m = pcl_ballot(keep);
         if (lane == 0) a.masks[tile * kTileRows + row] = m;
         kept += __popcll(m);
     }
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(kBlock) k_cross_mask(crossmask_args<T> a) {
             const T x = a.x[ti], prev = R::sub(x, a.dx[ti]);
             cross = (prev <= a.L && a.L <= x) || (prev >= a.L && a.L >= x);
         }
-        const uint64_t m = __ballot(cross);
+        const uint64_t m = pcl_ballot(cross);
         if (lane == 0) a.masks[tile * kTileRows + row] = m;
         kept += __popcll(m);
     }
@@ -598,7 +599,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask(newtonmask_args<T> a) {
             }
             keep = !(photon && (pcoll >= rand));
         }
-        const uint64_t m = __ballot(keep);
+        const uint64_t m = pcl_ballot(keep);
         if (lane == 0) a.masks[tile * kTileRows + row] = m;
         kept += __popcll(m);
     }
@@ -665,7 +666,7 @@ __global__ void __launch_bounds__(kBlock) k_flag_mask2(newtonmask_args<T> a) {
             keep0 = kp[0];
             keep1 = two && kp[1];
         }
-        const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+        const uint64_t b0 = pcl_ballot(keep0), b1 = pcl_ballot(keep1);
         if (lane == 0) {
             a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
             a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
@@ -833,7 +834,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                     }
                 }
                 const bool keep0 = al0 && kp[0], keep1 = al1 && kp[1];
-                const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+                const uint64_t b0 = pcl_ballot(keep0), b1 = pcl_ballot(keep1);
                 if (lane == 0) {
                     a.masks[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
                     a.masks[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
@@ -842,7 +843,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                 if (a.count && a.n_planes >= 0) { // wave-uniform
 #pragma unroll
                     for (int k = 0; k < 3; ++k)                                                                              // light.py:424-426
-                        w_s[k] += (uint32_t)__popcll(__ballot(keep0 && vv[u][k][0] > (T)0)) + (uint32_t)__popcll(__ballot(keep1 && vv[u][k][1] > (T)0));
+                        w_s[k] += (uint32_t)__popcll(pcl_ballot(keep0 && vv[u][k][0] > (T)0)) + (uint32_t)__popcll(pcl_ballot(keep1 && vv[u][k][1] > (T)0));
                     if constexpr (NEED_R) {
                         for (int p = 0; p < a.n_planes; ++p) {                                                               // light.py:385-399
                             const int ax = a.plane_ax[p];
@@ -852,7 +853,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_alive(alive_args<T> a) {
                             for (int e = 0; e < 2; ++e) {
                                 const T x = pcl_pick<T>(ax, xx[u][0][e], xx[u][1][e], xx[u][2][e]);
                                 const T prev = R::sub(x, R::mul(pcl_pick<T>(ax, vv[u][0][e], vv[u][1][e], vv[u][2][e]), a.dt));
-                                np += (uint32_t)__popcll(__ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                                np += (uint32_t)__popcll(pcl_ballot((e ? keep1 : keep0) && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                             }
                             if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
                         }
@@ -1065,7 +1066,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                         b = 1;
                     }
                     for (; b < a.K; b += 2) {
-                        if (__ballot(dth_e[0] == 255u || dth_e[1] == 255u) == 0ull) break; // every slot of the wave has its body
+                        if (pcl_ballot(dth_e[0] == 255u || dth_e[1] == 255u) == 0ull) break; // every slot of the wave has its body
                         block(a.step0 + (uint32_t)b, r_lo, r_hi);
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
@@ -1081,7 +1082,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                 uint64_t sg[3][2] = {{0ull, 0ull}, {0ull, 0ull}, {0ull, 0ull}};
                 if (a.n_planes >= 0) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) sg[k][0] = __ballot(vv[k][0] > (T)0), sg[k][1] = __ballot(vv[k][1] > (T)0);
+                    for (int k = 0; k < 3; ++k) sg[k][0] = pcl_ballot(vv[k][0] > (T)0), sg[k][1] = pcl_ballot(vv[k][1] > (T)0);
                 }
                 T xp[2] = {(T)0, (T)0}, dp[2] = {(T)0, (T)0};
                 const T L0 = a.n_planes > 0 ? a.plane_L[0] : (T)0;
@@ -1090,10 +1091,10 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) xp[e] = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]), dp[e] = pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]);
                 }
-                uint64_t cur0 = __ballot(al[0]), cur1 = __ballot(al[1]);
+                uint64_t cur0 = pcl_ballot(al[0]), cur1 = pcl_ballot(al[1]);
                 for (int b = 0; b < a.K; ++b) {
                     if ((cur0 | cur1) == 0ull) break; // nobody of these 128 slots was left before this body (wave-uniform)
-                    const uint64_t a0 = __ballot(dth_e[0] > (uint32_t)(b + 1)), a1 = __ballot(dth_e[1] > (uint32_t)(b + 1));
+                    const uint64_t a0 = pcl_ballot(dth_e[0] > (uint32_t)(b + 1)), a1 = pcl_ballot(dth_e[1] > (uint32_t)(b + 1));
                     const bool mine = lane == b;
                     t_kept += mine ? (uint32_t)(__popcll(a0) + __popcll(a1)) : 0u;
                     if (a.n_planes >= 0) { // (uniform)
@@ -1106,7 +1107,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                             for (int e = 0; e < 2; ++e) {
                                 xp[e] = R::add(xp[e], dp[e]);                                                                // newton.py:16
                                 const T prev = R::sub(xp[e], dp[e]);
-                                c[e] = __ballot((prev <= L0 && L0 <= xp[e]) || (prev >= L0 && L0 >= xp[e]));
+                                c[e] = pcl_ballot((prev <= L0 && L0 <= xp[e]) || (prev >= L0 && L0 >= xp[e]));
                             }
                             t_p0 += mine ? (uint32_t)(__popcll(a0 & c[0]) + __popcll(a1 & c[1])) : 0u;
                         }
@@ -1125,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
                                 for (int e = 0; e < 2; ++e) {
                                     const T x = pcl_pick<T>(ax, xx[0][e], xx[1][e], xx[2][e]);
                                     const T prev = R::sub(x, pcl_pick<T>(ax, dd[0][e], dd[1][e], dd[2][e]));
-                                    np += (uint32_t)__popcll((e ? a1 : a0) & __ballot((prev <= L && L <= x) || (prev >= L && L >= x)));
+                                    np += (uint32_t)__popcll((e ? a1 : a0) & pcl_ballot((prev <= L && L <= x) || (prev >= L && L >= x)));
                                 }
                                 if (lane == 0 && np) atomicAdd(&s_cnt[b * kAheadRow + 4 + p], np);
                             }
@@ -1239,16 +1240,16 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     // one body's row from the photons of a round that it leaves alive (``s``): into lane b's accumulators
     auto tally = [&](int b, bool s, uint32_t ix, bool cross) {
         const bool mine = lane == b;
-        const uint64_t bs = __ballot(s);
+        const uint64_t bs = pcl_ballot(s);
         t_kept += mine ? (uint32_t)__popcll(bs) : 0u;
         if (has_signs) {                                                                                                 // light.py:424-426
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const uint64_t bk = __ballot(s && ((ix >> (8 + k)) & 1u)); // (every lane votes: not inside the select)
+                const uint64_t bk = pcl_ballot(s && ((ix >> (8 + k)) & 1u)); // (every lane votes: not inside the select)
                 t_s[k] += mine ? (uint32_t)__popcll(bk) : 0u;
             }
             if (has_plane) {                                                                                             // light.py:385-399
-                const uint64_t bp = __ballot(s && cross);
+                const uint64_t bp = pcl_ballot(s && cross);
                 t_p0 += mine ? (uint32_t)__popcll(bp) : 0u;
             }
         }
@@ -1342,7 +1343,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                         uint32_t d;
                         const bool left = decide(0, single0, two0, a.step0, al[e], id[e], thr, x, dpe, ix, d);
                         if (e == 0) d0.x = (unsigned char)(al[e] ? d : 0u); else d0.y = (unsigned char)(al[e] ? d : 0u);
-                        const uint64_t bal = __ballot(left);
+                        const uint64_t bal = pcl_ballot(left);
                         if (left) { // still alive after the first pass: listed for the next ones
                             const uint32_t pos = n_list + (uint32_t)__popcll(bal & below);
                             if constexpr (IDS) s_id[wave][pos] = id[e];
@@ -1381,7 +1382,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
                     uint32_t d;
                     const bool left = decide(b, single, two, st, on, id, pc, xp, dp, ix, d);
                     if (on && d != 255u) s_death[wave][ix & 0xFFu] = (uint8_t)d;
-                    const uint64_t bal = __ballot(left);
+                    const uint64_t bal = pcl_ballot(left);
                     if (left) {
                         const uint32_t pos = w + (uint32_t)__popcll(bal & below);
                         if constexpr (IDS) s_id[wave][pos] = id;
@@ -1470,8 +1471,8 @@ __global__ void __launch_bounds__(kBlock) k_ahead_commit(ahead_args<T> a) {
             const int64_t i = tile * kTile + (int64_t)row * 64 + 2 * lane;
             const uchar2 d = *reinterpret_cast<const uchar2 *>(a.death + i);
             const uint32_t j = (uint32_t)a.j;
-            const uint64_t b0 = __ballot(d.x > j), b1 = __ballot(d.y > j);
-            const uint64_t p0 = __ballot(d.x >= j && d.x != 0), p1 = __ballot(d.y >= j && d.y != 0);
+            const uint64_t b0 = pcl_ballot(d.x > j), b1 = pcl_ballot(d.y > j);
+            const uint64_t p0 = pcl_ballot(d.x >= j && d.x != 0), p1 = pcl_ballot(d.y >= j && d.y != 0);
             if (lane == 0) {
                 a.masks_out[tile * kTileRows + row] = spread_bits((uint32_t)b0) | (spread_bits((uint32_t)b1) << 1);
                 a.masks_out[tile * kTileRows + row + 1] = spread_bits((uint32_t)(b0 >> 32)) | (spread_bits((uint32_t)(b1 >> 32)) << 1);
@@ -1604,7 +1605,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
             const T vk = a.v[k][ti];
             rv[k] = a.r[k][ti];
             d[k] = R::mul(vk, a.dt);                                  // newton.py:15
-            sgn[k] = __ballot(in && vk > (T)0);
+            sgn[k] = pcl_ballot(in && vk > (T)0);
         }
         const bool photon = in && (a.kind ? (a.kind[in ? i : 0] != 0) : true);
         const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])); // light.py:241-244
@@ -1612,7 +1613,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
         bool alive = in;
         pcl_u32 wodd0 = 0, wodd1 = 0;
         for (int k = 0; k < a.K; ++k) {
-            if (!__ballot(alive)) break; // nobody of this row is left: the remaining rows of the counters stay 0
+            if (!pcl_ballot(alive)) break; // nobody of this row is left: the remaining rows of the counters stay 0
             const pcl_u32 st = a.step + (pcl_u32)k;
             rv[0] = R::add(rv[0], d[0]);                              // newton.py:16
             rv[1] = R::add(rv[1], d[1]);
@@ -1627,7 +1628,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
                 rand = R::uniform(wodd0, wodd1);
             }
             alive = alive && !(photon && (pcoll >= rand));
-            const uint64_t m = __ballot(alive);
+            const uint64_t m = pcl_ballot(alive);
             uint32_t *c = &s_cnt[k * nslots];
             const bool mine = lane == k;
             t_alive += mine ? (uint32_t)__popcll(m) : 0u;
@@ -1639,7 +1640,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
                 const T L = a.plane_L[p];
                 const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
                 const T prev = R::sub(x, pcl_pick<T>(ax, d[0], d[1], d[2]));
-                const uint32_t nc = (uint32_t)__popcll(__ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                const uint32_t nc = (uint32_t)__popcll(pcl_ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                 if (lane == 0 && nc) atomicAdd(&c[4 + p], nc);
             }
         }
@@ -1648,7 +1649,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi(newtonmask_multi_a
             a.r[1][ti] = rv[1];
             a.r[2][ti] = rv[2];
         }
-        const uint64_t m = __ballot(alive);
+        const uint64_t m = pcl_ballot(alive);
         if (lane == 0) a.masks[tile * kTileRows + row] = m;
         kept += __popcll(m);
     }
@@ -1739,7 +1740,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_p(newtonmask_multi
 
     while (true) {
         // ---- idle lanes take the next photons of the pool, in order
-        const uint64_t fm = __ballot(!has);
+        const uint64_t fm = pcl_ballot(!has);
         const int want = __popcll(fm), left = n_pool - next;
         const int take = want < left ? want : left;
         if (take > 0) {
@@ -1763,14 +1764,14 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_p(newtonmask_multi
             }
             next += take;
         }
-        if (!__ballot(has)) break;
+        if (!pcl_ballot(has)) break;
         // ---- one round: the decision block of the lane's current step pair, then its one or two steps
         const pcl_u32 st = a.step + (pcl_u32)k;
         const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, k0, k1);
         bool through = false;
         if (has) through = body((st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y));
         if (has && (st & 1u) == 0u) through = body(R::uniform(w.z, w.w)) || through;
-        kept += __popcll(__ballot(through));
+        kept += __popcll(pcl_ballot(through));
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1846,7 +1847,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
                          uint64_t sy, uint64_t sz, int k_to) {
         pcl_u32 wodd0 = 0, wodd1 = 0;
         for (int k = k_from; k < k_to; ++k) {
-            if (!__ballot(alive)) break;
+            if (!pcl_ballot(alive)) break;
             const pcl_u32 st = a.step + (pcl_u32)k;
             rv[0] = R::add(rv[0], d[0]);                              // newton.py:16
             rv[1] = R::add(rv[1], d[1]);
@@ -1861,7 +1862,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
                 rand = R::uniform(wodd0, wodd1);
             }
             alive = alive && !(photon && (pcoll >= rand));
-            const uint64_t m = __ballot(alive);
+            const uint64_t m = pcl_ballot(alive);
             const bool mine = lane == k;
             t_alive += mine ? (uint32_t)__popcll(m) : 0u;
             t_sx += mine ? (uint32_t)__popcll(m & sx) : 0u;
@@ -1872,7 +1873,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
                 const T L = a.plane_L[p];
                 const T x = pcl_pick<T>(ax, rv[0], rv[1], rv[2]);
                 const T prev = R::sub(x, pcl_pick<T>(ax, d[0], d[1], d[2]));
-                const uint32_t nc = (uint32_t)__popcll(__ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                const uint32_t nc = (uint32_t)__popcll(pcl_ballot(alive && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                 if (lane == 0 && nc) atomicAdd(&s_cnt[k * nslots + 4 + p], nc);
             }
         }
@@ -1886,11 +1887,11 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
             a.r[2][ti] = rv[2];
             atomicOr(&s_mask[wave][slot >> 5], 1u << (slot & 31));
         }
-        kept += __popcll(__ballot(alive));
+        kept += __popcll(pcl_ballot(alive));
     };
     // park the lanes' surviving photons in ring ``lv``
     auto park = [&](int lv, bool alive, const T (&rv)[3], pcl_u64 id, uint32_t meta) {
-        const uint64_t m = __ballot(alive);
+        const uint64_t m = pcl_ballot(alive);
         if (alive) {
             const int pre = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             const int pos = (qhead[lv] + qcount[lv] + pre) & (kCap - 1);
@@ -1921,8 +1922,8 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
         const pcl_u64 id = q_id[wave][lv][pos];
         bool alive = have;
         const int k_from = lv == 0 ? first : mid, k_to = lv == 0 ? mid : a.K;
-        run_steps(k_from, alive, rv, d, pcoll, id, true, __ballot(have && (meta >> 9 & 1u)), __ballot(have && (meta >> 10 & 1u)),
-                  __ballot(have && (meta >> 11 & 1u)), k_to);
+        run_steps(k_from, alive, rv, d, pcoll, id, true, pcl_ballot(have && (meta >> 9 & 1u)), pcl_ballot(have && (meta >> 10 & 1u)),
+                  pcl_ballot(have && (meta >> 11 & 1u)), k_to);
         qhead[lv] = (qhead[lv] + n) & (kCap - 1);
         qcount[lv] -= n;
         if (RINGS == 1 || k_to == a.K)
@@ -1966,7 +1967,7 @@ __global__ void __launch_bounds__(kBlock) k_newton_mask_multi_q(newtonmask_multi
         if (rr + 1 < kRowsPerWave) fetch(rr + 1);
         const T pcoll = R::mul(a.An, pcl_step_norm<T>(d[0], d[1], d[2])); // light.py:241-244
         bool alive = in;
-        run_steps(0, alive, rv, d, pcoll, id, photon, __ballot(sg[0]), __ballot(sg[1]), __ballot(sg[2]), first);
+        run_steps(0, alive, rv, d, pcoll, id, photon, pcl_ballot(sg[0]), pcl_ballot(sg[1]), pcl_ballot(sg[2]), first);
         const int slot = rr * 64 + lane;
         if (first == a.K) { // (K <= 2: nothing left to run densely)
             settle(alive, slot, rv);
@@ -2086,7 +2087,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
             for (int k = 0; k < 3; ++k) {
                 rv[k] = word_as<T, W>(val[k]);
                 vv[k] = word_as<T, W>(val[3 + k]);
-                w_s[k] += (uint32_t)__popcll(__ballot(keep && vv[k] > (T)0));
+                w_s[k] += (uint32_t)__popcll(pcl_ballot(keep && vv[k] > (T)0));
             }
             for (int p = 0; p < c.n_planes; ++p) {
                 const int ax = c.plane_ax[p];
@@ -2098,7 +2099,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_count(compact_args a, compac
                 else
                     dx = R::mul(pcl_pick<T>(ax, vv[0], vv[1], vv[2]), c.dt);
                 const T prev = R::sub(x, dx);
-                const uint32_t np = (uint32_t)__popcll(__ballot(keep && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                const uint32_t np = (uint32_t)__popcll(pcl_ballot(keep && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                 if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
             }
         }
@@ -2233,7 +2234,7 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
                 vkeep[j][t][0] = v0;
                 vkeep[j][t][1] = v1;
                 if (counters)
-                    w_s[j] += (uint32_t)__popcll(__ballot(k0[t] && v0 > (T)0)) + (uint32_t)__popcll(__ballot(k1[t] && v1 > (T)0));
+                    w_s[j] += (uint32_t)__popcll(pcl_ballot(k0[t] && v0 > (T)0)) + (uint32_t)__popcll(pcl_ballot(k1[t] && v1 > (T)0));
             } else if (j < 6) { // r rows: the survivors' move when pass 1 only flagged, then the planes on this axis
                 const int ax = j - 3;
                 T x0 = word_as<T, W>(x.x), x1 = word_as<T, W>(x.y);
@@ -2258,8 +2259,8 @@ __global__ void __launch_bounds__(kBlock) k_compact_lds(compact_args a, compact_
                         if (c.plane_ax[p] != ax) continue;
                         const T L = c.plane_L[p];
                         const T p0 = R::sub(x0, d0), p1 = R::sub(x1, d1);
-                        const uint32_t np = (uint32_t)__popcll(__ballot(k0[t] && ((p0 <= L && L <= x0) || (p0 >= L && L >= x0)))) +
-                                            (uint32_t)__popcll(__ballot(k1[t] && ((p1 <= L && L <= x1) || (p1 >= L && L >= x1))));
+                        const uint32_t np = (uint32_t)__popcll(pcl_ballot(k0[t] && ((p0 <= L && L <= x0) || (p0 >= L && L >= x0)))) +
+                                            (uint32_t)__popcll(pcl_ballot(k1[t] && ((p1 <= L && L <= x1) || (p1 >= L && L >= x1))));
                         if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
                     }
             }
@@ -2405,7 +2406,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a)
                 rand = in ? a.rand[i] : (T)0;
             keep[t][e] = in && !(pcoll >= rand);
         }
-        const uint64_t b0 = __ballot(keep[t][0]), b1 = __ballot(keep[t][1]);
+        const uint64_t b0 = pcl_ballot(keep[t][0]), b1 = pcl_ballot(keep[t][1]);
         pre[t] = (int)__popcll(b0 & below) + (int)__popcll(b1 & below);
         if (lane == 0) {
             s_drc[drow] = (int)__popcll(b0) + (int)__popcll(b1);
@@ -2416,8 +2417,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a)
         if (a.n_planes >= 0) { // the counters of the measure steps, on the survivors      light.py:385-399, 414-431
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                w_s[k] += (uint32_t)__popcll(__ballot(keep[t][0] && V[k][t][0] > (T)0)) +
-                          (uint32_t)__popcll(__ballot(keep[t][1] && V[k][t][1] > (T)0));
+                w_s[k] += (uint32_t)__popcll(pcl_ballot(keep[t][0] && V[k][t][0] > (T)0)) +
+                          (uint32_t)__popcll(pcl_ballot(keep[t][1] && V[k][t][1] > (T)0));
             for (int p = 0; p < a.n_planes; ++p) {
                 const int ax = a.plane_ax[p];
                 const T L = a.plane_L[p];
@@ -2426,7 +2427,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a)
                 for (int e = 0; e < 2; ++e) {
                     const T x = pcl_pick<T>(ax, Rn[0][t][e], Rn[1][t][e], Rn[2][t][e]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
-                    np += (uint32_t)__popcll(__ballot(keep[t][e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    np += (uint32_t)__popcll(pcl_ballot(keep[t][e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
                 }
                 if (lane == 0 && np) atomicAdd(&s_cnt[4 + p], np);
             }
@@ -2458,7 +2459,7 @@ __global__ void __launch_bounds__(kBlock) k_delete_onepass(onepass_args<T, W> a)
                 const unsigned long long val = idx >= 0 ? __hip_atomic_load(&a.status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                                         : kLbPrefix; // before unit 0: running total 0
                 const unsigned flag = (unsigned)(val >> 62);
-                const uint64_t has_prefix = __ballot(flag == 2u), not_ready = __ballot(flag == 0u);
+                const uint64_t has_prefix = pcl_ballot(flag == 2u), not_ready = pcl_ballot(flag == 0u);
                 const int first = has_prefix ? (int)__ffsll((long long)has_prefix) - 1 : 63;
                 const uint64_t window = first >= 63 ? ~0ull : ((2ull << first) - 1ull); // lanes 0..first: the units that count
                 if (not_ready & window) {
@@ -4486,16 +4487,10 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     int grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC), kBlock);
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
-    // 256 instead of 128 photons per wave when the previous launch's last step scattered fewer than 21.5 % of the photons
-    // (fuller dense passes; slower above that: one wave per SIMD fewer).  PCL_MULTI_NQ2=1 always, =0 never.
-    static knob k_nq2("PCL_MULTI_NQ2"), k_below("PCL_MULTI_NQ2_BELOW");
-    const int nq2_mode = !k_nq2.set() ? -1 : (k_nq2.off() ? 0 : 1);
-    // The hit fraction falls along a launch, so the previous launch's last step is (nearly) this launch's FIRST and
-    // busiest step: the form pays while the 256 photons of a wave seldom hold more than the 64 hits of one dense pass --
-    // 256 h + 2 sqrt(256 h (1 - h)) < 64, h < 0.21.  (Round 3 switched at 0.28: the driver's 20-step block that starts at
-    // h = 0.25 then ran at 1.25 passes per wave-step, 0.649 instead of 0.573 ms per step -- profiles/r04_driver_cmd_pmc.md.)
-    const double nq2_below = k_below.value(0.215);
-    const bool nq2 = nq2_mode == 1 || (nq2_mode == -1 && ctx->multi_last_h >= 0.0 && ctx->multi_last_h < nq2_below);
+    // 256 photons per wave (NQ = 2 in fp64): faster than 128 at every hit fraction since the velocities live in LDS
+    // (pcl_multi_body_lds).  PCL_MULTI_NQ2=0 takes the 128-photon instantiation (hipRTC, fp64), for A/B runs and the tests.
+    static knob k_nq2("PCL_MULTI_NQ2");
+    const bool nq2 = !(k_nq2.set() && k_nq2.off());
     set_np(f.np, ent);
     ctx->multi_work[2] = 64 * pcl_rt<T>::VEC;
     // The saturation probe (pcl_n_expr_sat; 128-photon form, fp64): worth its dozen instructions per wave-step only where
@@ -4524,6 +4519,8 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     } else if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
     } else {
+        ctx->multi_work[2] = 64 * pcl_rt<T>::VEC * kMultiNQ<T>;
+        grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * kMultiNQ<T>), kBlock);
         PCL_AOT_LAUNCH_SHAPED(k_multi, T, use_e, var_n, grid, f);
         PCL_TRY(launch_check("k_multi"));
     }

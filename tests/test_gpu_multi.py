@@ -266,33 +266,30 @@ def test_full_size_delete_multi_equals_single_steps_at_1e8(make_store, hip):
 
 def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
     """Four launches of 24 steps on the bench's workload (hit fraction 1.0 in the first step, below 25 % after ~70 steps):
-    whatever form each launch took -- the last one starts below the threshold --, the rows and the state equal 96 single
-    steps."""
+    the rows and the state equal 96 single steps.  Since round 5 a wave owns 256 photons at every hit fraction (their
+    velocities live in LDS: pcl_multi_body_lds); PCL_MULTI_NQ2=0 -- one of conftest.py's knob cases -- takes the
+    128-photon instantiation; the kernel's own tally says which one ran."""
     N, seed = 200_000, 5
     expr = "0.000000001 * exp(r0[gid] - 5)"
     sc = lambda k: dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=299792458.0, h=6.62607015e-34,
                         n_expr=expr, rng_mode=hip.RNG_PHILOX, seed=seed, step=k)
     out, forms = {}, []
-    hip.set_knob("PCL_MULTI_NQ2_BELOW", "0.25")       # (the shipped switch-over is 0.215, reached after ~100 steps of this workload)
-    try:
-        for how in ("multi", "single"):
-            with hip.Device(0) as d:
-                d.store_alloc(N)
-                d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
-                rows = []
-                if how == "multi":
-                    for k in range(0, 96, 24):
-                        rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
-                        forms.append(d.last_multi_work()[2])
-                else:
-                    rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
-                out[how] = (rows, d.download_state())
-    finally:
-        hip.set_knob("PCL_MULTI_NQ2_BELOW", None)
+    for how in ("multi", "single"):
+        with hip.Device(0) as d:
+            d.store_alloc(N)
+            d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, seed)
+            rows = []
+            if how == "multi":
+                for k in range(0, 96, 24):
+                    rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
+                    forms.append(d.last_multi_work()[2])
+                    assert 1.0 < d.last_multi_clock() < 2.6          # GHz the chip held under the launch, measured in the kernel
+            else:
+                rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
+            out[how] = (rows, d.download_state())
     assert out["multi"][0] == out["single"][0]
     assert out["multi"][0][71][0] < 0.25 * N < out["multi"][0][23][0]     # the last launch started below the threshold, the second above
-    if "PCL_MULTI_NQ2" not in os.environ:                                 # (the knob cases of conftest.py force one form)
-        assert forms == [128, 128, 128, 256]                              # ... and the kernel's own tally says which form ran
+    assert forms == [128 if os.environ.get("PCL_MULTI_NQ2") == "0" else 256] * 4
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)
