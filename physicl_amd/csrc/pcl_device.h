@@ -1285,6 +1285,9 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
         pcl_u64 id[NE];
         pcl_i64 ti[NE];
         bool in[NE], photon[NE], alive[NE];
+        // the same predicates as wave masks (scalar registers): the votes below are taken on bare compares and combined with
+        // these in the scalar unit -- a vote on a compound predicate costs a v_cndmask and a second v_cmp (pcl_ballot)
+        pcl_u64 am[NE], pm[NE];
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
@@ -1303,12 +1306,14 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             id[e] = (pcl_u64)(a.ids ? a.ids[is] : a.id_base + i);
             photon[e] = in[e] && (a.kind ? (a.kind[is] != 0) : true);
             alive[e] = in[e];
+            am[e] = pcl_ballot(in[e]);
+            pm[e] = a.kind ? (pcl_ballot(a.kind[is] != 0) & am[e]) : am[e];
             wodd0[e] = wodd1[e] = 0u;
             // |dr| = |v * dt| only changes when the photon scatters: kept here, recomputed with the new velocity
             NM[e] = pcl_step_norm<T>(R::mul(V[0][e], a.dt), R::mul(V[1][e], a.dt), R::mul(V[2][e], a.dt));
         }
         for (int ph = 0; ph < n_ph; ++ph) {
-            if (!(pcl_ballot(alive[0]) | pcl_ballot(alive[1]))) break; // nobody of these rows is left: their rows stay 0
+            if (!(am[0] | am[1])) break; // nobody of these rows is left: their rows stay 0
             const pcl_u32 st = a.step + (pcl_u32)ph;
             const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
             pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body: keeps the round keys off the VGPR spills
@@ -1340,8 +1345,10 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 for (int e = 0; e < NE; ++e) {
                     const T pc = R::mul(a.An_del, NM[e]);
                     const bool gone = alive[e] && photon[e] && (pc >= rand[e]);
-                    w_evt += (pcl_u32)__popcll(pcl_ballot(gone));
+                    const pcl_u64 gm = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
+                    w_evt += (pcl_u32)__popcll(gm);
                     alive[e] = alive[e] && !gone;
+                    am[e] &= ~gm;
                 }
             } else {
                 // ScatterIsotropicStep: decision in place, the hits densely through the wave's queue   light.py:303-331
@@ -1354,7 +1361,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                                                            Rr[1][e], Rr[2][e], Ev[e]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                     hit[e] = alive[e] && photon[e] && (pc >= rand[e]);
-                    const pcl_u64 b = pcl_ballot(hit[e]);
+                    const pcl_u64 b = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
                     slot[e] = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u));
                     wbase += (pcl_u32)__popcll(b);
                     if (hit[e]) s_q.id[slot[e]] = id[e];
@@ -1395,10 +1402,10 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             pcl_u32 w_n = 0, w_sx = 0, w_sy = 0, w_sz = 0;
 #pragma unroll
             for (int e = 0; e < NE; ++e) {
-                w_n += (pcl_u32)__popcll(pcl_ballot(alive[e]));
-                w_sx += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[0][e] > (T)0));
-                w_sy += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[1][e] > (T)0));
-                w_sz += (pcl_u32)__popcll(pcl_ballot(alive[e] && V[2][e] > (T)0));
+                w_n += (pcl_u32)__popcll(am[e]);
+                w_sx += (pcl_u32)__popcll(pcl_ballot(V[0][e] > (T)0) & am[e]);
+                w_sy += (pcl_u32)__popcll(pcl_ballot(V[1][e] > (T)0) & am[e]);
+                w_sz += (pcl_u32)__popcll(pcl_ballot(V[2][e] > (T)0) & am[e]);
             }
             pcl_u32 *c = &s_cnt[nslots * ph];
             for (int p = 0; p < a.n_planes; ++p) {
@@ -1409,7 +1416,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 for (int e = 0; e < NE; ++e) {
                     const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
-                    nc += (pcl_u32)__popcll(pcl_ballot(alive[e] && ((prev <= L && L <= x) || (prev >= L && L >= x))));
+                    nc += (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & am[e]);
                 }
                 if (lane0 && nc) atomicAdd(&c[5 + p], nc);
             }
@@ -1432,7 +1439,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 a.v2[ti[e]] = V[2][e];
             }
             if (a.has_delete) {
-                const pcl_u64 m = pcl_ballot(alive[e]);
+                const pcl_u64 m = am[e];
                 if (lane0) a.masks[tile * 32 + row0 + e] = m;
                 kept += (int)__popcll(m);
             }

@@ -1237,19 +1237,20 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     // photons' first Philox block decided on the spot: two bodies, or one), rounds of 64 listed photons deciding two bodies,
     // rounds deciding one (pcl_store_ahead_work)
     uint32_t w_groups2 = 0, w_groups1 = 0, w_rounds2 = 0, w_rounds1 = 0;
-    // one body's row from the photons of a round that it leaves alive (``s``): into lane b's accumulators
-    auto tally = [&](int b, bool s, uint32_t ix, bool cross) {
+    // one body's row from the photons of a round that it leaves alive (``bs``: their wave mask): into lane b's accumulators.
+    // The votes are taken on bare compares and combined as masks in the scalar unit (a vote on a compound predicate costs a
+    // v_cndmask and a second v_cmp -- 8 SIMD-cycles, five votes per body: pcl_ballot)
+    auto tally = [&](int b, uint64_t bs, uint32_t ix, T prev, T xp) {
         const bool mine = lane == b;
-        const uint64_t bs = pcl_ballot(s);
         t_kept += mine ? (uint32_t)__popcll(bs) : 0u;
         if (has_signs) {                                                                                                 // light.py:424-426
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const uint64_t bk = pcl_ballot(s && ((ix >> (8 + k)) & 1u)); // (every lane votes: not inside the select)
+                const uint64_t bk = pcl_ballot((ix & (0x100u << k)) != 0u) & bs; // (every lane votes: not inside the select)
                 t_s[k] += mine ? (uint32_t)__popcll(bk) : 0u;
             }
             if (has_plane) {                                                                                             // light.py:385-399
-                const uint64_t bp = pcl_ballot(s && cross);
+                const uint64_t bp = ((pcl_ballot(prev <= L0) & pcl_ballot(L0 <= xp)) | (pcl_ballot(prev >= L0) & pcl_ballot(L0 >= xp))) & bs;
                 t_p0 += mine ? (uint32_t)__popcll(bp) : 0u;
             }
         }
@@ -1261,18 +1262,22 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead_live(ahead_args<T> a) {
     auto decide = [&](int b, bool single, bool two, uint32_t step, bool on, uint64_t id, thr_t pc, T &xp, T dp, uint32_t ix, uint32_t &d) -> bool {
         const pcl_u32x4 wd = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), step >> 1, 0u, (pcl_u32)a.seed, (pcl_u32)(a.seed >> 32));
         const thr_t m_first = single ? D::draw(wd.z, wd.w) : D::draw(wd.x, wd.y);
+        const uint64_t on_m = pcl_ballot(on);
         const bool s0 = on && !(m_first <= pc); // alive after body b                                                              light.py:243
+        const uint64_t b0 = ~pcl_ballot(m_first <= pc) & on_m;
         xp = R::add(xp, dp);                                                                                                 // newton.py:16
         T prev = R::sub(xp, dp);
-        tally(b, s0, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+        tally(b, b0, ix, prev, xp);
         bool left = s0;
         d = s0 ? 255u : (uint32_t)(b + 1);
         if (two) { // (uniform)
-            left = s0 && !(D::draw(wd.z, wd.w) <= pc);
+            const thr_t m_second = D::draw(wd.z, wd.w);
+            left = s0 && !(m_second <= pc);
+            const uint64_t b1 = ~pcl_ballot(m_second <= pc) & b0;
             if (s0 && !left) d = (uint32_t)(b + 2);
             xp = R::add(xp, dp);
             prev = R::sub(xp, dp);
-            tally(b + 1, left, ix, (prev <= L0 && L0 <= xp) || (prev >= L0 && L0 >= xp));
+            tally(b + 1, b1, ix, prev, xp);
         }
         return left;
     };

@@ -287,7 +287,8 @@ def main():
     print(json.dumps(rec, indent=1))
     if a.json:
         table = json.load(open(a.json)) if os.path.exists(a.json) else {}
-        old = table.get(a.expr, {}).get("kernels", {})
+        # (calibrations of OTHER device sources are history: a changed kernel starts from its static counts again)
+        old = table.get(a.expr, {}).get("kernels", {}) if table.get("csrc_sha") == build_sha() else {}
         for k, v in rec["kernels"].items():        # calibrated counts (tools/summarize_driver_prof.py) survive a re-count of the statics
             calibrated = any("calibration" in key for key in old.get(k, {}))
             for key, val in old.get(k, {}).items():
