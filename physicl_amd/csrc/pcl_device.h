@@ -178,7 +178,7 @@ template <> struct pcl_vec<float, 4> {
 // gets, per field, the address of that field's row in tile 0 plus ``ts`` = elements from one tile to the
 // next.  Lanes still read consecutive elements (full coalescing) but the 13+ streams of a pass now fall into
 // one contiguous ~100-270 KiB region per tile, so how the driver scatters large allocations over HBM
-// channels no longer decides the speed (tools/bw_probe2.hip).
+// channels no longer decides the speed (tools/attic/bw_probe2.hip).
 // ------------------------------------------------------------------------------------------------
 #define PCL_TLOG 11
 #define PCL_T (1 << PCL_TLOG)

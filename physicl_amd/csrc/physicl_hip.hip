@@ -3134,11 +3134,11 @@ size_t big_min_bytes() {
 //   2.07 ms per step (0.695 or 0.63 of the HBM peak) from one hipMalloc to the next, fixed for the life of the
 //   allocation, about half of the allocations each way (tools/alloc_variance.py, tools/alloc_candidates.py);
 //   hipExtMallocWithFlags(hipDeviceMallocContiguous) always gives the slow kind; row padding does not change it
-//   (tools/pad_sweep.py), nor does the order the tiles are visited in (tools/spread_probe.hip); ranges mapped from
-//   ~1 GB hipMemCreate handles came out at least as fast as the best hipMalloc blocks (tools/vmm_probe.hip) and are
+//   (tools/pad_sweep.py), nor does the order the tiles are visited in (tools/attic/spread_probe.hip); ranges mapped from
+//   ~1 GB hipMemCreate handles came out at least as fast as the best hipMalloc blocks (tools/attic/vmm_probe.hip) and are
 //   what alloc_slab's candidates are made of.  Blocks of >= 64 MB are built that way; PCL_VMM=0 goes back to hipMalloc
 //   and so does any failure of the virtual-memory calls.  hipMemcpy2DAsync refuses rows that reach from one handle into
-//   the next (tools/vmm_copy_test2.hip): handles hold whole tiles and copy_row cuts its strided copies at their ends.
+//   the next (tools/attic/vmm_copy_test2.hip): handles hold whole tiles and copy_row cuts its strided copies at their ends.
 //   A virtual address range is mapped ONCE (round 5).  Measured on this runtime (tools/attic/debug_shard.py,
 //   profiles/r05_vmm_remap.log): after hipMemUnmap + hipMemAddressFree of a 109 GB range, hipMemAddressReserve hands the
 //   same addresses out again, and the first kernels that go through the new hipMemMap'ing there still hit translations of
@@ -3569,7 +3569,7 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n, bool for_alive = false) {
 //   fixed when it is allocated, 10-15 % apart from one allocation to the next.)  A store of >= 512 MB takes the fastest
 //   of up to PCL_ALLOC_TRIES (default 4; 1 = take the first) candidate blocks -- idle pool blocks first, then fresh
 //   ones -- each measured with the 13-row write sweep over the WHOLE block (a block's speed is not the sum of its
-//   handles' speeds measured one at a time: tools/vmm_chunk_probe.hip); the others go (back) to the pool with their
+//   handles' speeds measured one at a time: tools/attic/vmm_chunk_probe.hip); the others go (back) to the pool with their
 //   rate remembered, where the compaction's second slab finds them.  ~10 ms per candidate at 1e8 photons, once per store.
 int tries_wanted() {
     static const int n = [] {

@@ -1,6 +1,6 @@
 // bw_probe.hip -- micro-benchmark: HBM throughput of the fused pass's access pattern under different
 // data layouts (plain SoA vs tiled AoSoA), to decide the store layout with measurements.
-// Build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/bw_probe.hip -o /tmp/bw_probe && /tmp/bw_probe
+// Build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 tools/attic/bw_probe.hip -o /tmp/bw_probe && /tmp/bw_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

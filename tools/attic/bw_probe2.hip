@@ -1,6 +1,6 @@
 // bw_probe2.hip -- HBM throughput of the FAST fused pass's stream mix (reads r0-2, v0-2, lam4; writes r0-2, vnew0-2:
 // 104 B per fp64 particle) under three placements: 17 separate hipMallocs (what the library does), one slab,
-// and tiled AoSoA.   hipcc --offload-arch=gfx950 -O3 tools/bw_probe2.hip -o /tmp/bw_probe2 && /tmp/bw_probe2
+// and tiled AoSoA.   hipcc --offload-arch=gfx950 -O3 tools/attic/bw_probe2.hip -o /tmp/bw_probe2 && /tmp/bw_probe2
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

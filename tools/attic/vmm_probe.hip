@@ -1,5 +1,5 @@
 // Which kind of device allocation gives the 13-stream tile sweep its fast mode?  ("Placement")
-//   hipcc --offload-arch=gfx950 -O3 tools/vmm_probe.hip -o gpurun_out/vmm_probe && gpurun_out/vmm_probe
+//   hipcc --offload-arch=gfx950 -O3 tools/attic/vmm_probe.hip -o gpurun_out/vmm_probe && gpurun_out/vmm_probe
 // For each allocation method: a kernel that writes 13 of the 17 rows of every [17][2048] fp64 tile (the store's fill
 // pattern), timed with HIP events over 4 sweeps; three allocations of each kind.
 #include <hip/hip_runtime.h>
