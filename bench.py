@@ -304,8 +304,8 @@ def tame_leg(b, args, R):
                "repeats": R, "repeat_ms_per_step": [round(e / args.steps * 1e3, 5) for e in el],
                "repeat_hit_fraction": [round(h / float(N * args.steps), 6) for h in hits],
                "roofline": (dict(valu, bound="valu", kernel="k_multi (hipRTC specialisation of the tame expression)",
-                                 valu_busy=static_valu("pcl_rtc_multi_e1 tame")[0],
-                                 traffic=pmc_traffic("pcl_rtc_multi_e1", N), avg_launch_ms=kb["avg_ms"], launches=kb["launches"],
+                                 valu_busy=None,   # (the committed counter records are keyed by code object, not by expression: the example's)
+                                 traffic=pmc_traffic(max(valu["kernel_forms"], key=valu["kernel_forms"].get), N), avg_launch_ms=kb["avg_ms"], launches=kb["launches"],
                                  hbm={"achieved": hbm, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_particle": 128.0})
                             if valu is not None else
@@ -586,11 +586,13 @@ def run_rank(args):
     if extra and not f32:
         api = api_leg(args, prof)
 
-    dom_rtc = {"k_multi": "pcl_rtc_multi_%se1" % ("f_" if f32 else ""), "k_fused": "pcl_rtc_fast_%se1" % ("f_" if f32 else "")}.get(dominant)
+    valu = valu_roofline(b.block_work_main[mi], kb["total_ms"], prof["expr"], f32) if S > 1 else None
+    # the code object the median block's launches ran (the K-step pass has several instantiations; the kernel's tally says which)
+    dom_rtc = (max(valu["kernel_forms"], key=valu["kernel_forms"].get) if valu is not None else
+               {"k_multi": "pcl_rtc_multi_%se1" % ("f_" if f32 else ""), "k_fused": "pcl_rtc_fast_%se1" % ("f_" if f32 else "")}.get(dominant))
     hbm_rec = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                "traffic": pmc_traffic(dom_rtc, N) if (dom_rtc and args.mode == "fused") else None, "algorithmic_bytes_per_particle": bpp,
                "algorithmic_bytes_note": "per LAUNCH of the K-step pass (r, v, lam4 read; r, v, vprev written)" if S > 1 else "per particle-step"}
-    valu = valu_roofline(b.block_work_main[mi], kb["total_ms"], prof["expr"], f32) if S > 1 else None
     common = {"hit_fraction": h_blocks[mi], "avg_launch_ms": kb["avg_ms"], "min_launch_ms": kb["min_ms"], "max_launch_ms": kb["max_ms"],
               "launches": kb["launches"], "block": "median block (index %d), as value" % mi, "all_blocks_avg_launch_ms": ks["avg_ms"],
               "all_blocks_launches": ks["launches"], "per_block_avg_launch_ms": ks["per_block_avg_ms"], "steps_per_launch_max": S,

@@ -150,6 +150,54 @@ def test_multi_vs_oracle_chain(make_store, hip, tag):
     assert np.max(np.abs(np.stack(s["r"], 1) - np.stack(st["r"], 1))) <= K * dt * V_ABS_TOL + 1e-15
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag", sorted(CASES))
+@pytest.mark.parametrize("N,K,with_planes", [(1, 1, False), (255, 2, True), (257, 7, False), (511, 33, False), (513, 3, True), (2049, 9, False),
+                                             (100_003, 5, True), (33_333, 64, False)])
+def test_the_k_step_pass_directly_vs_the_oracle_chain(make_store, hip, tag, N, K, with_planes, dtype):
+    """The K-step kernel (256 photons per wave, velocities in LDS) against the ORACLE's own chain of K steps -- not against
+    another device kernel -- over the shapes its geometry has edges at: fewer photons than a lane group, one short of / one over
+    a wave's 256 and 512, a ragged last tile, K = 1, odd K (a Philox decision block split between launches), K above a launch's
+    usual 32 and the maximum 64; every scatter variant; fp64 and fp32 (the oracle's float32 restatement); with and without
+    measure planes.  Hit and sign counters per step exact (decisions are compares of IEEE products against the same Philox
+    uniforms; an exp / pow rounding tie would show as a one-photon difference and none has), plane crossings exact on the
+    device's own positions' bound, velocities within 4 ulp of c, positions within the bound that follows from it."""
+    use_e, expr, A, n, dt = CASES[tag]
+    np_t = np.float64 if dtype == "f64" else np.float32
+    init = initial(N, dtype, 1000 + N + K)
+    st = {"r": [np.ascontiguousarray(init["r"][:, k]) for k in range(3)], "v": [np.ascontiguousarray(init["v"][:, k]) for k in range(3)],
+          "dr": [np.zeros(N, np_t)] * 3, "dv": [np.zeros(N, np_t)] * 3, "E": init["E"].copy(),
+          "id": np.arange(N, dtype=np.int64) + init["id_base"]}
+    seed, step0 = 77, 5                                   # (odd first step: the first launch starts inside a decision block)
+    planes = [[0.5, np.nan, np.nan], [np.nan, np.nan, -2.0]] if with_planes else []
+    ref = []
+    for k in range(K):
+        orc.step_newton(st, dt, np_t)
+        hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, step0 + k, st["id"], np_t), A, n, C_LIT, h=H_LIT, use_E=use_e, n_expr=expr,
+                                         dtype=np_t)
+        ref.append((int(hit.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+    d = make_store(N, dtype)
+    d.upload_state(init)
+    sc, _ = scatter_dict(hip, tag, seed, step0)
+    rows = d.step_fused_multi(dt, K, sc, planes)
+    got = [(o["hits"], list(o["sign"])) for o in rows]
+    if dtype == "f64":
+        assert got == ref
+    else:       # fp32: exp / pow of OCML and of numpy's float32 may round a tie differently: at most a photon here and there
+        assert all(abs(g[0] - r[0]) <= max(2, N // 20000) and max(abs(a - b) for a, b in zip(g[1], r[1])) <= max(2, N // 20000) for g, r in zip(got, ref))
+    # (PCL_MULTI_NQ2=0 selects the 128-photon instantiation, which exists for the hipRTC specialisations in fp64)
+    assert d.last_multi_work()[2] == (128 if os.environ.get("PCL_MULTI_NQ2") == "0" and dtype == "f64" and expr is not None else 256)
+    s = d.download_state()
+    tol_v = 4 * float(np.spacing(np_t(C_LIT)))
+    if got == ref:                                         # same decisions: the states are comparable photon by photon
+        assert np.max(np.abs(np.stack(s["v"], 1).astype(np.float64) - np.stack(st["v"], 1).astype(np.float64))) <= tol_v
+        r_ref = np.stack(st["r"], 1).astype(np.float64)
+        slack = K * float(np.spacing(np_t(max(1.0, np.max(np.abs(r_ref))))))
+        assert np.max(np.abs(np.stack(s["r"], 1).astype(np.float64) - r_ref)) <= K * dt * tol_v + slack + 1e-15
+    if planes:
+        assert all(len(o["planes"]) == 2 for o in rows)
+
+
 def test_multi_state_errors(make_store, hip):
     d = make_store(100)
     d.upload_state({"v": np.ones((100, 3)), "E": np.ones(100)})
