@@ -421,7 +421,8 @@ def ahead_valu_roofline(work, kern_ms, clock_ghz=0.0, ids=False):
             "work": {"groups_of_128_slots_first_pass_two_bodies": g2, "groups_of_128_slots_first_pass_one_body": g1, "rounds_two_bodies": r2,
                      "rounds_one_body": r1},
             "instruction_counts": {nm: c[nm] for nm in names},
-            "instruction_counts_source": c["source"], "total_ms": kern_ms,
+            # (False: the kernel has changed since its four counts were fitted -- tools/prof_calib_ahead.sh)
+            "instruction_counts_source": c["source"], "instruction_counts_current": c.get("csrc_sha") == csrc_sha(), "total_ms": kern_ms,
             "peak_note": "1024 SIMDs x the clock measured in the kernel (s_memtime / s_memrealtime); an instruction costs 2 / 4 / 8 / 16 cycles by class",
             "traffic": pmc_traffic("k_delete_ahead_live<double>", groups * 128),
             "hbm": {"achieved": 33.0 * groups * 128 / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -684,6 +685,9 @@ def run_rank(args):
             "counters_last_step": {"N": int(totals_main[0]), "hits": int(totals_main[1]), "xp": int(totals_main[2]),
                                    "yp": int(totals_main[3]), "zp": int(totals_main[4])},
             "device": info["name"],
+            # the device sources this process ran (physicl_amd.build.csrc_sha): what a profile summary of this run tags its
+            # counter records with -- the record is about THIS build, whatever the tree looks like when it is summarised
+            "csrc_sha": csrc_sha(),
         }
         if single is not None:
             out["single_step"] = single
@@ -1028,10 +1032,11 @@ def mixed_valu_record():
     """What binds k_mixed (the K-pass kernel of configs[4]): VALU issue.  Its instruction count per launch depends on the
     photons' histories, and the kernel keeps no tally of its own, so this record is NOT computed in this process: it is the
     committed rocprofv3 run of the same command (profiles/pmc_traffic.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU and
-    GRBM_GUI_ACTIVE of the fp64 16-iteration launches, durations from the trace pass).  ``frac`` = the counters' own ratio
-    (VALU busy: SIMD-cycles with a vector instruction in flight / SIMD-cycles of the launches), which needs no clock and no
-    price list; the priced form (wave-instructions x the mean price of the kernel's instruction mix / (1024 SIMDs x the
-    clock GRBM_GUI_ACTIVE gives)) rides along.  None when the device sources have changed since that run."""
+    GRBM_GUI_ACTIVE of the fp64 16-iteration launches, durations from the trace pass).  ``frac`` = wave-instructions x the
+    mean price of the kernel's instruction mix / (1024 SIMDs x the clock GRBM_GUI_ACTIVE gives); the counters' own ratio
+    (``valu_busy``: SQ_ACTIVE_INST_VALU x 4 / available SIMD-cycles) rides along -- it counts the cycles waves have a vector
+    instruction IN FLIGHT, which overlap between waves (k_delete_ahead_live reads 1.04-1.07), so it is an indicator, not a
+    ceiling fraction.  None when the device sources have changed since that run."""
     rec = pmc_record("k_mixed valu f64")
     if not rec:
         return None
@@ -1040,8 +1045,9 @@ def mixed_valu_record():
     peak = valu_peak(clock)
     priced = rec["wave_instructions"] * mix.get("cycles_per_valu", 4.0) / rec["seconds"]
     return {"bound": "valu", "kernel": "k_mixed<double> (16 iterations of [Newton, ScatterIsotropic, Newton, ScatterDelete] per launch)",
-            "achieved": rec["valu_busy"] * peak, "peak": peak, "unit": "SIMD-cycles/s", "frac": rec["valu_busy"],
-            "frac_priced": priced / peak, "cycles_per_wave_instruction": mix.get("cycles_per_valu"), "clock_GHz": clock,
+            "achieved": priced, "peak": peak, "unit": "SIMD-cycles/s", "frac": priced / peak,
+            "frac_at_4_waves_per_simd": rec["wave_instructions"] * mix.get("cycles_per_valu_at_4_waves", 4.3) / rec["seconds"] / peak,
+            "cycles_per_wave_instruction": mix.get("cycles_per_valu"), "clock_GHz": clock,
             "valu_busy": rec["valu_busy"], "lane_util": rec["lane_utilisation"], "useful": rec["valu_busy"] * rec["lane_utilisation"],
             "wave_instructions_per_s": rec["wave_instructions_per_s"], "launches": rec["launches"],
             "source": rec["source"], "measured_at_commit": rec.get("commit"), "csrc_sha": rec.get("csrc_sha"),

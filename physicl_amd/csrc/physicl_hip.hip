@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_pending(alive_args<T> a) {
 //   whenever anything else looks at the store, k_ahead_commit first makes the state after the bodies handed out so far
 //   real (masks, masks_prev, tile counts, r).  Nothing is guessed: a call that does not match simply commits and runs
 //   the ordinary way.  Same operations per photon as k_delete_alive (tests/test_gpu_alive_mask.py runs both).
-constexpr int kAheadMax = 32;                       // bodies per launch, at most
+constexpr int kAheadMax = 64;                       // bodies per launch, at most
 constexpr int kAheadRow = 4 + PCL_MAX_PLANES;       // counters per body: alive, sign x 3, planes
 constexpr int kAheadWork = 6;                       // k_delete_ahead_live's own work tally: groups loaded (first pass of two bodies, of one), rounds of two bodies, of one;
                                                     // [4], [5]: shader cycles and 100 MHz ticks of the workgroups' lifetimes (the clock under the launch)
@@ -4941,12 +4941,19 @@ int wait_alive_inner(pcl_ctx *ctx, int64_t before, int64_t *alive_out) {
 }
 
 // ---- delete loop bodies ahead of their calls (k_delete_ahead) ---------------------------------------------------------
-// PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 24, at most kAheadMax); extents up to
-// PCL_AHEAD_MAX_SLOTS (default 2^22); above it PCL_AHEAD_K_BIG bodies at most (default 16 up to 2^25 slots, 12 above; 0 or 1 = none)
+// PCL_AHEAD=0 switches it off; PCL_AHEAD_K bodies per launch (default 64 = kAheadMax); extents up to
+// PCL_AHEAD_MAX_SLOTS (default 2^22) take the small stores' form (r written at the commit); above it PCL_AHEAD_K_BIG bodies at
+// most (default 64; 0 or 1 = none).
+// Round 5: with k_delete_ahead_live a body costs what the photons still alive cost, and a delete loop runs until its store is
+// empty, so ONE launch for (nearly) the whole run beats several with a commit, a compaction and a host round trip each between
+// them.  Delete-until-empty at a survival rate of 0.70 per body, one call per body, ms per run (same box, tools/ab_knob.sh,
+// profiles/r05_ab_ahead_k.log): bodies per launch 16 / 32 / 48 / 64 -- 1e8 photons 2.21 / 2.14 / 2.09 / 1.90, 1e7 photons
+// 0.54 / 0.49 / 0.50 / 0.425; small stores 24 / 48 / 64 -- 3e6 photons 0.435 / 0.39 / 0.30, 1e6 0.304 / 0.218 / 0.215, 2e5
+// 0.26 / 0.185 / 0.185.  (Rounds 3-4, whose kernel gave every slot a lane through every body, had measured 12 to 24 as best.)
 int ahead_k() {
     static knob k_on("PCL_AHEAD"), k_k("PCL_AHEAD_K");
     if (k_on.off()) return 0;
-    const int k = (int)k_k.value(24.0);
+    const int k = (int)k_k.value((double)kAheadMax);
     return k < 2 ? 0 : (k > kAheadMax ? kAheadMax : k);
 }
 int64_t ahead_max_slots() {
@@ -4956,10 +4963,8 @@ int64_t ahead_max_slots() {
 }
 int ahead_k_big(int64_t slots) {
     static knob k("PCL_AHEAD_K_BIG");
-    // (with k_delete_ahead_live a body costs what the photons still alive cost, but every pass over a 256-slot batch is at
-    // least one round: measured 8 / 10 / 12 / 14 / 16 / 20 bodies, 1e8 photons: 2.85 / 2.55 / 2.48 / 2.55 / 2.6 / 2.65 ms per run,
-    // 1e7: 0.70 / 0.66 / 0.66 / 0.65 / 0.62 / 0.61)
-    const int v = (int)k.value(slots > ((int64_t)1 << 25) ? 12.0 : 16.0);
+    (void)slots;
+    const int v = (int)k.value((double)kAheadMax);
     return v < 0 ? 0 : (v > kAheadMax ? kAheadMax : v);
 }
 

@@ -147,7 +147,7 @@ def test_bench_line_has_the_contract_keys(extra):
         assert mx["iterations"] == 100 and mx["seconds_f64"] > 0 and mx["seconds_f32"] > 0 and set(mx["fp32_vs_fp64"]) == {"1", "10", "100"}
         # k_mixed keeps no tally of its own: its VALU record is the committed PMC run's, and says so
         assert mx["roofline"] is None or (mx["roofline"]["bound"] == "valu" and 0 < mx["roofline"]["frac"] <= 1.0 and
-                                          mx["roofline"]["frac"] == mx["roofline"]["valu_busy"] and "not this process" in mx["roofline"]["note"])
+                                          0 < mx["roofline"]["valu_busy"] < 1.2 and "not this process" in mx["roofline"]["note"])
         assert mx["fp32_vs_fp64"]["1"]["decision_mismatch_rate"] < 1e-3
     if not extra:
         assert d["config"]["steps_per_launch_max"] == 32 and d["config"]["steps_per_timed_launch"] == 6

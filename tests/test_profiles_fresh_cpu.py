@@ -37,3 +37,5 @@ def test_the_instruction_mixes_are_those_of_the_sources_in_the_tree():
     # static count, an upper estimate, would price the launch above the cycles there were)
     assert any("calibration" in key for key in k), "profile again: the K-step pass of the driver's command has no calibrated count"
     assert k["decision_valu_per_wave_step_shortcut"] < k["decision_valu_per_wave_step_static"]
+    # ... and the four counts of k_delete_ahead_live (tools/prof_calib_ahead.sh + tools/summarize_calib_ahead.py)
+    assert isa["k_delete_ahead_live<double>"].get("csrc_sha") == build.csrc_sha(), "fit k_delete_ahead_live's counts again"

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from physicl_amd import _hip  # noqa: E402
 
 C_LIT = 299792458.0
-CASES = [(2, 0), (4, 0), (8, 0), (12, 0), (16, 0), (3, 1), (12, 1), (7, 0), (6, 1), (2, 1)]
+CASES = [(2, 0), (4, 0), (8, 0), (12, 0), (16, 0), (3, 1), (12, 1), (7, 0), (6, 1), (2, 1), (32, 0), (64, 0), (33, 1), (64, 1)]
 
 
 def main():
@@ -32,7 +32,7 @@ def main():
         o = dev.step_fused_delete(1e-3, 1e-3, 1e-3, _hip.RNG_PHILOX, 1234, step0, plane, lazy=True)
         w1, l1 = dev.ahead_work(), dev.ahead_stats()[0]
         assert l1 == l0 + 1
-        print(json.dumps({"K": K, "step0": step0, "slots": N, "groups_two": w1[0] - w0[0], "groups_one": w1[1] - w0[1], "rounds_two": w1[2] - w0[2], "rounds_one": w1[3] - w0[3],
+        print(json.dumps({"K": K, "step0": step0, "slots": N, "clock_GHz": round(dev.ahead_clock(), 4), "groups_two": w1[0] - w0[0], "groups_one": w1[1] - w0[1], "rounds_two": w1[2] - w0[2], "rounds_one": w1[3] - w0[3],
                           "alive_after_first": o["N"]}), flush=True)
     dev.close()
 

@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
 """Fit of k_delete_ahead_live's VALU instruction counts to its own work tally: SQ_INSTS_VALU of each launch of
-tools/calib_ahead.py (gpurun_out/prof_calib_ahead, tools/prof_calib_ahead.sh) = a x groups + b x rounds_two + c x rounds_one
-(least squares over the cases).  Writes the three counts and the fit's residuals into profiles/isa_counts.json under
-"k_delete_ahead_live<double>" and prints the table (profiles/r04_calib_ahead.md)."""
+tools/calib_ahead.py (gpurun_out/prof_calib_ahead, tools/prof_calib_ahead.sh) = a2 x groups_two + a1 x groups_one + b x rounds_two
++ c x rounds_one (least squares over the cases).  Writes the four counts, the fit's residuals and the hash of the device sources
+they belong to into profiles/isa_counts.json under "k_delete_ahead_live<double>" and prints the table (profiles/r05_calib_ahead.md)."""
 import csv
 import glob
 import json
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main():
@@ -45,15 +48,26 @@ def main():
         L.append("| %d | %d | %d | %d | %d | %d | %.4g | %.4g | %.4f | %.4g | %.3f | %.2f |" % (
             c["K"], c["step0"], c["groups_two"], c["groups_one"], c["rounds_two"], c["rounds_one"], d["SQ_INSTS_VALU"], m, m / d["SQ_INSTS_VALU"], d.get("SQ_INSTS_SALU", 0),
             d["ms"], d.get("GRBM_GUI_ACTIVE", 0) / 8 / (d["ms"] * 1e-3) / 1e9))
-    L += ["", "VALU issue peak: 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction = 6.144e11 wave-instructions/s; the twelve-body launch: "
-          "%.3g / %.3f ms = %.3g = %.2f of it." % (y[3], disp[3]["ms"], y[3] / (disp[3]["ms"] * 1e-3), y[3] / (disp[3]["ms"] * 1e-3) / 6.144e11)]
-    open(os.path.join(ROOT, "profiles", "r04_calib_ahead.md"), "w").write("\n".join(L) + "\n")
+    from physicl_amd import build
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    price = isa.get("aot", {}).get("k_delete_ahead_live<double, false>", {}).get("cycles_per_valu", 0.0)
+    L += ["", "Priced (tools/isa_count.py --aot: %.2f cycles per instruction of the kernel's static mix; available = GRBM_GUI_ACTIVE / 8 x 1024 SIMDs; busy = "
+          "SQ_ACTIVE_INST_VALU x 4), case by case:" % price, "",
+          "| K | first step | priced / available | busy / available | GHz the kernel measured (s_memtime / s_memrealtime) |", "|---|---|---|---|---|"]
+    for c, d in zip(cases, disp):
+        avail = d.get("GRBM_GUI_ACTIVE", 0) / 8.0 * 1024
+        if avail:
+            L.append("| %d | %d | %.3f | %.3f | %s |" % (c["K"], c["step0"], d["SQ_INSTS_VALU"] * price / avail, d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / avail,
+                                                   c.get("clock_GHz", "-")))
+    open(os.path.join(ROOT, "profiles", "r05_calib_ahead.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
     j = json.load(open(p))
     j["k_delete_ahead_live<double>"] = {"valu_per_group_first_pass_two_bodies": round(float(coef[0]), 1), "valu_per_group_first_pass_one_body": round(float(coef[1]), 1),
                                         "valu_per_round_two_bodies": round(float(coef[2]), 1), "valu_per_round_one_body": round(float(coef[3]), 1), "max_relative_residual": round(float(np.max(np.abs(fit / y - 1))), 4),
-                                        "source": "profiles/r04_calib_ahead.md (SQ_INSTS_VALU of %d launches, least squares on the kernel's own tally)" % len(cases) + "", "commit": commit}
+                                        "source": "profiles/r05_calib_ahead.md (SQ_INSTS_VALU of %d launches, least squares on the kernel's own tally)" % len(cases) + "", "commit": commit,
+                                        # (the sources the launches ran: this script is run on the tree that was profiled)
+                                        "csrc_sha": build.csrc_sha()}
     json.dump(j, open(p, "w"), indent=1, sort_keys=True)
 
 

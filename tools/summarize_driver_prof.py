@@ -74,9 +74,15 @@ def main():
 
     line = record("trace")
     json.dump(line, open(os.path.join(dst, tag + "_bench_under_rocprof.json"), "w"))
+    # the records are about the build that RAN (the hash bench.py put into its record), not about the tree as it is now
+    sha = line.get("csrc_sha")
+    if not sha:
+        raise SystemExit("the run's record carries no csrc_sha (a bench.py from before round 5?): profile again")
     sys.path.insert(0, ROOT)
     from physicl_amd import build
-    sha = build.csrc_sha()
+    if sha != build.csrc_sha():
+        print("NOTE: this profile was taken on device sources %s, the tree has %s: bench.py will not quote its records" % (sha, build.csrc_sha()),
+              file=sys.stderr)
     N, steps, warmup, R = line["config"]["photons_per_gpu"], line["steps"], line["warmup"], line["repeats"]
     S = line["config"].get("steps_per_launch_max", line["config"].get("steps_per_launch"))
     # ---- per-dispatch trace
