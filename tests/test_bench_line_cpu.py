@@ -18,7 +18,8 @@ def bench_module():
     return mod
 
 
-RECORDS = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_*.json")))
+RECORDS = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_*.json")) if "_bench_line_" not in p)
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_line_*.json")))
 
 
 @pytest.mark.parametrize("path", RECORDS, ids=[os.path.basename(p) for p in RECORDS])
@@ -38,6 +39,22 @@ def test_contract_line_of_a_full_record_fits_the_drivers_window(path):
     assert "model" not in back["config"] and "workload" in back["config"]
     for k in ("per_block", "instruction_counts", "k_step_launch_work", "delete", "api", "mixed"):
         assert k not in back and k not in back["roofline"]
+
+
+@pytest.mark.parametrize("path", LINES, ids=[os.path.basename(p) for p in LINES])
+def test_the_committed_lines_are_what_the_driver_can_read(path):
+    """The stdout lines of the round's own runs (driver's command, default, 2-rank rehearsal), as printed."""
+    text = open(path).read()
+    assert text.count("\n") == 1 and len(text) < 4000
+    line = json.loads(text[-8000:].splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "roofline_hbm",
+              "cpu_baseline", "collective", "detail_file"):
+        assert k in line, k
+    r = line["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "SIMD-cycles/s" and 0 < r["frac"] <= 1.0 and 1.5 < r["clock_GHz"] < 2.6
+    assert isinstance(r["traffic"], (int, float)) and abs(r["traffic"] / line["config"]["photons_per_gpu"] - 128) < 2
+    if line["n_gpus"] == 1:
+        assert line["roofline_hbm"]["frac"] >= 0.6 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
 
 
 def test_line_sheds_optional_parts_rather_than_outgrow_the_window():
