@@ -335,7 +335,7 @@ __device__ __forceinline__ T pcl_n_expr_val(const pcl_nprof<T> &np, T r0v, T r1v
 }
 #undef exp
 
-// The K-step pass's "saturation probe" (hipRTC builds; pcl_multi_body<..., SATP = true>).  Where its argument lies beyond
+// The K-step pass's "saturation probe" (hipRTC builds; pcl_multi_body_lds<..., SATP = true>).  Where its argument lies beyond
 // the range in which exp saturates, the result is exactly +inf or +0 in any IEEE libm (fp64: x > 709.79 / x < -745.14;
 // fp32: 88.73 / -103.98).  The expression is first evaluated with exp() replaced by that shortcut for BOTH photons of a
 // lane, noting whether any argument was NOT that far out; when no lane of the wave noted one -- the state of
@@ -1035,7 +1035,9 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
         }
         for (int k = 0; k < a.K; ++k) {
             const pcl_u32 st = a.step + (pcl_u32)k;
-            // (see pcl_multi_body: opaque copies keep the 20 Philox round keys out of the scalar file's long-lived set)
+            // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push other scalars
+            // into VGPR-lane spills (v_readlane in the loop).  Opaque copies make the compiler rebuild them per iteration on the
+            // otherwise idle scalar unit instead.
             pcl_u32 kk0 = k0, kk1 = k1;
             asm volatile("" : "+s"(kk0), "+s"(kk1));
             const bool new_block = (st & 1u) == 0u || k == 0; // wave-uniform
@@ -1216,7 +1218,7 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
 // Level 2, K whole passes of a loop whose body holds an isotropic-scatter phase and/or a delete phase --
 //   [Newton, ScatterIsotropic] | [Newton, ScatterDelete] | [Newton, ScatterIsotropic, Newton, ScatterDelete] (either order)
 // -- in ONE pass over the store and (with a delete phase) ONE compaction afterwards.  It is the general form of
-// pcl_multi_body: any store (explicit ids after earlier compactions, plain Objects mixed in), photons that are removed
+// pcl_multi_body_lds: any store (explicit ids after earlier compactions, plain Objects mixed in), photons that are removed
 // stop where the reference's list.remove takes them out (physicl/__init__.py:455-459), and every phase tallies its
 // own measure row on the particles alive after it.  Per particle the operations are those of the single steps
 // (pcl_fast_body / k_newton_mask) in the same order with launch index step + phase number, so state, masks and rows
@@ -1316,7 +1318,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             if (!(am[0] | am[1])) break; // nobody of these rows is left: their rows stay 0
             const pcl_u32 st = a.step + (pcl_u32)ph;
             const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
-            pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body: keeps the round keys off the VGPR spills
+            pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body_lds: keeps the round keys off the VGPR spills
             asm volatile("" : "+s"(kk0), "+s"(kk1));
             const bool new_block = (st & 1u) == 0u || ph == 0;
             T d[3][NE], rand[NE];

@@ -2846,7 +2846,7 @@ struct rtc_entry {
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
-    hipFunction_t multis[2] = {nullptr, nullptr}; // 128 photons per wave with the saturation probe (pcl_n_expr_sat), fp64
+    hipFunction_t multis[2] = {nullptr, nullptr}; // the 128-photon instantiation (PCL_MULTI_NQ2=0) with the saturation probe (pcl_n_expr_sat), fp64
     hipFunction_t multi2s[2] = {nullptr, nullptr}; // 256 photons per wave with the probe
     std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
