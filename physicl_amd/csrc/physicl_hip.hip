@@ -3567,14 +3567,19 @@ int ensure_scratch(pcl_ctx *ctx, int64_t n, bool for_alive = false) {
 // ---- choosing the slab among a few candidates ----------------------------------------------------------------------
 //   (see "where big blocks come from": how fast the many-stream passes run is a property of the memory behind a slab,
 //   fixed when it is allocated, 10-15 % apart from one allocation to the next.)  A store of >= 512 MB takes the fastest
-//   of up to PCL_ALLOC_TRIES (default 4; 1 = take the first) candidate blocks -- idle pool blocks first, then fresh
+//   of up to PCL_ALLOC_TRIES (default 6; 1 = take the first) candidate blocks -- idle pool blocks first, then fresh
 //   ones -- each measured with the 13-row write sweep over the WHOLE block (a block's speed is not the sum of its
 //   handles' speeds measured one at a time: tools/attic/vmm_chunk_probe.hip); the others go (back) to the pool with their
 //   rate remembered, where the compaction's second slab finds them.  ~10 ms per candidate at 1e8 photons, once per store.
+//   Six since round 5 (four before): eight fresh processes with eight candidates each (tools/attic/alloc_tries.py,
+//   profiles/r05_alloc_tries.log) -- a candidate sweeps at 5.6-5.9 TB/s or at 6.4-7.0, about half of them each way, the
+//   one-step kernel runs at 0.73-0.74 of the HBM peak on any block that sweeps above ~6.7 and at 0.68 on one at 6.4; the best
+//   of the first four was below 6.6 in one process of eight (and in the driver's round-4 run: 5.75 5.55 5.98 6.39), the best
+//   of the first six at least 6.76 in all eight.
 int tries_wanted() {
     static const int n = [] {
         const char *e = getenv("PCL_ALLOC_TRIES");
-        const int v = e ? atoi(e) : 4;
+        const int v = e ? atoi(e) : 6;
         return v < 1 ? 1 : (v > 8 ? 8 : v);
     }();
     return n;
