@@ -447,7 +447,7 @@ def valu_roofline(work, kern_ms, expr, f32):
     for w in work:
         steps, hits, passes, wsteps, ppw, sat = w[:6]
         ghz = w[6] if len(w) > 6 else 0.0
-        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi%s%s_e1" % ("2" if ppw == 256 else "", "s" if sat >= 0 else ""))
+        name = "pcl_rtc_multi_f_e1" if f32 else ("pcl_rtc_multi%s%s_e1" % ({256: "2", 192: "3"}.get(ppw, ""), "s" if sat >= 0 else ""))
         c = table.get(name)
         if c is None or "dense_pass_cycles" not in c:
             return None

@@ -1593,5 +1593,26 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2
     pcl_multi_body_lds<double, true, true, 2, 2, true>(a);
 }
 #endif
+
+// three photons per lane (8-byte accesses), 192 per wave: between hit fractions of ~0.25 and ~0.32 a wave of 256 photons
+// queues 64 to 82 hits -- a full dense pass and a nearly empty one -- where 192 photons queue 48 to 62: one pass.
+// pcl_step_fused_multi takes this form for a launch that starts in that band.
+#if PCL_RTC_WANT(0, 0)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e0(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, false, true, 1, 3>(a);
+}
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3s_e0(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, false, true, 1, 3, true>(a);
+}
+#endif
+#if PCL_RTC_WANT(0, 1)
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e1(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, true, true, 1, 3>(a);
+}
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3s_e1(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, true, true, 1, 3, true>(a);
+}
+#endif
+
 #endif
 #endif // PCL_DEVICE_H

@@ -2848,6 +2848,7 @@ struct rtc_entry {
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
     hipFunction_t multis[2] = {nullptr, nullptr}; // the 128-photon instantiation (PCL_MULTI_NQ2=0) with the saturation probe (pcl_n_expr_sat), fp64
     hipFunction_t multi2s[2] = {nullptr, nullptr}; // 256 photons per wave with the probe
+    hipFunction_t multi3[2] = {nullptr, nullptr}, multi3s[2] = {nullptr, nullptr}; // 192 photons per wave (three per lane), without / with the probe
     std::shared_ptr<struct rtc_job> job;          // a specialisation still compiling in the background (get_rtc)
 };
 
@@ -4189,6 +4190,10 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
         if (hipModuleGetFunction(&ent.multis[e], ent.module, nm) != hipSuccess) ent.multis[e] = nullptr;
         snprintf(nm, sizeof nm, "pcl_rtc_multi2s_e%d", e);
         if (hipModuleGetFunction(&ent.multi2s[e], ent.module, nm) != hipSuccess) ent.multi2s[e] = nullptr;
+        snprintf(nm, sizeof nm, "pcl_rtc_multi3_e%d", e);
+        if (hipModuleGetFunction(&ent.multi3[e], ent.module, nm) != hipSuccess) ent.multi3[e] = nullptr;
+        snprintf(nm, sizeof nm, "pcl_rtc_multi3s_e%d", e);
+        if (hipModuleGetFunction(&ent.multi3s[e], ent.module, nm) != hipSuccess) ent.multi3s[e] = nullptr;
     }
     (void)hipGetLastError();
     return PCL_OK;
@@ -4516,7 +4521,20 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
     }
     ctx->multi_sat_used = sat;
     ++ctx->multi_launches;
-    if (sat && nq2) {
+    // 192 photons per wave (three per lane) for a launch that STARTS at a hit fraction between 0.28 and 0.355 -- about 0.25 to
+    // 0.32 over its steps: a wave of 256 photons then queues 64 to 82 hits per step, a full dense pass and a nearly empty one,
+    // where 192 photons queue 48 to 62, one pass (expected dense passes per photon, binomial: h = 0.27: 1.03 / 192 against
+    // 1.74 / 256; at h <= 0.234 and h >= 0.34 the 256-photon form is as good or better).  The previous launch's last step is
+    // (nearly) this launch's first.  PCL_MULTI_NQ3=1 always, =0 never.
+    static knob k_nq3("PCL_MULTI_NQ3");
+    const int nq3_mode = !k_nq3.set() ? -1 : (k_nq3.off() ? 0 : 1);
+    const bool have3 = var_n && ent->module && d == 0 && ent->multi3[use_e ? 1 : 0] && ent->multi3s[use_e ? 1 : 0];
+    const bool nq3 = have3 && nq2 && (nq3_mode == 1 || (nq3_mode == -1 && ctx->multi_last_h >= 0.28 && ctx->multi_last_h < 0.355));
+    if (nq3) {
+        ctx->multi_work[2] = 192;
+        grid = grid_for(ctx, div_up(N, (int64_t)3), kBlock);
+        PCL_TRY(launch_module(ctx, (sat ? ent->multi3s : ent->multi3)[use_e ? 1 : 0], grid, f, "step_fused_multi, 192 photons per wave (hipRTC)"));
+    } else if (sat && nq2) {
         ctx->multi_work[2] = 128 * pcl_rt<T>::VEC;
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * 2), kBlock);
         PCL_TRY(launch_module(ctx, ent->multi2s[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 with the saturation probe (hipRTC)"));

@@ -54,7 +54,9 @@ AHEAD_KNOBS = [("ahead_off", {"PCL_AHEAD": "0"}), ("ahead_k3", {"PCL_AHEAD_K": "
 MULTI_AHEAD_KNOBS = [("multi_flag_kernel", {"PCL_MULTI_AHEAD": "0"})]
 MULTI_AHEAD_FILES = {"test_gpu_multi.py", "test_gpu_simulation.py", "test_gpu_random_programs.py"}
 AHEAD_FILES = {"test_gpu_parity.py", "test_gpu_simulation.py", "test_gpu_random_programs.py", "test_gpu_fp32.py", "test_gpu_multi.py"}
-KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
+KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1", "PCL_MULTI_NQ3": "0"}), ("128_per_wave", {"PCL_MULTI_NQ2": "0"}),
+               # three photons per lane: the form a launch takes by itself when it starts at a hit fraction of 0.28 .. 0.355
+               ("192_per_wave", {"PCL_MULTI_NQ3": "1"}),
                # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's
                # photons start at the origin and fly out of exp's range), never
                ("saturation_probe", {"PCL_MULTI_SAT": "1", "PCL_MULTI_NQ2": "0"}), ("no_saturation_probe", {"PCL_MULTI_SAT": "0"})]

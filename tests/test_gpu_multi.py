@@ -186,7 +186,9 @@ def test_the_k_step_pass_directly_vs_the_oracle_chain(make_store, hip, tag, N, K
     else:       # fp32: exp / pow of OCML and of numpy's float32 may round a tie differently: at most a photon here and there
         assert all(abs(g[0] - r[0]) <= max(2, N // 20000) and max(abs(a - b) for a, b in zip(g[1], r[1])) <= max(2, N // 20000) for g, r in zip(got, ref))
     # (PCL_MULTI_NQ2=0 selects the 128-photon instantiation, which exists for the hipRTC specialisations in fp64)
-    assert d.last_multi_work()[2] == (128 if os.environ.get("PCL_MULTI_NQ2") == "0" and dtype == "f64" and expr is not None else 256)
+    rtc64 = dtype == "f64" and expr is not None
+    want = 128 if os.environ.get("PCL_MULTI_NQ2") == "0" and rtc64 else (192 if os.environ.get("PCL_MULTI_NQ3") == "1" and rtc64 else 256)
+    assert d.last_multi_work()[2] == want
     s = d.download_state()
     tol_v = 4 * float(np.spacing(np_t(C_LIT)))
     if got == ref:                                         # same decisions: the states are comparable photon by photon
@@ -337,7 +339,16 @@ def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
             out[how] = (rows, d.download_state())
     assert out["multi"][0] == out["single"][0]
     assert out["multi"][0][71][0] < 0.25 * N < out["multi"][0][23][0]     # the last launch started below the threshold, the second above
-    assert forms == [128 if os.environ.get("PCL_MULTI_NQ2") == "0" else 256] * 4
+    if os.environ.get("PCL_MULTI_NQ2") == "0":
+        assert forms == [128] * 4
+    elif os.environ.get("PCL_MULTI_NQ3") == "1":
+        assert forms == [192] * 4
+    elif os.environ.get("PCL_MULTI_NQ3") == "0":
+        assert forms == [256] * 4
+    else:                                       # by itself: 192 photons per wave for the launch that starts at h = 0.28 .. 0.355
+        assert forms[0] == 256 and set(forms) <= {192, 256}
+        starts = [N] + [out["multi"][0][k - 1][0] for k in (24, 48, 72)]       # hits of the step before each launch (the first: unknown)
+        assert forms[1:] == [192 if 0.28 * N <= h < 0.355 * N else 256 for h in starts[1:]]
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)

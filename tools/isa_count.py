@@ -4,7 +4,7 @@ compiles for an expression (``#define PCL_N_EXPR ...`` + physicl_amd/csrc/pcl_de
 
     python tools/isa_count.py ["<variable_n_fn>"] [--json profiles/isa_counts.json] [--md]
 
-For each kernel (pcl_rtc_multi_e1: 128 photons per wave, pcl_rtc_multi2_e1: 256) the loop nest is recovered from the
+For each kernel (pcl_rtc_multi_e1: 128 photons per wave, pcl_rtc_multi2_e1: 256, pcl_rtc_multi3_e1: 192) the loop nest is recovered from the
 backward branches: the grid-stride loop, the K loop inside it, the dense pass of the hit queue inside that.  Reported per
 kernel: VALU instructions (v_*) of the K loop's body outside the dense-pass loop, split into the blocks every step runs and
 the blocks only some steps run (the Philox decision block: every second step; the vprev store: the last step), and of one
@@ -263,7 +263,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("expr", nargs="?", default="0.000000001 * exp(r0[gid] - 5)")
     ap.add_argument("--json", default=None, help="merge the result into this file under the expression's text")
-    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1,pcl_rtc_multi2s_e1")
+    ap.add_argument("--kernels", default="pcl_rtc_multi_e1,pcl_rtc_multis_e1,pcl_rtc_multi2_e1,pcl_rtc_multi2s_e1,pcl_rtc_multi3_e1,pcl_rtc_multi3s_e1")
     ap.add_argument("--extra", default="", help="comma separated PCL_RTC_EXTRA names")
     ap.add_argument("--keep", default=None, help="directory to keep tu.hip / tu.s in")
     ap.add_argument("--aot", default=None, help="comma separated ahead-of-time kernels (demangled, e.g. 'k_delete_ahead_live<double, false>'): "

@@ -106,14 +106,17 @@ def main():
          "`single_step` leg (3 + %d x %d launches of the one-step kernel), the `delete`, `iso_1e7` and `mixed` legs and the `api` leg "
          "(three 500-pass simulations and a delete-until-empty run through the plugin API)."
          % (warmup, min(S, warmup), R, steps, min(S, steps), R, steps), "",
-         "## K-step pass (`pcl_rtc_multi_e1`: 128 photons per wave, `pcl_rtc_multi2_e1`: 256), every dispatch in order (bench.py's own "
+         "## K-step pass (`pcl_rtc_multi2*_e1`: 256 photons per wave, `pcl_rtc_multi3*_e1`: 192, `pcl_rtc_multi*_e1`: 128; `s` = with the saturation probe), every dispatch in order (bench.py's own "
          "launches first; the later ones belong to the `api` leg); the form is in brackets behind K", "",
          "Bytes = FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024.  valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); "
          "lane_util = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64); VALU instr / particle-step = SQ_INSTS_VALU x 64 / (N x K).", "",
          "| # | K | duration ms (trace pass) | HBM bytes / photon | 128 B x N / t (GB/s) | frac of 8 TB/s | valu_busy | lane_util | VALU instr / particle-step |",
          "|---|---|---|---|---|---|---|---|---|"]
     # the K-step pass has two forms (128 / 256 photons per wave: pcl_rtc_multi_e1 / pcl_rtc_multi2_e1), picked per launch
-    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multis_e1", "pcl_rtc_multi2s_e1")
+    kms = ("pcl_rtc_multi_e1", "pcl_rtc_multi2_e1", "pcl_rtc_multis_e1", "pcl_rtc_multi2s_e1", "pcl_rtc_multi3_e1", "pcl_rtc_multi3s_e1")
+    FORM = {"pcl_rtc_multi2_e1": "256", "pcl_rtc_multis_e1": "128 probe", "pcl_rtc_multi2s_e1": "256 probe", "pcl_rtc_multi3_e1": "192",
+            "pcl_rtc_multi3s_e1": "192 probe", "pcl_rtc_multi_e1": "128"}
+    KERNEL_OF = {v: k for k, v in FORM.items()}
     seq = sorted(((int(r["Dispatch_Id"]), short(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                   for r in rows if short(r["Kernel_Name"]) in kms))
     f_seq = read_counter_seq(os.path.join(src, "pmc_fetch", "pmc_counter_collection.csv"), kms)
@@ -208,7 +211,7 @@ def main():
     forms = []
     for i, (_, kname, d) in enumerate(seq[:len(ks) + 2]):
         K = ks[i] if i < len(ks) else None
-        forms.append({"pcl_rtc_multi2_e1": "256", "pcl_rtc_multis_e1": "128 probe", "pcl_rtc_multi2s_e1": "256 probe"}.get(kname, "128"))
+        forms.append(FORM.get(kname, "128"))
         fb = f_seq[i][1].get("FETCH_SIZE", 0) * 2 * 1024 if i < len(f_seq) else 0
         wb = w_seq[i][1].get("WRITE_SIZE", 0) * 1024 if i < len(w_seq) else 0
         c = s_seq[i][1] if i < len(s_seq) else {}
@@ -351,7 +354,7 @@ def main():
     kern_t = allt.setdefault("kernels", {})
     src_md = "profiles/%s_pmc.md" % tag
     for i, (K, d, b_hbm, busy, util, per_ps) in enumerate(multi_rows[1:1 + R]):
-        kern_t[{"256": "pcl_rtc_multi2_e1", "128 probe": "pcl_rtc_multis_e1", "256 probe": "pcl_rtc_multi2s_e1"}.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
+        kern_t[KERNEL_OF.get(forms[1 + i], "pcl_rtc_multi_e1")] = {
             "bytes_per_unit": round(b_hbm / N, 2), "unit": "photon (per launch)", "valu_busy": round(busy, 4), "lane_utilisation": round(util, 4),
             "source": src_md, "commit": commit, "csrc_sha": sha}
     if single:
