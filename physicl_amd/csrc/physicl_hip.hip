@@ -4070,7 +4070,15 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, int
     const char *extra = getenv("PCL_RTC_DEFINE"); // timing experiments only: e.g. -DPCL_ABLATE_TRIG
     // code objects are kept on disk, keyed by a hash of everything that determines them (the whole specialised source
     // text, target, options, hipRTC version): a second process starts without the ~2 s compile
-    const std::string disk = rtc_cache_path(src, arch, extra ? extra : "");
+    // Every option of the compile in one blank-separated string (it is part of the cache key).  -disable-machine-licm: the
+    // pre-RA pass hoists every scalar constant of the K loop (Philox keys, exp / sincos coefficients) out of it, the scalar
+    // register file overflows, and the overflow comes back into the loop as v_readlane -- VALU work in kernels bound by
+    // VALU issue.  Without the pass the constants are rebuilt in the loop by the otherwise idle scalar unit: K-step pass
+    // +1 .. 3 %, same bits (profiles/r05_ab_machine_licm.md; PCL_RTC_LICM=1 compiles with the pass, for A/B runs).
+    std::string all_opts = "-O3 -ffp-contract=off -std=c++17";
+    if (!getenv("PCL_RTC_LICM")) all_opts += " -mllvm -disable-machine-licm";
+    if (extra && *extra) all_opts += std::string(" ") + extra;
+    const std::string disk = rtc_cache_path(src, arch, all_opts);
     if (!disk.empty()) {
         std::vector<char> cached;
         if (read_cached_code(disk, &cached)) {
@@ -4093,8 +4101,16 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, int
             *err = std::string("hiprtcCreateProgram: ") + rtc_api().GetErrorString(r);
             return false;
         }
-        const char *opts[] = {arch.c_str(), "-O3", "-ffp-contract=off", "-std=c++17", extra.c_str()};
-        r = rtc_api().CompileProgram(prog, extra.empty() ? 4 : 5, opts);
+        std::vector<std::string> more; // the options, one per blank-separated word
+        for (size_t i = 0; i < extra.size();) {
+            const size_t j = extra.find(' ', i);
+            if (j != i) more.push_back(extra.substr(i, j == std::string::npos ? j : j - i));
+            if (j == std::string::npos) break;
+            i = j + 1;
+        }
+        std::vector<const char *> opts = {arch.c_str()};
+        for (const std::string &m : more) opts.push_back(m.c_str());
+        r = rtc_api().CompileProgram(prog, (int)opts.size(), opts.data());
         if (r != HIPRTC_SUCCESS) {
             size_t n = 0;
             rtc_api().GetProgramLogSize(prog, &n);
@@ -4116,7 +4132,7 @@ int compile_rtc(pcl_ctx *ctx, const char *expr, const std::string &expr_f32, int
         if (!disk.empty()) write_cached_code(disk, *code);
         return true;
     };
-    const std::string extra_s = (extra && *extra) ? extra : "";
+    const std::string extra_s = all_opts;
     // One of the built-in shapes, nothing cached: the ahead-of-time kernels start at once and the specialisation is
     // compiled beside them (~2 s); get_rtc takes it over when it is ready, pcl_ctx_rtc_wait waits for it.  Same bits
     // either way (tests/test_gpu_aot_fallback.py).  Asked for per context (pcl_ctx_set_rtc_background: Simulation does,

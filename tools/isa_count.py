@@ -111,11 +111,22 @@ def rtc_source(expr, expr_f32=None, dt=0, use_e=1, extra=()):
     return head + "#define PCL_N_EXPR (%s)\n#define PCL_N_EXPR_F (%s)\n" % (expr, expr_f32) + text
 
 
+# what the library adds to every compile, ahead-of-time and hipRTC (physicl_amd/build.py: EXTRA_OPTS); PCL_ISA_OPTS overrides
+def _extra_opts():
+    if "PCL_ISA_OPTS" in os.environ:
+        return os.environ["PCL_ISA_OPTS"].split()
+    from physicl_amd import build
+    return list(build.EXTRA_OPTS)
+
+
+EXTRA_OPTS = _extra_opts()
+
+
 def compile_asm(src, workdir):
     hip, asm = os.path.join(workdir, "tu.hip"), os.path.join(workdir, "tu.s")
     open(hip, "w").write(src)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-include", "hip/hip_runtime.h", "--offload-arch=gfx950", "-O3",
-                           "-ffp-contract=off", "-std=c++17", "--cuda-device-only", "-Wno-unused-command-line-argument", "-S", "-o", asm, hip],
+                           "-ffp-contract=off", "-std=c++17", "--cuda-device-only", "-Wno-unused-command-line-argument"] + EXTRA_OPTS + ["-S", "-o", asm, hip],
                           stderr=subprocess.DEVNULL)
     return open(asm).read()
 
@@ -283,7 +294,7 @@ def main():
     asm = compile_asm(rtc_source(a.expr, extra=[x for x in a.extra.split(",") if x]), work)
     out = {k: analyse(asm, k) for k in a.kernels.split(",")}
     hipcc = subprocess.check_output(["/opt/rocm/bin/hipcc", "--version"]).decode().splitlines()[0]
-    rec = {"expression": a.expr, "compiler": hipcc, "options": "--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17", "kernels": out}
+    rec = {"expression": a.expr, "compiler": hipcc, "options": "--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 " + " ".join(EXTRA_OPTS), "kernels": out}
     print(json.dumps(rec, indent=1))
     if a.json:
         table = json.load(open(a.json)) if os.path.exists(a.json) else {}
