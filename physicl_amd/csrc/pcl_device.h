@@ -1597,19 +1597,24 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2
 // three photons per lane (8-byte accesses), 192 per wave: between hit fractions of ~0.25 and ~0.32 a wave of 256 photons
 // queues 64 to 82 hits -- a full dense pass and a nearly empty one -- where 192 photons queue 48 to 62: one pass.
 // pcl_step_fused_multi takes this form for a launch that starts in that band.
+// 28 KB of LDS per workgroup and 89-90 VGPRs: FIVE waves per SIMD (the 256-photon forms' 37 KB allow four) -- same-box
+// -3.3 % on the form's block of the driver's command, six no better (profiles/r05_ab_occupancy.log).
+#ifndef PCL_MULTI3_ATTR
+#define PCL_MULTI3_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
+#endif
 #if PCL_RTC_WANT(0, 0)
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e0(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3_e0(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, false, true, 1, 3>(a);
 }
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3s_e0(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3s_e0(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, false, true, 1, 3, true>(a);
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e1(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3_e1(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, true, true, 1, 3>(a);
 }
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3s_e1(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3s_e1(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, true, true, 1, 3, true>(a);
 }
 #endif
