@@ -478,7 +478,10 @@ def valu_roofline(work, kern_ms, expr, f32):
             "lane_util": useful / cycles, "wave_instructions": instr, "issue_cycles": cycles, "dense_passes": sum(w[2] for w in work),
             "wave_steps": sum(w[3] for w in work), "dense_passes_per_wave_step": sum(w[2] for w in work) / float(sum(w[3] for w in work)),
             "saturated_wave_steps": sum(max(w[5], 0) for w in work),
-            "kernel_forms": forms, "instruction_counts": {k: {key: table[k][key] for key in ("decision_valu_per_wave_step", "decision_valu_per_wave_step_shortcut",
+            "kernel_forms": forms,
+            # (the 192-photon form keeps FIVE waves per SIMD: its instructions cost ~1.5 % less than the at-4-waves price)
+            "waves_per_simd": {k: (5 if "multi3" in k else 4) for k in forms},
+            "instruction_counts": {k: {key: table[k][key] for key in ("decision_valu_per_wave_step", "decision_valu_per_wave_step_shortcut",
                                                                                            "decision_valu_per_wave_trip", "decision_valu_per_wave_trip_shortcut",
                                                                                            "dense_pass_valu", "dense_pass_cycles", "decision_cycles_per_valu",
                                                                                            "dense_pass_cycles_at_4_waves", "decision_cycles_per_valu_at_4_waves",
