@@ -1043,11 +1043,12 @@ def mixed_valu_record():
     rec = pmc_record("k_mixed valu f64")
     if not rec:
         return None
-    mix = _json_file("isa_counts.json").get("aot", {}).get("k_mixed<double, false, 0>", {})
+    kname = rec.get("kernel", "k_mixed<double, false, 0>")     # (k_mixed3<double, false> for configs[4]'s loop: three rows per wave and trip)
+    mix = _json_file("isa_counts.json").get("aot", {}).get(kname, {})
     clock = rec.get("clock_GHz")
     peak = valu_peak(clock)
     priced = rec["wave_instructions"] * mix.get("cycles_per_valu", 4.0) / rec["seconds"]
-    return {"bound": "valu", "kernel": "k_mixed<double> (16 iterations of [Newton, ScatterIsotropic, Newton, ScatterDelete] per launch)",
+    return {"bound": "valu", "kernel": "%s (16 iterations of [Newton, ScatterIsotropic, Newton, ScatterDelete] per launch)" % kname,
             "achieved": priced, "peak": peak, "unit": "SIMD-cycles/s", "frac": priced / peak,
             "frac_at_4_waves_per_simd": rec["wave_instructions"] * mix.get("cycles_per_valu_at_4_waves", 4.3) / rec["seconds"] / peak,
             "cycles_per_wave_instruction": mix.get("cycles_per_valu"), "clock_GHz": clock,

@@ -384,6 +384,10 @@ int pcl_store_last_multi_work(pcl_ctx *ctx, int64_t *dense_passes_out, int64_t *
  * by VALU issue is 1024 SIMDs x THIS clock, in SIMD-cycles per second (bench.py's roofline record); 0 before any launch.
  * No counterpart in the reference (instrumentation of this library).                                                    */
 int pcl_store_last_multi_clock(pcl_ctx *ctx, double *ghz_out);
+/* Rows of 64 particles a wave kept per trip in the last pcl_step_mixed_multi launch: 2 (pcl_mixed_body, every variable-n
+ * form) or 3 (pcl_mixed_body_lds: constant n while a photon's hit probability A n c dt is below 0.33; PCL_MIXED_NE3 = 1 / 0
+ * forces); 0 before any.  No counterpart in the reference (instrumentation of this library).                            */
+int pcl_store_last_mixed_rows(pcl_ctx *ctx, int *rows_out);
 /* Debug builds of the K-step kernels only (environment PCL_RTC_EXTRA=PCL_HIT_HIST, knob PCL_MULTI_HIST=1): the last
  * launch's histogram of hits queued per wave and step (per round in the 256-photon form), bins 0 .. 127 and ">= 128"
  * (host pointer, 129 elements).  tools/hit_hist.py; PCL_ERR_STATE otherwise.                                          */

@@ -58,6 +58,7 @@ _PROTOTYPES = {
     "pcl_comm_destroy": [_vp],
     "pcl_store_last_multi_work": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int), POINTER(c_int64)],
     "pcl_store_last_multi_clock": [_vp, POINTER(c_double)],
+    "pcl_store_last_mixed_rows": [_vp, POINTER(c_int)],
     "pcl_store_ahead_clock": [_vp, POINTER(c_double)],
     "pcl_store_last_multi_hist": [_vp, _vp],
     "pcl_store_ahead_stats": [_vp, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)],
@@ -437,6 +438,12 @@ class Device:
         """GHz the chip held under the last step_fused_multi launch (pcl_store_last_multi_clock); 0.0 before any."""
         g = c_double()
         check(self.lib.pcl_store_last_multi_clock(self.ctx, byref(g)))
+        return g.value
+
+    def last_mixed_rows(self):
+        """Rows of 64 particles per wave and trip in the last step_mixed_multi launch (pcl_store_last_mixed_rows): 2 or 3."""
+        g = c_int()
+        check(self.lib.pcl_store_last_mixed_rows(self.ctx, byref(g)))
         return g.value
 
     def ahead_clock(self):

@@ -1454,6 +1454,217 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// pcl_mixed_body with the velocities (and |v dt|) of a wave's particles in LDS "homes", as pcl_multi_body_lds keeps them:
+// NE rows of 64 particles per trip instead of two, the dense pass writes the new velocity straight into its owner's home.
+// What it buys is fuller dense passes: a wave's pass costs the same for 38 hits as for 64, and at a hit fraction of 0.3
+// (BASELINE configs[4]: A = n = 1e-3, dt = 1e-3) 128 particles queue 38 hits a step -- 0.50 passes per 64 particles --
+// where 192 queue 58 -- 0.38; from a hit fraction of ~0.33 up two rows per trip are the better form again (the host
+// picks: step_mixed_t).  Same operations per particle in the same order, same launch indices: bit-identical to
+// pcl_mixed_body (tests/test_gpu_mixed.py runs both).  Rows past the wave's eight (NE = 3: the ninth) are empty.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NE>
+struct pcl_mixed_home {
+    T c[4][NE][256];                 // v0, v1, v2, |v dt| of row e of thread t
+    pcl_u64 qid[256 * NE];           // the queued hits: photon id ...
+    unsigned short owner[256 * NE];  // ... and home, e * 64 + lane (a wave's part of the queue is its own)
+};
+
+template <typename T, bool USE_E, int VAR_N, int NE>
+__device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
+    typedef pcl_rt<T> R;
+    constexpr int ROWS = 8; // rows of 64 particles a wave owns in its tile
+    constexpr int TRIPS = (ROWS + NE - 1) / NE;
+    __shared__ pcl_u32 s_cnt[(5 + PCL_MAXPL) * PCL_MULTI_MAX];
+    __shared__ pcl_mixed_home<T, NE> s_h;
+    __shared__ int s_keep[4];
+    const int nslots = 5 + a.n_planes;
+    const int n_ph = a.K * a.P;
+    for (int k = threadIdx.x; k < nslots * n_ph; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool lane0 = lane == 0;
+    const pcl_i64 tile = blockIdx.x;
+    const pcl_u32 qbase = (pcl_u32)wave * 64u * NE; // this wave's part of the hit queue
+    int kept = 0;
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        const int row0 = wave * ROWS + trip * NE;
+        T Rr[3][NE], L4[NE], Ev[NE];
+        pcl_u32 wodd0[NE], wodd1[NE];
+        pcl_u64 id[NE];
+        bool in[NE];
+        pcl_u64 am[NE], pm[NE]; // alive / photon, as wave masks: the votes are taken on bare compares (pcl_ballot)
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
+            in[e] = trip * NE + e < ROWS && i < a.N;
+            const pcl_i64 is = in[e] ? i : 0;
+            const pcl_i64 ti = pcl_tix(is, a.ts);
+            Rr[0][e] = a.r0[ti];
+            Rr[1][e] = a.r1[ti];
+            Rr[2][e] = a.r2[ti];
+            const T v0 = a.v0[ti], v1 = a.v1[ti], v2 = a.v2[ti];
+            L4[e] = (T)1;
+            if constexpr (USE_E) L4[e] = a.lam4[ti];
+            Ev[e] = a.E[ti];
+            id[e] = (pcl_u64)(a.ids ? a.ids[is] : a.id_base + i);
+            am[e] = pcl_ballot(in[e]);
+            pm[e] = a.kind ? (pcl_ballot(a.kind[is] != 0) & am[e]) : am[e];
+            wodd0[e] = wodd1[e] = 0u;
+            s_h.c[0][e][tid] = v0;
+            s_h.c[1][e][tid] = v1;
+            s_h.c[2][e][tid] = v2;
+            // |dr| = |v * dt| only changes when the photon scatters: kept beside v, recomputed with the new velocity
+            s_h.c[3][e][tid] = pcl_step_norm<T>(R::mul(v0, a.dt), R::mul(v1, a.dt), R::mul(v2, a.dt));
+        }
+        for (int ph = 0; ph < n_ph; ++ph) {
+            pcl_u64 any = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) any |= am[e];
+            if (!any) break; // nobody of these rows is left: their rows stay 0
+            const pcl_u32 st = a.step + (pcl_u32)ph;
+            const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
+            pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body_lds: keeps the round keys off the VGPR spills
+            asm volatile("" : "+s"(kk0), "+s"(kk1));
+            const bool new_block = (st & 1u) == 0u || ph == 0;
+            T d[3][NE], rand[NE], nm[NE];
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
+                d[0][e] = R::mul(s_h.c[0][e][tid], a.dt);
+                d[1][e] = R::mul(s_h.c[1][e][tid], a.dt);
+                d[2][e] = R::mul(s_h.c[2][e][tid], a.dt);
+                nm[e] = s_h.c[3][e][tid];
+                Rr[0][e] = R::add(Rr[0][e], d[0][e]);
+                Rr[1][e] = R::add(Rr[1][e], d[1][e]);
+                Rr[2][e] = R::add(Rr[2][e], d[2][e]);
+                if (new_block) { // decision block of the launch pair (st & ~1, st | 1): computed once for both
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
+                    rand[e] = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    wodd0[e] = w.z;
+                    wodd1[e] = w.w;
+                } else {
+                    rand[e] = R::uniform(wodd0[e], wodd1[e]);
+                }
+            }
+            pcl_u32 w_evt = 0; // hits (isotropic phase) or removals (delete phase) of this wave
+            pcl_u32 wbase = qbase;
+            if (is_del) {
+                // ScatterDeleteStep: flag = (A*n*norm >= rand), flagged photons leave the list      light.py:239-260
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const T pc = R::mul(a.An_del, nm[e]);
+                    const pcl_u64 gm = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
+                    w_evt += (pcl_u32)__popcll(gm);
+                    am[e] &= ~gm;
+                }
+            } else {
+                // ScatterIsotropicStep: decision in place, the hits densely through the wave's queue   light.py:303-331
+                wbase = qbase;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, nm[e], d[0][e], d[1][e], d[2][e], Rr[0][e],
+                                                           Rr[1][e], Rr[2][e], Ev[e]);
+                    if constexpr (USE_E) pc = R::mul(pc, L4[e]);
+                    const pcl_u64 b = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
+                    if ((b >> lane) & 1ull) {
+                        const pcl_u32 slot = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u));
+                        s_h.qid[slot] = id[e];
+                        s_h.owner[slot] = (unsigned short)(e * 64 + lane);
+                    }
+                    wbase += (pcl_u32)__popcll(b);
+                }
+                w_evt = wbase - qbase;
+                if (ph == a.last_iso) { // the velocity before the LAST scatter phase is what dv = v - v_prev needs
+                    int lane_here = lane; // (opaque: the slab indices are worked out HERE, not carried in registers through every phase)
+                    asm volatile("" : "+v"(lane_here));
+#pragma unroll
+                    for (int e = 0; e < NE; ++e)
+                        if (in[e]) {
+                            const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_here, a.ts);
+                            a.vp0[ti] = s_h.c[0][e][tid];
+                            a.vp1[ti] = s_h.c[1][e][tid];
+                            a.vp2[ti] = s_h.c[2][e][tid];
+                        }
+                }
+            }
+            // plane crossings of this phase's move, on the particles alive after the phase (an isotropic phase removes nobody): counted
+            // HERE, so that dr = v * dt need not live through the dense pass, where the registers are needed                light.py:385-399
+            pcl_u32 *c = &s_cnt[nslots * ph];
+            for (int p = 0; p < a.n_planes; ++p) {
+                const int ax = a.plane_ax[p];
+                const T L = a.plane_L[p];
+                pcl_u32 nc = 0;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
+                    const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
+                    nc += (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & am[e]);
+                }
+                if (lane0 && nc) atomicAdd(&c[5 + p], nc);
+            }
+            if (!is_del) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); // wave-private queue and homes: ordering only, no barrier
+                __builtin_amdgcn_wave_barrier();
+                for (pcl_u32 j = qbase + (pcl_u32)lane; j < wbase; j += 64) {
+                    const pcl_u32 o = s_h.owner[j];
+                    const pcl_u32 oe = o >> 6, ot = (pcl_u32)wave * 64u + (o & 63u);
+                    T rtheta, rphi, o0, o1, o2;
+                    pcl_draw_angles<T>(s_h.qid[j], st, kk0, kk1, rtheta, rphi);
+                    pcl_new_velocity<T, true>(a.c, rtheta, rphi, o0, o1, o2);
+                    s_h.c[0][oe][ot] = o0;
+                    s_h.c[1][oe][ot] = o1;
+                    s_h.c[2][oe][ot] = o2;
+                    s_h.c[3][oe][ot] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // this phase's measure row, on the particles alive after it            light.py:414-431
+            pcl_u32 w_n = 0, w_sx = 0, w_sy = 0, w_sz = 0;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                w_n += (pcl_u32)__popcll(am[e]);
+                w_sx += (pcl_u32)__popcll(pcl_ballot(s_h.c[0][e][tid] > (T)0) & am[e]);
+                w_sy += (pcl_u32)__popcll(pcl_ballot(s_h.c[1][e][tid] > (T)0) & am[e]);
+                w_sz += (pcl_u32)__popcll(pcl_ballot(s_h.c[2][e][tid] > (T)0) & am[e]);
+            }
+            if (lane0) {
+                if (w_n) atomicAdd(&c[0], w_n);
+                if (w_evt) atomicAdd(&c[1], w_evt);
+                if (w_sx) atomicAdd(&c[2], w_sx);
+                if (w_sy) atomicAdd(&c[3], w_sy);
+                if (w_sz) atomicAdd(&c[4], w_sz);
+            }
+        }
+        int lane_end = lane;
+        asm volatile("" : "+v"(lane_end));
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            if ((am[e] >> lane) & 1ull) { // (alive lanes are in range)
+                const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_end, a.ts);
+                a.r0[ti] = Rr[0][e];
+                a.r1[ti] = Rr[1][e];
+                a.r2[ti] = Rr[2][e];
+                a.v0[ti] = s_h.c[0][e][tid];
+                a.v1[ti] = s_h.c[1][e][tid];
+                a.v2[ti] = s_h.c[2][e][tid];
+            }
+            if (a.has_delete && trip * NE + e < ROWS) {
+                const pcl_u64 m = am[e];
+                if (lane0) a.masks[tile * 32 + row0 + e] = m;
+                kept += (int)__popcll(m);
+            }
+        }
+    }
+    if (a.has_delete && lane0) s_keep[wave] = kept;
+    __syncthreads();
+    if (a.has_delete && threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
+    for (int k = threadIdx.x; k < nslots * n_ph; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
+}
+
 #ifdef PCL_RTC
 // hipRTC translation unit: one expression; both wavelength variants of every kernel, fp64 and fp32.
 #define PCL_RTC_KERNEL(name, argtype, call) \

@@ -267,6 +267,13 @@ __global__ void __launch_bounds__(kBlock, (VAR_N == 0 && !USE_E && sizeof(T) == 
     pcl_mixed_body<T, USE_E, VAR_N>(a);
 }
 
+// constant n, three rows of 64 particles per trip, velocities in LDS (pcl_mixed_body_lds): fuller dense passes below a hit
+// fraction of ~0.33 (step_mixed_t picks)
+template <typename T, bool USE_E>
+__global__ void __launch_bounds__(kBlock, 4) k_mixed3(pcl_mixed_args<T> a) {
+    pcl_mixed_body_lds<T, USE_E, 0, 3>(a);
+}
+
 // The variable-n shape is an argument of the ahead-of-time kernels, so a body compiled once carries all three expressions and
 // the axis select through its loops: the K-step pass ran 11 % slower than its hipRTC specialisation for that alone (1.60e11
 // against 1.78e11; with one literal shape: 1.78e11).  The arithmetic-heavy kernels therefore exist once more for each of the
@@ -2916,6 +2923,7 @@ struct pcl_ctx {
     int64_t multi_launches = 0;      // pcl_step_fused_multi launches on this population
     bool multi_sat_on = false, multi_sat_used = false; // the probing variant paid on its last launch / the current launch uses it
     int multi_sat_next = 0;          // launches until the probing variant is tried again
+    int mixed_rows = 0;              // rows of 64 particles per wave and trip in the last pcl_step_mixed_multi launch (2: k_mixed, 3: k_mixed3)
     double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
@@ -5547,10 +5555,26 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
     const int d = sizeof(T) == 8 ? 0 : 1;
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
     set_np(f.np, ent);
+    ctx->mixed_rows = 2;
     if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
     } else {
-        PCL_AOT_LAUNCH_SHAPED(k_mixed, T, use_e, var_n, tiles, f);
+        // Constant n: a photon at speed c scatters with probability A n c dt a step.  Below ~0.33 three rows of 64 particles per
+        // wave and trip (k_mixed3: velocities in LDS) fill the dense passes better than two -- expected passes per 64
+        // particles, binomial: 0.33 / 0.38 / 0.48 at h = 0.25 / 0.30 / 0.33 against 0.50 --, above it two rows do.  With the
+        // wavelength term the probability differs from photon to photon: two rows.  PCL_MIXED_NE3=1 always (constant n), =0 never.
+        static knob k_ne3("PCL_MIXED_NE3");
+        const int ne3_mode = !k_ne3.set() ? -1 : (k_ne3.off() ? 0 : 1);
+        const double h_est = A * n * c * dt;
+        const bool ne3 = !var_n && (ne3_mode == 1 || (ne3_mode == -1 && !use_e && h_est < 0.33));
+        ctx->mixed_rows = ne3 ? 3 : 2;
+        if (ne3 && use_e) {
+            hipLaunchKernelGGL((k_mixed3<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
+        } else if (ne3) {
+            hipLaunchKernelGGL((k_mixed3<T, false>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
+        } else {
+            PCL_AOT_LAUNCH_SHAPED(k_mixed, T, use_e, var_n, tiles, f);
+        }
         PCL_TRY(launch_check("k_mixed"));
     }
     prof_end(ctx, ps);
@@ -5661,6 +5685,12 @@ int pcl_store_ahead_stats(pcl_ctx *ctx, int64_t *launches_out, int64_t *served_o
 int pcl_store_last_multi_clock(pcl_ctx *ctx, double *ghz_out) {
     if (!ctx || !ghz_out) return fail(PCL_ERR_ARG, "NULL argument");
     *ghz_out = ctx->multi_clock_ghz;
+    return PCL_OK;
+}
+
+int pcl_store_last_mixed_rows(pcl_ctx *ctx, int *rows_out) {
+    if (!ctx || !rows_out) return fail(PCL_ERR_ARG, "NULL argument");
+    *rows_out = ctx->mixed_rows;
     return PCL_OK;
 }
 

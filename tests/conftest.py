@@ -60,6 +60,10 @@ KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1", "PCL_MULTI_NQ3": "0"}), (
                # the variant that tries exp's saturation shortcut wave by wave: always (both of its branches run: the suite's
                # photons start at the origin and fly out of exp's range), never
                ("saturation_probe", {"PCL_MULTI_SAT": "1", "PCL_MULTI_NQ2": "0"}), ("no_saturation_probe", {"PCL_MULTI_SAT": "0"})]
+# the mixed K-pass kernel: three rows of 64 particles per wave and trip with the velocities in LDS (k_mixed3: what constant-n loops take by
+# themselves below a hit probability of 0.33) forced for every constant-n loop, and never
+MIXED_KNOBS = [("mixed_rows3", {"PCL_MIXED_NE3": "1"}), ("mixed_rows2", {"PCL_MIXED_NE3": "0"})]
+MIXED_FILES = {"test_gpu_mixed.py", "test_gpu_random_programs.py"}
 DELETE_FILES = {"test_gpu_parity.py", "test_gpu_multi.py", "test_gpu_mixed.py", "test_gpu_simulation.py", "test_gpu_random_programs.py",
                 "test_gpu_fp32.py"}
 KSTEP_FILES = {"test_gpu_multi.py", "test_gpu_bench_regime.py", "test_gpu_rtc_background.py"}
@@ -75,6 +79,7 @@ def pytest_generate_tests(metafunc):
         # (the mixed K-pass kernel has its own delete phase: of the single calls' knobs it only meets the compaction's)
         sets += [k for k in DELETE_KNOBS if fname != "test_gpu_mixed.py" or "flush_kernel" not in k[0]]
         sets += (AHEAD_KNOBS if fname in AHEAD_FILES else []) + (MULTI_AHEAD_KNOBS if fname in MULTI_AHEAD_FILES else [])
+        sets += MIXED_KNOBS if fname in MIXED_FILES else []
     if fname in KSTEP_FILES and "photons_per_wave" not in node:
         sets += KSTEP_KNOBS
     if sets:

@@ -9,6 +9,8 @@ fp32; against the CPU oracle run on its own: equal counters per phase, identical
 K * dt * 4 ulp(c).  Reference semantics exercised: ``type(obj) != PhotonObject`` skips plain objects
 (physicl/light.py:233, 283), stable removal (physicl/__init__.py:455-459).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -192,6 +194,13 @@ def test_mixed_multi_is_bit_identical_to_single_launches(make_store, hip, tag, N
     b.upload_state(init)
     got = mixed_launch(hip, b, tag, phases, K, seed, step0, planes)
     assert got == ref
+    # which form of the kernel ran: three rows of 64 particles per wave and trip (k_mixed3, velocities in LDS) for constant n while
+    # a photon's hit probability A n c dt is below 0.33 -- "base": 0.3 --, two rows (k_mixed) with the wavelength term or a
+    # variable_n_fn; conftest.py's knob cases force either form for constant n
+    use_e, expr, A, n, dt = CASES[tag] if "iso" in phases else (False, None, 0.0, 0.0, CASES[tag][4])    # (no scatter phase: nothing hits)
+    forced = os.environ.get("PCL_MIXED_NE3")
+    want = 3 if expr is None and (forced == "1" or (forced is None and not use_e and A * n * C_LIT * dt < 0.33)) else 2
+    assert b.last_mixed_rows() == want
     assert a.count == b.count
     state_equal(snapshot(a), snapshot(b))          # includes the implicit dr / dv of the last phases
     if "delete" in phases and N > 1000:

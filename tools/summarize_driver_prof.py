@@ -383,7 +383,9 @@ def main():
                              "unit": "slot (the compactions of the 1e8-slot extent in the delete leg)", "source": src_md, "commit": commit, "csrc_sha": sha}
     # k_mixed (configs[4]): VALU issue of its 16-iteration launches -- SQ_INSTS_VALU of the SQ pass over their durations in the
     # trace pass (the run is deterministic: same dispatches, same order) -- for the bench line's ``mixed.roofline``
-    for kname, tag_t in (("k_mixed<double, false, 0>", "f64"), ("k_mixed<float, false, 0>", "f32")):
+    # (configs[4]'s constant-n loop at a hit probability of 0.3 takes k_mixed3, three rows per wave and trip; k_mixed otherwise)
+    for knames, tag_t in ((("k_mixed3<double, false>", "k_mixed<double, false, 0>"), "f64"), (("k_mixed3<float, false>", "k_mixed<float, false, 0>"), "f32")):
+        kname = next((k for k in knames if any(c.get("SQ_INSTS_VALU", 0) > 1e9 for c in sq.get(k, []))), knames[0])
         pairs = [(c, d) for c, d in zip(sq.get(kname, []), disp.get(kname, [])) if c.get("SQ_INSTS_VALU", 0) > 1e9 and c.get("GRBM_GUI_ACTIVE")]
         if pairs:
             insts, dur = sum(c["SQ_INSTS_VALU"] for c, _ in pairs), sum(d for _, d in pairs) * 1e-9
@@ -393,7 +395,7 @@ def main():
                 "lane_utilisation": round(sum(c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) for c, _ in pairs) / len(pairs), 4),
                 # (the SQ pass's own GRBM cycles over the trace pass's durations of the same dispatches)
                 "clock_GHz": round(sum(c["GRBM_GUI_ACTIVE"] for c, _ in pairs) / 8.0 / (sum(d for _, d in pairs)), 4),
-                "source": src_md, "commit": commit, "csrc_sha": sha}
+                "kernel": kname, "source": src_md, "commit": commit, "csrc_sha": sha}
             mixk = isa.get("aot", {}).get(kname, {})
             ghz = kern_t["k_mixed valu " + tag_t]["clock_GHz"]
             L += ["", "`%s`, the %d launches of 16 iterations: %.4g VALU wave-instructions in %.2f ms at %.3f GHz (GRBM_GUI_ACTIVE / 8 / duration); "
