@@ -1748,6 +1748,23 @@ PCL_RTC_KERNEL(pcl_rtc_mixed_f_e0, pcl_mixed_args<float>, (pcl_mixed_body<float,
 #if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_mixed_f_e1, pcl_mixed_args<float>, (pcl_mixed_body<float, true, true>))
 #endif
+// three rows of 64 particles per wave and trip, velocities in LDS (pcl_mixed_body_lds): what a loop with a variable_n_fn takes once
+// a launch has shown its hit fraction to be below 0.33 (step_mixed_t)
+#ifndef PCL_MIXED3_ATTR
+#define PCL_MIXED3_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
+#if PCL_RTC_WANT(0, 0)
+extern "C" __global__ void __launch_bounds__(256) PCL_MIXED3_ATTR pcl_rtc_mixed3_e0(pcl_mixed_args<double> a) { pcl_mixed_body_lds<double, false, true, 3>(a); }
+#endif
+#if PCL_RTC_WANT(0, 1)
+extern "C" __global__ void __launch_bounds__(256) PCL_MIXED3_ATTR pcl_rtc_mixed3_e1(pcl_mixed_args<double> a) { pcl_mixed_body_lds<double, true, true, 3>(a); }
+#endif
+#if PCL_RTC_WANT(1, 0)
+extern "C" __global__ void __launch_bounds__(256) PCL_MIXED3_ATTR pcl_rtc_mixed3_f_e0(pcl_mixed_args<float> a) { pcl_mixed_body_lds<float, false, true, 3>(a); }
+#endif
+#if PCL_RTC_WANT(1, 1)
+extern "C" __global__ void __launch_bounds__(256) PCL_MIXED3_ATTR pcl_rtc_mixed3_f_e1(pcl_mixed_args<float> a) { pcl_mixed_body_lds<float, true, true, 3>(a); }
+#endif
 #ifndef PCL_MULTI_ATTR /* timing experiments: e.g. -DPCL_MULTI_ATTR=__attribute__((amdgpu_waves_per_eu(5,5))) */
 #define PCL_MULTI_ATTR
 #endif

@@ -2852,6 +2852,7 @@ struct rtc_entry {
     hipFunction_t multi[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipFunction_t mixed3[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // three rows per wave and trip, velocities in LDS
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
     hipFunction_t multis[2] = {nullptr, nullptr}; // the 128-photon instantiation (PCL_MULTI_NQ2=0) with the saturation probe (pcl_n_expr_sat), fp64
     hipFunction_t multi2s[2] = {nullptr, nullptr}; // 256 photons per wave with the probe
@@ -2924,6 +2925,7 @@ struct pcl_ctx {
     bool multi_sat_on = false, multi_sat_used = false; // the probing variant paid on its last launch / the current launch uses it
     int multi_sat_next = 0;          // launches until the probing variant is tried again
     int mixed_rows = 0;              // rows of 64 particles per wave and trip in the last pcl_step_mixed_multi launch (2: k_mixed, 3: k_mixed3)
+    double mixed_last_h = -1.0;      // hit fraction of the last scatter phase of the previous pcl_step_mixed_multi launch (-1: unknown)
     double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
@@ -4205,6 +4207,8 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
             get(&ent.fastg[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_mixed_%se%d", dt_tag[d], e);
             get(&ent.mixed[d][e], nm);
+            snprintf(nm, sizeof nm, "pcl_rtc_mixed3_%se%d", dt_tag[d], e);
+            if (hipModuleGetFunction(&ent.mixed3[d][e], ent.module, nm) != hipSuccess) ent.mixed3[d][e] = nullptr;
         }
     for (int e = 0; e < 2; ++e) { // fp64 modules only
         char nm[64];
@@ -5189,7 +5193,7 @@ int ahead_resources(pcl_ctx *ctx, int64_t slots) {
 }
 
 void drop_holes(pcl_ctx *ctx) {
-    ctx->multi_last_h = -1.0; // (called whenever the population is replaced)
+    ctx->multi_last_h = ctx->mixed_last_h = -1.0; // (called whenever the population is replaced)
     ctx->multi_launches = 0;
     ctx->multi_sat_on = false;
     ctx->multi_sat_next = 0;
@@ -5556,17 +5560,22 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
     const int ps = prof_begin(ctx, PCL_PROF_MULTI);
     set_np(f.np, ent);
     ctx->mixed_rows = 2;
+    // Three rows of 64 particles per wave and trip (velocities in LDS: pcl_mixed_body_lds) fill the dense passes better than two
+    // while fewer than a third of the photons scatter per step -- expected passes per 64 particles, binomial: 0.33 / 0.38 / 0.48
+    // at h = 0.25 / 0.30 / 0.33 against 0.50 --, above that two rows do.  PCL_MIXED_NE3=1 always, =0 never.
+    static knob k_ne3("PCL_MIXED_NE3");
+    const int ne3_mode = !k_ne3.set() ? -1 : (k_ne3.off() ? 0 : 1);
     if (var_n && ent->module) {
-        PCL_TRY(launch_module(ctx, ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
+        // a variable_n_fn: the hit fraction is whatever the last scatter phase of the launch before showed (unknown: two rows)
+        hipFunction_t fn3 = ent->mixed3[d][use_e ? 1 : 0];
+        const bool ne3 = fn3 && (ne3_mode == 1 || (ne3_mode == -1 && ctx->mixed_last_h >= 0.0 && ctx->mixed_last_h < 0.33));
+        ctx->mixed_rows = ne3 ? 3 : 2;
+        PCL_TRY(launch_module(ctx, ne3 ? fn3 : ent->mixed[d][use_e ? 1 : 0], tiles, f, "step_mixed_multi (hipRTC)"));
     } else {
-        // Constant n: a photon at speed c scatters with probability A n c dt a step.  Below ~0.33 three rows of 64 particles per
-        // wave and trip (k_mixed3: velocities in LDS) fill the dense passes better than two -- expected passes per 64
-        // particles, binomial: 0.33 / 0.38 / 0.48 at h = 0.25 / 0.30 / 0.33 against 0.50 --, above it two rows do.  With the
-        // wavelength term the probability differs from photon to photon: two rows.  PCL_MIXED_NE3=1 always (constant n), =0 never.
-        static knob k_ne3("PCL_MIXED_NE3");
-        const int ne3_mode = !k_ne3.set() ? -1 : (k_ne3.off() ? 0 : 1);
-        const double h_est = A * n * c * dt;
-        const bool ne3 = !var_n && (ne3_mode == 1 || (ne3_mode == -1 && !use_e && h_est < 0.33));
+        // constant n: a photon at speed c scatters with probability A n c dt a step -- known before the first launch.  With the
+        // wavelength term the probability differs from photon to photon: by the launch before, as above.
+        const double h_est = use_e ? ctx->mixed_last_h : A * n * c * dt;
+        const bool ne3 = !var_n && (ne3_mode == 1 || (ne3_mode == -1 && h_est >= 0.0 && h_est < 0.33));
         ctx->mixed_rows = ne3 ? 3 : 2;
         if (ne3 && use_e) {
             hipLaunchKernelGGL((k_mixed3<T, true>), dim3(tiles), dim3(kBlock), 0, ctx->stream, f);
@@ -7039,6 +7048,10 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     }
     if (has_iso) // pcl_store_last_scatter_hits() reports the last scatter phase
         ctx->h_cnt[0] = ctx->h_multi[(int64_t)((k_passes - 1) * n_phases + last_iso_in_pass) * nslots + 1], ctx->hits_on_host = true;
+    if (has_iso) { // what the next launch's form goes by (step_mixed_t)
+        const uint64_t *row = ctx->h_multi + (int64_t)((k_passes - 1) * n_phases + last_iso_in_pass) * nslots;
+        ctx->mixed_last_h = row[0] ? (double)row[1] / (double)row[0] : -1.0;
+    }
     if (out_host)
         for (int k = 0; k < n_rows; ++k) {
             int64_t *o = out_host + (int64_t)k * (5 + np);

@@ -194,13 +194,13 @@ def test_mixed_multi_is_bit_identical_to_single_launches(make_store, hip, tag, N
     b.upload_state(init)
     got = mixed_launch(hip, b, tag, phases, K, seed, step0, planes)
     assert got == ref
-    # which form of the kernel ran: three rows of 64 particles per wave and trip (k_mixed3, velocities in LDS) for constant n while
-    # a photon's hit probability A n c dt is below 0.33 -- "base": 0.3 --, two rows (k_mixed) with the wavelength term or a
-    # variable_n_fn; conftest.py's knob cases force either form for constant n
+    # which form of the kernel ran: three rows of 64 particles per wave and trip (velocities in LDS) while fewer than a third of the
+    # photons scatter per step -- known ahead for constant n without the wavelength term (A n c dt; "base": 0.3), otherwise
+    # taken from the launch before (this store's first launch: two rows); conftest.py's knob cases force either form
     use_e, expr, A, n, dt = CASES[tag] if "iso" in phases else (False, None, 0.0, 0.0, CASES[tag][4])    # (no scatter phase: nothing hits)
     forced = os.environ.get("PCL_MIXED_NE3")
-    want = 3 if expr is None and (forced == "1" or (forced is None and not use_e and A * n * C_LIT * dt < 0.33)) else 2
-    assert b.last_mixed_rows() == want
+    known_ahead = expr is None and not use_e and A * n * C_LIT * dt < 0.33
+    assert b.last_mixed_rows() == (3 if forced == "1" or (forced is None and known_ahead) else 2)
     assert a.count == b.count
     state_equal(snapshot(a), snapshot(b))          # includes the implicit dr / dv of the last phases
     if "delete" in phases and N > 1000:
@@ -360,3 +360,27 @@ def test_full_size_mixed_multi_equals_single_launches_at_1e8(make_store, hip):
     assert out[0][0] == out[1][0] and out[0][1] == out[1][1]
     assert all(np.array_equal(a, b) for a, b in zip(out[0][2], out[1][2]))
     assert abs(out[0][1] / N - (1 - 5.9958e-3) ** K) < 2e-4 and abs(out[0][0][0][1] / N - 0.2998) < 1e-3
+
+
+@pytest.mark.parametrize("tag", ["lambda", "varn"])
+def test_mixed_form_follows_the_hit_fraction_of_the_launch_before(make_store, hip, tag):
+    """Loops whose hit probability is not known ahead of a launch (wavelength term, variable_n_fn): the first mixed launch of a
+    population runs two rows per wave and trip, the next ones three while the launch before showed fewer than a third of the
+    photons scattering in its last scatter phase -- and the rows equal single launches whatever ran (the knob cases of
+    conftest.py force either form)."""
+    N, K, seed = 50_000, 3, 99
+    init = initial(N, "f64", 5, "uniform")
+    a, b = make_store(N), make_store(N)
+    a.upload_state(init)
+    b.upload_state(init)
+    forced = os.environ.get("PCL_MIXED_NE3")
+    step, last_h = 1, None
+    for launch in range(3):
+        ref = single_launches(hip, a, tag, ("iso", "delete"), K, seed, step, [])
+        got = mixed_launch(hip, b, tag, ("iso", "delete"), K, seed, step, [])
+        assert got == ref
+        want = 3 if forced == "1" else (2 if forced == "0" or last_h is None or not last_h < 0.33 else 3)
+        assert b.last_mixed_rows() == want, (launch, last_h)
+        last_h = got[-2][1] / got[-2][0] if got[-2][0] else None         # (hits of the last scatter phase over the photons alive in it)
+        step += 2 * K
+    state_equal(snapshot(a), snapshot(b))
