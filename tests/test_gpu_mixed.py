@@ -384,3 +384,45 @@ def test_mixed_form_follows_the_hit_fraction_of_the_launch_before(make_store, hi
         last_h = got[-2][1] / got[-2][0] if got[-2][0] else None         # (hits of the last scatter phase over the photons alive in it)
         step += 2 * K
     state_equal(snapshot(a), snapshot(b))
+
+
+@pytest.mark.parametrize("order", [("iso", "delete"), ("delete", "iso")])
+@pytest.mark.parametrize("store", ["uniform", "ids"])
+@pytest.mark.parametrize("tag,N,K", [("base", 1, 2), ("base", 191, 3), ("base", 193, 3), ("base", 385, 2), ("base", 2049, 4), ("base", 70_001, 6),
+                                     ("lambda", 4099, 3), ("varn", 2047, 3), ("varn", 513, 2)])
+def test_the_mixed_kernels_directly_vs_the_oracle_chain(make_store, hip, tag, N, K, store, order):
+    """The mixed K-pass kernels -- k_mixed, two rows of 64 particles per wave and trip, and k_mixed3, three rows with the velocities
+    in LDS (what the constant-n cases take by themselves; conftest.py's knob cases force either) -- against the ORACLE's own chain
+    of Newton / scatter / Newton / delete steps, not against other device kernels: one particle, one short of / one over three
+    rows (the three-row form's trip), one over six rows, one over a tile, a ragged last tile; both phase orders; implicit and
+    explicit ids; every scatter variant.  Counters per phase exact, the survivors' ids and order exact, velocities within 4 ulp
+    of c, positions within the bound that follows."""
+    use_e, expr, A, n, dt = CASES[tag]
+    init = initial(N, "f64", 900 + N + K, store)
+    ids = init["id"].copy() if "id" in init else np.arange(N, dtype=np.int64) + init["id_base"]
+    st = {"r": [np.ascontiguousarray(init["r"][:, k]) for k in range(3)], "v": [np.ascontiguousarray(init["v"][:, k]) for k in range(3)],
+          "dr": [np.zeros(N)] * 3, "dv": [np.zeros(N)] * 3, "E": init["E"].copy(), "id": ids}
+    seed, step0 = 4711, 3                                    # (odd first launch number: a Philox decision block split by the launch)
+    A_d, n_d = A_DEL, N_DEL * 1e-3 / dt
+    ref, step = [], step0
+    for k in range(K):
+        for ph in order:
+            orc.step_newton(st, dt)
+            if ph == "iso":
+                hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, step, st["id"]), A, n, C_LIT, h=H_LIT, use_E=use_e, n_expr=expr)
+                ref.append((len(st["id"]), int(hit.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+            else:
+                flags, keep = orc.step_scatter_delete(st, orc.philox_draws(seed, step, st["id"])[2], A_d, n_d)
+                ref.append((len(st["id"]), int(flags.sum()), [int((st["v"][j] > 0).sum()) for j in range(3)]))
+            step += 1
+    d = make_store(N)
+    d.upload_state(init)
+    sc, _ = scatter_dict(hip, tag, seed, step0)
+    rows = d.step_mixed_multi(dt, K, order, sc, (A_d, n_d), [], seed, step0)
+    assert [(o["N"], o["hits"] if o["phase"] == "iso" else o["removed"], list(o["sign"])) for o in rows] == ref
+    assert d.count == len(st["id"])
+    if d.count:
+        s = d.download_state()
+        assert np.array_equal(s["id"], st["id"])
+        assert np.max(np.abs(np.stack(s["v"], 1) - np.stack(st["v"], 1))) <= V_ABS_TOL
+        assert np.max(np.abs(np.stack(s["r"], 1) - np.stack(st["r"], 1))) <= 2 * K * dt * V_ABS_TOL + 1e-15
