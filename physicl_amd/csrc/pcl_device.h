@@ -971,7 +971,8 @@ struct pcl_multi_args {
 template <typename T, int NP>
 struct pcl_multi_home {
     T c[4][NP][256];                   // v0, v1, v2, |v dt| of photon p of thread t (component-major: lanes read consecutive words)
-    unsigned short owner[4][NP * 64];  // per wave: the step's hits, p * 64 + lane
+    unsigned short owner[4][NP * 64 + 64]; // per wave: the step's hits, p * 64 + lane; behind them a slot per lane for the writes of the
+                                           // lanes that did not hit (the queue is written without a branch)
 };
 
 template <typename T, bool USE_E, int VAR_N, int VEC, int NQ, bool SATP = false>
@@ -1033,6 +1034,7 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 s_h.c[3][p][tid] = pcl_step_norm<T>(R::mul(t3[e], a.dt), R::mul(t4[e], a.dt), R::mul(t5[e], a.dt));
             }
         }
+        pcl_u32 hits_prev = 0; // the hits of the step before (wave-uniform)
         for (int k = 0; k < a.K; ++k) {
             const pcl_u32 st = a.step + (pcl_u32)k;
             // the 20 Philox round keys are loop-invariant; hoisted out of the k loop they cost 20 SGPRs and push other scalars
@@ -1077,15 +1079,8 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 Rr[0][p] = R::add(Rr[0][p], d0);
                 Rr[1][p] = R::add(Rr[1][p], d1);
                 Rr[2][p] = R::add(Rr[2][p], d2);
-                // plane crossings of this step's move (r - dr, r)                        light.py:385-399
-                for (int pl = 0; pl < a.n_planes; ++pl) {
-                    const int ax = a.plane_ax[pl];
-                    const T L = a.plane_L[pl];
-                    const T x = pcl_pick<T>(ax, Rr[0][p], Rr[1][p], Rr[2][p]);
-                    const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
-                    const pcl_u32 nc = (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & lm[p]);
-                    if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
-                }
+                // (the plane crossings of this move are counted behind this loop: a loop over the planes HERE would cut the NP photons'
+                // moves and decisions into NP basic blocks, each waiting for its own LDS reads)
                 // scatter decision                                                       light.py:303-308
 #ifdef PCL_N_EXPR
                 if constexpr (SATP && VAR_N != 0) { // by exp's saturation shortcut first (pcl_n_expr_sat): settled wave-wide below
@@ -1099,10 +1094,26 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                     pcn[p] = pc;
                 }
             }
-            if (k > 0 && lane0) { // (row k - 1)
-                if (w_sx) atomicAdd(&s_cnt[nslots * (k - 1) + 1], w_sx);
-                if (w_sy) atomicAdd(&s_cnt[nslots * (k - 1) + 2], w_sy);
-                if (w_sz) atomicAdd(&s_cnt[nslots * (k - 1) + 3], w_sz);
+            // plane crossings of this step's move (r - dr, r)                            light.py:385-399
+            if (a.n_planes > 0) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const T d0 = R::mul(s_h.c[0][p][tid], a.dt), d1 = R::mul(s_h.c[1][p][tid], a.dt), d2 = R::mul(s_h.c[2][p][tid], a.dt); // (as above)
+                    for (int pl = 0; pl < a.n_planes; ++pl) {
+                        const int ax = a.plane_ax[pl];
+                        const T L = a.plane_L[pl];
+                        const T x = pcl_pick<T>(ax, Rr[0][p], Rr[1][p], Rr[2][p]);
+                        const T prev = R::sub(x, pcl_pick<T>(ax, d0, d1, d2));
+                        const pcl_u32 nc = (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & lm[p]);
+                        if (lane0 && nc) atomicAdd(&s_cnt[nslots * k + 4 + pl], nc);
+                    }
+                }
+            }
+            // row k - 1: its hits and the sign counts of the state it left, ONE LDS atomic of four lanes (one per column) instead of
+            // four single-lane ones, each in a basic block of its own
+            if (k > 0 && lane < 4) {
+                const pcl_u32 val = lane == 0 ? hits_prev : (lane == 1 ? w_sx : (lane == 2 ? w_sy : w_sz));
+                if (val) atomicAdd(&s_cnt[nslots * (k - 1) + lane], val);
             }
 #ifdef PCL_N_EXPR
             if constexpr (SATP && VAR_N != 0) {
@@ -1124,22 +1135,55 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 }
             }
 #endif
+            // The draws of all NP photons first, in one straight-line block: a Philox chain is ten dependent rounds, and the
+            // queue writes below are control flow -- with a photon's draw between two of them the compiler kept the NP chains in
+            // NP basic blocks, one after the other (5.1 cycles an instruction at four waves per SIMD,
+            // profiles/r05_valu_issue_probe.txt); side by side they fill each other's latencies.
+            T rnd[NP];
+#ifndef PCL_PHILOX_SIDE_BY_SIDE
+#define PCL_PHILOX_SIDE_BY_SIDE 2 /* chains the scheduler may interleave at a time */
+#endif
+            if (new_block && (st & 1u) == 0u) { // decision block of steps (st, st | 1): computed once for the pair
 #pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                const int g = p / VEC, e = p % VEC;
-                const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)g * blockDim.x + tid) * VEC + e);
-                T rand;
-                if (new_block) { // decision block of steps (st & ~1, st | 1): computed once for the pair
+                for (int p = 0; p < NP; ++p) {
+                    if (p > 0 && p % PCL_PHILOX_SIDE_BY_SIDE == 0) __builtin_amdgcn_sched_barrier(0);
+                    const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(p / VEC) * blockDim.x + tid) * VEC + (p % VEC));
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
-                    rand = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    rnd[p] = R::uniform(w.x, w.y);
                     wodd0[p] = w.z;
                     wodd1[p] = w.w;
-                } else {
-                    rand = R::uniform(wodd0[p], wodd1[p]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (new_block) { // a launch that starts on an odd step: the second half of the block of (st - 1, st)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if (p > 0 && p % PCL_PHILOX_SIDE_BY_SIDE == 0) __builtin_amdgcn_sched_barrier(0);
+                    const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(p / VEC) * blockDim.x + tid) * VEC + (p % VEC));
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
+                    rnd[p] = R::uniform(w.z, w.w);
+                    wodd0[p] = w.z;
+                    wodd1[p] = w.w;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) rnd[p] = R::uniform(wodd0[p], wodd1[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const T rand = rnd[p];
                 const pcl_u64 bal = pcl_ballot(pcn[p] >= rand) & lm[p]; // (NaN compares false, +inf true: the reference's ``pcoll >= rand``)
                 const bool hit = (bal >> lane) & 1ull;
-                if (hit) s_h.owner[wave][w_hits + __builtin_amdgcn_mbcnt_hi((pcl_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)bal, 0u))] = (unsigned short)(p * 64 + lane);
+                // (unconditional: a lane that did not hit writes its own slot behind the queue -- an ``if (hit)`` is a basic block per
+                // photon, and the NP compares, votes and writes schedule better as one)
+                // (three photons per lane: the branches are kept -- the straight-line form costs the two registers that decide between
+                // five waves per SIMD and four for that form)
+                const pcl_u32 pos = w_hits + __builtin_amdgcn_mbcnt_hi((pcl_u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)bal, 0u));
+                if constexpr (NP >= 4) {
+                    s_h.owner[wave][hit ? pos : (pcl_u32)(NP * 64 + lane)] = (unsigned short)(p * 64 + lane);
+                } else {
+                    if (hit) s_h.owner[wave][pos] = (unsigned short)(p * 64 + lane);
+                }
                 w_hits += (pcl_u32)__popcll(bal);
             }
             // the queue and the homes of a wave's photons are private to the wave: LDS executes a wave's accesses in order, so
@@ -1167,7 +1211,7 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            if (lane0 && w_hits) atomicAdd(&s_cnt[nslots * k + 0], w_hits);
+            hits_prev = w_hits; // (joins row k's sign counts in one atomic, above or behind the loop)
         }
         // the last step's sign counts, and the store
         pcl_u32 w_sx = 0, w_sy = 0, w_sz = 0;
@@ -1198,10 +1242,9 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 VV::st(a.v2, qs, t5);
             }
         }
-        if (lane0) {
-            if (w_sx) atomicAdd(&s_cnt[nslots * (a.K - 1) + 1], w_sx);
-            if (w_sy) atomicAdd(&s_cnt[nslots * (a.K - 1) + 2], w_sy);
-            if (w_sz) atomicAdd(&s_cnt[nslots * (a.K - 1) + 3], w_sz);
+        if (lane < 4) {
+            const pcl_u32 val = lane == 0 ? hits_prev : (lane == 1 ? w_sx : (lane == 2 ? w_sy : w_sz));
+            if (val) atomicAdd(&s_cnt[nslots * (a.K - 1) + lane], val);
         }
     }
     if (lane0 && w_passes) atomicAdd(&s_pass, w_passes);
@@ -1422,12 +1465,9 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 }
                 if (lane0 && nc) atomicAdd(&c[5 + p], nc);
             }
-            if (lane0) {
-                if (w_n) atomicAdd(&c[0], w_n);
-                if (w_evt) atomicAdd(&c[1], w_evt);
-                if (w_sx) atomicAdd(&c[2], w_sx);
-                if (w_sy) atomicAdd(&c[3], w_sy);
-                if (w_sz) atomicAdd(&c[4], w_sz);
+            if (lane < 5) { // the row's five columns: ONE LDS atomic of five lanes, not five single-lane ones in five basic blocks
+                const pcl_u32 val = lane == 0 ? w_n : (lane == 1 ? w_evt : (lane == 2 ? w_sx : (lane == 3 ? w_sy : w_sz)));
+                if (val) atomicAdd(&c[lane], val);
             }
         }
 #pragma unroll
@@ -1466,8 +1506,9 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
 template <typename T, int NE>
 struct pcl_mixed_home {
     T c[4][NE][256];                 // v0, v1, v2, |v dt| of row e of thread t
-    pcl_u64 qid[256 * NE];           // the queued hits: photon id ...
-    unsigned short owner[256 * NE];  // ... and home, e * 64 + lane (a wave's part of the queue is its own)
+    pcl_u64 qid[256 * NE + 256];           // the queued hits: photon id ...
+    unsigned short owner[256 * NE + 256];  // ... and home, e * 64 + lane (a wave's part of the queue is its own); behind the queues a
+                                           // slot per thread for the writes of the lanes that did not hit (no branch around the writes)
 };
 
 template <typename T, bool USE_E, int VAR_N, int NE>
@@ -1568,11 +1609,10 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                                                            Rr[1][e], Rr[2][e], Ev[e]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[e]);
                     const pcl_u64 b = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
-                    if ((b >> lane) & 1ull) {
-                        const pcl_u32 slot = wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u));
-                        s_h.qid[slot] = id[e];
-                        s_h.owner[slot] = (unsigned short)(e * 64 + lane);
-                    }
+                    const pcl_u32 slot = ((b >> lane) & 1ull) ? wbase + __builtin_amdgcn_mbcnt_hi((pcl_u32)(b >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)b, 0u))
+                                                              : (pcl_u32)(256 * NE + tid);
+                    s_h.qid[slot] = id[e];
+                    s_h.owner[slot] = (unsigned short)(e * 64 + lane);
                     wbase += (pcl_u32)__popcll(b);
                 }
                 w_evt = wbase - qbase;
@@ -1630,12 +1670,9 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 w_sy += (pcl_u32)__popcll(pcl_ballot(s_h.c[1][e][tid] > (T)0) & am[e]);
                 w_sz += (pcl_u32)__popcll(pcl_ballot(s_h.c[2][e][tid] > (T)0) & am[e]);
             }
-            if (lane0) {
-                if (w_n) atomicAdd(&c[0], w_n);
-                if (w_evt) atomicAdd(&c[1], w_evt);
-                if (w_sx) atomicAdd(&c[2], w_sx);
-                if (w_sy) atomicAdd(&c[3], w_sy);
-                if (w_sz) atomicAdd(&c[4], w_sz);
+            if (lane < 5) { // the row's five columns: ONE LDS atomic of five lanes, not five single-lane ones in five basic blocks
+                const pcl_u32 val = lane == 0 ? w_n : (lane == 1 ? w_evt : (lane == 2 ? w_sx : (lane == 3 ? w_sy : w_sz)));
+                if (val) atomicAdd(&c[lane], val);
             }
         }
         int lane_end = lane;
@@ -1827,11 +1864,12 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi2
 // pcl_step_fused_multi takes this form for a launch that starts in that band.
 // 28 KB of LDS per workgroup and 89-90 VGPRs: FIVE waves per SIMD (the 256-photon forms' 37 KB allow four) -- same-box
 // -3.3 % on the form's block of the driver's command, six no better (profiles/r05_ab_occupancy.log).
+// (the variant with the saturation probe: its exp polynomial is off the hot path; the one without keeps 96-116 VGPRs: four waves)
 #ifndef PCL_MULTI3_ATTR
 #define PCL_MULTI3_ATTR __attribute__((amdgpu_waves_per_eu(5, 5)))
 #endif
 #if PCL_RTC_WANT(0, 0)
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3_e0(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e0(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, false, true, 1, 3>(a);
 }
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3s_e0(pcl_multi_args<double> a) {
@@ -1839,7 +1877,7 @@ extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3
 }
 #endif
 #if PCL_RTC_WANT(0, 1)
-extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3_e1(pcl_multi_args<double> a) {
+extern "C" __global__ void __launch_bounds__(256) PCL_MULTI2_ATTR pcl_rtc_multi3_e1(pcl_multi_args<double> a) {
     pcl_multi_body_lds<double, true, true, 1, 3>(a);
 }
 extern "C" __global__ void __launch_bounds__(256) PCL_MULTI3_ATTR pcl_rtc_multi3s_e1(pcl_multi_args<double> a) {
