@@ -1374,14 +1374,28 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 Rr[0][e] = R::add(Rr[0][e], d[0][e]);
                 Rr[1][e] = R::add(Rr[1][e], d[1][e]);
                 Rr[2][e] = R::add(Rr[2][e], d[2][e]);
-                if (new_block) { // decision block of the launch pair (st & ~1, st | 1): computed once for both
+            }
+            // the rows' draws side by side in ONE basic block (a Philox chain is ten dependent rounds; the uniform select of the
+            // block's half stays outside the chains: pcl_multi_body_lds)
+            if (new_block && (st & 1u) == 0u) { // decision block of the launch pair (st, st | 1): computed once for both
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
-                    rand[e] = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    rand[e] = R::uniform(w.x, w.y);
                     wodd0[e] = w.z;
                     wodd1[e] = w.w;
-                } else {
-                    rand[e] = R::uniform(wodd0[e], wodd1[e]);
                 }
+            } else if (new_block) { // a launch that starts on an odd index: the second half of the block of (st - 1, st)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
+                    rand[e] = R::uniform(w.z, w.w);
+                    wodd0[e] = w.z;
+                    wodd1[e] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) rand[e] = R::uniform(wodd0[e], wodd1[e]);
             }
             pcl_u32 w_evt = 0; // hits (isotropic phase) or removals (delete phase) of this wave
             if (is_del) {
@@ -1580,14 +1594,28 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 Rr[0][e] = R::add(Rr[0][e], d[0][e]);
                 Rr[1][e] = R::add(Rr[1][e], d[1][e]);
                 Rr[2][e] = R::add(Rr[2][e], d[2][e]);
-                if (new_block) { // decision block of the launch pair (st & ~1, st | 1): computed once for both
+            }
+            // the rows' draws side by side in ONE basic block (a Philox chain is ten dependent rounds; the uniform select of the
+            // block's half stays outside the chains: pcl_multi_body_lds)
+            if (new_block && (st & 1u) == 0u) { // decision block of the launch pair (st, st | 1): computed once for both
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
-                    rand[e] = (st & 1u) ? R::uniform(w.z, w.w) : R::uniform(w.x, w.y);
+                    rand[e] = R::uniform(w.x, w.y);
                     wodd0[e] = w.z;
                     wodd1[e] = w.w;
-                } else {
-                    rand[e] = R::uniform(wodd0[e], wodd1[e]);
                 }
+            } else if (new_block) { // a launch that starts on an odd index: the second half of the block of (st - 1, st)
+#pragma unroll
+                for (int e = 0; e < NE; ++e) {
+                    const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
+                    rand[e] = R::uniform(w.z, w.w);
+                    wodd0[e] = w.z;
+                    wodd1[e] = w.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < NE; ++e) rand[e] = R::uniform(wodd0[e], wodd1[e]);
             }
             pcl_u32 w_evt = 0; // hits (isotropic phase) or removals (delete phase) of this wave
             pcl_u32 wbase = qbase;
