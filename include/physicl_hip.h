@@ -446,6 +446,25 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
                          int flags, double c, double h, const char *n_expr, double A_del, double n_del, uint64_t seed,
                          uint32_t step0, const double *planes_host, int n_planes, int64_t *out_host);
 
+/* TracePathMeasureStep.run for a tracked subset (physicl/light.py:447-458), worked out AHEAD of the K-pass launch that
+ * will move the store: the positions the particles with the ids ``ids_host`` (strictly ascending, n_ids <= PCL_TRACE_MAX)
+ * will have when the trace step runs in each of the next k_passes passes of a loop whose body holds the phases
+ * ``phase_kinds_host`` -- the same description of the loop, with the same constants, seed and step0, that is about to be
+ * handed to pcl_step_fused_multi (n_phases = 1, ISOTROPIC), pcl_step_fused_delete_multi (n_phases = 1, DELETE) or
+ * pcl_step_mixed_multi.  ``record_phase``: the trace step sits behind that phase's light step (and its counting measures)
+ * in the pass.  A photon's history is a pure function of its own state and of (seed, launch index, id) -- photons do not
+ * interact, the device random stream is keyed by the id -- so one thread per TRACKED photon runs the per-photon
+ * operations of the K-step kernels on the store as it stands and writes one row per pass; the store is NOT changed, and the
+ * K-step kernels (bound by VALU issue) carry nothing for the trace.  Bit-identical to downloading r after every pass.
+ * Works on any store (explicit ids after compactions, plain Objects, behind an alive mask, either dtype).
+ * out_host: double[k_passes][n_ids][4] = { r0, r1, r2, moved } -- moved = 1 if the particle's dv is not the zero vector
+ * at that point (trace_dv, light.py:456) else 0; four NaNs where the particle is not in the store at that point (removed
+ * by a delete phase, or never there: the reference traces 'nan;nan;nan', light.py:435).  Device RNG only.  Synchronises. */
+#define PCL_TRACE_MAX 65536
+int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, double dt, int k_passes, int n_phases,
+                          const int *phase_kinds_host, int record_phase, double A, double n, int flags, double c, double h,
+                          const char *n_expr, double A_del, double n_del, uint64_t seed, uint32_t step0, double *out_host);
+
 /* The int32 flag array of the most recent pcl_step_scatter_delete / pcl_step_fused_delete, in PRE-compaction order
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */
 int pcl_store_last_delete_flags(pcl_ctx *ctx, int32_t *flags_host, int64_t n);

@@ -582,7 +582,7 @@ class Simulation(threading.Thread):
                     group.append(steps[j])
                     j += 1
                 n_planes = 0
-                while j < len(steps) and getattr(steps[j], "_fuse_role", None) == "measure" and \
+                while j < len(steps) and getattr(steps[j], "_fuse_role", None) in ("measure", "trace") and \
                         n_planes + steps[j]._n_planes() <= _MAX_PLANES:
                     n_planes += steps[j]._n_planes()
                     group.append(steps[j])
@@ -645,12 +645,22 @@ class Simulation(threading.Thread):
                 return False
             roles = [s._fuse_role for s in group]
             if roles[0] != "newton" or len(roles) < 2 or roles[1] not in ("scatter_iso", "scatter_delete") or \
-                    any(r != "measure" for r in roles[2:]) or roles[1] in seen:
+                    any(r not in ("measure", "trace") for r in roles[2:]) or roles[1] in seen:
                 return False
             seen.append(roles[1])
         if sum(m._n_planes() for _, group in plan[1:] for m in group[2:]) > self._hip.MAX_PLANES:
             return False
-        return self._rng_mode() == self._hip.RNG_PHILOX
+        if self._rng_mode() != self._hip.RNG_PHILOX:
+            return False
+        # a TracePathMeasureStep in the loop: its tracked subset is worked out on the device ahead of every launch
+        # (pcl_store_trace_ahead) -- or, if it cannot be (it asks for more particles than that takes), the loop runs one
+        # launch per light step with the step as a host plugin
+        tracers = [m for _, group in plan[1:] for m in group[2:] if m._fuse_role == "trace"]
+        if tracers:
+            self._to_device()
+            if any(m._ahead_set(self) is None for m in tracers):
+                return False
+        return True
 
     def _k_wanted(self):
         k = self.steps_per_launch
@@ -776,6 +786,13 @@ class Simulation(threading.Thread):
                 dl = s._kernel_consts()
         step0 = self._launch + 1
         self._launch += k * P
+        # TracePathMeasureStep: where its tracked particles will be behind its group's light step in each of the k passes --
+        # worked out from the store as it stands, BEFORE the launch that moves it (same constants, same launch indices)
+        traced = []
+        for j, g in enumerate(groups):
+            for m in g[2:]:
+                if m._fuse_role == "trace":
+                    traced.append((m, dev.trace_ahead(m._ahead_set(self), dt0, k, phases, j, sc, dl, self.seed, step0)))
         # raw rows from the library: one per light step per pass, columns [N, sign x 3, planes ..., hits | removed]
         if phases == ["iso"] and dev.is_uniform():
             sc.update(rng_mode=hip.RNG_PHILOX, seed=self.seed, step=step0)
@@ -819,10 +836,14 @@ class Simulation(threading.Thread):
                     self._alive, lights[j].removed = int(last[0]), int(last[1])
                 at = 5 + span[j][0]
                 for m in g[2:]:
+                    if m._fuse_role == "trace":
+                        continue
                     n_m = m._n_planes()
                     m._record_rows(self, [times[i][0] for i in range(lo, upto)], glob[lo * P + j:upto * P:P, 0],
                                    glob[lo * P + j:upto * P:P, 2:5], glob[lo * P + j:upto * P:P, at:at + n_m])
                     at += n_m
+            for m, rows in traced:
+                m._ahead_record(self, [times[i][0] for i in range(lo, upto)], rows[lo:upto])
             done[0] = upto
 
         keep = k
@@ -845,13 +866,37 @@ class Simulation(threading.Thread):
         scatter = next((s for s in group if s._fuse_role == "scatter_iso"), None)
         delete = next((s for s in group if s._fuse_role == "scatter_delete"), None)
         measures = [s for s in group if s._fuse_role == "measure"]
+        tracers = [s for s in group if s._fuse_role == "trace"]
         planes = [p for m in measures for p in m._plane_rows()]
+
+        def trace_ahead(phase, sc_, dl_, step):
+            """The tracers of this group, before the launch: on the device where that works (a light step in the group, device
+            RNG), the others run as host plugins behind it."""
+            ahead = []
+            for m in tracers:
+                ids = m._ahead_set(self) if phase is not None and self._rng_mode() == hip.RNG_PHILOX else None
+                ahead.append((m, None if ids is None else dev.trace_ahead(ids, self._dt_code(), 1, [phase], 0, sc_, dl_, self.seed, step)))
+            return ahead
+
+        def trace_file(ahead):
+            for m, rows in ahead:
+                if rows is not None:
+                    m._ahead_record(self, [self.t], rows)
+                else:
+                    self._readonly_scope = True
+                    try:
+                        m.run(self)
+                    finally:
+                        self._readonly_scope = False
+
         if delete is not None:
             mode = self._rng_mode()
             if mode == hip.RNG_INPUT:
                 self._host_randoms("delete")
             A_k, n_k = delete._kernel_consts()
-            out = dev.step_fused_delete(self._dt_code(), A_k, n_k, mode, self.seed, self._next_launch(),
+            step = self._next_launch()
+            ahead = trace_ahead("delete", None, (A_k, n_k), step)
+            out = dev.step_fused_delete(self._dt_code(), A_k, n_k, mode, self.seed, step,
                                         planes if measures else None, lazy=True)
             self.schedule["fused_delete"] += 1
             g = self._global(np.concatenate([[out["N"], out["removed"]], out["sign"], out["planes"]]))
@@ -861,14 +906,19 @@ class Simulation(threading.Thread):
                 npl = m._n_planes()
                 m._record(self, int(g[0]), g[2:5], g[k:k + npl])
                 k += npl
+            trace_file(ahead)
             return
         sc = None
+        ahead = []
         if scatter is not None:
             sc = scatter._kernel_params(self)
             sc.update(rng_mode=self._rng_mode(), seed=self.seed, step=self._next_launch())
             if sc["rng_mode"] == hip.RNG_INPUT:
                 self._host_randoms("iso")
             self._scattered = True
+            ahead = trace_ahead("iso", sc, None, sc["step"])
+        else:
+            ahead = trace_ahead(None, None, None, 0)
         # dr/dv stay implicit unless something after this pass looks at them (the store materialises on demand)
         out = dev.step_fused(self._dt_code(), sc, planes if (measures or scatter) else None, sync=True, lazy=True)
         self.schedule["fused"] += 1
@@ -881,6 +931,7 @@ class Simulation(threading.Thread):
                 npl = m._n_planes()
                 m._record(self, int(glob[0]), glob[1:4], glob[k:k + npl])
                 k += npl
+        trace_file(ahead)
 
     def run(self):
         # HIP's current device is per thread and a thread's first HIP call sets its runtime state up (tenths of a millisecond):

@@ -1730,6 +1730,126 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
         if (s_cnt[k]) atomicAdd(&a.cnt[k], (pcl_u64)s_cnt[k]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// TracePathMeasureStep for a tracked subset (physicl/light.py:447-458), worked out AHEAD of the K-pass launch that will
+// move the store.  A photon's history over the next K passes is a pure function of its own state and of (seed, launch
+// index, id): photons do not interact and the random stream is keyed by the id.  So the positions the tracked photons
+// will have after every pass need not be written by the K-step kernels (which are bound by VALU issue and keep no
+// register to spare): one thread per TRACKED photon reads its state from the store as it stands, runs the same per-photon
+// operations the K-step kernels will run -- Newton (newton.py:15-16), the isotropic decision and re-direction
+// (light.py:303-315) and/or the delete decision (light.py:239-249), launch index step + pass * P + phase -- and writes
+// one row per pass; the store is not touched.  Same operations on the same operands in the same order as
+// pcl_fast_body / pcl_multi_body_lds / pcl_mixed_body: the rows are bit-identical to what a download after each pass
+// would show (tests/test_gpu_trace.py checks exactly that, and the last row against the store after the launch).
+//   out[(pass * n_want + j) * 4 + {0, 1, 2}] = r of tracked photon j when the trace step of that pass runs (behind phase
+//   ``record_phase``), NaN when it is not in the store then (removed, or never there);  [.. + 3] = 1 if its dv is not
+//   the zero vector at that point (TracePathMeasureStep(trace_dv=True), light.py:456), else 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct pcl_trace_args {
+    const T *r0, *r1, *r2;
+    const T *v0, *v1, *v2;
+    const T *p0, *p1, *p2;     // the vprev rows: dv_mode 1 = the photons' dv is implicit, v - vprev (plain Objects keep real dv rows)
+    const T *q0, *q1, *q2;     // the dv rows: dv_mode 2 = everybody's dv is there; dv_mode 0 = every dv is known to be the zero vector
+    const T *lam4;             // pow((h*c)/E, -4) per photon            (USE_E)
+    const T *E;
+    const pcl_i64 *ids;        // explicit ids of the store's slots, NULL: id = id_base + slot
+    const unsigned char *kind; // NULL: every particle is a photon
+    const pcl_u64 *alive;      // a store behind an alive mask: one bit per slot; NULL: every slot holds a particle
+    const pcl_i64 *want;       // [n_want] the tracked ids, ascending
+    const pcl_i64 *slot;       // [n_want] where each of them is in the store (-1: nowhere); NULL: slot = id - id_base
+    double *out;               // [K][n_want][4]
+    pcl_i64 id_base, N, ts;    // N = the store's extent in slots
+    int n_want;
+    T dt, A, n, c;             // isotropic phase: kernel constants after the reference's swap (light.py:287)
+    T An_del;                  // delete phase: A * n rounded once (light.py:243)
+    pcl_u64 seed;
+    pcl_u32 step;              // launch index of the first phase
+    int K, P;                  // passes, phases per pass
+    int phase_del[PCL_MIXED_MAXPH];
+    int record_phase;          // the trace step runs behind this phase of every pass
+    int dv_mode;
+    int n_pend;                // Newton moves r has not seen yet (stores behind an alive mask, pcl_fast_args)
+    T pend_dt[PCL_PEND_MAX];
+    int pend_rep[PCL_PEND_MAX];
+    pcl_nprof<T> np;           // ahead-of-time VAR_N kernels only
+};
+
+template <typename T, bool USE_E, int VAR_N>
+__device__ __forceinline__ void pcl_trace_body(const pcl_trace_args<T> &a) {
+    typedef pcl_rt<T> R;
+    const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (j >= a.n_want) return;
+    const double nan = __builtin_nan("");
+    const pcl_u64 id = (pcl_u64)a.want[j];
+    const pcl_i64 s = a.slot ? a.slot[j] : (pcl_i64)id - a.id_base;
+    bool here = s >= 0 && s < a.N;
+    if (here && a.alive) here = (a.alive[s >> 6] >> (s & 63)) & 1ull;
+    int k = 0;
+    if (here) {
+        const pcl_u32 k0 = (pcl_u32)a.seed, k1 = (pcl_u32)(a.seed >> 32);
+        const pcl_i64 ti = pcl_tix(s, a.ts);
+        T r[3] = {a.r0[ti], a.r1[ti], a.r2[ti]}, v[3] = {a.v0[ti], a.v1[ti], a.v2[ti]};
+        const T Ev = a.E[ti];
+        T L4 = (T)1;
+        if constexpr (USE_E) L4 = a.lam4[ti];
+        const bool photon = a.kind ? (a.kind[s] != 0) : true;
+        bool moved = false; // is dv anything but the zero vector?
+        if (a.dv_mode == 1 && photon) moved = R::sub(v[0], a.p0[ti]) != (T)0 || R::sub(v[1], a.p1[ti]) != (T)0 || R::sub(v[2], a.p2[ti]) != (T)0;
+        else if (a.dv_mode != 0) moved = a.q0[ti] != (T)0 || a.q1[ti] != (T)0 || a.q2[ti] != (T)0;
+        for (int p = 0; p < a.n_pend; ++p) { // moves of earlier delete bodies that r has not seen yet (pcl_fast_body)
+            const T m0 = R::mul(v[0], a.pend_dt[p]), m1 = R::mul(v[1], a.pend_dt[p]), m2 = R::mul(v[2], a.pend_dt[p]);
+            for (int w = 0; w < a.pend_rep[p]; ++w) {
+                r[0] = R::add(r[0], m0);
+                r[1] = R::add(r[1], m1);
+                r[2] = R::add(r[2], m2);
+            }
+        }
+        for (; k < a.K && here; ++k) {
+            for (int ph = 0; ph < a.P; ++ph) {
+                const pcl_u32 st = a.step + (pcl_u32)(k * a.P + ph);
+                // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
+                const T d0 = R::mul(v[0], a.dt), d1 = R::mul(v[1], a.dt), d2 = R::mul(v[2], a.dt);
+                r[0] = R::add(r[0], d0);
+                r[1] = R::add(r[1], d1);
+                r[2] = R::add(r[2], d2);
+                if (photon && here) {
+                    const T rand = pcl_draw_rand<T>(id, st, k0, k1);
+                    if (a.phase_del[ph]) {
+                        // ScatterDeleteStep: flag = (A*n*norm >= rand), flagged photons leave the list      light.py:239-260
+                        if (R::mul(a.An_del, pcl_step_norm<T>(d0, d1, d2)) >= rand) here = false;
+                    } else {
+                        // ScatterIsotropicStep                                                              light.py:303-331
+                        T pc = pcl_pcoll<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, d0, d1, d2, r[0], r[1], r[2], Ev);
+                        if constexpr (USE_E) pc = R::mul(pc, L4);
+                        moved = false; // a miss leaves dv = 0                                               light.py:330-331
+                        if (pc >= rand) {
+                            T rtheta, rphi, n0, n1, n2;
+                            pcl_draw_angles<T>(id, st, k0, k1, rtheta, rphi);
+                            pcl_new_velocity<T, true>(a.c, rtheta, rphi, n0, n1, n2);
+                            moved = R::sub(n0, v[0]) != (T)0 || R::sub(n1, v[1]) != (T)0 || R::sub(n2, v[2]) != (T)0;
+                            v[0] = n0;
+                            v[1] = n1;
+                            v[2] = n2;
+                        }
+                    }
+                }
+                if (ph == a.record_phase) {
+                    double *o = a.out + ((pcl_i64)k * a.n_want + j) * 4;
+                    o[0] = here ? (double)r[0] : nan;
+                    o[1] = here ? (double)r[1] : nan;
+                    o[2] = here ? (double)r[2] : nan;
+                    o[3] = here ? (moved ? 1.0 : 0.0) : nan;
+                }
+            }
+        }
+    }
+    for (; k < a.K; ++k) { // not in the store (any more): "nan;nan;nan"                                      light.py:435
+        double *o = a.out + ((pcl_i64)k * a.n_want + j) * 4;
+        o[0] = o[1] = o[2] = o[3] = nan;
+    }
+}
+
 #ifdef PCL_RTC
 // hipRTC translation unit: one expression; both wavelength variants of every kernel, fp64 and fp32.
 #define PCL_RTC_KERNEL(name, argtype, call) \
@@ -1812,6 +1932,19 @@ PCL_RTC_KERNEL(pcl_rtc_mixed_f_e0, pcl_mixed_args<float>, (pcl_mixed_body<float,
 #endif
 #if PCL_RTC_WANT(1, 1)
 PCL_RTC_KERNEL(pcl_rtc_mixed_f_e1, pcl_mixed_args<float>, (pcl_mixed_body<float, true, true>))
+#endif
+// the tracked subset's positions over the passes of the next K-pass launch (pcl_trace_body)
+#if PCL_RTC_WANT(0, 0)
+PCL_RTC_KERNEL(pcl_rtc_trace_e0, pcl_trace_args<double>, (pcl_trace_body<double, false, true>))
+#endif
+#if PCL_RTC_WANT(0, 1)
+PCL_RTC_KERNEL(pcl_rtc_trace_e1, pcl_trace_args<double>, (pcl_trace_body<double, true, true>))
+#endif
+#if PCL_RTC_WANT(1, 0)
+PCL_RTC_KERNEL(pcl_rtc_trace_f_e0, pcl_trace_args<float>, (pcl_trace_body<float, false, true>))
+#endif
+#if PCL_RTC_WANT(1, 1)
+PCL_RTC_KERNEL(pcl_rtc_trace_f_e1, pcl_trace_args<float>, (pcl_trace_body<float, true, true>))
 #endif
 // three rows of 64 particles per wave and trip, velocities in LDS (pcl_mixed_body_lds): what a loop with a variable_n_fn takes once
 // a launch has shown its hit fraction to be below 0.33 (step_mixed_t)

@@ -274,6 +274,31 @@ __global__ void __launch_bounds__(kBlock, 4) k_mixed3(pcl_mixed_args<T> a) {
     pcl_mixed_body_lds<T, USE_E, 0, 3>(a);
 }
 
+// the tracked subset's positions over the passes of the next K-pass launch (pcl_trace_body): one thread per tracked photon
+template <typename T, bool USE_E, int VAR_N>
+__global__ void __launch_bounds__(kBlock) k_trace(pcl_trace_args<T> a) {
+    pcl_trace_body<T, USE_E, VAR_N>(a);
+}
+
+// where are the tracked ids in a store whose ids are explicit (it has been compacted, or was uploaded with ids)?  One sweep
+// over the id row: a slot whose id is in ``want`` (ascending) writes itself into slot_out (preset to -1).  8 B per slot.
+__global__ void __launch_bounds__(kBlock) k_trace_slots(const int64_t *__restrict__ ids, int64_t N, const int64_t *__restrict__ want,
+                                                        int n_want, int64_t *__restrict__ slot_out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t lo_id = want[0], hi_id = want[n_want - 1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        const int64_t id = ids[i];
+        if (id < lo_id || id > hi_id) continue;
+        int lo = 0, hi = n_want - 1;
+        while (lo < hi) { // first element >= id
+            const int mid = (lo + hi) >> 1;
+            if (want[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        if (want[lo] == id) slot_out[lo] = i;
+    }
+}
+
 // The variable-n shape is an argument of the ahead-of-time kernels, so a body compiled once carries all three expressions and
 // the axis select through its loops: the K-step pass ran 11 % slower than its hipRTC specialisation for that alone (1.60e11
 // against 1.78e11; with one literal shape: 1.78e11).  The arithmetic-heavy kernels therefore exist once more for each of the
@@ -2853,6 +2878,7 @@ struct rtc_entry {
     hipFunction_t fastg[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     hipFunction_t mixed3[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; // three rows per wave and trip, velocities in LDS
+    hipFunction_t trace[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // the tracked subset's positions, ahead of a K-pass launch
     hipFunction_t multi2[2] = {nullptr, nullptr}; // two groups per lane and trip (256 photons per wave), fp64: low hit fractions
     hipFunction_t multis[2] = {nullptr, nullptr}; // the 128-photon instantiation (PCL_MULTI_NQ2=0) with the saturation probe (pcl_n_expr_sat), fp64
     hipFunction_t multi2s[2] = {nullptr, nullptr}; // 256 photons per wave with the probe
@@ -2979,6 +3005,11 @@ struct pcl_ctx {
     uint64_t *d_multi = nullptr, *h_multi = nullptr; // kMultiSlots counters of a K-step pass
     void *e_out = nullptr;                           // dense gather buffer of pcl_step_plane_energies
     int64_t e_out_cap = 0;
+    // pcl_store_trace_ahead: the tracked ids (host copy + device), their slots, the rows
+    std::vector<int64_t> trace_ids;
+    int64_t *trace_want = nullptr, *trace_slot = nullptr;
+    double *trace_out = nullptr;
+    int64_t trace_want_cap = 0, trace_out_cap = 0;
     uint64_t *d_bank[2] = {nullptr, nullptr};
     uint64_t *h_bank[2] = {nullptr, nullptr};
     hipEvent_t bank_ev[2] = {nullptr, nullptr};
@@ -4209,6 +4240,8 @@ int load_rtc_into(const std::vector<char> &code, rtc_entry &ent) {
             get(&ent.mixed[d][e], nm);
             snprintf(nm, sizeof nm, "pcl_rtc_mixed3_%se%d", dt_tag[d], e);
             if (hipModuleGetFunction(&ent.mixed3[d][e], ent.module, nm) != hipSuccess) ent.mixed3[d][e] = nullptr;
+            snprintf(nm, sizeof nm, "pcl_rtc_trace_%se%d", dt_tag[d], e);
+            get(&ent.trace[d][e], nm);
         }
     for (int e = 0; e < 2; ++e) { // fp64 modules only
         char nm[64];
@@ -5523,6 +5556,60 @@ int fused_delete_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double 
     return launch_compact_count<T>(ctx, false, dv_mode, cc);
 }
 
+// the tracked subset's positions over the next K passes (pcl_trace_body), from the store as it stands
+template <typename T>
+int trace_ahead_t(pcl_ctx *ctx, int n_ids, double dt, int k_passes, int n_phases, const int *phase_del, int record_phase, double A,
+                  double n, bool use_e, bool var_n, rtc_entry *ent, double c, double h, double A_del, double n_del, uint64_t seed,
+                  uint32_t step0) {
+    if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
+    pcl_trace_args<T> f{};
+    f.r0 = F<T>(ctx, PCL_R0); f.r1 = F<T>(ctx, PCL_R1); f.r2 = F<T>(ctx, PCL_R2);
+    f.v0 = F<T>(ctx, PCL_V0); f.v1 = F<T>(ctx, PCL_V1); f.v2 = F<T>(ctx, PCL_V2);
+    f.p0 = static_cast<const T *>(ctx->vprev[0]); f.p1 = static_cast<const T *>(ctx->vprev[1]); f.p2 = static_cast<const T *>(ctx->vprev[2]);
+    f.q0 = F<T>(ctx, PCL_DV0); f.q1 = F<T>(ctx, PCL_DV1); f.q2 = F<T>(ctx, PCL_DV2);
+    f.dv_mode = ctx->lazy_dv ? 1 : (ctx->dv_zero == 1 ? 0 : 2);
+    f.lam4 = static_cast<const T *>(ctx->lam4);
+    f.E = F<T>(ctx, PCL_E);
+    f.ids = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->ids);
+    f.kind = ctx->kind;
+    f.want = reinterpret_cast<const pcl_i64 *>(ctx->trace_want);
+    f.slot = ctx->ids_iota ? nullptr : reinterpret_cast<const pcl_i64 *>(ctx->trace_slot);
+    f.out = ctx->trace_out;
+    f.id_base = ctx->id_base;
+    f.N = ctx->holes ? ctx->slots : ctx->count;
+    f.ts = tile_stride(ctx);
+    f.n_want = n_ids;
+    f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
+    f.An_del = (T)A_del * (T)n_del; // one IEEE multiply in the store's precision == the kernels' (A * n)
+    f.seed = seed;
+    f.step = step0;
+    f.K = k_passes;
+    f.P = n_phases;
+    for (int j = 0; j < PCL_MIXED_MAXPH; ++j) f.phase_del[j] = j < n_phases ? phase_del[j] : 0;
+    f.record_phase = record_phase;
+    if (ctx->holes) { // the store keeps removed photons' slots: the alive bits, and the moves r has not seen yet
+        f.alive = reinterpret_cast<const pcl_u64 *>(ctx->masks);
+        f.n_pend = ctx->pend_n;
+        for (int q = 0; q < ctx->pend_n; ++q) f.pend_dt[q] = (T)ctx->pend_dt[q], f.pend_rep[q] = ctx->pend_rep[q];
+    }
+    if (f.slot) { // explicit ids: one sweep over the id row finds the tracked photons' slots
+        PCL_HIP(hipMemsetAsync(ctx->trace_slot, 0xFF, (size_t)n_ids * sizeof(int64_t), ctx->stream));
+        hipLaunchKernelGGL(k_trace_slots, dim3(grid_for(ctx, f.N, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->ids, f.N, ctx->trace_want,
+                           n_ids, ctx->trace_slot);
+        PCL_TRY(launch_check("k_trace_slots"));
+    }
+    const int grid = (int)div_up(n_ids, kBlock);
+    const int d = sizeof(T) == 8 ? 0 : 1;
+    set_np(f.np, ent);
+    if (var_n && ent->module && ent->trace[d][use_e ? 1 : 0]) {
+        PCL_TRY(launch_module(ctx, ent->trace[d][use_e ? 1 : 0], grid, f, "trace_ahead (hipRTC)"));
+    } else {
+        PCL_AOT_LAUNCH(k_trace, T, use_e, var_n, grid, f);
+        PCL_TRY(launch_check("k_trace"));
+    }
+    return PCL_OK;
+}
+
 // K passes of a loop with an isotropic-scatter phase and/or a delete phase (pcl_mixed_body): the pass itself.
 template <typename T>
 int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int *phase_del, double A, double n, bool use_e,
@@ -6204,6 +6291,11 @@ int pcl_store_free(pcl_ctx *ctx) {
     dev_free(ctx->slab_alt);
     dev_free(ctx->e_out);
     ctx->e_out_cap = 0;
+    dev_free(ctx->trace_want);
+    dev_free(ctx->trace_slot);
+    dev_free(ctx->trace_out);
+    ctx->trace_want_cap = ctx->trace_out_cap = 0;
+    ctx->trace_ids.clear();
     ctx->tiles = 0;
     refresh_rows(ctx); // all row addresses -> NULL
     ctx->lazy_dr = ctx->lazy_dv = false;
@@ -7066,6 +7158,66 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
             for (int j = 0; j < 3 + np; ++j) o[1 + j] = (int64_t)cr[2 + j];
             o[4 + np] = (int64_t)cr[1];
         }
+    return PCL_OK;
+}
+
+int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, double dt, int k_passes, int n_phases,
+                          const int *phase_kinds_host, int record_phase, double A, double n, int flags, double c, double h,
+                          const char *n_expr, double A_del, double n_del, uint64_t seed, uint32_t step0, double *out_host) {
+    PCL_TRY(need_store_raw(ctx)); // (bodies worked out ahead of their calls are committed: the trace starts from the state they left)
+    if (flags & ~(PCL_SCATTER_WAVELENGTH | PCL_SCATTER_VARIABLE_N)) return fail(PCL_ERR_ARG, "unknown flag bits");
+    if (n_phases < 1 || n_phases > PCL_MIXED_MAXPH || !phase_kinds_host)
+        return fail(PCL_ERR_ARG, "n_phases outside [1, %d]", PCL_MIXED_MAXPH);
+    if (k_passes < 1 || k_passes * n_phases > PCL_MULTI_MAX)
+        return fail(PCL_ERR_ARG, "k_passes * n_phases outside [1, %d]", PCL_MULTI_MAX);
+    if (record_phase < 0 || record_phase >= n_phases) return fail(PCL_ERR_ARG, "record_phase outside [0, n_phases)");
+    if (n_ids < 0 || n_ids > PCL_TRACE_MAX) return fail(PCL_ERR_ARG, "n_ids outside [0, %d]", PCL_TRACE_MAX);
+    if (n_ids > 0 && (!ids_host || !out_host)) return fail(PCL_ERR_ARG, "ids_host / out_host is NULL");
+    int phase_del[PCL_MIXED_MAXPH] = {0, 0};
+    bool has_iso = false;
+    for (int j = 0; j < n_phases; ++j) {
+        if (phase_kinds_host[j] != PCL_PHASE_ISOTROPIC && phase_kinds_host[j] != PCL_PHASE_DELETE)
+            return fail(PCL_ERR_ARG, "unknown phase kind %d", phase_kinds_host[j]);
+        phase_del[j] = phase_kinds_host[j] == PCL_PHASE_DELETE;
+        has_iso = has_iso || !phase_del[j];
+    }
+    for (int j = 1; j < n_ids; ++j)
+        if (ids_host[j] <= ids_host[j - 1]) return fail(PCL_ERR_ARG, "ids_host must be strictly ascending");
+    const bool use_e = has_iso && (flags & PCL_SCATTER_WAVELENGTH), var_n = has_iso && (flags & PCL_SCATTER_VARIABLE_N);
+    rtc_entry *ent = nullptr;
+    if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
+    if (n_ids == 0) return PCL_OK;
+    // the tracked ids go over once per set, not once per launch
+    if (ctx->trace_want_cap < n_ids) {
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->trace_want);
+        dev_free(ctx->trace_slot);
+        ctx->trace_want_cap = 0;
+        ctx->trace_ids.clear();
+        PCL_TRY(dev_alloc(&ctx->trace_want, n_ids));
+        PCL_TRY(dev_alloc(&ctx->trace_slot, n_ids));
+        ctx->trace_want_cap = n_ids;
+    }
+    if ((int64_t)ctx->trace_ids.size() != n_ids || memcmp(ctx->trace_ids.data(), ids_host, (size_t)n_ids * sizeof(int64_t)) != 0) {
+        PCL_HIP(hipStreamSynchronize(ctx->stream)); // (an earlier trace may still be reading the old set)
+        ctx->trace_ids.assign(ids_host, ids_host + n_ids);
+        PCL_HIP(hipMemcpyAsync(ctx->trace_want, ctx->trace_ids.data(), (size_t)n_ids * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const int64_t n_out = (int64_t)k_passes * n_ids * 4;
+    if (ctx->trace_out_cap < n_out) {
+        PCL_HIP(hipStreamSynchronize(ctx->stream));
+        dev_free(ctx->trace_out);
+        ctx->trace_out_cap = 0;
+        PCL_TRY(dev_alloc(&ctx->trace_out, n_out));
+        ctx->trace_out_cap = n_out;
+    }
+    PCL_TRY(PCL_DISPATCH(ctx,
+                         trace_ahead_t<double>(ctx, n_ids, dt, k_passes, n_phases, phase_del, record_phase, A, n, use_e, var_n, ent, c, h,
+                                               A_del, n_del, seed, step0),
+                         trace_ahead_t<float>(ctx, n_ids, dt, k_passes, n_phases, phase_del, record_phase, A, n, use_e, var_n, ent, c, h,
+                                              A_del, n_del, seed, step0)));
+    PCL_HIP(hipMemcpyAsync(out_host, ctx->trace_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCL_TRY(stream_wait(ctx));
     return PCL_OK;
 }
 

@@ -342,21 +342,118 @@ class ScatterSignMeasureStep(_CountingMeasure):
         return ([n] if self.measure_n else []) + [sign[:, k] for k in range(3)]
 
 
-class TracePathMeasureStep(MeasureStep):
-    """Records every object's position at every step (physicl/light.py:433-483): O(N*T) host memory, a
-    diagnostic for small N.  Host plugin.  The first time an object is seen it is looked at as a Python object
-    (``id_info_fn(obj)``, exactly as in the reference); after that, while the particles live on the device, a step
-    costs three array downloads (ids, r, dv) instead of rebuilding every Python object: the positions are filed
-    under the objects' trace ids when the table is built."""
-    _reads_only = True
+_DEFAULT_ID_INFO = lambda x: str(type(x))      # noqa: E731 -- the reference's default (light.py:438), recognised by identity
 
-    def __init__(self, out_fn, trace_type=Object, id_info_fn=lambda x: str(type(x)), trace_dv=False):
+
+class TracePathMeasureStep(MeasureStep):
+    """Records objects' positions at every step (physicl/light.py:433-483).
+
+    Two ways of running:
+
+    * **tracked subset, on the device** -- when the step sits behind a light step in a fused group ([Newton][ScatterIsotropic |
+      ScatterDelete][measures / this step]) and the run uses the device RNG: the positions of the tracked particles over
+      the next launch's passes are worked out ahead of the launch by one thread per tracked particle
+      (``pcl_store_trace_ahead``; photons do not interact and their random streams are keyed by their ids, so a particle's
+      history is a function of its own state) -- nothing is downloaded per step, no Python object is built, the K-passes-
+      per-launch schedule stays, and it works for a ``PhotonBatch`` of 1e8 photons and for sharded runs.  Which particles:
+      ``trace_ids=[...]`` (ids = positions in the object list at upload, or photon numbers of a PhotonBatch), ``track=K``
+      (the first K), default: every object of an explicit-object run (up to 65536), the first 1000 photons of a
+      PhotonBatch.  The reference traces every object (O(N*T) host memory): with explicit objects that is the default here too.
+    * **host plugin** otherwise (host-drawn randoms, ``cl_on=False``, a step list that is not fused): the first time an
+      object is seen it is looked at as a Python object (``id_info_fn(obj)``, exactly as in the reference); after that, while
+      the particles live on the device, a step costs three array downloads (ids, r, dv)."""
+    _reads_only = True
+    _fuse_role = "trace"
+    MAX_TRACKED = 65536          # == PCL_TRACE_MAX (include/physicl_hip.h)
+
+    def __init__(self, out_fn, trace_type=Object, id_info_fn=_DEFAULT_ID_INFO, trace_dv=False, track=None, trace_ids=None):
         super().__init__(out_fn)
         self.trace_type, self.id_info_fn, self.trace_dv = trace_type, id_info_fn, trace_dv
+        self.track, self.trace_ids = track, trace_ids
         self.id_counter = 0
         self.id_dict, self.pos_dict = {}, {}
         self._tid_map, self._map_gen, self._log = None, None, []
+        self._ahead_ids, self._ahead_gen, self._ahead_log, self._ahead_tids = None, None, [], None
 
+    # fused-group protocol of the counting measures (core.Simulation._build_plan): no planes, no counter row
+    def _n_planes(self):
+        return 0
+
+    def _plane_rows(self):
+        return []
+
+    # ------------------------------------------------------------------ tracked subset, ahead of the launch
+    def _ahead_set(self, sim):
+        """The tracked ids (ascending int64) if this run can be traced on the device, else None."""
+        if sim._py_semantics() or sim._dev is None or sim._rng_mode() != sim._hip.RNG_PHILOX:
+            return None
+        if self._ahead_ids is not None and self._ahead_gen == sim._upload_gen:
+            return self._ahead_ids
+        if self._ahead_ids is not None:
+            self._flush_ahead(sim)                        # a new upload: file what the old population left
+        n_all = sim._batch.n if sim._batch is not None else len(sim._objects._items) if isinstance(sim._uploaded, list) else None
+        if n_all is None:
+            return None                                   # (a materialised batch that went back up: host plugin)
+        if self.trace_ids is not None:
+            ids = np.unique(np.asarray(self.trace_ids, dtype=np.int64))
+        else:
+            k = self.track if self.track is not None else (1000 if sim._batch is not None else n_all)
+            ids = np.arange(min(int(k), n_all), dtype=np.int64)
+        ids = ids[(ids >= 0) & (ids < n_all)]
+        if len(ids) > self.MAX_TRACKED:
+            if self.track is None and self.trace_ids is None:
+                return None                               # every object of a big explicit-object run: the host plugin, as before
+            raise ValueError("TracePathMeasureStep tracks at most %d particles on the device, %d asked for" % (self.MAX_TRACKED, len(ids)))
+        self._ahead_ids, self._ahead_gen = ids, sim._upload_gen
+        self._ahead_tids = None
+        return ids
+
+    def _ahead_record(self, sim, ts, rows):
+        """``rows`` = (len(ts), n_tracked, 4) of pcl_store_trace_ahead for the passes whose times are ``ts``."""
+        if self._ahead_tids is None:
+            self._ahead_tids = self._assign_tids(sim, ts[0])
+        self._ahead_log.append(np.array(rows[:len(ts)], dtype=np.float64))
+
+    def _assign_tids(self, sim, t0):
+        """First sight of the tracked particles (light.py:450-455): a trace id each, in object order, unless the object
+        already carries one (the host plugin saw it earlier, or an earlier upload of the same objects was traced)."""
+        explicit = sim._batch is None and isinstance(sim._uploaded, list)
+        tids = np.empty(len(self._ahead_ids), dtype=np.int64)
+        for j, i in enumerate(self._ahead_ids.tolist()):
+            obj = sim._objects._items[i] if explicit else None
+            tid = obj.__dict__.get("__trace_path_id") if explicit else (self._uid_tid or {}).get(i)
+            if tid is None:
+                tid = self.id_counter
+                self.id_counter += 1
+                if explicit:
+                    obj.__dict__["__trace_path_id"] = tid
+                    self.id_dict[tid] = self.id_info_fn(obj)
+                else:
+                    self.id_dict[tid] = str(PhotonObject) if self.id_info_fn is _DEFAULT_ID_INFO else self.id_info_fn(_batch_photon(sim, i))
+                self.pos_dict[tid] = {"start": _snap_t(t0), "pos": []}
+                if self.trace_dv:
+                    self.pos_dict[tid]["freq"] = 0
+            tids[j] = tid
+        return tids
+
+    def _flush_ahead(self, sim=None):
+        """File the device rows under the trace ids (a photon's list ends where it was removed)."""
+        if not self._ahead_log or self._ahead_tids is None:
+            self._ahead_log = []
+            return
+        rows = np.concatenate(self._ahead_log, axis=0)                        # (T, n, 4)
+        comm = getattr(sim, "comm", None) if sim is not None else None
+        if comm is not None and comm.world > 1:
+            rows = _merge_shards(comm, rows)
+        there = ~np.isnan(rows[:, :, 0])
+        for j, tid in enumerate(self._ahead_tids.tolist()):
+            n_there = int(there[:, j].sum())                                  # removal is for good: a prefix
+            self.pos_dict[tid]["pos"].extend(list(rows[:n_there, j, :3]))
+            if self.trace_dv:
+                self.pos_dict[tid]["freq"] += int((rows[:n_there, j, 3] != 0).sum())
+        self._ahead_log = []
+
+    # ------------------------------------------------------------------ host plugin
     def _device_rows(self, sim):
         """(trace ids, positions, moved flags) of the resident particles straight from the device, or None when some
         particle has not been seen as an object yet / the state is not on the device / the run is sharded."""
@@ -383,7 +480,8 @@ class TracePathMeasureStep(MeasureStep):
                     moved |= dev.download(f, n) != 0
         return tids, r, moved
 
-    def _flush(self):
+    def _flush(self, sim=None):
+        self._flush_ahead(sim)
         for tids, r, moved in self._log:
             for k, tid in enumerate(tids.tolist()):
                 self.pos_dict[tid]["pos"].append(r[k])
@@ -393,14 +491,23 @@ class TracePathMeasureStep(MeasureStep):
         self._log = []
 
     def run(self, sim):
+        if self._ahead_ids is not None:
+            # the tracked subset has been traced on the device so far: the objects the host plugin is about to walk carry
+            # those trace ids on (explicit objects; a PhotonBatch's photons are looked up by their uid)
+            self._flush(sim)
+            self._adopt_ahead(sim)
         rows = self._device_rows(sim)
         if rows is not None:
             self._log.append(rows)
             return
-        self._flush()
+        self._flush(sim)
         self._tid_map = None
         for obj in sim.objects:
             tid = obj.__dict__.get("__trace_path_id")
+            if tid is None and self._uid_tid:
+                tid = self._uid_tid.get(obj.__dict__.get("uid"))
+                if tid is not None:
+                    obj.__dict__["__trace_path_id"] = tid
             if tid is None:
                 tid = obj.__dict__["__trace_path_id"] = self.id_counter
                 self.id_dict[tid] = self.id_info_fn(obj)
@@ -412,9 +519,20 @@ class TracePathMeasureStep(MeasureStep):
             if self.trace_dv and np.any(np.asarray(obj.dv) != 0):
                 self.pos_dict[tid]["freq"] += 1
 
+    _uid_tid = None
+
+    def _adopt_ahead(self, sim):
+        """The run leaves the device-traced schedule (a host plugin joined, the objects were taken back, ...): from here on the
+        particles are walked as Python objects, which must find the trace ids the device rows were filed under -- explicit
+        objects carry them (_assign_tids), a PhotonBatch's photons are looked up by their uid."""
+        ids, tids = self._ahead_ids, self._ahead_tids
+        self._ahead_ids = self._ahead_gen = self._ahead_tids = None
+        if tids is not None and not (sim._batch is None and isinstance(sim._uploaded, list)):
+            self._uid_tid = dict(self._uid_tid or {}, **{int(i): int(t) for i, t in zip(ids, tids)})
+
     def terminate(self, sim):
         """data[0] = ["t", t0, t1, ...]; data[1+i] = [id info, (freq,) NaN-padded positions of object i]."""
-        self._flush()
+        self._flush(sim)
         cols = len(sim.ts)
         table = [["t"] + copy.deepcopy(sim.ts)]
         for i in range(len(self.id_dict)):
@@ -422,9 +540,35 @@ class TracePathMeasureStep(MeasureStep):
             if self.trace_dv:
                 row.append(self.pos_dict[i]["freq"])
             before = sim.ts.index(self.pos_dict[i]["start"])
-            after = cols - len(self.pos_dict[i]["pos"])
+            after = cols - len(self.pos_dict[i]["pos"])                      # (as the reference counts it, light.py:477)
             row.extend([np.nan, np.nan, np.nan] * before)
             row.extend(self.pos_dict[i]["pos"])
             row.extend([np.nan, np.nan, np.nan] * after)
             table.append(row)
         self.data = table
+
+
+def _snap_t(t):
+    return t if isinstance(t, (int, float, np.generic)) else copy.deepcopy(t)
+
+
+def _batch_photon(sim, i):
+    """Photon ``i`` of a PhotonBatch as generate_photons would have made it (physicl/light.py:126-128), for id_info_fn."""
+    # (the energy is looked up while the store still holds every photon at its own index; afterwards it is not known here)
+    E = sim._dev.download(sim._hip.E, 1, int(i)) if (sim.comm is None and sim._dev.is_uniform() and i < sim._dev.count) else np.nan
+    o = PhotonObject.__new__(PhotonObject)
+    Object.__init__(o, E=np.double(np.asarray(E).reshape(-1)[0]), v=Measurement._from_code([float(np.asarray(c)), 0, 0], units="m**1 s**-1"),
+                    uid=int(i))
+    return o
+
+
+def _merge_shards(comm, rows):
+    """Every rank traced the same ids and holds NaN rows for the particles of other shards: one int64 sum all-reduce of the
+    bit patterns (zeros where a rank has nothing) + of the "I have it" flags puts the table together on every rank."""
+    mine = ~np.isnan(rows[:, :, 0])
+    bits = np.where(mine[:, :, None], rows, 0.0).view(np.int64)
+    tot = comm.allreduce_sum(np.concatenate([bits.reshape(-1), mine.astype(np.int64).reshape(-1)]))
+    got = tot[:bits.size].reshape(rows.shape).view(np.float64).copy()
+    owners = tot[bits.size:].reshape(mine.shape)
+    got[owners != 1] = np.nan
+    return got
