@@ -410,19 +410,20 @@ class TracePathMeasureStep(MeasureStep):
 
     def _ahead_record(self, sim, ts, rows):
         """``rows`` = (len(ts), n_tracked, 4) of pcl_store_trace_ahead for the passes whose times are ``ts``."""
-        if self._ahead_tids is None:
-            self._ahead_tids = self._assign_tids(sim, ts[0])
+        if not self._ahead_log:
+            self._ahead_t0 = _snap_t(ts[0])
         self._ahead_log.append(np.array(rows[:len(ts)], dtype=np.float64))
 
-    def _assign_tids(self, sim, t0):
+    def _assign_tids(self, sim, t0, present):
         """First sight of the tracked particles (light.py:450-455): a trace id each, in object order, unless the object
-        already carries one (the host plugin saw it earlier, or an earlier upload of the same objects was traced)."""
+        already carries one (the host plugin saw it earlier, or an earlier upload of the same objects was traced).  A
+        particle that is gone before the step first runs is never seen (``present``): no id, no row -- as in the reference."""
         explicit = sim._batch is None and isinstance(sim._uploaded, list)
-        tids = np.empty(len(self._ahead_ids), dtype=np.int64)
+        tids = np.full(len(self._ahead_ids), -1, dtype=np.int64)
         for j, i in enumerate(self._ahead_ids.tolist()):
             obj = sim._objects._items[i] if explicit else None
             tid = obj.__dict__.get("__trace_path_id") if explicit else (self._uid_tid or {}).get(i)
-            if tid is None:
+            if tid is None and present[j]:
                 tid = self.id_counter
                 self.id_counter += 1
                 if explicit:
@@ -430,28 +431,32 @@ class TracePathMeasureStep(MeasureStep):
                     self.id_dict[tid] = self.id_info_fn(obj)
                 else:
                     self.id_dict[tid] = str(PhotonObject) if self.id_info_fn is _DEFAULT_ID_INFO else self.id_info_fn(_batch_photon(sim, i))
-                self.pos_dict[tid] = {"start": _snap_t(t0), "pos": []}
+                self.pos_dict[tid] = {"start": t0, "pos": []}
                 if self.trace_dv:
                     self.pos_dict[tid]["freq"] = 0
-            tids[j] = tid
+            if tid is not None:
+                tids[j] = tid
         return tids
 
     def _flush_ahead(self, sim=None):
         """File the device rows under the trace ids (a photon's list ends where it was removed)."""
-        if not self._ahead_log or self._ahead_tids is None:
-            self._ahead_log = []
+        if not self._ahead_log:
             return
         rows = np.concatenate(self._ahead_log, axis=0)                        # (T, n, 4)
-        comm = getattr(sim, "comm", None) if sim is not None else None
+        self._ahead_log = []
+        comm = getattr(sim, "comm", None)
         if comm is not None and comm.world > 1:
             rows = _merge_shards(comm, rows)
         there = ~np.isnan(rows[:, :, 0])
+        if self._ahead_tids is None:
+            self._ahead_tids = self._assign_tids(sim, self._ahead_t0, there[0])
         for j, tid in enumerate(self._ahead_tids.tolist()):
+            if tid < 0:
+                continue
             n_there = int(there[:, j].sum())                                  # removal is for good: a prefix
             self.pos_dict[tid]["pos"].extend(list(rows[:n_there, j, :3]))
             if self.trace_dv:
                 self.pos_dict[tid]["freq"] += int((rows[:n_there, j, 3] != 0).sum())
-        self._ahead_log = []
 
     # ------------------------------------------------------------------ host plugin
     def _device_rows(self, sim):
@@ -480,7 +485,7 @@ class TracePathMeasureStep(MeasureStep):
                     moved |= dev.download(f, n) != 0
         return tids, r, moved
 
-    def _flush(self, sim=None):
+    def _flush(self, sim):
         self._flush_ahead(sim)
         for tids, r, moved in self._log:
             for k, tid in enumerate(tids.tolist()):
@@ -528,7 +533,7 @@ class TracePathMeasureStep(MeasureStep):
         ids, tids = self._ahead_ids, self._ahead_tids
         self._ahead_ids = self._ahead_gen = self._ahead_tids = None
         if tids is not None and not (sim._batch is None and isinstance(sim._uploaded, list)):
-            self._uid_tid = dict(self._uid_tid or {}, **{int(i): int(t) for i, t in zip(ids, tids)})
+            self._uid_tid = dict(self._uid_tid or {}, **{int(i): int(t) for i, t in zip(ids, tids) if t >= 0})
 
     def terminate(self, sim):
         """data[0] = ["t", t0, t1, ...]; data[1+i] = [id info, (freq,) NaN-padded positions of object i]."""

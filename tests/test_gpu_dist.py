@@ -22,6 +22,8 @@ import physicl as phys, physicl.light, physicl.newton
 from physicl_amd.dist import CounterComm
 comm = CounterComm.from_env(backend="gloo")
 kind, spl = %(kind)r, %(spl)d
+trace = kind.endswith("_trace")
+kind = kind[:-6] if trace else kind
 sim = phys.Simulation(cl_on=True, device=0, comm=comm if comm.world > 1 else None, seed=21, rng="philox", steps_per_launch=spl,
                       exit=(lambda s: len(s.objects) < 2000) if kind == "delete" else
                            (lambda s: len(s.objects) == 0) if kind == "delete_empty" else (lambda s: s.t >= 0.0055))
@@ -48,10 +50,16 @@ if kind == "mixed":          # BASELINE configs[4]'s loop with a measure step be
 else:
     sim.add_step(3, m1)
     sim.add_step(4, m2)
+tp = None
+if trace:        # a tracked subset that straddles the boundary between the two shards (ids 75000 | 75001)
+    tp = phys.light.TracePathMeasureStep(None, trace_ids=list(range(200)) + list(range(74990, 75012)) + [N - 1], trace_dv=True)
+    sim.add_step(9, tp)
 sim.run()
 flat = lambda r: [x if isinstance(x, list) else float(x) for x in r]       # measure_E rows carry energy lists
 print(json.dumps({"rank": comm.rank, "m1": [flat(r) for r in m1.data], "m2": [[float(x) for x in r] for r in m2.data],
-                  "alive": len(sim.objects), "hits": int(sim.hits), "local": int(sim._dev.count)}))
+                  "alive": len(sim.objects), "hits": int(sim.hits), "local": int(sim._dev.count), "sched": dict(sim.schedule),
+                  "trace": None if tp is None else [[r[0], int(r[1])] + [np.asarray(x, dtype=float).reshape(-1).tolist() for x in r[2:]]
+                                                    for r in tp.data[1:]]}))
 comm.close()
 """
 
@@ -105,6 +113,23 @@ def test_two_shards_with_several_passes_per_launch_reproduce_the_single_process_
         assert rank["alive"] == one["alive"] and rank["hits"] == one["hits"]
     assert two[0]["local"] + two[1]["local"] == one["local"]
     assert len(one["m1"]) >= 5
+
+
+@pytest.mark.parametrize("kind", ["batch_trace", "delete_empty_trace", "mixed_trace"])
+def test_two_shards_trace_the_tracked_subset_of_the_single_process_run(kind):
+    """TracePathMeasureStep on a sharded run: every rank works the tracked ids it holds out on the device, ahead of its K-pass
+    launches, and the table is put together with one int64 sum all-reduce at the end -- the single-process table, on every
+    rank (NaN == NaN: json carries them)."""
+    one = run_world(1, kind, 1)[0]
+    two = run_world(2, kind, 4)
+    same = lambda a, b: json.dumps(a) == json.dumps(b)               # (NaN-safe comparison of the nested lists)
+    assert len(one["trace"]) >= 100 and any(len(r) > 3 for r in one["trace"])
+    for rank in two:
+        assert same(rank["trace"], one["trace"])
+        assert rank["m2"] == one["m2"]
+        assert any(k.endswith("_multi") for k in rank["sched"])      # the K-passes-per-launch schedule stayed
+    if kind != "batch_trace":                                        # removed photons: their lists end early
+        assert len({len(r) for r in one["trace"]}) > 1 or any("nan" in json.dumps(r).lower() for r in one["trace"])
 
 
 def test_rccl_group_comes_up_with_one_rank():

@@ -187,8 +187,7 @@ def test_trace_ahead_on_every_kind_of_store(make_store, hip, state, loop, pcl_kn
     ids = tracked(N, id_base)
     sc, _ = scatter_dict(hip, tag, seed, step)
     if state == "alive_mask":
-        slots, pend = a.slots
-        assert slots > a.count                       # the store really is behind a mask
+        assert a.slots > a.count                     # the store really is behind a mask
     rows = a.trace_ahead(ids, dt, K, phases, rec, sc, DELETE, seed, step)
     ref = chain_by_single_launches(b, hip, ids, tag, dt, K, phases, rec, seed, step)
     assert eq_nan(rows, ref)
@@ -332,7 +331,8 @@ def test_simulation_traces_on_the_device_what_the_host_plugin_traces(kind, trace
         tables_equal(runs[0][1], tp)
         assert [list(r) for r in signs.data] == [list(r) for r in runs[0][2].data]
     t, rows = table(runs[0][1])
-    assert len(rows) == 700 and len(t) == 13
+    # (a photon removed before the step first runs is never seen: no row, as in the reference)
+    assert len(t) == 13 and (len(rows) == 700 if (base == "iso" or first) else 500 < len(rows) < 700)
     if base != "iso":                                                # removed photons: shorter lists, NaN padding
         assert any(np.isnan(r[-1]).all() for r in rows)
     if trace_dv and base != "delete":
@@ -368,7 +368,7 @@ def test_photon_batch_is_traced_on_the_k_pass_schedule():
     # the default: the first 1000
     sim, tp, _ = build_sim("mixed", 50_000, None, batch=True, passes=6)
     sim.run()
-    assert len(tp.data) == 1001 and sim.schedule["mixed_multi"] >= 1
+    assert 800 < len(tp.data) - 1 <= 1000 and sim.schedule["mixed_multi"] >= 1      # (the first pass's delete phase removed some unseen)
     sim.close(download=False)
 
 
