@@ -790,7 +790,8 @@ def contract_line(out, detail_file):
     legs = {}
     for name, path in (("iso_1e7_per_step", ("iso_1e7", "per_step", "value")), ("iso_1e7_multi", ("iso_1e7", "multi", "value")),
                        ("mixed_f64", ("mixed", "value_f64")), ("mixed_f32", ("mixed", "value_f32")), ("tame", ("tame", "value")),
-                       ("api_default", ("api", "default", "value")), ("api_delete_default", ("api", "delete_default", "value"))):
+                       ("api_default", ("api", "default", "value")), ("api_trace", ("api", "trace_default", "value")),
+                       ("api_delete_default", ("api", "delete_default", "value"))):
         v = out
         for k in path:
             v = v.get(k) if isinstance(v, dict) else None
@@ -802,6 +803,10 @@ def contract_line(out, detail_file):
                 legs["delete_%s_%s" % (size.replace("+", ""), mode)] = float("%.4g" % rec[mode]["value"])
     if legs:
         line["legs"] = legs
+    # ``value`` is the median timed block of a run whose hit fraction falls from block to block; the same workload's WHOLE run
+    # (500 passes through the plugin API, start() .. join()) is the steady figure: beside it, one key away
+    if "api_default" in legs:
+        line["whole_run_value"] = legs["api_default"]
     line["device"] = out.get("device")
     line["detail_file"] = detail_file
     s = json.dumps(line)
@@ -1122,6 +1127,35 @@ def api_leg(args, prof):
         out[name] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s", "steps": len(sim.ts),
                      "run_time_s": sim.run_time, "rows": len(m.data), "schedule": dict(sim.schedule), "note": sim.launch_note}
         sim.close(download=False)
+    # the example's own four steps (examples/variable_n_scattering.ipynb:52-60): UpdateTimeStep, NewtonianKinematicsStep,
+    # ScatterSphericalStep and TracePathMeasureStep -- the first 1000 photons traced (the notebook's population), worked out on
+    # the device ahead of every launch (pcl_store_trace_ahead), default constructor
+    sim = phys.Simulation(exit=lambda s: len(s.ts) >= steps, seed=args.seed)
+    sim.add_objs(light.generate_photons_bulk(N, min=light.E_from_wavelength(700e-9), max=light.E_from_wavelength(200e-9), seed=args.seed))
+    sim.add_step(2, phys.UpdateTimeStep(lambda s: dt))
+    sim.add_step(1, newton.NewtonianKinematicsStep())
+    sim.add_step(3, light.ScatterSphericalStep(0.000000000000001, 0.0000000000000000001, wavelength_dep_scattering=True,
+                                               variable_n=True, variable_n_fn=prof["expr"]))
+    tp = light.TracePathMeasureStep(None)
+    sim.add_step(0, tp)
+    sim._to_device()
+    sim._dev.sync()
+    sim.start()
+    sim.join()
+    if sim.error is not None:
+        raise sim.error
+    n_tr = len(tp.data) - 1
+    # the last traced position of every tracked photon is where the store has it (the trace is worked out ahead of the launches)
+    last = np.array([np.asarray(tp.data[1 + j][-1], dtype=np.float64) for j in range(n_tr)])
+    here = np.stack([sim._dev.download(f, n_tr, 0) for f in (0, 1, 2)], 1) if n_tr else last
+    out["trace_default"] = {"value": N * len(sim.ts) / sim.run_time, "unit": "particle-steps/s", "steps": len(sim.ts),
+                            "run_time_s": sim.run_time, "tracked": n_tr, "schedule": dict(sim.schedule), "note": sim.launch_note,
+                            "trace_matches_store": bool(np.array_equal(last, here)),
+                            "what": "[UpdateTimeStep, NewtonianKinematicsStep, ScatterSphericalStep, TracePathMeasureStep]: the "
+                                    "step list of examples/variable_n_scattering.ipynb:52-60"}
+    if not out["trace_default"]["trace_matches_store"]:
+        raise RuntimeError("bench: the traced positions differ from the store's")
+    sim.close(download=False)
     # the delete loop of test/test_light.py:52-59 with the constructor's defaults (exit: no objects left).  The whole run is
     # under a millisecond at 1e7 photons: five simulations, the median run time (every run listed; the first one of a
     # process also pays for Python's own first pass through the host layer and the library's first allocations of the path)

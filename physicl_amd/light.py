@@ -1,6 +1,7 @@
 """physicl.light equivalent: photons, scatter / delete steps and the counting measure steps, all on
 the device store.  Public names follow the reference module (physicl/light.py); the OpenCL kernels
 it builds at run time are replaced by the hand-written HIP kernels of libphysicl_hip.so."""
+import collections.abc
 import copy
 
 import numpy as np
@@ -345,6 +346,58 @@ class ScatterSignMeasureStep(_CountingMeasure):
 _DEFAULT_ID_INFO = lambda x: str(type(x))      # noqa: E731 -- the reference's default (light.py:438), recognised by identity
 
 
+class _Lazy(collections.abc.MutableSequence):
+    """A list whose elements are made when somebody looks at them: the concatenation of ``parts`` (lists, or 2-D arrays whose
+    rows are the elements).  The trace of 1000 photons over 500 passes is half a million position vectors; kept as the blocks
+    the device returned, ``terminate`` costs a millisecond instead of a tenth of a second -- as long as the run itself
+    (physicl/__init__.py:519-524 stops the run's clock after the steps' terminate).  Behaves like the reference's plain
+    lists (``pos_dict[i]["pos"]``, the rows of ``data``) for everything a script does with them."""
+
+    def __init__(self, parts=()):
+        self._parts, self._list = list(parts), None
+
+    def _all(self):
+        if self._list is None:
+            self._list = [x for part in self._parts for x in part]
+            self._parts = None
+        return self._list
+
+    def __len__(self):
+        return len(self._list) if self._list is not None else sum(len(part) for part in self._parts)
+
+    def __getitem__(self, i):
+        return self._all()[i]
+
+    def __setitem__(self, i, x):
+        self._all()[i] = x
+
+    def __delitem__(self, i):
+        del self._all()[i]
+
+    def insert(self, i, x):
+        self._all().insert(i, x)
+
+    def append(self, x):
+        self.extend([x])
+
+    def extend(self, seq):
+        if self._list is not None:
+            self._list.extend(seq)
+        elif self._parts and type(self._parts[-1]) is list and type(seq) is list:
+            self._parts[-1].extend(seq)
+        else:
+            self._parts.append(seq)
+
+    def __iter__(self):
+        return iter(self._all())
+
+    def __eq__(self, other):
+        return list(self) == list(other)
+
+    def __repr__(self):
+        return repr(self._all())
+
+
 class TracePathMeasureStep(MeasureStep):
     """Records objects' positions at every step (physicl/light.py:433-483).
 
@@ -431,7 +484,7 @@ class TracePathMeasureStep(MeasureStep):
                     self.id_dict[tid] = self.id_info_fn(obj)
                 else:
                     self.id_dict[tid] = str(PhotonObject) if self.id_info_fn is _DEFAULT_ID_INFO else self.id_info_fn(_batch_photon(sim, i))
-                self.pos_dict[tid] = {"start": t0, "pos": []}
+                self.pos_dict[tid] = {"start": t0, "pos": _Lazy()}
                 if self.trace_dv:
                     self.pos_dict[tid]["freq"] = 0
             if tid is not None:
@@ -450,13 +503,15 @@ class TracePathMeasureStep(MeasureStep):
         there = ~np.isnan(rows[:, :, 0])
         if self._ahead_tids is None:
             self._ahead_tids = self._assign_tids(sim, self._ahead_t0, there[0])
+        n_there = there.sum(axis=0).tolist()                                  # removal is for good: a prefix
+        freq = ((rows[:, :, 3] != 0) & there).sum(axis=0).tolist()
         for j, tid in enumerate(self._ahead_tids.tolist()):
-            if tid < 0:
+            if tid < 0 or not n_there[j]:
                 continue
-            n_there = int(there[:, j].sum())                                  # removal is for good: a prefix
-            self.pos_dict[tid]["pos"].extend(list(rows[:n_there, j, :3]))
+            entry = self.pos_dict[tid]
+            entry["pos"].extend(rows[:n_there[j], j, :3])                      # (the block's rows: vectors are made when looked at)
             if self.trace_dv:
-                self.pos_dict[tid]["freq"] += int((rows[:n_there, j, 3] != 0).sum())
+                entry["freq"] += freq[j]
 
     # ------------------------------------------------------------------ host plugin
     def _device_rows(self, sim):
@@ -541,15 +596,13 @@ class TracePathMeasureStep(MeasureStep):
         cols = len(sim.ts)
         table = [["t"] + copy.deepcopy(sim.ts)]
         for i in range(len(self.id_dict)):
-            row = [self.id_dict[i]]
+            entry = self.pos_dict[i]
+            head = [self.id_dict[i]]
             if self.trace_dv:
-                row.append(self.pos_dict[i]["freq"])
-            before = sim.ts.index(self.pos_dict[i]["start"])
-            after = cols - len(self.pos_dict[i]["pos"])                      # (as the reference counts it, light.py:477)
-            row.extend([np.nan, np.nan, np.nan] * before)
-            row.extend(self.pos_dict[i]["pos"])
-            row.extend([np.nan, np.nan, np.nan] * after)
-            table.append(row)
+                head.append(entry["freq"])
+            before = sim.ts.index(entry["start"])
+            after = cols - len(entry["pos"])                                 # (as the reference counts it, light.py:477)
+            table.append(_Lazy([head, [np.nan, np.nan, np.nan] * before, entry["pos"], [np.nan, np.nan, np.nan] * after]))
         self.data = table
 
 

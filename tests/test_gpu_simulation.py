@@ -483,10 +483,11 @@ def test_scatter_measure_step_with_energies():
 
 @pytest.mark.parametrize("kind", ["scatter", "delete"])
 def test_trace_path_from_device_arrays_equals_the_per_object_walk(kind, monkeypatch):
-    """TracePathMeasureStep reads ids / r / dv arrays from the device once every object has been seen; the table is the
-    one the per-object walk of the reference (light.py:447-483) builds -- also when a delete step thins the list."""
+    """TracePathMeasureStep as a host plugin (fuse=False: behind separate steps; in a fused group its tracked subset is worked
+    out on the device, tests/test_gpu_trace.py) reads ids / r / dv arrays from the device once every object has been seen; the
+    table is the one the per-object walk of the reference (light.py:447-483) builds -- also when a delete step thins the list."""
     def build():
-        sim = phys.Simulation(cl_on=True, rng="philox", seed=4, exit=lambda s: s.t >= 0.0075 or len(s.objects) == 0)
+        sim = phys.Simulation(cl_on=True, rng="philox", seed=4, fuse=False, exit=lambda s: s.t >= 0.0075 or len(s.objects) == 0)
         sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0 + i), uid=i)
                       for i in range(300)])
         tp = phys.light.TracePathMeasureStep(None, id_info_fn=lambda o: str(o.E), trace_dv=True)
