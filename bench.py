@@ -176,6 +176,8 @@ class Bench:
         self.totals = None
         self.local_block_s = []        # this rank's own wall time of every timed block (the line reports min / max over ranks)
         self.work_log = []             # K-step launches: what each kernel tallied of its own work (pcl_store_last_multi_work)
+        self.rows_log = {}             # launch index k -> this rank's row [N, hits, xp, yp, zp] of step k of the MAIN run (checked against the CPU port)
+        self.log_rows = True
 
     def fill(self):
         self.dev.store_alloc(self.N, self.args.dtype)
@@ -218,6 +220,9 @@ class Bench:
             rows = self.dev.step_fused_multi(self.prof["dt"], ks, self.sc(k))
             c = np.array([[o["N"], o["hits"], o["sign"][0], o["sign"][1], o["sign"][2]] for o in rows], dtype=np.int64)
             hits += int(c[:, 1].sum())
+            if self.log_rows:
+                for j in range(ks):
+                    self.rows_log.setdefault(k + j, c[j].tolist())
             # steps, hits, dense passes, wave-steps, photons per wave, wave-steps on exp's shortcut (-1: no probe), GHz held under the launch
             self.work_log.append((ks, int(c[:, 1].sum())) + self.dev.last_multi_work() + (round(self.dev.last_multi_clock(), 4),))
             self.totals = self.comm.allreduce_sum(c.reshape(-1)).reshape(-1, 5)[-1]
@@ -238,6 +243,8 @@ class Bench:
                 self.launch(k)
                 c = self.collect()
                 hits += int(c[1])
+                if self.log_rows:
+                    self.rows_log.setdefault(k, c.tolist())
                 self.totals = self.comm.allreduce_sum(c)
             return hits
         if k1 > k0:
@@ -246,10 +253,14 @@ class Bench:
             self.launch(k)
             c = self.collect()                      # counters of step k-1
             hits += int(c[1])
+            if self.log_rows:
+                self.rows_log.setdefault(k - 1, c.tolist())
             self.totals = self.comm.allreduce_sum(c)
         if k1 > k0:
             c = self.collect()
             hits += int(c[1])
+            if self.log_rows:
+                self.rows_log.setdefault(k1 - 1, c.tolist())
             self.totals = self.comm.allreduce_sum(c)
         return hits
 
@@ -538,6 +549,7 @@ def run_rank(args):
 
     R = max(1, args.repeats)
     el, hits, kern, k_next = b.timed_blocks(args.warmup, args.steps, R)
+    b.log_rows = False                 # (the legs below run other formulations / profiles on the same store)
     b.block_work_main = b.block_work
     totals_main = b.totals
     rank_blocks = comm.allgather_object([round(x / args.steps * 1e3, 5) for x in b.local_block_s[:R]])
@@ -707,7 +719,7 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline and not f32:
             dev2 = hip.Device(b.dev_index)
             try:
-                out["cpu_baseline"] = cpu_baseline(dev2, args, prof)
+                out["cpu_baseline"] = cpu_baseline(dev2, args, prof, b.rows_log)
                 out["cpu_baseline_python"] = cpu_baseline_python(dev2, args, prof, 10_000)        # 1e4 and 1e5
                 out["cpu_baseline_python_1e5"] = cpu_baseline_python(dev2, args, prof, 100_000)
                 out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev2, args, prof)
@@ -777,7 +789,7 @@ def contract_line(out, detail_file):
     else:
         line["roofline_hbm"] = None
     c = out.get("cpu_baseline")
-    line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "nproc", "kind", "sample")) if c else None
+    line["cpu_baseline"] = _pick(c, ("value", "unit", "cores", "nproc", "kind", "sample", "rows_match", "rows_compared")) if c else None
     coll = out.get("collective")
     if coll is not None:
         line["collective"] = dict(_pick(coll, ("backend", "ranks_seen", "world", "rccl_version", "block_min_ms_per_step",
@@ -1185,10 +1197,13 @@ def api_leg(args, prof):
     return out
 
 
-def cpu_baseline(dev, args, prof):
+def cpu_baseline(dev, args, prof, gpu_rows=None):
     """The oracle's C/OpenMP port of the same step (newton + fused scatter + sign counters) on the first
     `cpu_photons` photons of the SAME initial workload, all host cores this process may use (BASELINE.md section 4
-    item 3: 1e8 photons).  Checker code timed as a baseline: never part of the GPU path."""
+    item 3: 1e8 photons).  Checker code timed as a baseline: never part of the GPU path.
+    When the port runs ALL of the run's photons (the default: 1e8 of 1e8) its rows [N, hits, xp, yp, zp] of steps 0, 1, 2 ...
+    are the rows the GPU produced for the same launch indices in this very run (``gpu_rows``): compared, ``rows_match`` in
+    the record, and a mismatch fails the bench -- whole-store parity at full size, every run."""
     from oracle import c_oracle as co
     if prof["c_profile"] is None:
         return {"value": None, "unit": "particle-steps/s", "cores": 0, "kind": "port",
@@ -1205,11 +1220,14 @@ def cpu_baseline(dev, args, prof):
     cores = co.threads()
     profile, pk, poff = prof["c_profile"]
 
+    cpu_rows = []
+
     def step(k):
         co.newton(st, prof["dt"])
-        co.scatter_isotropic(st, prof["A_kernel"], prof["n_kernel"], C_LIT, H_LIT, 1, profile, pk, poff, args.seed, k,
-                             ids=None, id_base=0)
-        co.counters(st)
+        hits = co.scatter_isotropic(st, prof["A_kernel"], prof["n_kernel"], C_LIT, H_LIT, 1, profile, pk, poff, args.seed, k,
+                                    ids=None, id_base=0)
+        sign = co.counters(st)
+        cpu_rows.append([n, int(hits), int(sign[0]), int(sign[1]), int(sign[2])])
 
     step(0)                                   # warm-up (first touch of the pages) + calibration
     t0 = time.perf_counter()
@@ -1220,9 +1238,20 @@ def cpu_baseline(dev, args, prof):
     for k in range(2, 2 + steps):
         step(k)
     el = time.perf_counter() - t0
-    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
-            "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads of %d "
-                      "CPUs on the box, %.1f s)" % (n, steps, cores, os.cpu_count() or 0, el)}
+    rec = {"value": n * steps / el, "unit": "particle-steps/s", "cores": cores, "nproc": os.cpu_count(), "kind": "port",
+           "sample": "%d photons x %d steps of the same workload (oracle/c/physicl_oracle.c, OpenMP, %d threads of %d "
+                     "CPUs on the box, %.1f s)" % (n, steps, cores, os.cpu_count() or 0, el)}
+    if gpu_rows is not None and n == int(args.photons):
+        both = [k for k in range(len(cpu_rows)) if k in gpu_rows]
+        bad = [k for k in both if list(gpu_rows[k]) != cpu_rows[k]]
+        rec["rows_compared"] = len(both)
+        rec["rows_match"] = (not bad) if both else None
+        rec["rows_note"] = ("rows [N, hits, xp, yp, zp] of launch indices 0 .. %d: the C port over ALL %d photons against the rows the GPU "
+                            "produced in this run" % (len(both) - 1, n))
+        if bad:
+            k = bad[0]
+            raise RuntimeError("bench: the GPU's row of step %d %r differs from the CPU port's %r" % (k, list(gpu_rows[k]), cpu_rows[k]))
+    return rec
 
 
 def cpu_baseline_numpy(dev, args, prof):

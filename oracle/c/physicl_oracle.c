@@ -59,6 +59,31 @@ void orc_delete_flags(const double *d0, const double *d1, const double *d2, cons
     for (int64_t i = 0; i < N; ++i) flags[i] = (An * step_norm(d0[i], d1[i], d2[i]) >= rand[i]) ? 1 : 0;
 }
 
+/* A delete run body after body (test/test_light.py:52-59: [UpdateTimeStep, NewtonianKinematicsStep, ScatterDeleteStep]): a photon of
+ * such a run never changes its velocity, so body k moves it by dr = v*dt (newton.py:15), flags it if (A*n)*|dr| >= rand(id, step0 + k)
+ * (light.py:239-249; the device draw of oracle/physicl_oracle.py:philox_draws: decision block (id, step >> 1, 0), even step
+ * u53(w0, w1), odd step u53(w2, w3)) and the flagged photon leaves the list (light.py:258-260).
+ * death[i] = the body that removes photon i (0 .. K-1), K if none of the K bodies does.  ids == NULL: id = id_base + i. */
+void orc_delete_chain(const double *v0, const double *v1, const double *v2, const int64_t *ids, int64_t id_base, int64_t N,
+                      double dt, double A, double n, uint64_t seed, uint32_t step0, int K, int32_t *death) {
+    const double An = A * n;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; ++i) {
+        const double p = An * step_norm(v0[i] * dt, v1[i] * dt, v2[i] * dt);
+        const uint64_t id = (uint64_t)(ids ? ids[i] : id_base + i);
+        int k = 0;
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (; k < K; ++k) {
+            const uint32_t step = step0 + (uint32_t)k;
+            if (k == 0 || (step & 1u) == 0u)
+                philox((uint32_t)id, (uint32_t)(id >> 32), step >> 1, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            const double rand = (step & 1u) ? u53(w[2], w[3]) : u53(w[0], w[1]);
+            if (p >= rand) break;
+        }
+        death[i] = k;
+    }
+}
+
 /* light.py:258-260 + __init__.py:455-459 : stable removal; returns the survivor count */
 int64_t orc_compact_indices(const int32_t *flags, int64_t N, int64_t *idx) {
     int64_t k = 0;

@@ -70,6 +70,24 @@ def delete_flags(d, rand, A, n):
     return flags
 
 
+def delete_chain(v, dt, A, n, seed, step0, K, ids=None, id_base=0):
+    """The body (0 .. K-1) that removes each photon of a delete run, K if none of the K bodies does (orc_delete_chain)."""
+    N = len(v[0])
+    death = np.empty(N, dtype=np.int32)
+    if ids is not None:
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+    load().orc_delete_chain(_p(v[0]), _p(v[1]), _p(v[2]), _p(ids), c_int64(id_base), c_int64(N), c_double(dt), c_double(A), c_double(n),
+                            c_uint64(seed), c_uint32(step0), c_int(K), _p(death))
+    return death
+
+
+def order_checksum(ids):
+    """Order-sensitive checksum of a survivor list: sum of id * (position + 1) mod 2**64."""
+    ids = np.asarray(ids).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((ids * (np.arange(len(ids), dtype=np.uint64) + np.uint64(1))).sum(dtype=np.uint64))
+
+
 def compact_indices(flags):
     flags = np.ascontiguousarray(flags, dtype=np.int32)
     idx = np.empty(len(flags), dtype=np.int64)

@@ -18,7 +18,17 @@ the inf / 0 handling itself is pinned by g2_iso_varn_overflow):
 * positions within K * (dt * 4 ulp(c) + ulp(max |r|)) (a scattered velocity feeds every later Euler move, whose sum
   is rounded at |r| ~ 1e7);
 * fp32 store: the same against the oracle's float32 restatement (ulp of float32(c)).
+
+Both of bench.py's profiles are pinned this way (the test reads bench.PROFILES, so a change of the bench's constants changes
+the test): "example" as above, and "tame" -- ``2.5E+25 * exp(r2[gid] / 8600.0)`` (examples/presentation_example_2.ipynb:41's
+shape), kernel A = 4.08e-56, dt = 1e-5: exp never saturates, pcoll spans 0.013 .. 1.9 with the photon's energy and falls
+with z, so every decision goes through the general branch of the kernels (pcl_rtc_multi2_e1 / multi3_e1 / multi_e1 without
+the saturation shortcut) with a relative sensitivity of ~1e-14 to the libm differences: ~3e-8 expected flipped decisions in
+3.2e6 photon-steps, equality asked for.  conftest.py runs every case on the 256-, 192- and 128-photons-per-wave forms and
+with the saturation probe forced on and off.
 """
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -26,10 +36,12 @@ from oracle import physicl_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import PROFILES                                    # noqa: E402 -- the bench's own constants
+
 C_LIT = 299792458.0
 H_LIT = 6.62607015e-34
-EXPR = "0.000000001 * exp(r0[gid] - 5)"
-A_KERNEL, N_KERNEL, DT, SEED = 1e-15, 1e-19, 5e-3, 1234       # bench.py PROFILES["example"], --seed default
+SEED = 1234                                                   # bench.py's --seed default
 N, K = 100_000, 32
 
 
@@ -39,7 +51,8 @@ def hip():
     return _hip
 
 
-def oracle_chain(E, dtype):
+def oracle_chain(E, dtype, prof):
+    EXPR, A_KERNEL, N_KERNEL, DT = prof["expr"], prof["A_kernel"], prof["n_kernel"], prof["dt"]
     ids = np.arange(N, dtype=np.int64)
     z = lambda: np.zeros(N, dtype=dtype)
     st = {"r": [z(), z(), z()], "v": [np.full(N, C_LIT, dtype=dtype), z(), z()], "dr": [z(), z(), z()],
@@ -54,7 +67,10 @@ def oracle_chain(E, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype):
+@pytest.mark.parametrize("profile", sorted(PROFILES))
+def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype, profile, pcl_knobs):
+    prof = PROFILES[profile]
+    EXPR, A_KERNEL, N_KERNEL, DT = prof["expr"], prof["A_kernel"], prof["n_kernel"], prof["dt"]
     npdt = np.float64 if dtype == "f64" else np.float32
     sc = lambda k: dict(A=A_KERNEL, n=N_KERNEL, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=C_LIT, h=H_LIT,
                         n_expr=EXPR, rng_mode=hip.RNG_PHILOX, seed=SEED, step=k)
@@ -68,13 +84,16 @@ def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype):
             E = d.download(hip.E)
             if how == "multi":
                 rows = d.step_fused_multi(DT, K, sc(0))
+                if dtype == "f64" and pcl_knobs:       # the form the knob asks for is the form that ran (fp64 hipRTC specialisations)
+                    want = 128 if pcl_knobs.get("PCL_MULTI_NQ2") == "0" else (192 if pcl_knobs.get("PCL_MULTI_NQ3") == "1" else 256)
+                    assert d.last_multi_work()[2] == want, (pcl_knobs, d.last_multi_work())
             else:
                 rows = [d.step_fused(DT, sc(k), [], lazy=True) for k in range(K)]
             got[how] = ([(o["hits"], list(o["sign"])) for o in rows], d.download_state(), E)
     # the photons are the bench's: E = e_min + (e_max - e_min) * U^(1/3) from Philox block 2 (device pow vs numpy power)
     E_orc = orc.philox_energy(SEED, np.arange(N), e_lo, e_hi)
     assert np.max(np.abs(got["multi"][2].astype(np.float64) - E_orc) / E_orc) <= (4e-16 if dtype == "f64" else 6e-8)
-    ref_rows, st = oracle_chain(got["multi"][2], npdt)
+    ref_rows, st = oracle_chain(got["multi"][2], npdt, prof)
     ulp_c = float(np.spacing(npdt(C_LIT)))
     for how in ("multi", "single"):
         rows, s, _ = got[how]
@@ -91,6 +110,8 @@ def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype):
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(got["multi"][1][f][k], got["single"][1][f][k]), (f, k)
-    # the regime really is the bench's: every photon scatters in step 1, then a fraction escapes to x << 0 for good
     hits = [h for h, _ in ref_rows]
-    assert hits[0] == N and 0.25 * N < hits[-1] < 0.9 * N
+    if profile == "example":      # the regime really is the bench's: every photon scatters in step 1, then a fraction escapes to x << 0 for good
+        assert hits[0] == N and 0.25 * N < hits[-1] < 0.9 * N
+    else:                         # tame: a position- and energy-dependent share of the photons scatters, step after step
+        assert all(0.2 * N < h < 0.8 * N for h in hits)

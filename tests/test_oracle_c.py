@@ -95,3 +95,26 @@ def test_counters_match():
     out = co.counters(st, 1, 0.25)
     assert tuple(out[:3]) == orc.sign_counts(st["v"])
     assert out[3] == orc.plane_crossings(st["r"], st["dr"], [np.nan, 0.25, np.nan])
+
+
+@pytest.mark.parametrize("step0", [0, 3])
+def test_delete_chain_is_the_numpy_oracle_body_after_body(step0):
+    """orc_delete_chain (the body that removes each photon of a delete run) against Newton + step_scatter_delete of the numpy
+    oracle applied body after body: the survivor ids after every body, in order."""
+    N, K, seed = 30_011, 14, 99
+    rs = np.random.RandomState(4)
+    ang = rs.uniform(0, np.pi, N)
+    v = [np.ascontiguousarray(C * np.cos(ang)), np.ascontiguousarray(C * np.sin(ang)), np.zeros(N)]
+    ids = np.arange(N, dtype=np.int64) + (1 << 32) - 7
+    death = co.delete_chain(v, 1e-3, 1e-3, 0.7e-3, seed, step0, K, ids=ids)
+    death_base = co.delete_chain(v, 1e-3, 1e-3, 0.7e-3, seed, step0, K, id_base=int(ids[0]))
+    assert np.array_equal(death, death_base)
+    st = {"r": [np.zeros(N) for _ in range(3)], "v": [x.copy() for x in v], "dr": [np.zeros(N) for _ in range(3)],
+          "dv": [np.zeros(N) for _ in range(3)], "E": np.ones(N), "id": ids.copy()}
+    for k in range(K):
+        orc.step_newton(st, 1e-3)
+        orc.step_scatter_delete(st, orc.philox_draws(seed, step0 + k, st["id"])[2], 1e-3, 0.7e-3)
+        assert np.array_equal(st["id"], ids[death > k])
+    assert 0 < (death == K).sum() < N
+    a, b = ids[death == K], ids[death == K][::-1]
+    assert co.order_checksum(a) != co.order_checksum(b) and co.order_checksum(a) == co.order_checksum(a.copy())
