@@ -113,5 +113,7 @@ def test_bench_workload_32_steps_multi_and_single_vs_oracle(hip, dtype, profile,
     hits = [h for h, _ in ref_rows]
     if profile == "example":      # the regime really is the bench's: every photon scatters in step 1, then a fraction escapes to x << 0 for good
         assert hits[0] == N and 0.25 * N < hits[-1] < 0.9 * N
-    else:                         # tame: a position- and energy-dependent share of the photons scatters, step after step
+    elif dtype == "f64":          # tame: a position- and energy-dependent share of the photons scatters, step after step
         assert all(0.2 * N < h < 0.8 * N for h in hits)
+    else:                         # (the profile's kernel constant 4.08e-56 is below float32's range: zero, nobody scatters --
+        assert sum(hits) == 0     #  on the device as in the oracle's float32 restatement; bench.py runs this profile in fp64 only)
