@@ -132,9 +132,25 @@ class PhotonBatch:
     (physicl/light.py:112-128).  ``Simulation.add_objs(batch)`` creates them directly in device
     memory (1e8 photons take milliseconds instead of hours and ~100 GB of Python objects)."""
 
-    def __init__(self, n, e_min, e_max, seed=0, table=None):
+    def __init__(self, n, e_min, e_max, seed=0, table=None, fn_vec=None):
         self.n, self.e_min, self.e_max, self.seed = int(n), float(np.asarray(e_min)), float(np.asarray(e_max)), int(seed)
         self.table = table        # (cdf, grid): tabulated energy distribution instead of the power law
+        self.fn_vec = fn_vec      # fn_vec(size) -> size numbers: the user's own sampler, evaluated on the host in chunks
+
+    FN_CHUNK = 1 << 22
+
+    def host_energies(self, lo, hi):
+        """Chunks (offset in [lo, hi), energies) of ``e_min + (e_max - e_min) * fn_vec(...)`` for the photons [lo, hi) of the
+        batch.  The sampler is called for EVERY photon of the batch, in order, whatever the shard: a sampler that walks a
+        seeded stream (np.random) hands photon i the same number in a sharded run as in an unsharded one."""
+        for at in range(0, self.n, self.FN_CHUNK):
+            m = min(self.FN_CHUNK, self.n - at)
+            u = np.asarray(self.fn_vec(m), dtype=np.float64).reshape(-1)
+            if u.shape[0] != m:
+                raise ValueError("fn_vec(%d) returned %d numbers" % (m, u.shape[0]))
+            a, b = max(at, lo), min(at + m, hi)
+            if b > a:
+                yield a - lo, self.e_min + (self.e_max - self.e_min) * u[a - at:b - at]
 
     def __len__(self):
         return self.n
@@ -419,6 +435,9 @@ class Simulation(threading.Thread):
                 dev.fill_photons_table(hi - lo, lo, float(np.asarray(_c)), b.table[0], b.table[1], b.seed)
             else:
                 dev.fill_photons(hi - lo, lo, float(np.asarray(_c)), b.e_min, b.e_max, b.seed)
+                if b.fn_vec is not None:                  # the user's sampler: r, v, ids as filled, E from the host
+                    for off, E in b.host_energies(lo, hi):
+                        dev.upload(self._hip.E, E.astype(dev.np_dtype, copy=False), off)
             self._all_photons = True
             self._alive = b.n
             self._residency = DEVICE

@@ -82,13 +82,22 @@ def generate_photons(n, fn=lambda: np.random.power(3), min=0, max=0, bins=-1, di
     return [PhotonObject(E=min + (max - min) * fn(), v=Measurement([c, 0, 0], "m**1 s**-1")) for _ in range(int(n))]
 
 
-def generate_photons_bulk(n, min=0, max=0, seed=0, T=None, bins=1000):
+def generate_photons_bulk(n, min=0, max=0, seed=0, T=None, bins=1000, fn_vec=None):
     """``n`` photons created directly in device memory when the simulation first needs them (returns a
     PhotonBatch for ``sim.add_objs``).  Default: the distribution of ``generate_photons`` with its default
     sampler.  With a temperature ``T``: energies from the binned Planck distribution between ``min`` and
     ``max`` -- ``generate_photons_from_E([planck_phot_distribution(min, max, T, bins) ...])``
     (physicl/light.py:73-110) for all photons at once; the bin masses use the closed-form integral of the
-    Planck density instead of ``bins`` calls to scipy.quad."""
+    Planck density instead of ``bins`` calls to scipy.quad.
+    ``fn_vec``: any other sampler, vectorised -- ``fn_vec(size) -> size numbers`` -- the bulk form of ``generate_photons``'s
+    ``fn`` (physicl/light.py:112-128: ``E = min + (max - min) * fn()`` per photon): evaluated on the host in chunks of 4M
+    photons, in photon order, and uploaded; ``fn_vec=lambda size: np.random.power(3, size)`` after ``np.random.seed(s)``
+    gives photon i the energy ``generate_photons`` gives it after the same seed (numpy fills an array from the stream
+    its scalar calls walk).  No Python object per photon either way."""
+    if fn_vec is not None:
+        if T is not None:
+            raise ValueError("generate_photons_bulk: give a temperature T or a sampler fn_vec, not both")
+        return PhotonBatch(n, min, max, seed, fn_vec=fn_vec)
     if T is None:
         return PhotonBatch(n, min, max, seed)
     lo, hi, T_ = (float(np.asarray(v.__unscaled__() if isinstance(v, Measurement) else v)) for v in (min, max, T))

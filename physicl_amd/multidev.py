@@ -177,6 +177,15 @@ class MultiDevice:
             return sub
         self._each(lambda s, b: s.upload_state(part(b)), self._bounds)
 
+    def upload(self, field, host, offset=0):
+        """Elements [offset, offset + len(host)) of one field, in global particle order, to the shards that hold them."""
+        host = np.ascontiguousarray(host)
+        at = 0
+        for s, (n, off) in zip(self.shards, self._window(len(host), offset)):
+            if n:
+                s.upload(field, host[at:at + n], off)
+                at += n
+
     def upload_rand(self, which, host):
         self._each(lambda s, h: s.upload_rand(which, np.ascontiguousarray(h)), self._split(host))
 

@@ -551,3 +551,31 @@ def test_steps_per_launch_survives_another_thread_looking_at_the_objects():
     assert [[float(x) for x in r] for r in sign.data] == [[float(x) for x in r] for r in ref_sign.data] and len(sign.data) == 24
     for f in ("r", "v", "dv", "id"):
         assert np.array_equal(sim.download(f), ref.download(f)), f
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0]])
+def test_bulk_photons_from_a_user_sampler_never_become_python_objects(devices):
+    """generate_photons_bulk(fn_vec=...): the energies of physicl/light.py:112-128 with the user's own (vectorised) sampler, on
+    the device without a Python object per photon -- photon i has the energy generate_photons gives it after the same seed,
+    on one context and sharded over two."""
+    n = 100_003
+    lo_e, hi_e = phys.light.E_from_wavelength(700e-9), phys.light.E_from_wavelength(200e-9)
+    np.random.seed(5)
+    want = np.array([float(np.asarray(o.E)) for o in phys.light.generate_photons(2000, fn=lambda: np.random.beta(2.0, 5.0), min=lo_e, max=hi_e)])
+    kw = dict(cl_on=True, seed=3, exit=lambda s: s.t >= 0.0035)
+    if devices:
+        kw["devices"] = devices
+    sim = phys.Simulation(**kw)
+    np.random.seed(5)
+    sim.add_objs(phys.light.generate_photons_bulk(n, min=lo_e, max=hi_e, fn_vec=lambda size: np.random.beta(2.0, 5.0, size)))
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    sim.add_step(3, sign)
+    run(sim)
+    assert sim._batch is not None and len(sign.data) == 4 and sign.data[-1][1] == n
+    E = sim.download("E")
+    assert E.shape == (n,) and np.array_equal(E[:2000], want)
+    assert float(lo_e) <= E.min() and E.max() <= float(hi_e) and abs(E.mean() - (float(lo_e) + (float(hi_e) - float(lo_e)) * 2 / 7)) < 0.01 * float(hi_e)
+    sim.close(download=False)

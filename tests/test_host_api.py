@@ -203,3 +203,35 @@ def test_alias_package_does_not_import_light_eagerly():
                 __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-500:]
+
+
+def test_bulk_photons_from_a_vectorised_sampler_are_the_per_object_photons():
+    """generate_photons_bulk(fn_vec=...) (physicl/light.py:112-128's ``fn``, vectorised): photon i gets the energy
+    generate_photons gives it after the same seed; the sampler is walked for every photon of the batch whatever the shard."""
+    import physicl_amd as phys
+    from physicl_amd import light
+    from physicl_amd.core import PhotonBatch
+    lo_e, hi_e = float(light.E_from_wavelength(700e-9)), float(light.E_from_wavelength(200e-9))
+    np.random.seed(11)
+    objs = light.generate_photons(300, min=lo_e, max=hi_e)
+    want = np.array([float(np.asarray(o.E)) for o in objs])
+    b = light.generate_photons_bulk(300, min=lo_e, max=hi_e, fn_vec=lambda size: np.random.power(3, size))
+    assert isinstance(b, PhotonBatch) and b.fn_vec is not None
+    PhotonBatch.FN_CHUNK = 128                     # three chunks
+    try:
+        np.random.seed(11)
+        got = np.empty(300)
+        for off, E in b.host_energies(0, 300):
+            got[off:off + len(E)] = E
+        assert np.array_equal(got, want)
+        np.random.seed(11)                          # a shard [100, 250): the same numbers for its photons
+        part = np.empty(150)
+        for off, E in b.host_energies(100, 250):
+            part[off:off + len(E)] = E
+        assert np.array_equal(part, want[100:250])
+        with pytest.raises(ValueError):
+            list(light.generate_photons_bulk(10, fn_vec=lambda size: np.zeros(size + 1)).host_energies(0, 10))
+    finally:
+        PhotonBatch.FN_CHUNK = 1 << 22
+    with pytest.raises(ValueError):
+        light.generate_photons_bulk(10, T=300.0, fn_vec=lambda size: np.zeros(size))
