@@ -109,6 +109,13 @@ int         pcl_set_knob(const char *name, const char *value);
  * pcl_pool_bytes() tells how much it holds.                                                                          */
 int         pcl_pool_trim(int64_t *released_out);
 int         pcl_pool_bytes(int64_t *idle_out);
+/* The same in detail (host pointers, any may be NULL): bytes of idle blocks; bytes of physical handles kept of ranges that were
+ * unmapped (both count against PCL_POOL_GB); bytes of ADDRESS SPACE parked behind freed ranges -- on this runtime a new mapping at
+ * addresses that were mapped before loses writes, so a freed range's addresses are reserved again at once and never mapped
+ * (bounded at 32 TB of the 128 TB address space, then big blocks come from hipMalloc) --; how many times a fresh reservation was
+ * found to overlap a formerly mapped range and was set aside; 1 while big blocks are still built with the virtual-memory API. */
+int         pcl_pool_info(int64_t *idle_blocks_out, int64_t *idle_handles_out, int64_t *parked_va_out, int64_t *remaps_avoided_out,
+                          int *vmm_on_out);
 
 /* ``stream``: a hipStream_t to adopt (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let
  * the context create its own non-blocking stream.  Replaces cl.create_some_context() +

@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "pcl_ctx_rtc_wait": [_vp, POINTER(c_int)],
     "pcl_pool_trim": [POINTER(c_int64)],
     "pcl_pool_bytes": [POINTER(c_int64)],
+    "pcl_pool_info": [POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int)],
     "pcl_ctx_create": [c_int, _vp, POINTER(_vp)],
     "pcl_ctx_destroy": [_vp],
     "pcl_ctx_sync": [_vp],
@@ -209,6 +210,13 @@ def pool_bytes():
     n = c_int64(0)
     check(load().pcl_pool_bytes(byref(n)))
     return n.value
+
+
+def pool_info():
+    """{'idle_blocks', 'idle_handles', 'parked_va', 'remaps_avoided', 'vmm_on'} (pcl_pool_info)."""
+    a, b, c, d, e = c_int64(0), c_int64(0), c_int64(0), c_int64(0), c_int(0)
+    check(load().pcl_pool_info(byref(a), byref(b), byref(c), byref(d), byref(e)))
+    return {"idle_blocks": a.value, "idle_handles": b.value, "parked_va": c.value, "remaps_avoided": d.value, "vmm_on": bool(e.value)}
 
 
 def pool_trim():

@@ -3211,6 +3211,19 @@ std::unordered_map<void *, vmm_block> g_vmm; // guarded by g_vmm_mu
 std::vector<vmm_idle_handle> g_vmm_idle;     // physical handles of freed ranges, kept for the next ones; guarded by g_vmm_mu
 size_t g_vmm_idle_bytes = 0;
 std::mutex g_vmm_mu;
+// Address ranges that WERE mapped once (guarded by g_vmm_mu).  ``parked``: freed and reserved again at once, never to be mapped --
+// the runtime cannot hand those addresses out a second time.  ``tainted``: the second reservation failed or came back
+// somewhere else, so the addresses are back in circulation: every new range is checked against these (vmm_malloc) and a
+// reservation that overlaps one is parked too.  The address space is 2^47 bytes; the parked total is bounded at a quarter of
+// it (kParkedVaMax: ~300 stores of 8e8 photons), beyond which big blocks come from hipMalloc for the rest of the process.
+struct va_range {
+    uintptr_t base;
+    size_t bytes;
+};
+std::vector<va_range> g_vmm_tainted;
+size_t g_vmm_parked_bytes = 0, g_vmm_remaps_avoided = 0;
+std::atomic<bool> g_vmm_off{false}; // the virtual-memory path is switched off for the rest of the process (with the reason on stderr)
+constexpr size_t kParkedVaMax = (size_t)32 << 40;
 std::unordered_map<void *, double> g_rate; // whole-block sweep rate (GB/s) of live and idle blocks (alloc_slab); guarded by g_vmm_mu
 
 bool vmm_enabled() {
@@ -3218,7 +3231,44 @@ bool vmm_enabled() {
         const char *e = getenv("PCL_VMM");
         return !(e && e[0] == '0');
     }();
-    return on;
+    return on && !g_vmm_off.load(std::memory_order_relaxed);
+}
+
+void vmm_switch_off(const char *why) {
+    if (!g_vmm_off.exchange(true)) fprintf(stderr, "libphysicl_hip: big blocks come from hipMalloc from here on: %s\n", why);
+}
+
+// A range that was mapped (in whole or in part) is unmapped for good: its addresses are freed -- the runtime lets go of the
+// physical memory only there -- and reserved again at once, never to be mapped (profiles/r05_vmm_remap.log: a new mapping at
+// addresses that were mapped before loses writes; a device-wide synchronise before the unmap and seconds of sleep did not
+// change that, so it is not work in flight but translations of the old mapping that the runtime leaves behind).  If the
+// second reservation cannot be had, the range is remembered as tainted and every later range is checked against it.
+void vmm_park(void *p, size_t bytes) {
+    (void)hipMemAddressFree(p, bytes);
+    static const bool park = [] { const char *e = getenv("PCL_VMM_KEEP_VA"); return !(e && e[0] == '0'); }();
+    static const bool test_fail = getenv("PCL_VMM_TEST_PARK_FAIL") != nullptr; // tests: behave as if the second reservation had failed
+    bool parked = false;
+    if (park && !test_fail) {
+        void *again = nullptr;
+        if (hipMemAddressReserve(&again, bytes, (size_t)2 << 20, p, 0) != hipSuccess) {
+            (void)hipGetLastError();
+        } else if (again != p) { // (somebody else's addresses: not ours to hold)
+            (void)hipMemAddressFree(again, bytes);
+        } else {
+            parked = true;
+        }
+    }
+    if (!park) return; // (PCL_VMM_KEEP_VA=0: the round-5 fault on purpose, for A/B)
+    bool too_much = false;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        if (parked)
+            g_vmm_parked_bytes += bytes;
+        else
+            g_vmm_tainted.push_back({reinterpret_cast<uintptr_t>(p), bytes});
+        too_much = g_vmm_parked_bytes > kParkedVaMax;
+    }
+    if (too_much) vmm_switch_off("a quarter of the address space is parked behind freed ranges");
 }
 
 // the store's own access pattern, as a probe: every workgroup writes the 13 field rows of a [17][2048] fp64 tile
@@ -3313,8 +3363,27 @@ hipError_t vmm_malloc(void **p, size_t bytes, int device) {
     const size_t tail = bytes - (need - 1) * chunk, tail_len = (tail + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
     const size_t total = (need - 1) * chunk + (tail_len < chunk ? tail_len : chunk);
     void *va = nullptr;
-    hipError_t e = hipMemAddressReserve(&va, total, (size_t)2 << 20, nullptr, 0);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    for (int attempt = 0;; ++attempt) { // a range must never lie where a mapped range of this process lay before (vmm_park)
+        e = hipMemAddressReserve(&va, total, (size_t)2 << 20, nullptr, 0);
+        if (e != hipSuccess) return e;
+        bool clash = false;
+        {
+            std::lock_guard<std::mutex> lk(g_vmm_mu);
+            const uintptr_t a = reinterpret_cast<uintptr_t>(va);
+            for (const va_range &t : g_vmm_tainted)
+                if (a < t.base + t.bytes && t.base < a + total) clash = true;
+            if (clash) { // the reservation is kept, unmapped: these addresses are out of circulation now
+                g_vmm_parked_bytes += total;
+                ++g_vmm_remaps_avoided;
+            }
+        }
+        if (!clash) break;
+        if (attempt == 7) {
+            vmm_switch_off("the runtime keeps handing out addresses of freed ranges");
+            return hipErrorNotSupported;
+        }
+    }
     vmm_block blk;
     blk.bytes = total;
     blk.chunk = chunk;
@@ -3348,8 +3417,9 @@ hipError_t vmm_malloc(void **p, size_t bytes, int device) {
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (mapped) (void)hipMemUnmap(va, mapped);
-        vmm_keep_idle(blk.handles, mapped, chunk, device); // (the handles stay with the process)
-        if (!mapped) (void)hipMemAddressFree(va, total);   // (a range that was mapped, even in part, stays reserved)
+        vmm_keep_idle(blk.handles, mapped, chunk, device); // (the handles stay with the process: the caller's retry maps them again)
+        if (!mapped) (void)hipMemAddressFree(va, total);
+        else vmm_park(va, total);                          // (a range that was mapped, even in part, is never mapped again)
         return e;
     }
     {
@@ -3373,7 +3443,13 @@ hipError_t raw_malloc(void **p, size_t bytes, int device) {
 
 size_t pool_limit();
 
-void raw_free(void *p) {
+// ``release``: the caller wants the memory back at the driver (out of memory, the device is short, the pool is being emptied):
+// no physical handle is kept.  Otherwise handles are kept for the next range only within the pool's own bounds -- they are
+// memory the process holds, like the pool's idle blocks: pool_limit() together with those, and pool_may_keep().
+bool pool_may_keep(size_t bytes);
+std::atomic<size_t> g_pool_bytes_seen{0}; // g_pool_bytes as last written (raw_free runs with and without g_pool_mu held)
+
+void raw_free(void *p, bool release = false) {
     if (!p) return;
     vmm_block blk;
     bool mine = false;
@@ -3393,18 +3469,31 @@ void raw_free(void *p) {
     }
     (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block
     (void)hipMemUnmap(p, blk.bytes);
-    (void)hipMemAddressFree(p, blk.bytes); // (the runtime lets go of the physical memory only here, not at the unmap)
-    static const bool park = [] { const char *e = getenv("PCL_VMM_KEEP_VA"); return !(e && e[0] == '0'); }();
-    if (park) { // the addresses are reserved again at once, never to be mapped: nothing of this process lands where the range was
-        void *again = nullptr;
-        if (hipMemAddressReserve(&again, blk.bytes, (size_t)2 << 20, p, 0) != hipSuccess) {
-            (void)hipGetLastError();
-        } else if (again != p) { // (somebody else's addresses: not ours to hold)
-            (void)hipMemAddressFree(again, blk.bytes);
+    vmm_park(p, blk.bytes);
+    // which of the handles stay with the process?  As many as fit under the pool's limit beside what idles already
+    size_t budget = 0;
+    if (!release && pool_limit() > 0 && pool_may_keep(blk.bytes)) {
+        size_t idle;
+        {
+            std::lock_guard<std::mutex> lk(g_vmm_mu);
+            idle = g_vmm_idle_bytes;
+        }
+        const size_t held = g_pool_bytes_seen.load() + idle;
+        budget = pool_limit() > held ? pool_limit() - held : 0;
+    }
+    std::vector<hipMemGenericAllocationHandle_t> keep;
+    size_t off = 0, kept = 0;
+    for (auto h : blk.handles) {
+        const size_t len = blk.bytes - off < blk.chunk ? blk.bytes - off : blk.chunk;
+        off += len;
+        if (len == blk.chunk && kept + len <= budget) { // (whole chunks only: an odd-sized tail would never be asked for again)
+            keep.push_back(h);
+            kept += len;
+        } else {
+            (void)hipMemRelease(h);
         }
     }
-    vmm_keep_idle(blk.handles, blk.bytes, blk.chunk, blk.device); // the physical memory stays with the process (see vmm_block)
-    if (pool_limit() == 0) (void)vmm_release_idle();              // PCL_POOL_GB=0: nothing is kept
+    if (!keep.empty()) vmm_keep_idle(keep, kept, blk.chunk, blk.device);
 }
 
 // hipMemcpy2DAsync refuses a copy that reaches from one physical handle of a mapped range into the next (measured:
@@ -3444,13 +3533,14 @@ size_t pool_limit() {
     return lim;
 }
 
-void pool_flush_locked() {
+void pool_flush_locked() { // (everything back to the driver: no handle is kept)
+    g_pool_bytes = 0;
+    g_pool_bytes_seen = 0;
     for (const pool_block &b : g_pool) {
         (void)hipSetDevice(b.device);
-        raw_free(b.p);
+        raw_free(b.p, true);
     }
     g_pool.clear();
-    g_pool_bytes = 0;
 }
 
 hipError_t big_malloc(void **p, size_t bytes) {
@@ -3468,35 +3558,27 @@ hipError_t big_malloc(void **p, size_t bytes) {
             *p = g_pool[best].p;
             g_big[*p] = {g_pool[best].bytes, device};
             g_pool_bytes -= g_pool[best].bytes;
+            g_pool_bytes_seen = g_pool_bytes;
             g_pool.erase(g_pool.begin() + best);
             return hipSuccess;
         }
     }
     hipError_t e = raw_malloc(p, bytes, device);
     if (e == hipErrorOutOfMemory) {
+        // whichever allocator ran out (hipMemCreate of a mapped range, or hipMalloc: small blocks, the fallback): everything this
+        // process holds idle goes back to the driver first -- the pool's blocks and the physical handles of unmapped ranges --,
+        // then the device is synchronised (what was released is the device's again once the work that used it has ended) and the
+        // request is made again, once
         (void)hipGetLastError();
         {
             std::lock_guard<std::mutex> lk(g_pool_mu);
             pool_flush_locked();
         }
+        (void)vmm_release_idle();
         (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
         e = raw_malloc(p, bytes, device);
-        // Memory this process has just handed back (tens of GB of released handles, pcl_pool_trim) is the driver's for a
-        // while before it is anybody's again: hipMemCreate says "out of memory" where hipMalloc used to stall (measured:
-        // a 13.6 GB slab refused right after 218 GB had been released).  While the device reports more free memory from
-        // one look to the next, wait and try again -- 3 s at most; a real shortage is reported after the first look that
-        // shows no progress.
-        size_t free_prev = 0, total_b = 0;
-        if (e == hipErrorOutOfMemory && hipMemGetInfo(&free_prev, &total_b) != hipSuccess) free_prev = 0;
-        for (int k = 0; e == hipErrorOutOfMemory && k < 30; ++k) {
-            (void)hipGetLastError();
-            std::this_thread::sleep_for(std::chrono::milliseconds(100));
-            size_t free_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
-            e = raw_malloc(p, bytes, device);
-            if (e == hipErrorOutOfMemory && free_b <= free_prev && k >= 2) break; // nothing is coming back
-            free_prev = free_b;
-        }
+        if (e == hipErrorOutOfMemory) (void)hipGetLastError();
     }
     if (e == hipSuccess && eligible) {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -3530,7 +3612,7 @@ void big_free(void *p) {
             g_big.erase(it);
         }
     }
-    if (blk.device < 0 || blk.bytes > pool_limit()) {
+    if (blk.device < 0 || blk.bytes > pool_limit()) { // (not pooled: raw_free keeps what handles fit under the pool's limit)
         raw_free(p);
         return;
     }
@@ -3539,6 +3621,14 @@ void big_free(void *p) {
     (void)hipSetDevice(blk.device);
     (void)hipDeviceSynchronize(); // hipFree would have waited for the work that still uses the block (no lock held here)
     const bool keep = pool_may_keep(blk.bytes);
+    {   // physical handles kept of unmapped ranges are idle memory like the pool's blocks, and the cheaper kind to give up
+        size_t idle;
+        {
+            std::lock_guard<std::mutex> lk(g_vmm_mu);
+            idle = g_vmm_idle_bytes;
+        }
+        if (idle && (!keep || g_pool_bytes_seen.load() + idle + blk.bytes > pool_limit())) (void)vmm_release_idle();
+    }
     std::vector<pool_block> drop;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -3552,14 +3642,15 @@ void big_free(void *p) {
             g_pool.push_back({p, blk.bytes, blk.device});
             g_pool_bytes += blk.bytes;
         }
+        g_pool_bytes_seen = g_pool_bytes;
     }
-    for (const pool_block &d : drop) {
+    for (const pool_block &d : drop) { // (evicted to make room, or because the device is short of memory: back to the driver)
         (void)hipSetDevice(d.device);
-        raw_free(d.p);
+        raw_free(d.p, true);
     }
     if (!keep) {
         (void)hipSetDevice(blk.device);
-        raw_free(p);
+        raw_free(p, true);
     }
     (void)hipSetDevice(device);
 }
@@ -5830,11 +5921,24 @@ int pcl_pool_trim(int64_t *released_out) {
         held = g_pool_bytes;
         int device = 0;
         const bool had = hipGetDevice(&device) == hipSuccess;
-        pool_flush_locked(); // (mapped ranges give their handles to the idle list ...)
+        pool_flush_locked(); // (the idle blocks, physical handles and all, go back to the driver ...)
         if (had) (void)hipSetDevice(device);
     }
-    const size_t idle = vmm_release_idle(); // (... which goes back to the driver here: the memory is the device's again)
-    if (released_out) *released_out = (int64_t)(idle > held ? idle : held);
+    const size_t idle = vmm_release_idle(); // (... and so do the handles that were kept of ranges unmapped earlier)
+    if (released_out) *released_out = (int64_t)(held + idle);
+    return PCL_OK;
+}
+
+int pcl_pool_info(int64_t *idle_blocks_out, int64_t *idle_handles_out, int64_t *parked_va_out, int64_t *remaps_avoided_out, int *vmm_on_out) {
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        if (idle_handles_out) *idle_handles_out = (int64_t)g_vmm_idle_bytes;
+        if (parked_va_out) *parked_va_out = (int64_t)g_vmm_parked_bytes;
+        if (remaps_avoided_out) *remaps_avoided_out = (int64_t)g_vmm_remaps_avoided;
+    }
+    if (vmm_on_out) *vmm_on_out = vmm_enabled() ? 1 : 0;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (idle_blocks_out) *idle_blocks_out = (int64_t)g_pool_bytes;
     return PCL_OK;
 }
 

@@ -131,7 +131,9 @@ def test_a_store_created_after_a_much_bigger_one_was_freed_keeps_what_kernels_wr
     109 GB store, hipMemAddressReserve handed the same addresses out again and the first kernels through the new mapping
     still hit translations of the old one -- 10 % to 76 % of what a fill kernel wrote was not in the new store.  A freed
     range now keeps its addresses reserved (never mapped twice) and its physical handles serve the next range
-    (``handles_kept``) unless pcl_pool_trim handed them back to the driver in between (``handles_released``)."""
+    (``handles_kept``) unless pcl_pool_trim handed them back to the driver in between (``handles_released``).  The handles
+    that are kept are idle memory like the pool's blocks: together with those never more than PCL_POOL_GB (a third of the
+    device), the rest of the 109 GB goes back to the driver at once."""
     code = ("import numpy as np, sys\n"
             "from physicl_amd import _hip as hip\n"
             "C = 299792458.0\n"
@@ -139,10 +141,12 @@ def test_a_store_created_after_a_much_bigger_one_was_freed_keeps_what_kernels_wr
             "f, t = d.mem_info()\n"
             "BIG = 800_000_000 if t > 250 * 2**30 else 200_000_000\n"
             "d.store_alloc(BIG); d.fill_photons(BIG, 0, C, 1.0, 2.0, 3); d.sync(); d.store_free()\n"
-            "held = hip.pool_bytes()\n"
-            "assert held >= BIG * 17 * 8\n"
+            "held = hip.pool_bytes(); info = hip.pool_info()\n"
+            "assert 0 < held <= t // 3 and held == info['idle_blocks'] + info['idle_handles'], (held, t, info)\n"
+            "assert info['parked_va'] >= BIG * 17 * 8 and info['vmm_on']\n"      # the big range's addresses are out of circulation
+            "f2, _ = d.mem_info(); assert f2 >= f - held - (4 << 30), (f, f2, held)\n"   # what is not kept is the device's again
             "if sys.argv[1] == 'trim':\n"
-            "    assert hip.pool_trim() >= BIG * 17 * 8 and hip.pool_bytes() == 0\n"
+            "    assert hip.pool_trim() == held and hip.pool_bytes() == 0\n"
             "N = 100_000_000\n"
             "d.store_alloc(N)\n"
             "for g in range(2):\n"
@@ -153,3 +157,51 @@ def test_a_store_created_after_a_much_bigger_one_was_freed_keeps_what_kernels_wr
             "d.close(); print('ok')\n")
     out = subprocess.check_output([sys.executable, "-c", code, "trim" if trim else "keep"], cwd=ROOT, timeout=600)
     assert out.decode().strip().endswith("ok")
+
+
+def test_thirty_stores_of_1e8_photons_one_after_the_other_park_no_address_space():
+    """A script that creates and drops its store over and over (one Simulation per parameter set) gets the pooled block back,
+    still mapped: nothing is unmapped, so no address range is parked and the idle memory stays within the pool's limit."""
+    code = ("from physicl_amd import _hip as hip\n"
+            "N = 100_000_000\n"
+            "d = hip.Device(0)\n"
+            "f, t = d.mem_info()\n"
+            "d.store_alloc(N); d.fill_photons(N, 0, 299792458.0, 1.0, 2.0, 3); d.store_free()\n"
+            "i0 = hip.pool_info()\n"
+            "for k in range(30):\n"
+            "    d.store_alloc(N); d.fill_photons(N, k, 299792458.0, 1.0, 2.0, 3)\n"
+            "    assert d.step_counters([])[0] == N\n"
+            "    d.store_free()\n"
+            "i1 = hip.pool_info()\n"
+            "assert i1['parked_va'] - i0['parked_va'] <= N * 17 * 8, (i0, i1)\n"
+            "assert i1['idle_blocks'] + i1['idle_handles'] <= t // 3 and i1['vmm_on'], i1\n"
+            "d.close(); print('ok', i0, i1)\n")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, timeout=900)
+    assert out.decode().strip().splitlines()[-1].startswith("ok")
+
+
+def test_a_range_whose_addresses_could_not_be_kept_is_never_mapped_over():
+    """parking a freed range (free its addresses, reserve the same ones again) can fail, and then the addresses are
+    back in circulation.  PCL_VMM_TEST_PARK_FAIL makes every parking "fail": the freed ranges are remembered, a fresh
+    reservation that overlaps one of them is set aside, and the next store lies somewhere else -- with everything a kernel
+    writes into it in place."""
+    code = ("import numpy as np\n"
+            "from physicl_amd import _hip as hip\n"
+            "N, C = 3_000_000, 299792458.0\n"                       # 408 MB: a mapped range of several 64 MB handles under the knobs
+            "d = hip.Device(0)\n"
+            "old = []\n"
+            "for k in range(4):\n"
+            "    d.store_alloc(N)\n"
+            "    p = d.field_ptr(hip.R0)\n"
+            "    assert all(not (p < q + N * 17 * 8 and q < p + N * 17 * 8) for q in old), (hex(p), [hex(q) for q in old])\n"
+            "    d.fill_photons(N, k * N, C, 1.0, 2.0, 3)\n"
+            "    v0 = d.download(hip.V0); E = d.download(hip.E)\n"
+            "    assert int((v0 != C).sum()) == 0 and int(((E < 1.0) | (E > 2.0)).sum()) == 0\n"
+            "    old.append(p)\n"
+            "    d.store_free()\n"
+            "info = hip.pool_info()\n"
+            "assert info['vmm_on'] and info['idle_blocks'] == 0, info\n"
+            "d.close(); print('ok', info)\n")
+    env = dict(os.environ, PCL_VMM_TEST_PARK_FAIL="1", PCL_POOL_GB="0", PCL_VMM_CHUNK_TILES="240", PCL_ALLOC_TRIES="1")
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=ROOT, env=env, timeout=600)
+    assert out.decode().strip().splitlines()[-1].startswith("ok")
