@@ -333,7 +333,8 @@ def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
                 for k in range(0, 96, 24):
                     rows += [(o["hits"], tuple(int(x) for x in o["sign"])) for o in d.step_fused_multi(5e-3, 24, sc(k))]
                     forms.append(d.last_multi_work()[2])
-                    assert 1.0 < d.last_multi_clock() < 2.6          # GHz the chip held under the launch, measured in the kernel
+                    ghz = d.last_multi_clock()                       # GHz the chip held under the launch, measured in the kernel
+                    assert np.isfinite(ghz) and ghz > 0              # (which band it falls in is the box's business: the instrumentation test below)
             else:
                 rows = [(o["hits"], tuple(int(x) for x in o["sign"])) for o in (d.step_fused(5e-3, sc(k), [], lazy=True) for k in range(96))]
             out[how] = (rows, d.download_state())
@@ -352,3 +353,15 @@ def test_the_formulation_follows_the_hit_fraction_and_nothing_shows(hip):
     for f in ("r", "v", "dr", "dv"):
         for k in range(3):
             assert np.array_equal(out["multi"][1][f][k], out["single"][1][f][k]), (f, k)
+
+
+def test_instrumentation_the_clock_the_kernel_measures_is_a_plausible_engine_clock(hip):
+    """INSTRUMENTATION, not parity: pcl_store_last_multi_clock (shader cycles over 100 MHz ticks, pcl_clock_begin / _end) reads
+    between 1.0 and 2.6 GHz on an MI355X under its default power cap.  A box that clocks otherwise fails HERE and nowhere else."""
+    N = 2_000_000
+    with hip.Device(0) as d:
+        d.store_alloc(N)
+        d.fill_photons(N, 0, 299792458.0, 2.8e-19, 9.9e-19, 5)
+        d.step_fused_multi(5e-3, 24, dict(A=1e-15, n=1e-19, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=299792458.0,
+                                          h=6.62607015e-34, n_expr="0.000000001 * exp(r0[gid] - 5)", rng_mode=hip.RNG_PHILOX, seed=5, step=0))
+        assert 1.0 < d.last_multi_clock() < 2.6

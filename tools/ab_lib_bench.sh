@@ -3,6 +3,9 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 L=physicl_amd/_lib
 cp $L/libphysicl_hip.so $L/new.so
+# whatever ends this script (a timeout, Ctrl-C, a failing run), the tree's own build is what stays installed: later tests
+# and benches must never measure the old library under the new sources' hash
+trap 'cp $L/new.so $L/libphysicl_hip.so' EXIT
 for rep in 1 2; do
   for which in old new; do
     cp $L/${which/old/libphysicl_hip_old}.so $L/libphysicl_hip.so 2>/dev/null || cp $L/new.so $L/libphysicl_hip.so

@@ -4,6 +4,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 O=gpurun_out
 L=physicl_amd/_lib
 cp $L/libphysicl_hip.so $L/keep.so
+trap 'cp $L/keep.so $L/libphysicl_hip.so' EXIT    # (a timeout or a failing run must not leave the other build installed)
 run() { PCL_BENCH_DETAIL=$O/licm_$1.json timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/licm_$1.line 2> $O/licm_$1.err; }
 run A && cp $L/libphysicl_hip_nolicm.so $L/libphysicl_hip.so && run B && cp $L/keep.so $L/libphysicl_hip.so && PCL_RTC_DEFINE="-mllvm -disable-machine-licm" run C
 rc=$?
