@@ -97,7 +97,8 @@ const char *pcl_last_error(void);                 /* thread-local, never NULL */
 int         pcl_device_count(int *n_out);         /* host pointer */
 /* A/B switches ("knobs").  Every PCL_* environment variable the library reads at call time (the delete path's: PCL_ALIVE,
  * PCL_ALIVE_RATIO, PCL_ALIVE_MIN_SLOTS, PCL_ALIVE_POLL, PCL_ALIVE_FLUSH_KERNEL, PCL_COMPACT_SPARSE, PCL_AHEAD, PCL_AHEAD_K,
- * PCL_AHEAD_MAX_SLOTS, PCL_AHEAD_K_BIG, PCL_AHEAD_LIVE, PCL_MULTI_AHEAD; the K-step pass's: PCL_MULTI_NQ2, PCL_MULTI_NQ2_BELOW, PCL_MULTI_SAT) can also be set from the program:
+ * PCL_AHEAD_MAX_SLOTS, PCL_AHEAD_K_BIG, PCL_AHEAD_LIVE, PCL_MULTI_AHEAD; the K-step passes': PCL_MULTI_NQ2, PCL_MULTI_NQ3, PCL_MULTI_SAT,
+ * PCL_MIXED_NE3, PCL_MIXED_INPLACE, PCL_MIXED_COMPACT_BELOW) can also be set from the program:
  * value = its text, NULL = back to the environment.  Process-wide, takes effect at the next call; results never depend
  * on a knob (that is what the tests that flip them check), only which formulation runs.                            */
 int         pcl_set_knob(const char *name, const char *value);

@@ -1285,6 +1285,16 @@ struct pcl_mixed_args {
     pcl_u64 *cnt;
     pcl_i64 id_base, N;
     pcl_i64 ts;
+    // ``inplace`` (all-photon stores, loops with a delete phase): the survivors of a wave's 512-slot segment (its eight rows of
+    // the tile) are written back to the FRONT of that segment, in order, with every field they own -- r, v, the vprev rows, E,
+    // lam4, the id -- so that the store needs no compaction pass behind the launch: ``masks`` then holds a prefix of set bits per
+    // segment, which is what the next launch takes as ``alive_in`` (N = the extent in slots).  The global compaction only runs
+    // once fewer than half of the slots are alive (pcl_step_mixed_multi).  Stable: segments in order, each in order.
+    const pcl_u64 *alive_in; // NULL: slots [0, N) all hold a particle; else one bit per slot, a prefix per 512-slot segment
+    T *E_w, *lam4_w;         // inplace: the E and lam4 rows, writable (lam4_w NULL: the cache is not in use)
+    pcl_i64 *ids_out;        // inplace: the store's id array (may be the array ``ids`` points to)
+    int inplace;
+    int move_vp;             // inplace: the vprev rows hold something (a scatter phase of this launch, or an earlier implicit dv)
     T dt, A, n, c;      // isotropic phase: kernel constants after the reference's swap (light.py:287)
     T An_del;           // delete phase: A * n rounded once (light.py:243)
     pcl_u64 seed;
@@ -1306,6 +1316,63 @@ struct pcl_mixed_queue {
     T out[4][256 * 2];   // the new velocity and its step length |v' * dt|
 };
 
+// particles a wave's segment (rows 8w .. 8w+7 of its tile: 512 slots) holds on entry: the set bits of its eight alive words --
+// a prefix of the segment by construction (inplace launches leave it so) -- or, for a dense store, what lies below N
+template <typename T>
+__device__ __forceinline__ int pcl_mixed_seg_count(const pcl_mixed_args<T> &a, pcl_i64 tile, int wave) {
+    if (a.alive_in) {
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) n += (int)__popcll(a.alive_in[tile * 32 + wave * 8 + j]);
+        return n;
+    }
+    const pcl_i64 left = a.N - (tile * PCL_T + (pcl_i64)wave * 512);
+    return left <= 0 ? 0 : (left >= 512 ? 512 : (int)left);
+}
+
+// the end of a trip of an inplace launch, one row: the row's survivors (wave mask ``m``) go to positions kept .. kept + popc(m) - 1
+// of the wave's segment with everything they own.  ``pos_in``: the row's first position in the segment.  The vprev rows were
+// written at the particle's OLD position when the last scatter phase began (or hold an earlier launch's): read back from
+// there.  A row's destinations lie below its own first position and below every later row's: nothing unread is overwritten.
+template <typename T, bool USE_E>
+__device__ __forceinline__ void pcl_mixed_put(const pcl_mixed_args<T> &a, pcl_i64 seg0, int pos_in, pcl_u32 kept, pcl_u64 m, int lane, T r0, T r1,
+                                              T r2, T v0, T v1, T v2, T L4, pcl_u64 id) {
+    if (!((m >> lane) & 1ull)) return;
+    // (the addresses are worked out HERE, from an opaque copy of the lane: hoisted out of the phase loop they would have to live --
+    // or spill -- through every phase; what a particle owns goes out first, the vprev rows are read back last: few values live at a time)
+    asm volatile("" : "+v"(lane));
+    const pcl_u32 rank = __builtin_amdgcn_mbcnt_hi((pcl_u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((pcl_u32)m, 0u));
+    const pcl_i64 i_out = seg0 + (pcl_i64)(kept + rank);
+    const pcl_i64 tout = pcl_tix(i_out, a.ts);
+    const pcl_i64 tin = pcl_tix(seg0 + pos_in + lane, a.ts);
+    a.ids_out[i_out] = (pcl_i64)id;
+    a.E_w[tout] = a.E_w[tin]; // (read back from where the particle was: E need not live in a register through the phases)
+    if constexpr (USE_E) {
+        if (a.lam4_w) a.lam4_w[tout] = L4;
+    }
+    a.r0[tout] = r0;
+    a.r1[tout] = r1;
+    a.r2[tout] = r2;
+    a.v0[tout] = v0;
+    a.v1[tout] = v1;
+    a.v2[tout] = v2;
+    if (a.move_vp) {
+        const T p0 = a.vp0[tin], p1 = a.vp1[tin], p2 = a.vp2[tin];
+        a.vp0[tout] = p0;
+        a.vp1[tout] = p1;
+        a.vp2[tout] = p2;
+    }
+}
+
+// the eight alive words of a wave's segment after an inplace launch: a prefix of ``kept`` set bits
+template <typename T>
+__device__ __forceinline__ void pcl_mixed_put_masks(const pcl_mixed_args<T> &a, pcl_i64 tile, int wave, int lane, int kept) {
+    if (lane < 8) {
+        const int n = kept - 64 * lane;
+        a.masks[tile * 32 + wave * 8 + lane] = n >= 64 ? ~(pcl_u64)0 : (n <= 0 ? (pcl_u64)0 : (((pcl_u64)1 << n) - 1ull));
+    }
+}
+
 template <typename T, bool USE_E, int VAR_N>
 __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
     typedef pcl_rt<T> R;
@@ -1323,12 +1390,14 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
     const pcl_i64 tile = blockIdx.x;
     const pcl_u32 qbase = (pcl_u32)wave * 64u * NE; // this wave's part of the hit queue
     int kept = 0;
+    const int cnt_in = pcl_mixed_seg_count(a, tile, wave); // particles of this wave's segment: they sit at its front
+    const pcl_i64 seg0 = tile * PCL_T + (pcl_i64)wave * 512;
     for (int trip = 0; trip < 4; ++trip) {
+        if (a.inplace && trip * NE * 64 >= cnt_in) break; // (wave-uniform) the rest of the segment is empty
         const int row0 = wave * 8 + trip * NE;
         T Rr[3][NE], V[3][NE], L4[NE], Ev[NE], NM[NE];
         pcl_u32 wodd0[NE], wodd1[NE];
         pcl_u64 id[NE];
-        pcl_i64 ti[NE];
         bool in[NE], photon[NE], alive[NE];
         // the same predicates as wave masks (scalar registers): the votes below are taken on bare compares and combined with
         // these in the scalar unit -- a vote on a compound predicate costs a v_cndmask and a second v_cmp (pcl_ballot)
@@ -1336,18 +1405,18 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
-            in[e] = i < a.N;
+            in[e] = (trip * NE + e) * 64 + lane < cnt_in;
             const pcl_i64 is = in[e] ? i : 0;
-            ti[e] = pcl_tix(is, a.ts);
-            Rr[0][e] = a.r0[ti[e]];
-            Rr[1][e] = a.r1[ti[e]];
-            Rr[2][e] = a.r2[ti[e]];
-            V[0][e] = a.v0[ti[e]];
-            V[1][e] = a.v1[ti[e]];
-            V[2][e] = a.v2[ti[e]];
+            const pcl_i64 ti = pcl_tix(is, a.ts);
+            Rr[0][e] = a.r0[ti];
+            Rr[1][e] = a.r1[ti];
+            Rr[2][e] = a.r2[ti];
+            V[0][e] = a.v0[ti];
+            V[1][e] = a.v1[ti];
+            V[2][e] = a.v2[ti];
             L4[e] = (T)1;
-            if constexpr (USE_E) L4[e] = a.lam4[ti[e]];
-            Ev[e] = a.E[ti[e]];
+            if constexpr (USE_E) L4[e] = a.lam4[ti];
+            Ev[e] = a.E[ti];
             id[e] = (pcl_u64)(a.ids ? a.ids[is] : a.id_base + i);
             photon[e] = in[e] && (a.kind ? (a.kind[is] != 0) : true);
             alive[e] = in[e];
@@ -1440,12 +1509,15 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 if (ph == a.last_iso) { // the velocity before the LAST scatter phase is what dv = v - v_prev needs
+                    int lane_here = lane; // (opaque: the slab indices are worked out HERE, not carried in registers through every phase)
+                    asm volatile("" : "+v"(lane_here));
 #pragma unroll
                     for (int e = 0; e < NE; ++e)
                         if (in[e]) {
-                            a.vp0[ti[e]] = V[0][e];
-                            a.vp1[ti[e]] = V[1][e];
-                            a.vp2[ti[e]] = V[2][e];
+                            const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_here, a.ts);
+                            a.vp0[ti] = V[0][e];
+                            a.vp1[ti] = V[1][e];
+                            a.vp2[ti] = V[2][e];
                         }
                 }
 #pragma unroll
@@ -1484,15 +1556,27 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
                 if (val) atomicAdd(&c[lane], val);
             }
         }
+        if (a.inplace) { // the trip's survivors to the front of the wave's segment, row after row, with everything they own
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                pcl_mixed_put<T, USE_E>(a, seg0, (trip * NE + e) * 64, (pcl_u32)kept, am[e], lane, Rr[0][e], Rr[1][e], Rr[2][e], V[0][e], V[1][e],
+                                        V[2][e], L4[e], id[e]);
+                kept += (int)__popcll(am[e]);
+            }
+            continue;
+        }
+        int lane_end = lane;
+        asm volatile("" : "+v"(lane_end));
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if (alive[e]) {
-                a.r0[ti[e]] = Rr[0][e];
-                a.r1[ti[e]] = Rr[1][e];
-                a.r2[ti[e]] = Rr[2][e];
-                a.v0[ti[e]] = V[0][e];
-                a.v1[ti[e]] = V[1][e];
-                a.v2[ti[e]] = V[2][e];
+                const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_end, a.ts);
+                a.r0[ti] = Rr[0][e];
+                a.r1[ti] = Rr[1][e];
+                a.r2[ti] = Rr[2][e];
+                a.v0[ti] = V[0][e];
+                a.v1[ti] = V[1][e];
+                a.v2[ti] = V[2][e];
             }
             if (a.has_delete) {
                 const pcl_u64 m = am[e];
@@ -1501,6 +1585,7 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
             }
         }
     }
+    if (a.inplace) pcl_mixed_put_masks(a, tile, wave, lane, kept);
     if (a.has_delete && lane0) s_keep[wave] = kept;
     __syncthreads();
     if (a.has_delete && threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];
@@ -1543,7 +1628,10 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
     const pcl_i64 tile = blockIdx.x;
     const pcl_u32 qbase = (pcl_u32)wave * 64u * NE; // this wave's part of the hit queue
     int kept = 0;
+    const int cnt_in = pcl_mixed_seg_count(a, tile, wave); // particles of this wave's segment: they sit at its front
+    const pcl_i64 seg0 = tile * PCL_T + (pcl_i64)wave * 512;
     for (int trip = 0; trip < TRIPS; ++trip) {
+        if (a.inplace && trip * NE * 64 >= cnt_in) break; // (wave-uniform) the rest of the segment is empty
         const int row0 = wave * ROWS + trip * NE;
         T Rr[3][NE], L4[NE], Ev[NE];
         pcl_u32 wodd0[NE], wodd1[NE];
@@ -1553,7 +1641,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
-            in[e] = trip * NE + e < ROWS && i < a.N;
+            in[e] = trip * NE + e < ROWS && (trip * NE + e) * 64 + lane < cnt_in;
             const pcl_i64 is = in[e] ? i : 0;
             const pcl_i64 ti = pcl_tix(is, a.ts);
             Rr[0][e] = a.r0[ti];
@@ -1705,6 +1793,18 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
         }
         int lane_end = lane;
         asm volatile("" : "+v"(lane_end));
+        pcl_i64 tile_end = tile; // (opaque as well: the address of the rows' mask words is not carried -- or spilled -- through the phases)
+        asm volatile("" : "+s"(tile_end));
+        if (a.inplace) { // the trip's survivors to the front of the wave's segment, row after row, with everything they own
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                if (trip * NE + e >= ROWS) continue;
+                pcl_mixed_put<T, USE_E>(a, seg0, (trip * NE + e) * 64, (pcl_u32)kept, am[e], lane_end, Rr[0][e], Rr[1][e], Rr[2][e], s_h.c[0][e][tid],
+                                        s_h.c[1][e][tid], s_h.c[2][e][tid], L4[e], id[e]);
+                kept += (int)__popcll(am[e]);
+            }
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
             if ((am[e] >> lane) & 1ull) { // (alive lanes are in range)
@@ -1718,11 +1818,12 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
             }
             if (a.has_delete && trip * NE + e < ROWS) {
                 const pcl_u64 m = am[e];
-                if (lane0) a.masks[tile * 32 + row0 + e] = m;
+                if (lane0) a.masks[tile_end * 32 + row0 + e] = m;
                 kept += (int)__popcll(m);
             }
         }
     }
+    if (a.inplace) pcl_mixed_put_masks(a, tile, wave, lane, kept);
     if (a.has_delete && lane0) s_keep[wave] = kept;
     __syncthreads();
     if (a.has_delete && threadIdx.x == 0) a.tile_keep[tile] = s_keep[0] + s_keep[1] + s_keep[2] + s_keep[3];

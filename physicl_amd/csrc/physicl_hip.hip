@@ -282,11 +282,14 @@ __global__ void __launch_bounds__(kBlock) k_trace(pcl_trace_args<T> a) {
 
 // where are the tracked ids in a store whose ids are explicit (it has been compacted, or was uploaded with ids)?  One sweep
 // over the id row: a slot whose id is in ``want`` (ascending) writes itself into slot_out (preset to -1).  8 B per slot.
-__global__ void __launch_bounds__(kBlock) k_trace_slots(const int64_t *__restrict__ ids, int64_t N, const int64_t *__restrict__ want,
-                                                        int n_want, int64_t *__restrict__ slot_out) {
+// ``alive``: the store's alive bits, if it is behind a mask -- a dead slot's id is whatever was left there (the photon may live
+// on in another slot of its segment: pcl_mixed_put) and must not be taken for the photon.
+__global__ void __launch_bounds__(kBlock) k_trace_slots(const int64_t *__restrict__ ids, const uint64_t *__restrict__ alive, int64_t N,
+                                                        const int64_t *__restrict__ want, int n_want, int64_t *__restrict__ slot_out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t lo_id = want[0], hi_id = want[n_want - 1];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += stride) {
+        if (alive && !((alive[i >> 6] >> (i & 63)) & 1ull)) continue;
         const int64_t id = ids[i];
         if (id < lo_id || id > hi_id) continue;
         int lo = 0, hi = n_want - 1;
@@ -2954,6 +2957,8 @@ struct pcl_ctx {
     double mixed_last_h = -1.0;      // hit fraction of the last scatter phase of the previous pcl_step_mixed_multi launch (-1: unknown)
     double multi_last_h = -1.0;      // hit fraction of the last step of the previous pcl_step_fused_multi launch (-1: unknown)
     bool holes = false;
+    bool seg_prefix = false;         // holes, and the alive bits of every 512-slot segment are a prefix of it (an inplace launch of the mixed
+                                     // K-pass kernels left the store so: their next launch takes it as it is, pcl_step_mixed_multi)
     uint64_t alive_seq = 0;          // launches of k_delete_alive that reported to the host (h_cnt[kCounterSlots - 6])
     int64_t slots = 0;
     int pend_n = 0;                  // runs of equal moves r has not seen yet: pend_rep[q] moves of pend_dt[q], oldest first
@@ -5236,6 +5241,7 @@ int ahead_commit(pcl_ctx *ctx) {
     PCL_TRY(PCL_DISPATCH(ctx, ahead_commit_t<double>(ctx, write_r), ahead_commit_t<float>(ctx, write_r)));
     s.active = false;
     ctx->holes = true;
+    ctx->seg_prefix = false;
     ctx->slots = s.slots;
     if (write_r) {
         ctx->pend_n = 0; // the kernel wrote r with every move applied
@@ -5325,6 +5331,7 @@ void drop_holes(pcl_ctx *ctx) {
     ctx->ahead_last_valid = false;
     ctx->ahead_wait = ctx->ahead_backoff = 0;
     ctx->holes = false;
+    ctx->seg_prefix = false;
     ctx->slots = 0;
     ctx->pend_n = 0;
     ctx->last_delete_masked = false;
@@ -5361,6 +5368,7 @@ int densify(pcl_ctx *ctx) {
     ctx->last_delete_masked = last_masked; // the two mask arrays still describe the last delete
     ctx->slots = 0;
     ctx->pend_n = 0;
+    ctx->seg_prefix = false;
     return PCL_OK;
 }
 
@@ -5451,6 +5459,7 @@ int fused_delete_alive(pcl_ctx *ctx, double dt, double A, double n, uint64_t see
                              delete_alive_t<float>(ctx, slots, fresh, true, write_r, dt, A, n, seed, step, planes_host, n_planes)));
         PCL_TRY(wait_alive(ctx, before, &alive)); // the last workgroup wrote the totals into the pinned block
         ctx->holes = true;
+        ctx->seg_prefix = false;
         ctx->slots = slots;
         if (write_r)
             ctx->pend_n = 0;
@@ -5685,7 +5694,8 @@ int trace_ahead_t(pcl_ctx *ctx, int n_ids, double dt, int k_passes, int n_phases
     }
     if (f.slot) { // explicit ids: one sweep over the id row finds the tracked photons' slots
         PCL_HIP(hipMemsetAsync(ctx->trace_slot, 0xFF, (size_t)n_ids * sizeof(int64_t), ctx->stream));
-        hipLaunchKernelGGL(k_trace_slots, dim3(grid_for(ctx, f.N, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->ids, f.N, ctx->trace_want,
+        hipLaunchKernelGGL(k_trace_slots, dim3(grid_for(ctx, f.N, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->ids,
+                           ctx->holes ? ctx->masks : nullptr, f.N, ctx->trace_want,
                            n_ids, ctx->trace_slot);
         PCL_TRY(launch_check("k_trace_slots"));
     }
@@ -5705,8 +5715,8 @@ int trace_ahead_t(pcl_ctx *ctx, int n_ids, double dt, int k_passes, int n_phases
 template <typename T>
 int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int *phase_del, double A, double n, bool use_e,
                  bool var_n, rtc_entry *ent, double c, double h, double A_del, double n_del, uint64_t seed, uint32_t step,
-                 const double *planes_host, int n_planes, bool has_delete, int last_iso) {
-    const int64_t N = ctx->count;
+                 const double *planes_host, int n_planes, bool has_delete, int last_iso, bool inplace) {
+    const int64_t N = ctx->holes ? ctx->slots : ctx->count; // (behind a segment-prefix mask: the extent)
     const int tiles = (int)div_up(N, kTile);
     if (use_e) PCL_TRY(ensure_lam4_t<T>(ctx, h, c));
     pcl_mixed_args<T> f{};
@@ -5723,6 +5733,12 @@ int step_mixed_t(pcl_ctx *ctx, double dt, int k_passes, int n_phases, const int 
     f.id_base = ctx->id_base;
     f.N = N;
     f.ts = tile_stride(ctx);
+    f.alive_in = ctx->holes ? reinterpret_cast<const pcl_u64 *>(ctx->masks) : nullptr; // (a wave reads its eight words before it writes them)
+    f.inplace = inplace ? 1 : 0;
+    f.E_w = F<T>(ctx, PCL_E);
+    f.lam4_w = (use_e && ctx->lam4_valid) ? static_cast<T *>(ctx->lam4) : nullptr;
+    f.ids_out = reinterpret_cast<pcl_i64 *>(ctx->ids);
+    f.move_vp = (last_iso >= 0 || ctx->lazy_dv) ? 1 : 0;
     f.dt = (T)dt; f.A = (T)A; f.n = (T)n; f.c = (T)c;
     f.An_del = (T)A_del * (T)n_del;
     f.seed = seed;
@@ -7181,7 +7197,6 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     if (n_planes < 0 || n_planes > PCL_MAX_PLANES) return fail(PCL_ERR_ARG, "n_planes outside [0, %d]", PCL_MAX_PLANES);
     if (n_planes > 0 && !planes_host) return fail(PCL_ERR_ARG, "planes_host is NULL");
     if (ctx->bank_pending) return fail(PCL_ERR_STATE, "un-read asynchronous fused steps are outstanding");
-    PCL_TRY(densify(ctx));
     int phase_del[PCL_MIXED_MAXPH] = {0, 0};
     int n_iso = 0, n_delete = 0, last_iso_in_pass = -1;
     for (int j = 0; j < n_phases; ++j) {
@@ -7197,18 +7212,27 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     }
     if (n_iso > 1 || n_delete > 1) return fail(PCL_ERR_ARG, "at most one isotropic and one delete phase per pass");
     const bool has_iso = n_iso > 0, has_delete = n_delete > 0;
+    // Loops with a delete phase on all-photon stores: the kernel writes a wave's survivors back to the front of the wave's own
+    // 512-slot segment of the tile (stable, every field they own), so the launch needs NO compaction pass behind it -- the store
+    // stays behind an alive mask whose set bits are a prefix of every segment, the next launch of this entry point takes it as
+    // it is (its waves skip the empty rows), and the global compaction (scan + k_compact_*) only runs once fewer than half of the
+    // slots are alive.  Round 5 compacted after every launch: 30 % of configs[4]'s GPU time to drop 6 % of the slots
+    // (profiles/r05_driver_cmd_pmc.md).  PCL_MIXED_INPLACE=0: that form (A/B, and what stores with plain Objects take).
+    static knob k_inpl("PCL_MIXED_INPLACE");
+    const bool inplace = has_delete && !ctx->kind && !k_inpl.off() && (has_iso || ctx->lazy_dv || ctx->dv_zero == 1);
+    if (!(inplace && ctx->holes && ctx->seg_prefix && ctx->pend_n == 0)) PCL_TRY(densify(ctx));
     const bool use_e = has_iso && (flags & PCL_SCATTER_WAVELENGTH), var_n = has_iso && (flags & PCL_SCATTER_VARIABLE_N);
     rtc_entry *ent = nullptr;
     if (var_n) PCL_TRY(get_rtc(ctx, n_expr, ctx->dtype == PCL_DTYPE_F32 ? 1 : 0, use_e, &ent));
     const int np = n_planes, n_rows = k_passes * n_phases, nslots = 5 + np;
-    const int64_t N = ctx->count;
+    const int64_t N = ctx->count, extent = ctx->holes ? ctx->slots : ctx->count;
     if (out_host)
         for (int k = 0; k < n_rows * (5 + np); ++k) out_host[k] = 0;
     if (N == 0) return PCL_OK;
     // a pending implicit dv: superseded by the pass's own scatter phase; a pass without one (delete only) carries it
     // through the compaction (all-photon stores) or makes it real first
     if (has_delete) {
-        PCL_TRY(ensure_scratch(ctx, N));
+        PCL_TRY(ensure_scratch(ctx, extent, true)); // (a store behind its segment-prefix mask stays as it is)
         PCL_TRY(ensure_alt(ctx));
     }
     if (!has_iso && ctx->lazy_dv && ctx->kind) PCL_TRY(materialize(ctx));
@@ -7219,9 +7243,9 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     const int last_iso = has_iso ? (k_passes - 1) * n_phases + last_iso_in_pass : -1;
     PCL_TRY(PCL_DISPATCH(ctx,
                          step_mixed_t<double>(ctx, dt, k_passes, n_phases, phase_del, A, n, use_e, var_n, ent, c, h, A_del, n_del,
-                                              seed, step0, planes_host, np, has_delete, last_iso),
+                                              seed, step0, planes_host, np, has_delete, last_iso, inplace),
                          step_mixed_t<float>(ctx, dt, k_passes, n_phases, phase_del, A, n, use_e, var_n, ent, c, h, A_del, n_del,
-                                             seed, step0, planes_host, np, has_delete, last_iso)));
+                                             seed, step0, planes_host, np, has_delete, last_iso, inplace)));
     PCL_HIP(hipMemcpyAsync(ctx->h_multi, ctx->d_multi, (size_t)n_rows * nslots * sizeof(uint64_t), hipMemcpyDeviceToHost,
                            ctx->stream));
     // what is implicit now: dr = (velocity of the last move) * dt; dv = v - vprev once a scatter phase has run
@@ -7229,7 +7253,7 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
     ctx->lazy_dr = true;
     ctx->lazy_dr_vprev = has_iso && !phase_del[n_phases - 1]; // last phase scattered: its move used what is now vprev
     ctx->lazy_dt = dt;
-    if (has_delete) {
+    if (has_delete && !inplace) {
         bool has_dr = false;
         int dv_mode = (ctx->lazy_dv && !ctx->kind) ? kDvVprev : kDvMove;
         if (ctx->lazy_dv && ctx->kind) { // plain Objects keep real dv rows: make the photons' real too, move everything
@@ -7240,13 +7264,28 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
                              compact_after_pass_t<float>(ctx, dt, has_dr, dv_mode)));
     }
     PCL_TRY(stream_wait(ctx));
-    if (has_delete) {
+    if (has_delete && !inplace) {
         int64_t alive = 0;
         PCL_TRY(wait_count(ctx, N, &alive));
         if (alive != (int64_t)ctx->h_multi[(n_rows - 1) * nslots])
             return fail(PCL_ERR_HIP, "compaction kept %lld particles, the last phase counted %lld", (long long)alive,
                         (long long)ctx->h_multi[(n_rows - 1) * nslots]);
         adopt_compacted(ctx, alive, -1);
+    }
+    if (has_delete && inplace) { // the store is behind its alive mask now, a prefix of set bits per 512-slot segment, ids explicit
+        const int64_t alive = (int64_t)ctx->h_multi[(n_rows - 1) * nslots];
+        if (alive < 0 || alive > N) return fail(PCL_ERR_HIP, "the last phase counted an impossible %lld of %lld particles", (long long)alive, (long long)N);
+        ctx->holes = alive > 0;
+        ctx->seg_prefix = alive > 0;
+        ctx->slots = alive > 0 ? extent : 0;
+        ctx->count = alive;
+        ctx->pend_n = 0;
+        ctx->ids_iota = false;
+        ctx->last_delete_n = -1;
+        ctx->last_delete_masked = false;
+        if (!(use_e && ctx->lam4_valid)) ctx->lam4_valid = false; // (the cache travelled with the photons only when the launch used it)
+        static knob k_ratio("PCL_MIXED_COMPACT_BELOW");               // compact once fewer than this share of the slots is alive (default 0.5)
+        if (alive > 0 && (double)alive < k_ratio.value(0.5) * (double)extent) PCL_TRY(densify(ctx));
     }
     if (has_iso) // pcl_store_last_scatter_hits() reports the last scatter phase
         ctx->h_cnt[0] = ctx->h_multi[(int64_t)((k_passes - 1) * n_phases + last_iso_in_pass) * nslots + 1], ctx->hits_on_host = true;

@@ -62,10 +62,14 @@ KSTEP_KNOBS = [("256_per_wave", {"PCL_MULTI_NQ2": "1", "PCL_MULTI_NQ3": "0"}), (
                ("saturation_probe", {"PCL_MULTI_SAT": "1", "PCL_MULTI_NQ2": "0"}), ("no_saturation_probe", {"PCL_MULTI_SAT": "0"})]
 # the mixed K-pass kernel: three rows of 64 particles per wave and trip with the velocities in LDS (k_mixed3: what constant-n loops take by
 # themselves below a hit probability of 0.33) forced for every constant-n loop, and never
-MIXED_KNOBS = [("mixed_rows3", {"PCL_MIXED_NE3": "1"}), ("mixed_rows2", {"PCL_MIXED_NE3": "0"})]
-MIXED_FILES = {"test_gpu_mixed.py", "test_gpu_random_programs.py"}
+MIXED_KNOBS = [("mixed_rows3", {"PCL_MIXED_NE3": "1"}), ("mixed_rows2", {"PCL_MIXED_NE3": "0"}),
+               # round 6: loops with a delete phase compact each wave's survivors inside its own 512-slot segment and leave the global
+               # compaction until half of the slots are dead (pcl_step_mixed_multi); "0": a compaction behind every launch, round 5's
+               # form; PCL_MIXED_COMPACT_BELOW=0: in place and never a global compaction by itself (whoever needs the dense store asks)
+               ("mixed_compact_every_launch", {"PCL_MIXED_INPLACE": "0"}), ("mixed_inplace_never_compact", {"PCL_MIXED_COMPACT_BELOW": "0"})]
+MIXED_FILES = {"test_gpu_mixed.py", "test_gpu_random_programs.py", "test_gpu_trace.py"}
 DELETE_FILES = {"test_gpu_parity.py", "test_gpu_multi.py", "test_gpu_mixed.py", "test_gpu_simulation.py", "test_gpu_random_programs.py",
-                "test_gpu_fp32.py"}
+                "test_gpu_fp32.py", "test_gpu_trace.py"}
 KSTEP_FILES = {"test_gpu_multi.py", "test_gpu_bench_regime.py", "test_gpu_rtc_background.py"}
 
 

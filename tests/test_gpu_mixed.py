@@ -426,3 +426,50 @@ def test_the_mixed_kernels_directly_vs_the_oracle_chain(make_store, hip, tag, N,
         assert np.array_equal(s["id"], st["id"])
         assert np.max(np.abs(np.stack(s["v"], 1) - np.stack(st["v"], 1))) <= V_ABS_TOL
         assert np.max(np.abs(np.stack(s["r"], 1) - np.stack(st["r"], 1))) <= 2 * K * dt * V_ABS_TOL + 1e-15
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("tag,order", [("base", ("iso", "delete")), ("base", ("delete", "iso")), ("lambda", ("iso", "delete")), ("varn", ("iso", "delete")),
+                                       ("base", ("delete",))])
+def test_a_run_of_mixed_launches_stays_behind_its_segment_prefix_mask(make_store, hip, tag, order, dtype, pcl_knobs):
+    """Round 6: a loop with a delete phase leaves every wave's survivors at the front of the wave's 512-slot segment and the
+    store behind an alive mask (no compaction pass behind the launch); the next launch takes it as it is, other entry points
+    see the dense store, and the global compaction comes once fewer than half of the slots are alive.  Eight launches of
+    five passes, a slow delete (3 % per pass: the store stays ragged for several launches): rows, and -- after every second
+    launch, through entry points that make it dense -- ids and the whole state equal the same passes one launch per light step."""
+    N, K, L = 300_011, 5, 8
+    init = initial(N, dtype, 3, "uniform")
+    _, _, _, _, dt = CASES[tag]
+    dt = 1e-3 if tag == "base" else dt
+    a_del, n_del = (1e-3, 0.1e-3) if tag == "base" else ((1e-3, 0.1e-3 * 1e-3 / dt) if dt != 1e-3 else (1e-3, 0.1e-3))
+    seed = 77
+    a = make_store(N, dtype)
+    a.upload_state(init)
+    b = make_store(N, dtype)
+    b.upload_state(init)
+    step, ragged = 1, 0
+    for launch in range(L):
+        sc, _ = scatter_dict(hip, tag, seed, step)
+        rows = a.step_mixed_multi(dt, K, order, sc if "iso" in order else None, (a_del, n_del), (), seed, step)
+        ref = []
+        for k in range(K):
+            for ph in order:
+                if ph == "iso":
+                    o = b.step_fused(dt, dict(sc, step=step), [], lazy=True)
+                    ref.append((o["N"], o["hits"], list(o["sign"])))
+                else:
+                    o = b.step_fused_delete(dt, a_del, n_del, hip.RNG_PHILOX, seed, step, [], lazy=True)
+                    ref.append((o["N"], o["removed"], list(o["sign"])))
+                step += 1
+        assert [(o["N"], o.get("hits", o.get("removed")), list(o["sign"])) for o in rows] == ref, launch
+        ragged += a.slots > a.count
+        if launch % 2 == 1:
+            assert np.array_equal(a.download_ids(), b.download_ids())
+            sa, sb = a.download_state(), b.download_state()
+            for f in ("r", "v", "dr", "dv"):
+                for k in range(3):
+                    assert np.array_equal(sa[f][k], sb[f][k]), (launch, f, k)
+            assert np.array_equal(sa["E"], sb["E"])
+    if not os.environ.get("PCL_MIXED_INPLACE") == "0":
+        assert ragged >= 3                       # the store really stayed behind its mask between launches
+    assert 0 < a.count < 0.5 * N
