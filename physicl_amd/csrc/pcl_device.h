@@ -968,6 +968,35 @@ struct pcl_multi_args {
 // Same operations on the same operands per photon, in the same order, as K launches of pcl_fast_body: bit-identical state and rows
 // (tests/test_gpu_multi.py runs every form against the single steps and the oracle).
 // ------------------------------------------------------------------------------------------------
+// ``pcoll >= uniform`` without building the uniform: R::uniform is an integer m of 53 (fp32: 24) random bits times 2^-53 (2^-24),
+// both exact, so  pcoll >= m * 2^-53  <=>  m <= floor(pcoll * 2^53)  (the scaling is exact too; a pcoll of 1 or more passes whatever
+// m, a NaN or a negative one never does: threshold -1) -- the reference's ``pcoll >= rand`` (physicl/light.py:243, 306) bit for bit,
+// NaN and inf included (tests/test_draw_threshold_cpu.py).  Where pcoll only changes when the photon scatters (constant n, no
+// wavelength term: A * n * |v dt|) the threshold is worked out once per velocity and a step's decision is shifts and one integer compare.
+template <typename T> struct pcl_thr;
+template <> struct pcl_thr<double> {
+    typedef pcl_i64 thr_t;
+    static __device__ __forceinline__ thr_t threshold(double pc) {
+        if (!(pc >= 0.0)) return -1;
+        const double y = pc * 9007199254740992.0;
+        return y >= 9007199254740992.0 ? (thr_t)9007199254740992ll : (thr_t)y; // (truncation = floor: y >= 0)
+    }
+    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { return (thr_t)(((pcl_u64)(a >> 5) << 26) | (pcl_u64)(b >> 6)); } // pcl_u53
+    static __device__ __forceinline__ double as_real(thr_t t) { return __longlong_as_double(t); } // (the bits, kept where a T is kept)
+    static __device__ __forceinline__ thr_t of_real(double x) { return __double_as_longlong(x); }
+};
+template <> struct pcl_thr<float> {
+    typedef int thr_t;
+    static __device__ __forceinline__ thr_t threshold(float pc) {
+        if (!(pc >= 0.0f)) return -1;
+        const float y = pc * 16777216.0f;
+        return y >= 16777216.0f ? (thr_t)16777216 : (thr_t)y;
+    }
+    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { (void)b; return (thr_t)(a >> 8); } // pcl_rt<float>::uniform
+    static __device__ __forceinline__ float as_real(thr_t t) { return __int_as_float(t); }
+    static __device__ __forceinline__ thr_t of_real(float x) { return __float_as_int(x); }
+};
+
 template <typename T, int NP>
 struct pcl_multi_home {
     T c[4][NP][256];                   // v0, v1, v2, |v dt| of photon p of thread t (component-major: lanes read consecutive words)
@@ -979,6 +1008,10 @@ template <typename T, bool USE_E, int VAR_N, int VEC, int NQ, bool SATP = false>
 __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
     typedef pcl_rt<T> R;
     typedef pcl_vec<T, VEC> VV;
+    typedef pcl_thr<T> D;
+    // constant n, no wavelength term: pcoll = A * n * |v dt| only changes when the photon scatters -- its home keeps the decision's
+    // integer threshold (pcl_thr) in place of |v dt|, a step decides with shifts and one integer compare
+    constexpr bool THR = VAR_N == 0 && !USE_E;
     constexpr int NP = VEC * NQ; // photons per lane
     __shared__ pcl_u32 s_cnt[(4 + PCL_MAXPL) * PCL_MULTI_MAX];
     const int nslots = 4 + a.n_planes;
@@ -1031,7 +1064,9 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 s_h.c[1][p][tid] = t4[e];
                 s_h.c[2][p][tid] = t5[e];
                 // |dr| = |v * dt| only changes when the photon scatters: kept beside v, recomputed with the new velocity
-                s_h.c[3][p][tid] = pcl_step_norm<T>(R::mul(t3[e], a.dt), R::mul(t4[e], a.dt), R::mul(t5[e], a.dt));
+                const T nm0 = pcl_step_norm<T>(R::mul(t3[e], a.dt), R::mul(t4[e], a.dt), R::mul(t5[e], a.dt));
+                if constexpr (THR) s_h.c[3][p][tid] = D::as_real(D::threshold(R::mul(R::mul(a.A, a.n), nm0)));
+                else s_h.c[3][p][tid] = nm0;
             }
         }
         pcl_u32 hits_prev = 0; // the hits of the step before (wave-uniform)
@@ -1088,7 +1123,9 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                     nmv[p] = nm;
                 } else
 #endif
-                {
+                if constexpr (THR) {
+                    pcn[p] = nm; // (the threshold's bits)
+                } else {
                     T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, nm, d0, d1, d2, Rr[0][p], Rr[1][p], Rr[2][p], Ev[p]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[p]);
                     pcn[p] = pc;
@@ -1140,6 +1177,7 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
             // NP basic blocks, one after the other (5.1 cycles an instruction at four waves per SIMD,
             // profiles/r05_valu_issue_probe.txt); side by side they fill each other's latencies.
             T rnd[NP];
+            typename D::thr_t mdr[NP]; // THR: the draw as the integer it is
 #ifndef PCL_PHILOX_SIDE_BY_SIDE
 #define PCL_PHILOX_SIDE_BY_SIDE 2 /* chains the scheduler may interleave at a time */
 #endif
@@ -1149,7 +1187,8 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                     if (p > 0 && p % PCL_PHILOX_SIDE_BY_SIDE == 0) __builtin_amdgcn_sched_barrier(0);
                     const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(p / VEC) * blockDim.x + tid) * VEC + (p % VEC));
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
-                    rnd[p] = R::uniform(w.x, w.y);
+                    if constexpr (THR) mdr[p] = D::draw(w.x, w.y);
+                    else rnd[p] = R::uniform(w.x, w.y);
                     wodd0[p] = w.z;
                     wodd1[p] = w.w;
                 }
@@ -1160,19 +1199,25 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                     if (p > 0 && p % PCL_PHILOX_SIDE_BY_SIDE == 0) __builtin_amdgcn_sched_barrier(0);
                     const pcl_u64 id = (pcl_u64)(a.id_base + (base + (pcl_i64)(p / VEC) * blockDim.x + tid) * VEC + (p % VEC));
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id, (pcl_u32)(id >> 32), st >> 1, 0u, kk0, kk1);
-                    rnd[p] = R::uniform(w.z, w.w);
+                    if constexpr (THR) mdr[p] = D::draw(w.z, w.w);
+                    else rnd[p] = R::uniform(w.z, w.w);
                     wodd0[p] = w.z;
                     wodd1[p] = w.w;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) rnd[p] = R::uniform(wodd0[p], wodd1[p]);
+                for (int p = 0; p < NP; ++p) {
+                    if constexpr (THR) mdr[p] = D::draw(wodd0[p], wodd1[p]);
+                    else rnd[p] = R::uniform(wodd0[p], wodd1[p]);
+                }
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const T rand = rnd[p];
-                const pcl_u64 bal = pcl_ballot(pcn[p] >= rand) & lm[p]; // (NaN compares false, +inf true: the reference's ``pcoll >= rand``)
+                // (NaN compares false, +inf true: the reference's ``pcoll >= rand``; THR: the same decision as an integer compare, pcl_thr)
+                pcl_u64 bal;
+                if constexpr (THR) bal = pcl_ballot(mdr[p] <= D::of_real(pcn[p])) & lm[p];
+                else bal = pcl_ballot(pcn[p] >= rnd[p]) & lm[p];
                 const bool hit = (bal >> lane) & 1ull;
                 // (unconditional: a lane that did not hit writes its own slot behind the queue -- an ``if (hit)`` is a basic block per
                 // photon, and the NP compares, votes and writes schedule better as one)
@@ -1207,7 +1252,9 @@ __device__ __forceinline__ void pcl_multi_body_lds(const pcl_multi_args<T> &a) {
                 s_h.c[0][op][ot] = o0;
                 s_h.c[1][op][ot] = o1;
                 s_h.c[2][op][ot] = o2;
-                s_h.c[3][op][ot] = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
+                const T nm1 = pcl_step_norm<T>(R::mul(o0, a.dt), R::mul(o1, a.dt), R::mul(o2, a.dt));
+                if constexpr (THR) s_h.c[3][op][ot] = D::as_real(D::threshold(R::mul(R::mul(a.A, a.n), nm1)));
+                else s_h.c[3][op][ot] = nm1;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();

@@ -255,6 +255,14 @@ template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
     pcl_multi_body_lds<T, USE_E, VAR_N, pcl_rt<T>::VEC, kMultiNQ<T>>(a); // 256 photons per wave in either precision
 }
+// constant n, fp64, three photons per lane (192 per wave, 8-byte accesses): where a wave of 256 photons queues 64 to 85 hits a step --
+// a full dense pass and a nearly empty one -- 192 queue 48 to 64, one pass (pcl_rtc_multi3_*: the same form of the hipRTC
+// specialisations).  A constant-n loop knows its hit probability A n c dt before the first launch (step_multi_t picks).
+// 31 KB of LDS: five workgroups per CU, five waves per SIMD.
+template <bool USE_E>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) k_multi3(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, USE_E, 0, 1, 3>(a);
+}
 template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
     pcl_fast_body<T, USE_E, VAR_N, pcl_rt<T>::VEC, true>(a);
@@ -1205,28 +1213,8 @@ __global__ void __launch_bounds__(kBlock) k_delete_ahead(ahead_args<T> a) {
     }
 }
 
-// ``pcoll >= uniform`` without building the uniform: R::uniform is an integer m of 53 (fp32: 24) random bits times 2^-53
-// (2^-24), both exact, so  pcoll >= m * 2^-53  <=>  m <= floor(pcoll * 2^53)  (the scaling is exact too; a pcoll of 1 or
-// more removes whatever m, a NaN or a negative one never does: threshold -1).  The threshold is worked out once per photon.
-template <typename T> struct ahead_draw;
-template <> struct ahead_draw<double> {
-    typedef int64_t thr_t;
-    static __device__ __forceinline__ thr_t threshold(double pc) {
-        if (!(pc >= 0.0)) return -1;
-        const double y = pc * 9007199254740992.0;
-        return y >= 9007199254740992.0 ? (thr_t)9007199254740992ll : (thr_t)y; // (truncation = floor: y >= 0)
-    }
-    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { return (thr_t)(((pcl_u64)(a >> 5) << 26) | (pcl_u64)(b >> 6)); } // pcl_u53
-};
-template <> struct ahead_draw<float> {
-    typedef int32_t thr_t;
-    static __device__ __forceinline__ thr_t threshold(float pc) {
-        if (!(pc >= 0.0f)) return -1;
-        const float y = pc * 16777216.0f;
-        return y >= 16777216.0f ? (thr_t)16777216 : (thr_t)y;
-    }
-    static __device__ __forceinline__ thr_t draw(pcl_u32 a, pcl_u32 b) { (void)b; return (thr_t)(a >> 8); } // pcl_rt<float>::uniform
-};
+// (``pcoll >= uniform`` as an integer compare: pcl_thr in pcl_device.h)
+template <typename T> using ahead_draw = pcl_thr<T>;
 
 // ---- the same, for at most one plane: a body costs what the photons still ALIVE cost -----------------------------------
 //   k_delete_ahead decides every slot's bodies with the slot's own lane: after four bodies three quarters of the lanes
@@ -4703,6 +4691,15 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
         PCL_TRY(launch_module(ctx, ent->multi2[use_e ? 1 : 0], grid, f, "step_fused_multi NQ=2 (hipRTC)"));
     } else if (var_n && ent->module) {
         PCL_TRY(launch_module(ctx, ent->multi[d][use_e ? 1 : 0], grid, f, "step_fused_multi (hipRTC)"));
+    } else if (!var_n && d == 0 && nq2 && nq3_mode != 0 &&
+               (nq3_mode == 1 || (!use_e ? (A * n * c * dt >= 0.25 && A * n * c * dt < 0.333)           // constant n: known before the first launch
+                                          : (ctx->multi_last_h >= 0.28 && ctx->multi_last_h < 0.355)))) { // wavelength term: by the launch before
+        ctx->multi_work[2] = 192;
+        grid = grid_for(ctx, div_up(N, (int64_t)3), kBlock);
+        pcl_multi_args<double> &f64 = reinterpret_cast<pcl_multi_args<double> &>(f); // (d == 0: T is double)
+        if (use_e) hipLaunchKernelGGL((k_multi3<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
+        else hipLaunchKernelGGL((k_multi3<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
+        PCL_TRY(launch_check("k_multi3"));
     } else {
         ctx->multi_work[2] = 64 * pcl_rt<T>::VEC * kMultiNQ<T>;
         grid = grid_for(ctx, div_up(N, pcl_rt<T>::VEC * kMultiNQ<T>), kBlock);

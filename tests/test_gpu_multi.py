@@ -188,6 +188,11 @@ def test_the_k_step_pass_directly_vs_the_oracle_chain(make_store, hip, tag, N, K
     # (PCL_MULTI_NQ2=0 selects the 128-photon instantiation, which exists for the hipRTC specialisations in fp64)
     rtc64 = dtype == "f64" and expr is not None
     want = 128 if os.environ.get("PCL_MULTI_NQ2") == "0" and rtc64 else (192 if os.environ.get("PCL_MULTI_NQ3") == "1" and rtc64 else 256)
+    if dtype == "f64" and expr is None and os.environ.get("PCL_MULTI_NQ2") != "0":
+        # constant n, ahead-of-time kernels: 192 photons per wave (k_multi3) when forced, or by itself where the loop's hit
+        # probability A n c dt -- known before the first launch without the wavelength term -- lies in [0.25, 0.333)
+        nq3 = os.environ.get("PCL_MULTI_NQ3")
+        want = 192 if nq3 == "1" or (nq3 is None and not use_e and 0.25 <= A * n * C_LIT * dt < 0.333) else 256
     assert d.last_multi_work()[2] == want
     s = d.download_state()
     tol_v = 4 * float(np.spacing(np_t(C_LIT)))
