@@ -727,6 +727,7 @@ def run_rank(args):
                 out["cpu_baseline_python"] = cpu_baseline_python(dev2, args, prof, 10_000)        # 1e4 and 1e5
                 out["cpu_baseline_python_1e5"] = cpu_baseline_python(dev2, args, prof, 100_000)
                 out["cpu_baseline_numpy"] = cpu_baseline_numpy(dev2, args, prof)
+                out["cpu_baseline_python_units"] = cpu_baseline_python_units(args, prof)
             finally:
                 dev2.close()
 
@@ -1296,6 +1297,50 @@ def cpu_baseline_python(dev, args, prof, photons=10000):
     value, steps, el = pyloop.time_steps(E, prof["dt"], prof["A_kernel"], prof["n_kernel"], True, prof["c_profile"], 3.0)
     return {"value": value, "unit": "particle-steps/s", "cores": 1, "kind": "port",
             "sample": "%d photons x %d steps, per-object Python loops (oracle/pyloop.py), %.1f s" % (n, steps, el)}
+
+
+def cpu_baseline_python_units(args, prof, photons=2000, seconds=3.0):
+    """Fourth CPU figure: the reference's CPU path at its REAL cost -- per-object Python loops over objects whose fields are
+    ``Measurement``s (the code-units ndarray subclass, physicl/__init__.py:11-291: every ``obj.v * sim.dt`` and ``obj.r += obj.dr``
+    goes through its ``__array_ufunc__`` unit algebra), with the constants h and c as Measurements in the wavelength term
+    (physicl/newton.py:14-16, physicl/light.py:335-350).  oracle/pyloop.py runs the same loops on bare ndarrays and is ~10x
+    faster than the reference measured in the survey container (1.5e4 .. 2.4e4, 2.2e3 with the wavelength term: BASELINE.md
+    section 2); this leg uses the build's own ``Measurement`` (bug-compatible with the reference's, tests/test_units_parity.py),
+    so the figure quoted beside the GPU's is what a PhysiCL user's CPU run costs.  Host code only: nothing of it is on the GPU path."""
+    import physicl_amd.light as light
+    from physicl_amd.units import Measurement
+    n = int(min(photons, args.photons))
+    rs = np.random.RandomState(args.seed)
+    e_lo, e_hi = light.E_from_wavelength(700e-9), light.E_from_wavelength(200e-9)
+    objs = [light.PhotonObject(E=e_lo + (e_hi - e_lo) * rs.power(3), v=Measurement([light.c, 0, 0], "m**1 s**-1")) for _ in range(n)]
+    dt = Measurement(np.double(prof["dt"]), "s**1")
+    A, nn = prof["A_kernel"], prof["n_kernel"]
+    np.random.seed(0)
+    steps, t0 = 0, time.perf_counter()
+    with np.errstate(all="ignore"):
+        while True:
+            for o in objs:                                     # NewtonianKinematicsStep.run          newton.py:14-16
+                o.dr = o.v * dt
+                o.r += o.dr
+            for o in objs:                                     # ScatterIsotropicStep.__run_py        light.py:336-350
+                norm = np.linalg.norm(o.dr)
+                pcoll = nn * A * norm
+                pcoll *= ((light.h * light.c) / o.E) ** -4
+                if pcoll >= np.random.random():
+                    phi, theta = np.random.random() * np.pi, np.random.random() * np.pi * 2
+                    vold = o.v
+                    o.v = np.array([light.c * np.sin(theta) * np.cos(phi), light.c * np.sin(theta) * np.sin(phi), light.c * np.cos(theta)])
+                    o.dv = vold
+                else:
+                    o.dv = np.array([0, 0, 0])
+            xp = sum(int(o.v[0] > 0) for o in objs)           # ScatterSignMeasureStep.run            light.py:423-426
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= seconds:
+                break
+    return {"value": n * steps / el, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d PhotonObjects with Measurement fields x %d steps of [Newton, ScatterIsotropic (constant n, wavelength term), sign "
+                      "count], per-object Python loops as physicl/newton.py:14-16 and physicl/light.py:336-350, %.1f s" % (n, steps, el)}
 
 
 if __name__ == "__main__":

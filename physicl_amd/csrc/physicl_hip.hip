@@ -258,10 +258,13 @@ __global__ void __launch_bounds__(kBlock) k_multi(pcl_multi_args<T> a) {
 // constant n, fp64, three photons per lane (192 per wave, 8-byte accesses): where a wave of 256 photons queues 64 to 85 hits a step --
 // a full dense pass and a nearly empty one -- 192 queue 48 to 64, one pass (pcl_rtc_multi3_*: the same form of the hipRTC
 // specialisations).  A constant-n loop knows its hit probability A n c dt before the first launch (step_multi_t picks).
-// 31 KB of LDS: five workgroups per CU, five waves per SIMD.
-template <bool USE_E>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) k_multi3(pcl_multi_args<double> a) {
-    pcl_multi_body_lds<double, USE_E, 0, 1, 3>(a);
+// 31 KB of LDS: five workgroups per CU; five waves per SIMD (91 VGPRs) without the wavelength term, four with it (its lam4 values
+// are the registers that would spill under the bound of five).
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 5))) k_multi3_e0(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, false, 0, 1, 3>(a);
+}
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) k_multi3_e1(pcl_multi_args<double> a) {
+    pcl_multi_body_lds<double, true, 0, 1, 3>(a);
 }
 template <typename T, bool USE_E, int VAR_N>
 __global__ void __launch_bounds__(kBlock) k_fastg(pcl_fast_args<T> a) { // explicit ids and/or plain Objects
@@ -4697,8 +4700,8 @@ int step_multi_t(pcl_ctx *ctx, double dt, int k_steps, double A, double n, bool 
         ctx->multi_work[2] = 192;
         grid = grid_for(ctx, div_up(N, (int64_t)3), kBlock);
         pcl_multi_args<double> &f64 = reinterpret_cast<pcl_multi_args<double> &>(f); // (d == 0: T is double)
-        if (use_e) hipLaunchKernelGGL((k_multi3<true>), dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
-        else hipLaunchKernelGGL((k_multi3<false>), dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
+        if (use_e) hipLaunchKernelGGL(k_multi3_e1, dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
+        else hipLaunchKernelGGL(k_multi3_e0, dim3(grid), dim3(kBlock), 0, ctx->stream, f64);
         PCL_TRY(launch_check("k_multi3"));
     } else {
         ctx->multi_work[2] = 64 * pcl_rt<T>::VEC * kMultiNQ<T>;

@@ -19,7 +19,7 @@ def bench_module():
 
 
 RECORDS = sorted(p for p in glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_*.json")) if "_bench_line_" not in p)
-LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_line_*.json")))
+LINES = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[56]_bench_line_*.json")))
 
 
 @pytest.mark.parametrize("path", RECORDS, ids=[os.path.basename(p) for p in RECORDS])

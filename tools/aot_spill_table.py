@@ -1,6 +1,6 @@
 """Register / spill table of every ahead-of-time kernel of libphysicl_hip, and what the spills cost inside the loops:
 
-    python tools/aot_spill_table.py [--asm DIR/aot.s] [--json profiles/r05_isa_counts_aot.json]
+    python tools/aot_spill_table.py [--asm DIR/aot.s] [--json profiles/r06_isa_counts_aot.json]
 
 Per kernel: VGPRs, SGPR / VGPR spill counts and scratch bytes from the code object's metadata, and for its LARGEST loop
 (the K loop of the K-step kernels, the body loop of k_delete_ahead_live, the tile loop elsewhere) the VALU instructions and
@@ -27,7 +27,7 @@ def demangle(names):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--asm")
-    ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r05_isa_counts_aot.json"))
+    ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r06_isa_counts_aot.json"))
     a = ap.parse_args()
     from physicl_amd import build
     asm_path = a.asm

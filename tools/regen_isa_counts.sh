@@ -1,6 +1,6 @@
 #!/bin/bash
 # Static instruction counts and register tables on the sources in the tree (no GPU): profiles/isa_counts.json (both bench
-# expressions + the ahead-of-time kernels the bench's legs price) and profiles/r05_isa_counts_aot.json.  Run after ANY change to
+# expressions + the ahead-of-time kernels the bench's legs price) and profiles/r06_isa_counts_aot.json.  Run after ANY change to
 # physicl_amd/csrc/* or the build options, before tools/final_run.sh (calibrations in isa_counts.json start over when the
 # sources change: tools/summarize_driver_prof.py / summarize_calib_ahead.py write them back from the new profiles).
 set -e

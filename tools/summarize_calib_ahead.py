@@ -2,7 +2,7 @@
 """Fit of k_delete_ahead_live's VALU instruction counts to its own work tally: SQ_INSTS_VALU of each launch of
 tools/calib_ahead.py (gpurun_out/prof_calib_ahead, tools/prof_calib_ahead.sh) = a2 x groups_two + a1 x groups_one + b x rounds_two
 + c x rounds_one (least squares over the cases).  Writes the four counts, the fit's residuals and the hash of the device sources
-they belong to into profiles/isa_counts.json under "k_delete_ahead_live<double>" and prints the table (profiles/r05_calib_ahead.md)."""
+they belong to into profiles/isa_counts.json under "k_delete_ahead_live<double>" and prints the table (profiles/r06_calib_ahead.md)."""
 import csv
 import glob
 import json
@@ -59,13 +59,13 @@ def main():
         if avail:
             L.append("| %d | %d | %.3f | %.3f | %s |" % (c["K"], c["step0"], d["SQ_INSTS_VALU"] * price / avail, d.get("SQ_ACTIVE_INST_VALU", 0) * 4.0 / avail,
                                                    c.get("clock_GHz", "-")))
-    open(os.path.join(ROOT, "profiles", "r05_calib_ahead.md"), "w").write("\n".join(L) + "\n")
+    open(os.path.join(ROOT, "profiles", "r06_calib_ahead.md"), "w").write("\n".join(L) + "\n")
     print("\n".join(L))
     p = os.path.join(ROOT, "profiles", "isa_counts.json")
     j = json.load(open(p))
     j["k_delete_ahead_live<double>"] = {"valu_per_group_first_pass_two_bodies": round(float(coef[0]), 1), "valu_per_group_first_pass_one_body": round(float(coef[1]), 1),
                                         "valu_per_round_two_bodies": round(float(coef[2]), 1), "valu_per_round_one_body": round(float(coef[3]), 1), "max_relative_residual": round(float(np.max(np.abs(fit / y - 1))), 4),
-                                        "source": "profiles/r05_calib_ahead.md (SQ_INSTS_VALU of %d launches, least squares on the kernel's own tally)" % len(cases) + "", "commit": commit,
+                                        "source": "profiles/r06_calib_ahead.md (SQ_INSTS_VALU of %d launches, least squares on the kernel's own tally)" % len(cases) + "", "commit": commit,
                                         # (the sources the launches ran: this script is run on the tree that was profiled)
                                         "csrc_sha": build.csrc_sha()}
     json.dump(j, open(p, "w"), indent=1, sort_keys=True)
