@@ -467,11 +467,15 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
  * Works on any store (explicit ids after compactions, plain Objects, behind an alive mask, either dtype).
  * out_host: double[k_passes][n_ids][4] = { r0, r1, r2, moved } -- moved = 1 if the particle's dv is not the zero vector
  * at that point (trace_dv, light.py:456) else 0; four NaNs where the particle is not in the store at that point (removed
- * by a delete phase, or never there: the reference traces 'nan;nan;nan', light.py:435).  Device RNG only.  Synchronises. */
+ * by a delete phase, or never there: the reference traces 'nan;nan;nan', light.py:435).  Device RNG only.  Synchronises --
+ * unless out_host is NULL: the kernel is then only enqueued (it writes its rows into pinned host memory of the context) and the
+ * K-pass launch can follow at once on the same in-order stream; pcl_store_trace_read(ctx, out_host, k_passes * n_ids * 4) hands
+ * the rows out afterwards -- behind a launch that has returned its counter rows it does not wait at all.                     */
 #define PCL_TRACE_MAX 65536
 int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, double dt, int k_passes, int n_phases,
                           const int *phase_kinds_host, int record_phase, double A, double n, int flags, double c, double h,
                           const char *n_expr, double A_del, double n_del, uint64_t seed, uint32_t step0, double *out_host);
+int pcl_store_trace_read(pcl_ctx *ctx, double *out_host, int64_t n_doubles);
 
 /* The int32 flag array of the most recent pcl_step_scatter_delete / pcl_step_fused_delete, in PRE-compaction order
  * (what the reference's kernel returns in ``res``).  flags_host needs room for the pre-delete count. */

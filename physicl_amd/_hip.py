@@ -131,6 +131,7 @@ _PROTOTYPES = {
                              c_double, c_double, c_uint64, c_uint32, _vp, c_int, _vp],
     "pcl_store_trace_ahead": [_vp, _vp, c_int, c_double, c_int, c_int, _vp, c_int, c_double, c_double, c_int, c_double, c_double,
                               c_char_p, c_double, c_double, c_uint64, c_uint32, _vp],
+    "pcl_store_trace_read": [_vp, _vp, c_int64],
     "pcl_step_fused_read": [_vp, c_int, _vp],
     "pcl_store_last_scatter_hits": [_vp, POINTER(c_int64)],
     "pcl_step_scatter_delete": [_vp, c_double, c_double, c_int, c_uint64, c_uint32, POINTER(c_int64),
@@ -687,12 +688,14 @@ class Device:
                          ("hits" if ph == "iso" else "removed"): int(o[4 + npl])})
         return rows
 
-    def trace_ahead(self, ids, dt, k_passes, phases, record_phase=0, scatter=None, delete=None, seed=0, step=0):
+    def trace_ahead(self, ids, dt, k_passes, phases, record_phase=0, scatter=None, delete=None, seed=0, step=0, defer=False):
         """Where the particles with the (ascending) ids ``ids`` will be when a trace step behind phase ``record_phase`` runs
         in each of the next ``k_passes`` passes of a loop with the phases ``phases`` ("iso" / "delete"; arguments as
         step_mixed_multi's) -- worked out from the store as it stands, which is NOT changed (pcl_store_trace_ahead): call it
         with the arguments of the K-pass launch, before that launch.  Returns (k_passes, len(ids), 4) float64:
-        r0, r1, r2, moved (dv != 0); NaN rows where the particle is not in the store at that point."""
+        r0, r1, r2, moved (dv != 0); NaN rows where the particle is not in the store at that point.
+        ``defer=True``: the kernel is only enqueued and a function is returned that hands the rows out -- call it behind the
+        K-pass launch (same stream, in order: the rows are there when the launch's own counter rows are, no extra wait)."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         kinds = np.array([{"iso": PHASE_ISOTROPIC, "delete": PHASE_DELETE}[p] for p in phases], dtype=np.int32)
         sc = scatter or {}
@@ -703,8 +706,15 @@ class Device:
             self.ctx, ids.ctypes.data_as(c_void_p), len(ids), float(dt), int(k_passes), len(kinds), kinds.ctypes.data_as(c_void_p),
             int(record_phase), float(sc.get("A", 0.0)), float(sc.get("n", 0.0)), int(sc.get("flags", 0)), float(sc.get("c", 0.0)),
             float(sc.get("h", 0.0)), expr.encode() if expr is not None else None, float(A_d), float(n_d), int(seed),
-            int(step) & 0xFFFFFFFF, out.ctypes.data_as(c_void_p)))
-        return out
+            int(step) & 0xFFFFFFFF, None if (defer and out.size) else out.ctypes.data_as(c_void_p)))
+        if not defer:
+            return out
+
+        def read():
+            if out.size:
+                check(self.lib.pcl_store_trace_read(self.ctx, out.ctypes.data_as(c_void_p), out.size))
+            return out
+        return read
 
     def step_fused_read(self, n_planes=0):
         """Counters of the last ``step_fused(..., sync=False)``: same dict as the synchronous call."""

@@ -808,10 +808,12 @@ class Simulation(threading.Thread):
         # TracePathMeasureStep: where its tracked particles will be behind its group's light step in each of the k passes --
         # worked out from the store as it stands, BEFORE the launch that moves it (same constants, same launch indices)
         traced = []
-        for j, g in enumerate(groups):
-            for m in g[2:]:
-                if m._fuse_role == "trace":
-                    traced.append((m, dev.trace_ahead(m._ahead_set(self), dt0, k, phases, j, sc, dl, self.seed, step0)))
+        tracers = [(j, m) for j, g in enumerate(groups) for m in g[2:] if m._fuse_role == "trace"]
+        for j, m in tracers:
+            # (one tracer: its kernel is only enqueued, the rows -- pinned host memory of the context -- are read behind the launch;
+            #  several share that buffer and are read one by one)
+            got = dev.trace_ahead(m._ahead_set(self), dt0, k, phases, j, sc, dl, self.seed, step0, defer=len(tracers) == 1)
+            traced.append((m, got if len(tracers) == 1 else (lambda rows=got: rows)))
         # raw rows from the library: one per light step per pass, columns [N, sign x 3, planes ..., hits | removed]
         if phases == ["iso"] and dev.is_uniform():
             sc.update(rng_mode=hip.RNG_PHILOX, seed=self.seed, step=step0)
@@ -823,6 +825,7 @@ class Simulation(threading.Thread):
         else:
             raw = dev.step_mixed_multi(dt0, k, phases, sc, dl, planes, self.seed, step0, raw=True)
             self.schedule["mixed_multi"] += 1
+        traced = [(m, read()) for m, read in traced]   # (the rows were written while the launch ran: nothing to wait for)
         npl = len(planes)
         have = raw.shape[1] - 5                       # plane columns the library returned (0 when no measure step asked)
         flat = np.zeros((k * P, 5 + npl), dtype=np.int64)     # [N, event count, sign x 3, planes ...]: what is all-reduced

@@ -3004,8 +3004,8 @@ struct pcl_ctx {
     // pcl_store_trace_ahead: the tracked ids (host copy + device), their slots, the rows
     std::vector<int64_t> trace_ids;
     int64_t *trace_want = nullptr, *trace_slot = nullptr;
-    double *trace_out = nullptr;
-    int64_t trace_want_cap = 0, trace_out_cap = 0;
+    double *trace_out = nullptr;                     // PINNED HOST memory: the kernel writes its rows there, nothing is copied back
+    int64_t trace_want_cap = 0, trace_out_cap = 0, trace_out_n = 0; // (trace_out_n: doubles of the rows a launch has left to be read)
     uint64_t *d_bank[2] = {nullptr, nullptr};
     uint64_t *h_bank[2] = {nullptr, nullptr};
     hipEvent_t bank_ev[2] = {nullptr, nullptr};
@@ -6413,8 +6413,9 @@ int pcl_store_free(pcl_ctx *ctx) {
     ctx->e_out_cap = 0;
     dev_free(ctx->trace_want);
     dev_free(ctx->trace_slot);
-    dev_free(ctx->trace_out);
-    ctx->trace_want_cap = ctx->trace_out_cap = 0;
+    if (ctx->trace_out) (void)hipHostFree(ctx->trace_out);
+    ctx->trace_out = nullptr;
+    ctx->trace_want_cap = ctx->trace_out_cap = ctx->trace_out_n = 0;
     ctx->trace_ids.clear();
     ctx->tiles = 0;
     refresh_rows(ctx); // all row addresses -> NULL
@@ -7315,7 +7316,7 @@ int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, doub
         return fail(PCL_ERR_ARG, "k_passes * n_phases outside [1, %d]", PCL_MULTI_MAX);
     if (record_phase < 0 || record_phase >= n_phases) return fail(PCL_ERR_ARG, "record_phase outside [0, n_phases)");
     if (n_ids < 0 || n_ids > PCL_TRACE_MAX) return fail(PCL_ERR_ARG, "n_ids outside [0, %d]", PCL_TRACE_MAX);
-    if (n_ids > 0 && (!ids_host || !out_host)) return fail(PCL_ERR_ARG, "ids_host / out_host is NULL");
+    if (n_ids > 0 && !ids_host) return fail(PCL_ERR_ARG, "ids_host is NULL");
     int phase_del[PCL_MIXED_MAXPH] = {0, 0};
     bool has_iso = false;
     for (int j = 0; j < n_phases; ++j) {
@@ -7349,9 +7350,10 @@ int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, doub
     const int64_t n_out = (int64_t)k_passes * n_ids * 4;
     if (ctx->trace_out_cap < n_out) {
         PCL_HIP(hipStreamSynchronize(ctx->stream));
-        dev_free(ctx->trace_out);
+        if (ctx->trace_out) (void)hipHostFree(ctx->trace_out);
+        ctx->trace_out = nullptr;
         ctx->trace_out_cap = 0;
-        PCL_TRY(dev_alloc(&ctx->trace_out, n_out));
+        PCL_HIP(hipHostMalloc(reinterpret_cast<void **>(&ctx->trace_out), (size_t)n_out * sizeof(double)));
         ctx->trace_out_cap = n_out;
     }
     PCL_TRY(PCL_DISPATCH(ctx,
@@ -7359,8 +7361,19 @@ int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, doub
                                                A_del, n_del, seed, step0),
                          trace_ahead_t<float>(ctx, n_ids, dt, k_passes, n_phases, phase_del, record_phase, A, n, use_e, var_n, ent, c, h,
                                               A_del, n_del, seed, step0)));
-    PCL_HIP(hipMemcpyAsync(out_host, ctx->trace_out, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PCL_TRY(stream_wait(ctx));
+    ctx->trace_out_n = n_out;
+    if (!out_host) return PCL_OK; // enqueued only: the rows are read (pcl_store_trace_read) behind the launch they belong to
+    return pcl_store_trace_read(ctx, out_host, n_out);
+}
+
+int pcl_store_trace_read(pcl_ctx *ctx, double *out_host, int64_t n_doubles) {
+    PCL_TRY(bind(ctx));
+    if (!out_host || n_doubles != ctx->trace_out_n || n_doubles <= 0)
+        return fail(PCL_ERR_ARG, "pcl_store_trace_read: %lld doubles asked for, the last pcl_store_trace_ahead left %lld", (long long)n_doubles,
+                    (long long)ctx->trace_out_n);
+    PCL_TRY(stream_wait(ctx)); // (no wait at all behind a K-pass launch that has returned its rows: the stream is in order)
+    memcpy(out_host, ctx->trace_out, (size_t)n_doubles * sizeof(double));
+    ctx->trace_out_n = 0;
     return PCL_OK;
 }
 

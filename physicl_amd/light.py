@@ -355,6 +355,27 @@ class ScatterSignMeasureStep(_CountingMeasure):
 _DEFAULT_ID_INFO = lambda x: str(type(x))      # noqa: E731 -- the reference's default (light.py:438), recognised by identity
 
 
+class _Col:
+    """The positions of tracked particle ``j`` over the first ``n`` logged passes: column j of the blocks the device returned
+    ((passes, tracked, 4) arrays), made into vectors when somebody looks at them."""
+    __slots__ = ("blocks", "j", "n")
+
+    def __init__(self, blocks, j, n):
+        self.blocks, self.j, self.n = blocks, j, n
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        left = self.n
+        for b in self.blocks:
+            if left <= 0:
+                break
+            k = min(left, len(b))
+            yield from b[:k, self.j, :3]
+            left -= k
+
+
 class _Lazy(collections.abc.MutableSequence):
     """A list whose elements are made when somebody looks at them: the concatenation of ``parts`` (lists, or 2-D arrays whose
     rows are the elements).  The trace of 1000 photons over 500 passes is half a million position vectors; kept as the blocks
@@ -474,7 +495,7 @@ class TracePathMeasureStep(MeasureStep):
         """``rows`` = (len(ts), n_tracked, 4) of pcl_store_trace_ahead for the passes whose times are ``ts``."""
         if not self._ahead_log:
             self._ahead_t0 = _snap_t(ts[0])
-        self._ahead_log.append(np.array(rows[:len(ts)], dtype=np.float64))
+        self._ahead_log.append(rows[:len(ts)])        # (a view of the launch's own array: nobody else writes it)
 
     def _assign_tids(self, sim, t0, present):
         """First sight of the tracked particles (light.py:450-455): a trace id each, in object order, unless the object
@@ -501,24 +522,32 @@ class TracePathMeasureStep(MeasureStep):
         return tids
 
     def _flush_ahead(self, sim=None):
-        """File the device rows under the trace ids (a photon's list ends where it was removed)."""
+        """File the device rows under the trace ids (a photon's list ends where it was removed).  The blocks are not taken
+        apart: a particle's positions are a view of its column (_Col) -- terminate() belongs to the run's clock."""
         if not self._ahead_log:
             return
-        rows = np.concatenate(self._ahead_log, axis=0)                        # (T, n, 4)
-        self._ahead_log = []
+        blocks, self._ahead_log = self._ahead_log, []
         comm = getattr(sim, "comm", None)
         if comm is not None and comm.world > 1:
-            rows = _merge_shards(comm, rows)
-        there = ~np.isnan(rows[:, :, 0])
+            blocks = [_merge_shards(comm, np.concatenate(blocks, axis=0))]
+        n_there = np.zeros(blocks[0].shape[1], dtype=np.int64)               # removal is for good: a prefix of the passes
+        freq = np.zeros(blocks[0].shape[1], dtype=np.int64)
+        first = None
+        for blk in blocks:
+            there = ~np.isnan(blk[:, :, 0])
+            if first is None:
+                first = there[0]
+            n_there += there.sum(axis=0)
+            if self.trace_dv:
+                freq += ((blk[:, :, 3] != 0) & there).sum(axis=0)
         if self._ahead_tids is None:
-            self._ahead_tids = self._assign_tids(sim, self._ahead_t0, there[0])
-        n_there = there.sum(axis=0).tolist()                                  # removal is for good: a prefix
-        freq = ((rows[:, :, 3] != 0) & there).sum(axis=0).tolist()
+            self._ahead_tids = self._assign_tids(sim, self._ahead_t0, first)
+        n_there, freq = n_there.tolist(), freq.tolist()
         for j, tid in enumerate(self._ahead_tids.tolist()):
             if tid < 0 or not n_there[j]:
                 continue
             entry = self.pos_dict[tid]
-            entry["pos"].extend(rows[:n_there[j], j, :3])                      # (the block's rows: vectors are made when looked at)
+            entry["pos"].extend(_Col(blocks, j, n_there[j]))
             if self.trace_dv:
                 entry["freq"] += freq[j]
 

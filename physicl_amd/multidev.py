@@ -287,14 +287,19 @@ class MultiDevice:
         outs = self._each(lambda s: s.step_fused_multi(dt, k_steps, scatter, planes, sync, raw))
         return None if outs[0] is None else self._sum_rows(outs, raw)
 
-    def trace_ahead(self, ids, *a, **kw):
+    def trace_ahead(self, ids, *a, defer=False, **kw):
         """Every context is asked for every tracked id and answers NaN rows for the particles it does not hold; a particle
         lives in exactly one shard, so the first answer that is not NaN is the row."""
-        outs = self._each(lambda s: s.trace_ahead(ids, *a, **kw))
-        rows = outs[0]
-        for o in outs[1:]:
-            rows = np.where(np.isnan(rows[:, :, :1]), o, rows)
-        return rows
+        outs = self._each(lambda s: s.trace_ahead(ids, *a, defer=defer, **kw))
+
+        def merge(parts):
+            rows = parts[0]
+            for o in parts[1:]:
+                rows = np.where(np.isnan(rows[:, :, :1]), o, rows)
+            return rows
+        if not defer:
+            return merge(outs)
+        return lambda: merge([read() for read in outs])
 
     def step_fused_delete_multi(self, dt, k_steps, A, n, seed=0, step=0, planes=None, raw=False):
         return self._sum_rows(self._each(lambda s: s.step_fused_delete_multi(dt, k_steps, A, n, seed, step, planes, raw)), raw)
