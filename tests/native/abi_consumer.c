@@ -113,6 +113,28 @@ int main(int argc, char **argv) {
     int64_t cnt[PCL_CNT_PLANE0];
     CK(pcl_step_counters(ctx, NULL, 0, cnt));
     printf("counters %" PRId64 " %" PRId64 " %" PRId64 " %" PRId64 "\n", cnt[PCL_CNT_N], cnt[PCL_CNT_XP], cnt[PCL_CNT_YP], cnt[PCL_CNT_ZP]);
+    /* TracePathMeasureStep for a tracked subset (physicl/light.py:447-458): where photons 0 and N-1 will be after each of the
+     * next three passes of [Newton, ScatterIsotropic(A = n = 1e-3)], worked out BEFORE the launch that runs those passes -- and
+     * the launch then leaves them exactly where the last row says */
+    {
+        const int64_t ids[2] = {0, N - 1};
+        const int n_ids = N > 1 ? 2 : 1, kinds[1] = {PCL_PHASE_ISOTROPIC};
+        double rows[3 * 2 * 4];
+        int64_t mrows[3 * 5];
+        CK(pcl_store_trace_ahead(ctx, ids, n_ids, dt, 3, 1, kinds, 0, A, n, 0, 299792458.0, 6.62607015e-34, NULL, 0.0, 0.0, 9, 5, rows));
+        CK(pcl_step_fused_multi(ctx, dt, 3, A, n, 0, 299792458.0, 6.62607015e-34, NULL, 9, 5, NULL, 0, mrows));
+        print_hex("trace", rows, (int64_t)3 * n_ids * 4);
+        for (int j = 0; j < n_ids; ++j)
+            for (int k = 0; k < 3; ++k) {
+                double got;
+                CK(pcl_store_download(ctx, PCL_R0 + k, &got, ids[j], 1));
+                if (memcmp(&got, &rows[(2 * n_ids + j) * 4 + k], 8) != 0) {
+                    fprintf(stderr, "photon %" PRId64 ": the launch left r%d elsewhere than the trace said\n", ids[j], k);
+                    return 1;
+                }
+            }
+        printf("traced %d\n", n_ids);
+    }
     CK(pcl_store_free(ctx));
     for (int k = 0; k < 4; ++k) CK(pcl_dev_free(ctx, d[k]));
     CK(pcl_dev_free(ctx, res));

@@ -69,6 +69,14 @@ def test_c_host_program_gets_the_oracles_results(tmp_path, N):
     assert rec["r"] == hexes(rn)
     assert rec["dr"] == hexes(dr)
     assert rec["counters"] == "%d %d %d %d" % ((N,) + orc.sign_counts(v))
+    # the tracked subset's rows (pcl_store_trace_ahead from C) are the Python binding's on the same store
+    from physicl_amd import _hip as hip
+    ids = [0, N - 1] if N > 1 else [0]
+    with hip.Device(0) as dev:
+        dev.store_alloc(N)
+        dev.upload_state({"r": np.stack(rn, 1), "v": np.stack(v, 1), "dr": np.stack(dr, 1), "E": rand})
+        rows = dev.trace_ahead(ids, dt, 3, ("iso",), 0, dict(A=A, n=n, flags=0, c=299792458.0, h=6.62607015e-34), None, 9, 5)
+    assert rec["trace"] == " ".join("%016x" % x for x in rows.reshape(-1).view(np.uint64)) and rec["traced"] == str(len(ids))
 
 
 @pytest.mark.gpu
