@@ -116,3 +116,38 @@ def test_delete_until_empty_alive_counts_and_survivor_order_equal_the_c_oracle(d
             assert np.array_equal(have, ids_all[death > 31]) and co.order_checksum(have) == co.order_checksum(ids_all[death > 31])
         k += 16
     assert rows[:bodies_until_empty] == alive_after[:bodies_until_empty].tolist()
+
+
+def test_tracked_subset_of_a_1e8_photon_store_over_32_steps_equals_the_oracle_chain(dev, hip):
+    """SURVEY 8(f)-4 at full size: the positions pcl_store_trace_ahead works out for ids {0 .. 999, a window across a tile
+    boundary, a window across the 2^26 boundary, the last 64} of the 1e8-photon example workload over 32 steps == the numpy
+    oracle's chain on those ids (same decisions: the NaN-free rows' dv flags are the oracle's hits; positions within
+    32 * dt * 4 ulp(c) + the rounding of r at 1e7 m), and the K-pass launch that follows leaves them where the last row says.
+    Reference semantics: physicl/light.py:447-458 (what is traced), 303-331 (the step that moves them)."""
+    from oracle import physicl_oracle as orc
+    N, K, dt, seed = 100_000_000, 32, 0.005, 1234
+    A, n = 1e-15, 1e-19
+    sc = dict(A=A, n=n, flags=hip.SCATTER_WAVELENGTH | hip.SCATTER_VARIABLE_N, c=C_LIT, h=H_LIT, n_expr=EXPR, rng_mode=hip.RNG_PHILOX,
+              seed=seed, step=0)
+    dev.store_alloc(N)
+    dev.fill_photons(N, 0, C_LIT, E_LO, E_HI, seed)
+    ids = np.unique(np.concatenate([np.arange(1000), np.arange(2040, 2056), np.arange((1 << 26) - 8, (1 << 26) + 8), np.arange(N - 64, N)]))
+    E = np.concatenate([dev.download(hip.E, int(hi - lo + 1), int(lo)) for lo, hi in
+                        ((0, 999), (2040, 2055), ((1 << 26) - 8, (1 << 26) + 7), (N - 64, N - 1))])
+    rows = dev.trace_ahead(ids, dt, K, ("iso",), 0, sc, None, seed, 0)
+    m = len(ids)
+    st = {"r": [np.zeros(m) for _ in range(3)], "v": [np.full(m, C_LIT), np.zeros(m), np.zeros(m)], "dr": [np.zeros(m) for _ in range(3)],
+          "dv": [np.zeros(m) for _ in range(3)], "E": E.copy(), "id": ids.copy()}
+    assert not np.isnan(rows).any()
+    for k in range(K):
+        orc.step_newton(st, dt)
+        hit = orc.step_scatter_isotropic(st, orc.philox_draws(seed, k, st["id"]), A, n, C_LIT, h=H_LIT, use_E=True, n_expr=EXPR)
+        want = np.stack(st["r"], 1)
+        assert np.max(np.abs(rows[k, :, :3] - want)) <= (k + 1) * dt * V_ABS_TOL + (k + 1) * np.spacing(np.max(np.abs(want)))
+        assert np.array_equal(rows[k, :, 3] != 0, np.any(np.stack(st["dv"], 1) != 0, axis=1)) and int(hit.sum()) == int((rows[k, :, 3] != 0).sum())
+    got = dev.step_fused_multi(dt, K, sc)
+    assert got[0]["hits"] == N
+    for lo, cnt in ((0, 1000), (2040, 16), ((1 << 26) - 8, 16), (N - 64, 64)):
+        sel = (ids >= lo) & (ids < lo + cnt)
+        for k, f in enumerate((hip.R0, hip.R1, hip.R2)):
+            assert np.array_equal(dev.download(f, cnt, lo), rows[-1, sel, k])
