@@ -502,6 +502,9 @@ int pcl_step_counters(pcl_ctx *ctx, const double *planes_host, int n_planes, int
  * group's collective (the counters are the only global quantities of the path).  Windows of the
  * particle order are read shard after shard (contiguous blocks + stable compaction = global particle order).
  * pcl_group_ctx gives the i-th context for anything per shard (uploads, pcl_store_*).  One group call at a time.
+ * A tracked subset (pcl_store_trace_ahead) over a group: hand every shard's context the whole id list before the group's
+ * K-pass launch -- a shard answers NaN rows for the ids it does not hold, a particle lives in exactly one shard, so the row
+ * that is not NaN is the particle's (what physicl_amd.multidev.MultiDevice.trace_ahead does).
  * Errors: the first failing shard's code; pcl_last_error() names the shard.                                      */
 typedef struct pcl_group pcl_group;
 int pcl_group_create(int n_dev, const int *device_ids, pcl_group **group_out);
