@@ -1649,6 +1649,8 @@ __device__ __forceinline__ void pcl_mixed_body(const pcl_mixed_args<T> &a) {
 // picks: step_mixed_t).  Same operations per particle in the same order, same launch indices: bit-identical to
 // pcl_mixed_body (tests/test_gpu_mixed.py runs both).  Rows past the wave's eight (NE = 3: the ninth) are empty.
 // ------------------------------------------------------------------------------------------------
+template <int N> struct pcl_ic { static constexpr int value = N; }; // (an integer as a type: hipRTC has no <type_traits>)
+
 template <typename T, int NE>
 struct pcl_mixed_home {
     T c[4][NE][256];                 // v0, v1, v2, |v dt| of row e of thread t
@@ -1677,16 +1679,19 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
     int kept = 0;
     const int cnt_in = pcl_mixed_seg_count(a, tile, wave); // particles of this wave's segment: they sit at its front
     const pcl_i64 seg0 = tile * PCL_T + (pcl_i64)wave * 512;
-    for (int trip = 0; trip < TRIPS; ++trip) {
-        if (a.inplace && trip * NE * 64 >= cnt_in) break; // (wave-uniform) the rest of the segment is empty
+    // A trip takes up to NE rows of the wave's segment; its code exists once per NUMBER of rows (NA = 1 .. NE): a wave's eight rows
+    // are trips of 3 + 3 + 2, and a segment that has lost photons ends in a trip of one or two rows -- with NE-row code those trips
+    // issued every instruction for rows nobody is in (a ninth of a full tile's work, a fifth of a half-empty one's).
+    auto do_trip = [&](auto na_tag, const int trip) {
+        constexpr int NA = decltype(na_tag)::value;
         const int row0 = wave * ROWS + trip * NE;
-        T Rr[3][NE], L4[NE], Ev[NE];
-        pcl_u32 wodd0[NE], wodd1[NE];
-        pcl_u64 id[NE];
-        bool in[NE];
-        pcl_u64 am[NE], pm[NE]; // alive / photon, as wave masks: the votes are taken on bare compares (pcl_ballot)
+        T Rr[3][NA], L4[NA], Ev[NA];
+        pcl_u32 wodd0[NA], wodd1[NA];
+        pcl_u64 id[NA];
+        bool in[NA];
+        pcl_u64 am[NA], pm[NA]; // alive / photon, as wave masks: the votes are taken on bare compares (pcl_ballot)
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
+        for (int e = 0; e < NA; ++e) {
             const pcl_i64 i = tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane;
             in[e] = trip * NE + e < ROWS && (trip * NE + e) * 64 + lane < cnt_in;
             const pcl_i64 is = in[e] ? i : 0;
@@ -1711,16 +1716,16 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
         for (int ph = 0; ph < n_ph; ++ph) {
             pcl_u64 any = 0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) any |= am[e];
+            for (int e = 0; e < NA; ++e) any |= am[e];
             if (!any) break; // nobody of these rows is left: their rows stay 0
             const pcl_u32 st = a.step + (pcl_u32)ph;
             const bool is_del = a.phase_del[ph % a.P] != 0; // wave-uniform
             pcl_u32 kk0 = k0, kk1 = k1;                     // see pcl_multi_body_lds: keeps the round keys off the VGPR spills
             asm volatile("" : "+s"(kk0), "+s"(kk1));
             const bool new_block = (st & 1u) == 0u || ph == 0;
-            T d[3][NE], rand[NE], nm[NE];
+            T d[3][NA], rand[NA], nm[NA];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NA; ++e) {
                 // Newton: dr = v*dt (rounded), r = r + dr                                  newton.py:15-16
                 d[0][e] = R::mul(s_h.c[0][e][tid], a.dt);
                 d[1][e] = R::mul(s_h.c[1][e][tid], a.dt);
@@ -1734,7 +1739,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
             // block's half stays outside the chains: pcl_multi_body_lds)
             if (new_block && (st & 1u) == 0u) { // decision block of the launch pair (st, st | 1): computed once for both
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
+                for (int e = 0; e < NA; ++e) {
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
                     rand[e] = R::uniform(w.x, w.y);
                     wodd0[e] = w.z;
@@ -1742,7 +1747,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 }
             } else if (new_block) { // a launch that starts on an odd index: the second half of the block of (st - 1, st)
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
+                for (int e = 0; e < NA; ++e) {
                     const pcl_u32x4 w = pcl_philox4x32_10((pcl_u32)id[e], (pcl_u32)(id[e] >> 32), st >> 1, 0u, kk0, kk1);
                     rand[e] = R::uniform(w.z, w.w);
                     wodd0[e] = w.z;
@@ -1750,14 +1755,14 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < NE; ++e) rand[e] = R::uniform(wodd0[e], wodd1[e]);
+                for (int e = 0; e < NA; ++e) rand[e] = R::uniform(wodd0[e], wodd1[e]);
             }
             pcl_u32 w_evt = 0; // hits (isotropic phase) or removals (delete phase) of this wave
             pcl_u32 wbase = qbase;
             if (is_del) {
                 // ScatterDeleteStep: flag = (A*n*norm >= rand), flagged photons leave the list      light.py:239-260
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
+                for (int e = 0; e < NA; ++e) {
                     const T pc = R::mul(a.An_del, nm[e]);
                     const pcl_u64 gm = pcl_ballot(pc >= rand[e]) & am[e] & pm[e];
                     w_evt += (pcl_u32)__popcll(gm);
@@ -1767,7 +1772,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 // ScatterIsotropicStep: decision in place, the hits densely through the wave's queue   light.py:303-331
                 wbase = qbase;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
+                for (int e = 0; e < NA; ++e) {
                     T pc = pcl_pcoll_norm<T, false, VAR_N>(a.np, a.A, a.n, (T)0, a.c, nm[e], d[0][e], d[1][e], d[2][e], Rr[0][e],
                                                            Rr[1][e], Rr[2][e], Ev[e]);
                     if constexpr (USE_E) pc = R::mul(pc, L4[e]);
@@ -1783,7 +1788,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                     int lane_here = lane; // (opaque: the slab indices are worked out HERE, not carried in registers through every phase)
                     asm volatile("" : "+v"(lane_here));
 #pragma unroll
-                    for (int e = 0; e < NE; ++e)
+                    for (int e = 0; e < NA; ++e)
                         if (in[e]) {
                             const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_here, a.ts);
                             a.vp0[ti] = s_h.c[0][e][tid];
@@ -1800,7 +1805,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 const T L = a.plane_L[p];
                 pcl_u32 nc = 0;
 #pragma unroll
-                for (int e = 0; e < NE; ++e) {
+                for (int e = 0; e < NA; ++e) {
                     const T x = pcl_pick<T>(ax, Rr[0][e], Rr[1][e], Rr[2][e]);
                     const T prev = R::sub(x, pcl_pick<T>(ax, d[0][e], d[1][e], d[2][e]));
                     nc += (pcl_u32)__popcll(((pcl_ballot(prev <= L) & pcl_ballot(L <= x)) | (pcl_ballot(prev >= L) & pcl_ballot(L >= x))) & am[e]);
@@ -1827,7 +1832,7 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
             // this phase's measure row, on the particles alive after it            light.py:414-431
             pcl_u32 w_n = 0, w_sx = 0, w_sy = 0, w_sz = 0;
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NA; ++e) {
                 w_n += (pcl_u32)__popcll(am[e]);
                 w_sx += (pcl_u32)__popcll(pcl_ballot(s_h.c[0][e][tid] > (T)0) & am[e]);
                 w_sy += (pcl_u32)__popcll(pcl_ballot(s_h.c[1][e][tid] > (T)0) & am[e]);
@@ -1844,16 +1849,16 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
         asm volatile("" : "+s"(tile_end));
         if (a.inplace) { // the trip's survivors to the front of the wave's segment, row after row, with everything they own
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
+            for (int e = 0; e < NA; ++e) {
                 if (trip * NE + e >= ROWS) continue;
                 pcl_mixed_put<T, USE_E>(a, seg0, (trip * NE + e) * 64, (pcl_u32)kept, am[e], lane_end, Rr[0][e], Rr[1][e], Rr[2][e], s_h.c[0][e][tid],
                                         s_h.c[1][e][tid], s_h.c[2][e][tid], L4[e], id[e]);
                 kept += (int)__popcll(am[e]);
             }
-            continue;
+            return;
         }
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
+        for (int e = 0; e < NA; ++e) {
             if ((am[e] >> lane) & 1ull) { // (alive lanes are in range)
                 const pcl_i64 ti = pcl_tix(tile * PCL_T + (pcl_i64)(row0 + e) * 64 + lane_end, a.ts);
                 a.r0[ti] = Rr[0][e];
@@ -1869,6 +1874,23 @@ __device__ __forceinline__ void pcl_mixed_body_lds(const pcl_mixed_args<T> &a) {
                 kept += (int)__popcll(m);
             }
         }
+    };
+    const int rows_seg = (cnt_in + 63) >> 6; // rows of the segment that hold anybody (they sit at its front)
+    for (int trip = 0; trip < TRIPS; ++trip) {
+        int rows = rows_seg - trip * NE; // (wave-uniform)
+        rows = rows > NE ? NE : rows;
+        if (rows <= 0 && a.inplace) break; // the rest of the segment is empty
+        // (constant-n kernels only: the variable-n forms sit at their register bound -- 125-127 of 128 VGPRs -- and a second copy of the
+        //  trip pushed them into scratch; one shorter form, NE - 1 rows: a third copy for single rows cost registers, not time)
+        constexpr bool SPLIT = VAR_N == 0 && NE > 1;
+        if (rows >= NE || (!SPLIT && rows > 0)) {
+            do_trip(pcl_ic<NE>{}, trip);
+        } else if (rows > 0) {
+            if constexpr (SPLIT) do_trip(pcl_ic<(NE > 1 ? NE - 1 : 1)>{}, trip);
+        }
+        if (!a.inplace && a.has_delete && lane0) // rows of the trip nobody is in (a dense store's last tile): their keep-masks are empty
+            for (int e = (rows >= NE || (!SPLIT && rows > 0)) ? NE : (rows > 0 ? NE - 1 : 0); e < NE; ++e)
+                if (trip * NE + e < ROWS) a.masks[tile * 32 + wave * ROWS + trip * NE + e] = 0;
     }
     if (a.inplace) pcl_mixed_put_masks(a, tile, wave, lane, kept);
     if (a.has_delete && lane0) s_keep[wave] = kept;
