@@ -235,3 +235,16 @@ def test_bulk_photons_from_a_vectorised_sampler_are_the_per_object_photons():
         PhotonBatch.FN_CHUNK = 1 << 22
     with pytest.raises(ValueError):
         light.generate_photons_bulk(10, T=300.0, fn_vec=lambda size: np.zeros(size))
+
+
+def test_limits_of_the_host_layer_are_the_headers():
+    """Numbers the host layer repeats from include/physicl_hip.h: the measure planes a fused group may carry, the particles a
+    TracePathMeasureStep may track on the device, the rows of a K-pass launch."""
+    import os
+    import re
+    from physicl_amd import _hip, core
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "physicl_hip.h")).read()
+    define = lambda name: int(re.search(r"#define\s+%s\s+(\d+)" % name, text).group(1))
+    assert core._MAX_PLANES == _hip.MAX_PLANES == define("PCL_MAX_PLANES")
+    assert light.TracePathMeasureStep.MAX_TRACKED == define("PCL_TRACE_MAX")
+    assert (_hip.PHASE_ISOTROPIC, _hip.PHASE_DELETE) == (define("PCL_PHASE_ISOTROPIC"), define("PCL_PHASE_DELETE"))
