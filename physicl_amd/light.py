@@ -456,7 +456,7 @@ class TracePathMeasureStep(MeasureStep):
         self.id_counter = 0
         self.id_dict, self.pos_dict = {}, {}
         self._tid_map, self._map_gen, self._log = None, None, []
-        self._ahead_ids, self._ahead_gen, self._ahead_log, self._ahead_tids = None, None, [], None
+        self._ahead_ids, self._ahead_gen, self._ahead_log, self._ahead_tids, self._ahead_objs = None, None, [], None, None
 
     # fused-group protocol of the counting measures (core.Simulation._build_plan): no planes, no counter row
     def _n_planes(self):
@@ -489,6 +489,10 @@ class TracePathMeasureStep(MeasureStep):
             raise ValueError("TracePathMeasureStep tracks at most %d particles on the device, %d asked for" % (self.MAX_TRACKED, len(ids)))
         self._ahead_ids, self._ahead_gen = ids, sim._upload_gen
         self._ahead_tids = None
+        # explicit objects: the objects behind the ids NOW (device id == place in the list that was just uploaded) -- by the time the
+        # rows are filed the list may have lost its removed photons (a host visit) or been uploaded again
+        explicit = sim._batch is None and isinstance(sim._uploaded, list)
+        self._ahead_objs = [sim._objects._items[i] for i in ids.tolist()] if explicit else None
         return ids
 
     def _ahead_record(self, sim, ts, rows):
@@ -501,10 +505,10 @@ class TracePathMeasureStep(MeasureStep):
         """First sight of the tracked particles (light.py:450-455): a trace id each, in object order, unless the object
         already carries one (the host plugin saw it earlier, or an earlier upload of the same objects was traced).  A
         particle that is gone before the step first runs is never seen (``present``): no id, no row -- as in the reference."""
-        explicit = sim._batch is None and isinstance(sim._uploaded, list)
+        explicit = self._ahead_objs is not None
         tids = np.full(len(self._ahead_ids), -1, dtype=np.int64)
         for j, i in enumerate(self._ahead_ids.tolist()):
-            obj = sim._objects._items[i] if explicit else None
+            obj = self._ahead_objs[j] if explicit else None
             tid = obj.__dict__.get("__trace_path_id") if explicit else (self._uid_tid or {}).get(i)
             if tid is None and present[j]:
                 tid = self.id_counter
@@ -623,9 +627,9 @@ class TracePathMeasureStep(MeasureStep):
         """The run leaves the device-traced schedule (a host plugin joined, the objects were taken back, ...): from here on the
         particles are walked as Python objects, which must find the trace ids the device rows were filed under -- explicit
         objects carry them (_assign_tids), a PhotonBatch's photons are looked up by their uid."""
-        ids, tids = self._ahead_ids, self._ahead_tids
-        self._ahead_ids = self._ahead_gen = self._ahead_tids = None
-        if tids is not None and not (sim._batch is None and isinstance(sim._uploaded, list)):
+        ids, tids, explicit = self._ahead_ids, self._ahead_tids, self._ahead_objs is not None
+        self._ahead_ids = self._ahead_gen = self._ahead_tids = self._ahead_objs = None
+        if tids is not None and not explicit:
             self._uid_tid = dict(self._uid_tid or {}, **{int(i): int(t) for i, t in zip(ids, tids) if t >= 0})
 
     def terminate(self, sim):

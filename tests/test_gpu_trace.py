@@ -391,3 +391,28 @@ def test_leaving_the_device_traced_schedule_keeps_the_trace_ids():
     tables_equal(tp_ref, tp)
     sim.close(download=False)
     ref.close(download=False)
+
+
+def test_objects_taken_to_the_host_in_the_middle_of_a_traced_delete_run():
+    """Six device-traced passes of a delete loop, then a script looks at ``sim.objects`` (the list loses its removed photons and
+    is uploaded again, renumbered), six more passes: every row is filed under the OBJECT it belongs to -- the same table as the
+    host plugin builds over the very same sequence (fuse=False)."""
+    tables = []
+    for fuse, spl in ((True, 3), (False, 1)):
+        sim, tp, _ = build_sim("delete", 600, spl, fuse, passes=6)
+        sim.run()
+        n_mid = len(sim.objects)
+        first = sim.objects[0]                                   # residency -> host: the list now holds the survivors only
+        assert n_mid < 600 and first is sim.objects[0]
+        sim.exit = lambda s: s.t >= 11.5e-3
+        sim.running = True                                       # (Simulation.run would reset the clock: the loop by hand)
+        while not sim.exit(sim):
+            sim._run_pass()
+        tp.terminate(sim)
+        tables.append(tp)
+        assert len(sim.ts) == 12 and len(sim.objects) < n_mid
+        sim.close(download=False)
+    tables_equal(tables[0], tables[1])
+    t, rows = table(tables[0])
+    lens = sorted({len([x for x in r[1:] if len(x) == 3]) for r in rows})
+    assert lens[0] < 6 < lens[-1] == 12                          # photons removed early, photons that lived through both halves
