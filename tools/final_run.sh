@@ -8,7 +8,7 @@
 O=gpurun_out
 case "$1" in
 profiles)
-  timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r06_t_all.log 2>&1; rc=$?; tail -3 $O/r05_t_all.log
+  timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/r06_t_all.log 2>&1; rc=$?; tail -3 $O/r06_t_all.log
   [ $rc -eq 0 ] || exit $rc
   bash tools/prof_driver_cmd.sh r06_driver_cmd && bash tools/prof_driver_cmd.sh r06_default_cmd --gpus 1 && bash tools/prof_calib_ahead.sh > $O/r06_calib.log 2>&1
   ;;
