@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Cost of one pcl_store_trace_ahead call (1000 tracked ids, K = 32) beside the K-step launch it precedes, at 1e8 photons."""
+import os
 import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from physicl_amd import _hip as hip
 C, H = 299792458.0, 6.62607015e-34
 N = 100_000_000
