@@ -470,7 +470,9 @@ int pcl_step_mixed_multi(pcl_ctx *ctx, double dt, int k_passes, int n_phases, co
  * by a delete phase, or never there: the reference traces 'nan;nan;nan', light.py:435).  Device RNG only.  Synchronises --
  * unless out_host is NULL: the kernel is then only enqueued (it writes its rows into pinned host memory of the context) and the
  * K-pass launch can follow at once on the same in-order stream; pcl_store_trace_read(ctx, out_host, k_passes * n_ids * 4) hands
- * the rows out afterwards -- behind a launch that has returned its counter rows it does not wait at all.                     */
+ * the rows out afterwards -- behind a launch that has returned its counter rows it does not wait at all.  The context holds
+ * ONE set of rows: a second pcl_store_trace_ahead before the read waits for nothing and replaces them (several tracked sets
+ * per launch: pass out_host, as physicl_amd/core.py does for more than one TracePathMeasureStep).                            */
 #define PCL_TRACE_MAX 65536
 int pcl_store_trace_ahead(pcl_ctx *ctx, const int64_t *ids_host, int n_ids, double dt, int k_passes, int n_phases,
                           const int *phase_kinds_host, int record_phase, double A, double n, int flags, double c, double h,
