@@ -352,7 +352,14 @@ class ScatterSignMeasureStep(_CountingMeasure):
         return ([n] if self.measure_n else []) + [sign[:, k] for k in range(3)]
 
 
-_DEFAULT_ID_INFO = lambda x: str(type(x))      # noqa: E731 -- the reference's default (light.py:438), recognised by identity
+def _DEFAULT_ID_INFO(x):
+    """The reference's default ``lambda x: str(type(x))`` (light.py:438), recognised by identity.  The label goes into the trace
+    table's first column: this package's own classes read as the reference's (``<class 'physicl.light.PhotonObject'>``, what a
+    trace file written by the reference holds -- tests/golden/g5_trace.npz), anybody else's class as it is."""
+    return str(type(x)).replace("<class 'physicl_amd.", "<class 'physicl.", 1)
+
+
+_PHOTON_LABEL = "<class 'physicl.light.PhotonObject'>"
 
 
 class _Col:
@@ -517,7 +524,7 @@ class TracePathMeasureStep(MeasureStep):
                     obj.__dict__["__trace_path_id"] = tid
                     self.id_dict[tid] = self.id_info_fn(obj)
                 else:
-                    self.id_dict[tid] = str(PhotonObject) if self.id_info_fn is _DEFAULT_ID_INFO else self.id_info_fn(_batch_photon(sim, i))
+                    self.id_dict[tid] = _PHOTON_LABEL if self.id_info_fn is _DEFAULT_ID_INFO else self.id_info_fn(_batch_photon(sim, i))
                 self.pos_dict[tid] = {"start": t0, "pos": _Lazy()}
                 if self.trace_dv:
                     self.pos_dict[tid]["freq"] = 0

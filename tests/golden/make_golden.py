@@ -437,6 +437,89 @@ def g3_delete_py():
 
 
 # ----------------------------------------------------------------------------------------------
+# G5  TracePathMeasureStep (light.py:433-483), the reference's own run / terminate, behind the OpenCL light steps:
+#     (a) [UpdateTimeStep, Newton, ScatterIsotropic, TracePath(trace_dv=True)]  K passes, nobody leaves
+#     (b) [UpdateTimeStep, Newton, ScatterDelete, TracePath(id_info_fn=uid)]     until the list is empty
+#     The table terminate() builds is ragged (a row = id info [, freq], 3 NaN SCALARS per pass before the first sight, one
+#     position VECTOR per pass seen, 3 NaN scalars per pass after the last): stored per row as (info, freq, scalars in front,
+#     positions, scalars behind).
+# ----------------------------------------------------------------------------------------------
+def _trace_table(tr, trace_dv):
+    rows = tr.data
+    out = {"t_row": np.array(rows[0][1:], dtype=np.float64), "label": np.array(rows[0][0])}
+    info, freq, lead, trail, pos_len, pos = [], [], [], [], [], []
+    for row in rows[1:]:
+        info.append(str(row[0]))
+        k = 1
+        if trace_dv:
+            freq.append(int(row[1]))
+            k = 2
+        body = row[k:]
+        a = 0
+        while a < len(body) and np.ndim(body[a]) == 0:
+            assert np.isnan(body[a])
+            a += 1
+        b = len(body)
+        while b > a and np.ndim(body[b - 1]) == 0:
+            assert np.isnan(body[b - 1])
+            b -= 1
+        vec = [np.asarray(x, dtype=np.float64).reshape(3) for x in body[a:b]]
+        lead.append(a)
+        trail.append(len(body) - b)
+        pos_len.append(len(vec))
+        pos.extend(vec)
+    out.update(info=np.array(info), freq=np.array(freq, dtype=np.int64), lead_scalars=np.array(lead, dtype=np.int64),
+               trail_scalars=np.array(trail, dtype=np.int64), pos_len=np.array(pos_len, dtype=np.int64),
+               pos=np.array(pos, dtype=np.float64).reshape(-1, 3))
+    return out
+
+
+def g5_trace():
+    out = {}
+    # (a) isotropic, trace_dv: constants of test/test_light.py:34
+    N, K, dt, seed = 96, 6, 1e-3, 31
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True)
+    sim.add_objs(_photons(N, rng))
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    sc = light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001))
+    tr = light.TracePathMeasureStep(None, trace_dv=True)
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    for k in range(K):
+        for st in (upd, nk, sc, tr):
+            st.run(sim)
+    tr.terminate(sim)
+    for key, v in _trace_table(tr, True).items():
+        out["iso_" + key] = v
+    out.update(iso_N=np.int64(N), iso_K=np.int64(K), iso_dt=np.float64(dt), iso_seed=np.int64(seed), iso_A_user=np.float64(0.001),
+               iso_n_user=np.float64(0.001))
+    # (b) delete until empty, ids named by a user function
+    N, dt, seed, A, n = 96, 1e-3, 32, 0.001, 0.001
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True)
+    sim.add_objs(_photons(N, rng))
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    de = light.ScatterDeleteStep(np.double(n), np.double(A))
+    tr = light.TracePathMeasureStep(None, id_info_fn=lambda o: "photon %d" % o.uid)
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    alive = []
+    while len(sim.objects) > 0:
+        for st in (upd, nk, de, tr):
+            st.run(sim)
+        alive.append(len(sim.objects))
+    tr.terminate(sim)
+    for key, v in _trace_table(tr, False).items():
+        out["del_" + key] = v
+    out.update(del_N=np.int64(N), del_dt=np.float64(dt), del_seed=np.int64(seed), del_A_user=np.float64(A), del_n_user=np.float64(n),
+               del_alive=np.array(alive, dtype=np.int64))
+    _save("g5_trace", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -607,6 +690,7 @@ def main():
     g4_delete()
     g3_iso_py()
     g3_delete_py()
+    g5_trace()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

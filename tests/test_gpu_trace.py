@@ -354,8 +354,7 @@ def test_photon_batch_is_traced_on_the_k_pass_schedule():
         if spl > 1:
             assert sim.schedule["fused_multi"] >= 2 and not sim.schedule["fused"]
         t, rows = table(tp)
-        import physicl.light
-        assert len(rows) == len(ids) and rows[0][0] == str(physicl.light.PhotonObject)
+        assert len(rows) == len(ids) and rows[0][0] == "<class 'physicl.light.PhotonObject'>"     # the reference's label
         if ref is None:
             ref = (tp, [list(r) for r in signs.data])
             x = sim.download("r")
@@ -416,3 +415,75 @@ def test_objects_taken_to_the_host_in_the_middle_of_a_traced_delete_run():
     t, rows = table(tables[0])
     lens = sorted({len([x for x in r[1:] if len(x) == 3]) for r in rows})
     assert lens[0] < 6 < lens[-1] == 12                          # photons removed early, photons that lived through both halves
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's own TracePathMeasureStep (tests/golden/make_golden.py g5_trace: light.py:433-483 run unmodified behind the
+# OpenCL light steps): the same seeded flow here, on the K-passes-per-launch schedule, one launch per step, and as a host plugin
+# ---------------------------------------------------------------------------------------------------------------------
+def _fixture_rows(z, pre, trace_dv):
+    rows, at = [], 0
+    for i in range(len(z[pre + "info"])):
+        n = int(z[pre + "pos_len"][i])
+        rows.append((str(z[pre + "info"][i]), int(z[pre + "freq"][i]) if trace_dv else None, int(z[pre + "lead_scalars"][i]),
+                     z[pre + "pos"][at:at + n], int(z[pre + "trail_scalars"][i])))
+        at += n
+    return rows
+
+
+def _table_rows(tp, trace_dv):
+    """A table row of ours taken apart the way the generator took the reference's apart."""
+    out = []
+    for row in tp.data[1:]:
+        body = list(row[2:] if trace_dv else row[1:])
+        a = 0
+        while a < len(body) and np.ndim(body[a]) == 0:
+            assert np.isnan(body[a])
+            a += 1
+        b = len(body)
+        while b > a and np.ndim(body[b - 1]) == 0:
+            assert np.isnan(body[b - 1])
+            b -= 1
+        out.append((str(row[0]), int(row[1]) if trace_dv else None, a, np.array([np.asarray(x, dtype=np.float64).reshape(3) for x in body[a:b]]).reshape(-1, 3),
+                    len(body) - b))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["k_passes", "one_launch_per_step", "host_plugin"])
+@pytest.mark.parametrize("case", ["iso", "del"])
+def test_trace_table_is_the_reference_s_own(golden, case, mode):
+    import physicl as phys
+    import physicl.light
+    import physicl.newton
+    z = golden("g5_trace")
+    N, dt, seed = int(z[case + "_N"]), float(z[case + "_dt"]), int(z[case + "_seed"])
+    trace_dv = case == "iso"
+    kw = dict(cl_on=True, fuse=mode != "host_plugin", steps_per_launch=4 if mode == "k_passes" else 1)
+    if case == "iso":
+        K = int(z["iso_K"])
+        kw["exit"] = lambda s: s.t >= (K - 0.5) * dt
+    sim = phys.Simulation(**kw)                                          # rng: numpy's stream, as the reference draws it
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i) for i in range(N)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    if case == "iso":
+        sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(z["iso_A_user"]), n=np.double(z["iso_n_user"])))
+        tp = phys.light.TracePathMeasureStep(None, trace_dv=True)
+    else:
+        sim.add_step(2, phys.light.ScatterDeleteStep(np.double(z["del_n_user"]), np.double(z["del_A_user"])))
+        tp = phys.light.TracePathMeasureStep(None, id_info_fn=lambda o: "photon %d" % o.uid)
+    sim.add_step(3, tp)
+    np.random.seed(seed)
+    sim.start()
+    sim.join()
+    assert sim.error is None
+    assert tp.data[0][0] == str(z[case + "_label"])
+    assert np.array_equal(np.asarray(tp.data[0][1:], dtype=np.float64), z[case + "_t_row"])
+    want, got = _fixture_rows(z, case + "_", trace_dv), _table_rows(tp, trace_dv)
+    assert len(got) == len(want)
+    c_ulp = 4 * np.spacing(299792458.0)
+    for (wi, wf, wa, wp, wb), (gi, gf, ga, gp, gb) in zip(want, got):
+        assert (gi, gf, ga, gb) == (wi, wf, wa, wb) and gp.shape == wp.shape
+        # positions: Euler sums of v dt with v within 4 ulp(c) of the reference's after a scattering; exact while nothing scattered
+        assert np.max(np.abs(gp - wp), initial=0.0) <= (len(wp) * c_ulp * dt if case == "iso" else 0.0)
+    sim.close(download=False)

@@ -271,3 +271,58 @@ def test_delete_reference_py_path_skips_the_object_after_every_removal(golden):
     assert U[pos] == float(z["next_draw"])
     # the quirk itself: far fewer photons go than pcoll = 0.2998 would remove from 1818 photons in the first step
     assert N - len(z["k0_survivor_uid"]) < 0.85 * 0.2998 * ph_all.sum()
+
+
+# ------------------------------------------------------------------ G5 TracePathMeasureStep's table (light.py:433-483)
+def _g5_rows(z, pre):
+    at = 0
+    for i in range(len(z[pre + "info"])):
+        n = int(z[pre + "pos_len"][i])
+        yield i, z[pre + "pos"][at:at + n]
+        at += n
+
+
+def test_trace_table_delete_run_is_the_oracle_chain(golden):
+    """What the reference traced in a delete run until empty == the positions of the oracle's Newton + delete chain under
+    the same np.random stream: a row per photon that survived the first pass's delete (the step runs behind it), named by
+    uid, a position for every pass it was in the list at the trace step, 3 NaN scalars per pass after that; exact."""
+    z = golden("g5_trace")
+    n, dt = int(z["del_N"]), float(z["del_dt"])
+    st = {"r": [np.zeros(n)] * 3, "v": [np.full(n, C_LIT), np.zeros(n), np.zeros(n)],
+          "dr": [np.zeros(n)] * 3, "dv": [np.zeros(n)] * 3, "E": np.ones(n), "id": np.arange(n, dtype=np.int64)}
+    rs = np.random.RandomState(int(z["del_seed"]))
+    seen, passes = {}, len(z["del_t_row"])
+    for k in range(passes):
+        orc.step_newton(st, dt)
+        orc.step_scatter_delete(st, rs.random_sample(len(st["id"])), float(z["del_n_user"]), float(z["del_A_user"]))
+        assert len(st["id"]) == z["del_alive"][k]
+        for j, uid in enumerate(st["id"]):
+            seen.setdefault(int(uid), []).append([st["r"][a][j] for a in range(3)])
+    assert len(st["id"]) == 0 and np.array_equal(z["del_t_row"], np.cumsum(np.full(passes, dt)))
+    order = sorted(seen)                                   # trace ids are handed out in list order at the first sight: uid order
+    assert [str(x) for x in z["del_info"]] == ["photon %d" % u for u in order]
+    for i, pos in _g5_rows(z, "del_"):
+        assert np.array_equal(pos, np.array(seen[order[i]]))
+        assert z["del_lead_scalars"][i] == 0 and z["del_trail_scalars"][i] == 3 * (passes - len(pos))
+
+
+def test_trace_table_isotropic_run_is_the_oracle_chain(golden):
+    """The isotropic run with trace_dv: freq == the number of passes the oracle's chain scattered the photon in (dv is the
+    zero vector on a miss, light.py:331), positions within the chain's 4 ulp(c) dt per scattering before."""
+    z = golden("g5_trace")
+    n, dt, K = int(z["iso_N"]), float(z["iso_dt"]), int(z["iso_K"])
+    st = {"r": [np.zeros(n)] * 3, "v": [np.full(n, C_LIT), np.zeros(n), np.zeros(n)],
+          "dr": [np.zeros(n)] * 3, "dv": [np.zeros(n)] * 3, "E": np.ones(n), "id": np.arange(n, dtype=np.int64)}
+    rs = np.random.RandomState(int(z["iso_seed"]))
+    freq, pos = np.zeros(n, dtype=np.int64), []
+    for k in range(K):
+        orc.step_newton(st, dt)
+        hit = orc.step_scatter_isotropic(st, orc.reference_draws(n, rs), float(z["iso_n_user"]), float(z["iso_A_user"]), C_LIT)
+        freq += hit.astype(np.int64)
+        pos.append(np.stack(st["r"], 1))
+    pos = np.stack(pos, 1)                                 # (photon, pass, 3)
+    assert np.array_equal(z["iso_freq"], freq) and freq.sum() > 0
+    assert np.all(z["iso_pos_len"] == K) and not z["iso_lead_scalars"].any() and not z["iso_trail_scalars"].any()
+    assert len(set(str(x) for x in z["iso_info"])) == 1 and str(z["iso_info"][0]) == "<class 'physicl.light.PhotonObject'>"
+    for i, p in _g5_rows(z, "iso_"):
+        assert np.max(np.abs(p - pos[i])) <= K * dt * 4 * np.spacing(C_LIT)
