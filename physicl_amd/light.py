@@ -62,8 +62,10 @@ def planck_phot_distribution(E_min, E_max, T, bins=1000):
     lo, hi, T_, nb = key
     grid = np.linspace(lo, hi, int(nb))
     if _planck_cache["key"] != key:
-        area = np.array([planck_probability(grid[k], grid[k + 1], T_)[0] for k in range(len(grid) - 1)])
-        _planck_cache["key"], _planck_cache["cdf"] = key, np.cumsum(area / area.sum())
+        area = [planck_probability(grid[k], grid[k + 1], T_)[0] for k in range(len(grid) - 1)]
+        # left-to-right total and running sum, as the reference adds them (light.py:88-94; np.sum would pair the terms up):
+        # the table is the reference's bit for bit (tests/golden g7_setup), so a draw picks the same bin
+        _planck_cache["key"], _planck_cache["cdf"] = key, np.cumsum(np.array(area) / sum(area))
     cdf = _planck_cache["cdf"]
     u = np.random.rand()
     for k in range(1, len(cdf)):

@@ -520,6 +520,48 @@ def g5_trace():
 
 
 # ----------------------------------------------------------------------------------------------
+# G7  set-up functions of physicl/light.py: E_from_wavelength / wavelength_from_E (41-51), planck_distribution (53-60),
+#     planck_probability (63-64), planck_phot_distribution (73-104; returns None where the draw lies under the first
+#     bin's mass), generate_photons (112-128) and generate_photons_from_E (109-110) under recorded seeds
+# ----------------------------------------------------------------------------------------------
+def g7_setup():
+    out = {}
+    lam = np.array([200e-9, 350e-9, 700e-9, 2500e-9])
+    out["lam"] = lam
+    out["E_of_lam"] = np.array([_num(light.E_from_wavelength(x)) for x in lam])
+    out["lam_of_E"] = np.array([_num(light.wavelength_from_E(x)) for x in out["E_of_lam"]])
+    Es, Ts = np.array([7.9e-20, 3e-19, 5.5e-19, 9.9e-19]), np.array([300.0, 5778.0, 12000.0])
+    out["pd_E"], out["pd_T"] = Es, Ts
+    out["pd"] = np.array([[_num(light.planck_distribution(np.double(e), np.double(t))) for t in Ts] for e in Es])
+    out["pd_measurement_args"] = np.array(_num(light.planck_distribution(physicl.Measurement(np.double(3e-19), "J**1"), physicl.Measurement(np.double(5778.0), "K**1"))))
+    lo, hi, T, bins = float(_num(light.E_from_wavelength(2500e-9))), float(_num(light.E_from_wavelength(200e-9))), 5778.0, 40
+    out.update(pp_lo=np.float64(lo), pp_hi=np.float64(hi), pp_T=np.float64(T), pp_bins=np.int64(bins))
+    grid = np.linspace(lo, hi, bins)
+    out["pp_mass"] = np.array([light.planck_probability(grid[k], grid[k + 1], T)[0] for k in range(bins - 1)])
+    np.random.seed(41)
+    draws = [light.planck_phot_distribution(lo, hi, T, bins) for _ in range(400)]
+    out["ppd_seed"] = np.int64(41)
+    out["ppd_none"] = np.array([d is None for d in draws])
+    out["ppd_E"] = np.array([np.nan if d is None else _num(d) for d in draws])
+    out["ppd_next_random"] = np.float64(np.random.random())
+    out["ppd_cdf"] = np.array(light.last_planck_cdf)
+    # generate_photons: default sampler, and a user sampler
+    np.random.seed(42)
+    ph = light.generate_photons(64, min=light.E_from_wavelength(700e-9), max=light.E_from_wavelength(200e-9))
+    out["gp_seed"] = np.int64(42)
+    s = _state(ph)
+    out["gp_E"], out["gp_v"], out["gp_r"] = s["E"], s["v"], s["r"]
+    out["gp_next_random"] = np.float64(np.random.random())
+    np.random.seed(43)
+    ph = light.generate_photons(32, fn=lambda: np.random.random() ** 2, min=1.0, max=3.0)
+    out["gp_user_seed"], out["gp_user_E"] = np.int64(43), _state(ph)["E"]
+    ph = light.generate_photons_from_E([np.double(1.5), np.double(2.5e-19)])
+    s = _state(ph)
+    out["gpe_E"], out["gpe_v"] = s["E"], s["v"]
+    _save("g7_setup", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -691,6 +733,7 @@ def main():
     g3_iso_py()
     g3_delete_py()
     g5_trace()
+    g7_setup()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)
