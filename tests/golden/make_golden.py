@@ -562,6 +562,44 @@ def g7_setup():
 
 
 # ----------------------------------------------------------------------------------------------
+# G8  the files MeasureStep.terminate writes (__init__.py:360-378): the text of the counting measures' CSVs after a seeded
+#     isotropic run and a delete run until empty (OUTPUT of the reference: rows "t, N, counts...", str() of numpy scalars)
+# ----------------------------------------------------------------------------------------------
+def g8_csv():
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="pcl_g8_")
+    planes = [[3e5, np.nan, np.nan], [np.nan, 0.0, np.nan]]
+    for tag, seed in (("iso", 51), ("del", 52)):
+        N, dt = 256, 1e-3
+        rng = np.random.RandomState(seed + 1000)
+        sim = physicl.Simulation(cl_on=True)
+        sim.add_objs(_photons(N, rng))
+        upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+        nk = newton.NewtonianKinematicsStep()
+        sc = (light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)) if tag == "iso"
+              else light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        f_sign, f_meas = os.path.join(tmp, tag + "_sign.csv"), os.path.join(tmp, tag + "_meas.csv")
+        sign = light.ScatterSignMeasureStep(f_sign, True)
+        meas = light.ScatterMeasureStep(f_meas, True, [np.array(p, dtype=np.double) for p in planes])
+        meas_no_n = light.ScatterMeasureStep(os.path.join(tmp, tag + "_meas_no_n.csv"), False, [np.array(planes[0], dtype=np.double)])
+        sim.t, sim.dt, sim.ts = 0, 0, []
+        np.random.seed(seed)
+        k = 0
+        while (k < 5) if tag == "iso" else (len(sim.objects) > 0):
+            for st in (upd, nk, sc, sign, meas, meas_no_n):
+                st.run(sim)
+            k += 1
+        for st in (sign, meas, meas_no_n):
+            st.terminate(sim)
+        out[tag + "_sign_csv"] = np.array(open(f_sign).read())
+        out[tag + "_meas_csv"] = np.array(open(f_meas).read())
+        out[tag + "_meas_no_n_csv"] = np.array(open(os.path.join(tmp, tag + "_meas_no_n.csv")).read())
+        out.update({tag + "_N": np.int64(N), tag + "_dt": np.float64(dt), tag + "_seed": np.int64(seed), tag + "_passes": np.int64(k)})
+    out["planes"] = np.array(planes, dtype=np.float64)
+    _save("g8_csv", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -734,6 +772,7 @@ def main():
     g3_delete_py()
     g5_trace()
     g7_setup()
+    g8_csv()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

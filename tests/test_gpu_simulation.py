@@ -579,3 +579,30 @@ def test_bulk_photons_from_a_user_sampler_never_become_python_objects(devices):
     assert E.shape == (n,) and np.array_equal(E[:2000], want)
     assert float(lo_e) <= E.min() and E.max() <= float(hi_e) and abs(E.mean() - (float(lo_e) + (float(hi_e) - float(lo_e)) * 2 / 7)) < 0.01 * float(hi_e)
     sim.close(download=False)
+
+
+@pytest.mark.parametrize("spl", [None, 1])
+@pytest.mark.parametrize("tag", ["iso", "del"])
+def test_measure_files_are_the_reference_s_byte_for_byte(golden, tmp_path, tag, spl):
+    """The CSVs MeasureStep.terminate writes (physicl/__init__.py:360-378) after the reference's seeded runs
+    (tests/golden/make_golden.py g8_csv): the same text from the K-passes-per-launch schedule and from one launch per step."""
+    z = golden("g8_csv")
+    N, dt, passes = int(z[tag + "_N"]), float(z[tag + "_dt"]), int(z[tag + "_passes"])
+    kw = dict(cl_on=True, steps_per_launch=spl)
+    if tag == "iso":
+        kw["exit"] = lambda s: s.t >= (passes - 0.5) * dt
+    sim = phys.Simulation(**kw)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i) for i in range(N)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)) if tag == "iso"
+                 else phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+    files = [str(tmp_path / (tag + nm)) for nm in ("_sign.csv", "_meas.csv", "_meas_no_n.csv")]
+    sim.add_step(3, phys.light.ScatterSignMeasureStep(files[0], True))
+    sim.add_step(4, phys.light.ScatterMeasureStep(files[1], True, [np.array(p) for p in z["planes"]]))
+    sim.add_step(5, phys.light.ScatterMeasureStep(files[2], False, [np.array(z["planes"][0])]))
+    np.random.seed(int(z[tag + "_seed"]))
+    run(sim)
+    assert len(sim.ts) == passes
+    for f, key in zip(files, ("_sign_csv", "_meas_csv", "_meas_no_n_csv")):
+        assert open(f).read() == str(z[tag + key]), key
