@@ -600,6 +600,136 @@ def g8_csv():
 
 
 # ----------------------------------------------------------------------------------------------
+# G9  Simulation.run itself (__init__.py:501-524), start() / join() on its own thread: steps registered out of index order
+#     run in REGISTRATION order (the dict's), a user Step that removes an object and later adds one through the simulation's
+#     own methods, the clock (t, dt reset to int 0; ts), get_state() after the run
+# ----------------------------------------------------------------------------------------------
+def g9_run():
+    out = {}
+    N, dt, seed = 64, 1e-3, 61
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True, exit=lambda s: s.t >= 0.0075)
+    sim.add_objs(_photons(N, rng))
+    probe_rows = []
+
+    class Probe(physicl.Step):
+        def __init__(self):
+            self.passes = 0
+            self.terminated_at = None
+
+        def run(self, sim):
+            if self.passes == 2:
+                sim.remove_obj(sim.objects[0])
+            if self.passes == 4:
+                sim.add_obj(light.PhotonObject(v=np.array([light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=1000))
+            probe_rows.append((float(sim.t), float(sim.dt), [o.uid for o in sim.objects],
+                               [float(np.asarray(o.r)[0]) for o in sim.objects]))
+            self.passes += 1
+
+        def terminate(self, sim):
+            self.terminated_at = float(sim.t)
+
+    sign = light.ScatterSignMeasureStep(None, True)
+    probe = Probe()
+    sim.add_step(5, sign)                                             # registered first: runs first in every pass
+    sim.add_step(0, physicl.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, newton.NewtonianKinematicsStep())
+    sim.add_step(2, light.ScatterDeleteStep(np.double(0.0005), np.double(0.001)))
+    sim.add_step(7, probe)
+    try:
+        sim.add_step(7, probe)
+        out["duplicate_index_error"] = np.array("none")
+    except BaseException as e:                                        # (the reference raises a NameError here: IndexException is undefined)
+        out["duplicate_index_error"] = np.array(type(e).__name__)
+    np.random.seed(seed)
+    sim.start()
+    sim.join()
+    out["sign_rows"] = np.array(sign.data, dtype=np.float64)
+    out["ts"] = np.array(sim.ts, dtype=np.float64)
+    out["probe_t"] = np.array([p[0] for p in probe_rows])
+    out["probe_dt"] = np.array([p[1] for p in probe_rows])
+    out["probe_n"] = np.array([len(p[2]) for p in probe_rows], dtype=np.int64)
+    out["probe_uids"] = np.array([u for p in probe_rows for u in p[2]], dtype=np.int64)
+    out["probe_r0"] = np.array([x for p in probe_rows for x in p[3]], dtype=np.float64)
+    out["terminated_at"] = np.float64(probe.terminated_at)
+    st = sim.get_state()
+    out["state_keys"] = np.array(sorted(st.keys()))
+    out["state_objects"], out["state_t"], out["state_dt"] = np.int64(st["objects"]), np.float64(st["t"]), np.float64(st["dt"])
+    out["running_after"] = np.bool_(sim.running)
+    out["next_random"] = np.float64(np.random.random())
+    try:
+        sim.remove_step(7)
+        out["steps_after_remove"] = np.array(list(sim.steps.keys()), dtype=np.int64)
+    except BaseException as e:
+        out["steps_after_remove"] = np.array([-1], dtype=np.int64)
+    out.update(N=np.int64(N), dt=np.float64(dt), seed=np.int64(seed))
+    _save("g9_run", **out)
+
+
+# ----------------------------------------------------------------------------------------------
+# G10  the kernel-glue classes with a USER's kernel (CLInput / CLOutput / CLProgram, __init__.py:543-664): a Step of this
+#      repo's own making (an absorber with its own kernel text; every input type: obj, obj_def, obj_action with a
+#      ``continue``, obj_track, const; an int and a double output) run by the reference for three passes
+# ----------------------------------------------------------------------------------------------
+ABSORB_BODY = """
+    int gid = get_global_id(0);
+    double path = sqrt(d0[gid] * d0[gid] + d1[gid] * d1[gid] + d2[gid] * d2[gid]);
+    gone[gid] = (sigma * path >= u[gid]) ? 1 : 0;
+    depth[gid] = sigma * path + 0.25 * e2[gid];
+"""
+
+
+def g10_clprogram():
+    out = {}
+    N, seed, sigma = 300, 71, np.double(1e-6)
+
+    class Absorber(physicl.Step):
+        def __init__(self):
+            self.prog, self.outs = None, []
+
+        def run(self, sim):
+            if self.prog is None:
+                skip = physicl.CLInput(name="only_photons", type="obj_action",
+                                       code="if type(obj) != physicl.light.PhotonObject:\n \t\t continue")
+                d = [physicl.CLInput(name="d%d" % k, type="obj", obj_attr="dr[%d]" % k) for k in range(3)]
+                u = physicl.CLInput(name="u", type="obj_def", obj_def="np.random.random()")
+                e2 = physicl.CLInput(name="e2", type="obj_def", obj_def="obj.E * 2")
+                sg = physicl.CLInput(name="sigma", type="const", const_value=str(sigma))
+                who = physicl.CLInput(name="who", type="obj_track", obj_track="obj")
+                self.prog = physicl.CLProgram(sim, "absorb", ABSORB_BODY)
+                self.prog.prep_metadata = [skip] + d + [u, e2, who, sg]
+                self.prog.output_metadata = [physicl.CLOutput(name="gone", ctype="int"), physicl.CLOutput(name="depth")]
+                self.prog.build_kernel()
+            res = self.prog.run()
+            self.outs.append({k: np.array(v) for k, v in res.items()})
+            for idx, x in enumerate(res["gone"]):
+                if x == 1:
+                    sim.remove_obj(self.prog.who[idx])
+
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True, exit=lambda s: s.t >= 0.0025)
+    objs = _photons(N, rng, 1.0, 3.0)
+    objs.insert(10, physicl.Object(v=physicl.Measurement([5.0, 0, 0], "m**1 s**-1"), uid=-1))
+    sim.add_objs(objs)
+    out["init_E"] = np.array([float(np.asarray(getattr(o, "E", np.nan))) for o in objs])
+    ab = Absorber()
+    sim.add_step(0, physicl.UpdateTimeStep(lambda s: np.double(0.001)))
+    sim.add_step(1, newton.NewtonianKinematicsStep())
+    sim.add_step(2, ab)
+    np.random.seed(seed)
+    sim.start()
+    sim.join()
+    out["passes"] = np.int64(len(ab.outs))
+    for k, o in enumerate(ab.outs):
+        out["k%d_gone" % k], out["k%d_depth" % k] = o["gone"], o["depth"]
+        out["k%d_keys" % k] = np.array(sorted(o.keys()))
+    out["survivor_uid"] = np.array([o.uid for o in sim.objects], dtype=np.int64)
+    out["next_random"] = np.float64(np.random.random())
+    out.update(N=np.int64(N), seed=np.int64(seed), sigma=np.float64(sigma))
+    _save("g10_clprogram", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -773,6 +903,8 @@ def main():
     g5_trace()
     g7_setup()
     g8_csv()
+    g9_run()
+    g10_clprogram()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)
