@@ -730,6 +730,37 @@ def g10_clprogram():
 
 
 # ----------------------------------------------------------------------------------------------
+# G11  BASELINE configs[4]'s loop by the reference: [UpdateTimeStep, Newton, ScatterIsotropic, sign measure, Newton,
+#      ScatterDelete, plane measure] -- one np.random stream feeds both light steps (three draws per photon in the
+#      isotropic step, then one per photon in the delete step, every pass)
+# ----------------------------------------------------------------------------------------------
+def g11_mixed():
+    out = {}
+    N, dt, seed, K = 512, 1e-3, 81, 7
+    planes = [[3e5, np.nan, np.nan], [np.nan, 0.0, np.nan]]
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True)
+    sim.add_objs(_photons(N, rng))
+    steps = [physicl.UpdateTimeStep(lambda s: np.double(dt)), newton.NewtonianKinematicsStep(),
+             light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)), light.ScatterSignMeasureStep(None, True),
+             newton.NewtonianKinematicsStep(), light.ScatterDeleteStep(np.double(0.0004), np.double(0.001)),
+             light.ScatterMeasureStep(None, True, [np.array(p, dtype=np.double) for p in planes])]
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    uids = []
+    for k in range(K):
+        for st in steps:
+            st.run(sim)
+        uids.append(np.array([o.uid for o in sim.objects], dtype=np.int64))
+    s = _state(sim.objects)
+    out.update(sign_rows=np.array(steps[3].data, dtype=np.float64), measure_rows=np.array(steps[6].data, dtype=np.float64),
+               planes=np.array(planes, dtype=np.float64), final_uid=s["uid"], final_r=s["r"], final_v=s["v"],
+               alive=np.array([len(u) for u in uids], dtype=np.int64), uid_after_pass_2=uids[2],
+               next_random=np.float64(np.random.random()), N=np.int64(N), dt=np.float64(dt), seed=np.int64(seed), K=np.int64(K))
+    _save("g11_mixed", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -905,6 +936,7 @@ def main():
     g8_csv()
     g9_run()
     g10_clprogram()
+    g11_mixed()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

@@ -718,3 +718,33 @@ def test_user_kernel_through_clprogram_is_the_reference_s_own(golden):
         assert o["depth"].dtype == np.float64 and np.array_equal(o["depth"], z["k%d_depth" % k])      # *, +, sqrt: exact
     assert np.array_equal([o.uid for o in sim.objects], z["survivor_uid"])
     assert np.random.random() == float(z["next_random"])
+
+
+@pytest.mark.parametrize("spl", [None, 1])
+def test_mixed_loop_is_the_reference_s_own(golden, spl):
+    """BASELINE configs[4]'s loop as the reference ran it (tests/golden/make_golden.py g11_mixed): one np.random stream feeds
+    the isotropic step (three draws per photon) and the delete step (one) of every pass; rows of both measures, who is left,
+    where, and the stream afterwards."""
+    z = golden("g11_mixed")
+    N, dt, K = int(z["N"]), float(z["dt"]), int(z["K"])
+    sim = phys.Simulation(cl_on=True, steps_per_launch=spl, exit=lambda s: s.t >= (K - 0.5) * dt)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i) for i in range(N)])
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
+    for i, st in enumerate([phys.UpdateTimeStep(lambda s: np.double(dt)), phys.newton.NewtonianKinematicsStep(),
+                            phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)), sign,
+                            phys.newton.NewtonianKinematicsStep(), phys.light.ScatterDeleteStep(np.double(0.0004), np.double(0.001)), meas]):
+        sim.add_step(i, st)
+    np.random.seed(int(z["seed"]))
+    run(sim)
+    # (numpy's stream is drawn on the host in the reference's order and uploaded: such a run takes one launch per light step
+    # whatever steps_per_launch says -- the K-passes-per-launch kernels draw on the device)
+    assert not sim.schedule.get("mixed_multi")
+    assert np.array_equal(np.array(sign.data, dtype=np.float64), z["sign_rows"])
+    assert np.array_equal(np.array(meas.data, dtype=np.float64), z["measure_rows"])
+    assert np.array_equal([o.uid for o in sim.objects], z["final_uid"])
+    v = np.array([np.asarray(o.v) for o in sim.objects])
+    r = np.array([np.asarray(o.r) for o in sim.objects])
+    assert np.max(np.abs(v - z["final_v"])) <= V_ABS_TOL
+    assert np.max(np.abs(r - z["final_r"])) <= 2 * K * V_ABS_TOL * dt + 4 * np.spacing(np.abs(r).max())
+    assert np.random.random() == float(z["next_random"])
