@@ -748,3 +748,49 @@ def test_mixed_loop_is_the_reference_s_own(golden, spl):
     assert np.max(np.abs(v - z["final_v"])) <= V_ABS_TOL
     assert np.max(np.abs(r - z["final_r"])) <= 2 * K * V_ABS_TOL * dt + 4 * np.spacing(np.abs(r).max())
     assert np.random.random() == float(z["next_random"])
+
+
+ISO_API = {                                         # the step arguments make_golden.py's g2_iso gave the reference, tag by tag
+    "lambda": dict(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True),
+    "varn": dict(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True, variable_n=True,
+                 variable_n_fn="0.000000001 * exp(r0[gid] - 5)"),
+    "varn_radial": dict(n=0.5, A=123.0, variable_n=True,
+                        variable_n_fn="2.5 * exp(-1 * (sqrt(pow(r0[gid], 2) + pow(r1[gid], 2) + pow(r2[gid], 2)) - 6.0)/(3.5))"),
+    "varn_overflow": dict(n=0.000000000000001, A=0.0000000000000000001, wavelength_dep_scattering=True, variable_n=True,
+                          variable_n_fn="0.000000001 * exp(r0[gid] - 5)"),
+}
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("tag", sorted(ISO_API))
+def test_seeded_variable_n_runs_reproduce_the_reference(golden, tag, fuse):
+    """The wavelength term and variable_n_fn through the plugin API's ScatterIsotropicStep (A and n reach the kernel swapped,
+    light.py:287; with variable_n the user's A is not used at all, light.py:299) after np.random.seed: the reference's measure
+    rows and its final state.  A photon whose pcoll lies within 1e-14 of its draw may decide the other way (exp / pow of
+    another maths library): none does in these fixtures, the rows are compared exactly."""
+    z = golden("g2_iso_" + tag)
+    N, K, dt = len(z["k0_rand"]), int(z["K"]), float(z["dt"])
+    sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= (K - 0.5) * dt, fuse=fuse)
+    objs = []
+    for i in range(N):
+        p = phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(z["init_E"][i]), uid=i)
+        p.r = phys.Measurement(z["init_r"][i], "m**1")
+        objs.append(p)
+    sim.add_objs(objs)
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(**ISO_API[tag]))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
+    sim.add_step(3, sign)
+    sim.add_step(4, meas)
+    np.random.seed(int(z["seed"]))
+    run(sim)
+    assert np.array_equal(np.array(sign.data, dtype=np.float64), z["sign_rows"])
+    assert np.array_equal(np.array(meas.data, dtype=np.float64).reshape(z["measure_rows"].shape), z["measure_rows"])
+    last = "k%d_post_" % (K - 1)
+    v = np.array([np.asarray(o.v) for o in sim.objects])
+    r = np.array([np.asarray(o.r) for o in sim.objects])
+    assert np.max(np.abs(v - z[last + "v"])) <= V_ABS_TOL
+    assert np.max(np.abs(r - z[last + "r"])) <= K * V_ABS_TOL * dt + 4 * np.spacing(np.abs(z[last + "r"]).max())
+    assert sim.hits == (~np.isnan(z["k%d_res0" % (K - 1)])).sum()
