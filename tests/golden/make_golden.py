@@ -516,6 +516,36 @@ def g5_trace():
         out["del_" + key] = v
     out.update(del_N=np.int64(N), del_dt=np.float64(dt), del_seed=np.int64(seed), del_A_user=np.float64(A), del_n_user=np.float64(n),
                del_alive=np.array(alive, dtype=np.int64))
+    # (c) photons that join in the middle of the run (a user Step adds one in pass 2 and two in pass 4, in front of the trace
+    #     step): their rows start with 3 NaN scalars per pass they missed
+    N, K, dt, seed = 48, 6, 1e-3, 33
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True)
+    sim.add_objs(_photons(N, rng))
+
+    class Joiner(physicl.Step):
+        def __init__(self):
+            self.k = 0
+
+        def run(self, sim):
+            for j in range({2: 1, 4: 2}.get(self.k, 0)):
+                sim.add_obj(light.PhotonObject(v=np.array([0, light.c, 0], dtype=np.double), E=np.double(1.0), uid=900 + 10 * self.k + j))
+            self.k += 1
+
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    sc = light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001))
+    jn = Joiner()
+    tr = light.TracePathMeasureStep(None, id_info_fn=lambda o: "uid %d" % o.uid)
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    for k in range(K):
+        for st in (upd, nk, sc, jn, tr):
+            st.run(sim)
+    tr.terminate(sim)
+    for key, v in _trace_table(tr, False).items():
+        out["join_" + key] = v
+    out.update(join_N=np.int64(N), join_K=np.int64(K), join_dt=np.float64(dt), join_seed=np.int64(seed))
     _save("g5_trace", **out)
 
 

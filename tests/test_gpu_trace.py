@@ -487,3 +487,46 @@ def test_trace_table_is_the_reference_s_own(golden, case, mode):
         # positions: Euler sums of v dt with v within 4 ulp(c) of the reference's after a scattering; exact while nothing scattered
         assert np.max(np.abs(gp - wp), initial=0.0) <= (len(wp) * c_ulp * dt if case == "iso" else 0.0)
     sim.close(download=False)
+
+
+@pytest.mark.parametrize("mode", ["fused", "host_plugin"])
+def test_trace_table_of_photons_that_join_mid_run_is_the_reference_s_own(golden, mode):
+    """g5_trace (c): a user Step adds photons in passes 2 and 4.  The reference pads a late joiner's row with 3 NaN scalars per
+    missed pass in front AND as many again behind (``a = cols - len(pos)`` does not know about ``b``, light.py:474-479): the same
+    table here."""
+    import physicl as phys
+    import physicl.light
+    import physicl.newton
+    z = golden("g5_trace")
+    N, K, dt = int(z["join_N"]), int(z["join_K"]), float(z["join_dt"])
+
+    class Joiner(phys.Step):
+        def __init__(self):
+            self.k = 0
+
+        def run(self, sim):
+            for j in range({2: 1, 4: 2}.get(self.k, 0)):
+                sim.add_obj(phys.light.PhotonObject(v=np.array([0, phys.light.c, 0], dtype=np.double), E=np.double(1.0), uid=900 + 10 * self.k + j))
+            self.k += 1
+
+    sim = phys.Simulation(cl_on=True, fuse=mode == "fused", exit=lambda s: s.t >= (K - 0.5) * dt)
+    sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i) for i in range(N)])
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)))
+    sim.add_step(3, Joiner())
+    tp = phys.light.TracePathMeasureStep(None, id_info_fn=lambda o: "uid %d" % o.uid)
+    sim.add_step(4, tp)
+    np.random.seed(int(z["join_seed"]))
+    sim.start()
+    sim.join()
+    assert sim.error is None
+    assert np.array_equal(np.asarray(tp.data[0][1:], dtype=np.float64), z["join_t_row"])
+    want, got = _fixture_rows(z, "join_", False), _table_rows(tp, False)
+    assert len(got) == len(want) == N + 3
+    c_ulp = 4 * np.spacing(299792458.0)
+    for (wi, wf, wa, wp, wb), (gi, gf, ga, gp, gb) in zip(want, got):
+        assert (gi, ga, gb) == (wi, wa, wb) and gp.shape == wp.shape
+        assert np.max(np.abs(gp - wp), initial=0.0) <= K * c_ulp * dt
+    assert [w[2] for w in want[-3:]] == [6, 12, 12] and [w[4] for w in want[-3:]] == [6, 12, 12]
+    sim.close(download=False)
