@@ -791,6 +791,43 @@ def g11_mixed():
 
 
 # ----------------------------------------------------------------------------------------------
+# G12  plain Objects among the photons (OpenCL paths): the light steps skip them -- no random number drawn for them
+#      (light.py:233, 283) --, Newton moves them, the measures count them
+# ----------------------------------------------------------------------------------------------
+def g12_kinds():
+    out = {}
+    planes = [[3e5, np.nan, np.nan], [np.nan, -0.004, np.nan]]
+    for tag, seed in (("iso", 91), ("del", 92)):
+        N, dt = 210, 1e-3
+        rng = np.random.RandomState(seed + 1000)
+        objs = _photons(N, rng)
+        is_obj = np.zeros(N, dtype=bool)
+        for i in range(3, N, 7):
+            objs[i] = physicl.Object(v=physicl.Measurement(np.array([5.0, -3.0, 2.0]) * (1 + i % 3), "m**1 s**-1"), uid=i)
+            is_obj[i] = True
+        sim = physicl.Simulation(cl_on=True)
+        sim.add_objs(objs)
+        upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+        nk = newton.NewtonianKinematicsStep()
+        sc = (light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)) if tag == "iso"
+              else light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+        sign = light.ScatterSignMeasureStep(None, True)
+        meas = light.ScatterMeasureStep(None, True, [np.array(p, dtype=np.double) for p in planes])
+        sim.t, sim.dt, sim.ts = 0, 0, []
+        np.random.seed(seed)
+        for k in range(6):
+            for st in (upd, nk, sc, sign, meas):
+                st.run(sim)
+        s = _state(sim.objects)
+        out.update({tag + "_is_obj": is_obj, tag + "_sign_rows": np.array(sign.data, dtype=np.float64),
+                    tag + "_measure_rows": np.array(meas.data, dtype=np.float64), tag + "_final_uid": s["uid"],
+                    tag + "_final_r": s["r"], tag + "_final_v": s["v"], tag + "_next_random": np.float64(np.random.random()),
+                    tag + "_seed": np.int64(seed), tag + "_N": np.int64(N), tag + "_dt": np.float64(dt)})
+    out["planes"] = np.array(planes, dtype=np.float64)
+    _save("g12_kinds", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -967,6 +1004,7 @@ def main():
     g9_run()
     g10_clprogram()
     g11_mixed()
+    g12_kinds()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

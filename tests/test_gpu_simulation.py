@@ -794,3 +794,40 @@ def test_seeded_variable_n_runs_reproduce_the_reference(golden, tag, fuse):
     assert np.max(np.abs(v - z[last + "v"])) <= V_ABS_TOL
     assert np.max(np.abs(r - z[last + "r"])) <= K * V_ABS_TOL * dt + 4 * np.spacing(np.abs(z[last + "r"]).max())
     assert sim.hits == (~np.isnan(z["k%d_res0" % (K - 1)])).sum()
+
+
+@pytest.mark.parametrize("spl", [None, 1])
+@pytest.mark.parametrize("tag", ["iso", "del"])
+def test_plain_objects_among_the_photons_as_the_reference_treats_them(golden, tag, spl):
+    """g12_kinds: every seventh object is a plain Object.  The light steps skip it without drawing a random number
+    (light.py:233, 283), Newton moves it, both measures count it: the reference's rows, survivors, final state and random stream."""
+    z = golden("g12_kinds")
+    N, dt = int(z[tag + "_N"]), float(z[tag + "_dt"])
+    sim = phys.Simulation(cl_on=True, steps_per_launch=spl, exit=lambda s: s.t >= 5.5 * dt)
+    objs = []
+    for i in range(N):
+        if z[tag + "_is_obj"][i]:
+            objs.append(phys.Object(v=phys.Measurement(np.array([5.0, -3.0, 2.0]) * (1 + i % 3), "m**1 s**-1"), uid=i))
+        else:
+            objs.append(phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i))
+    sim.add_objs(objs)
+    sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
+    sim.add_step(1, phys.newton.NewtonianKinematicsStep())
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.001), n=np.double(0.001)) if tag == "iso"
+                 else phys.light.ScatterDeleteStep(np.double(0.001), np.double(0.001)))
+    sign = phys.light.ScatterSignMeasureStep(None, True)
+    meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
+    sim.add_step(3, sign)
+    sim.add_step(4, meas)
+    np.random.seed(int(z[tag + "_seed"]))
+    run(sim)
+    assert np.array_equal(np.array(sign.data, dtype=np.float64), z[tag + "_sign_rows"])
+    assert np.array_equal(np.array(meas.data, dtype=np.float64), z[tag + "_measure_rows"])
+    assert np.array_equal([o.uid for o in sim.objects], z[tag + "_final_uid"])
+    v = np.array([np.asarray(o.v) for o in sim.objects])
+    r = np.array([np.asarray(o.r) for o in sim.objects])
+    assert np.max(np.abs(v - z[tag + "_final_v"])) <= V_ABS_TOL
+    assert np.max(np.abs(r - z[tag + "_final_r"])) <= 6 * V_ABS_TOL * dt + 4 * np.spacing(np.abs(r).max())
+    plain = np.array([type(o) is phys.Object for o in sim.objects])
+    assert plain.sum() == z[tag + "_is_obj"].sum() and np.array_equal(r[plain], z[tag + "_final_r"][plain])    # Euler: exact
+    assert np.random.random() == float(z[tag + "_next_random"])
