@@ -828,6 +828,33 @@ def g12_kinds():
 
 
 # ----------------------------------------------------------------------------------------------
+# G13  planes that lie EXACTLY where unscattered photons stop after a pass (x = k * fl(c * dt)): the crossing test is
+#      ``r - dr <= loc <= r`` with both ends included (light.py:385-399), so such a photon is counted when it arrives and --
+#      where fl(r - dr) gives the plane back -- again when it leaves; delete flow (nobody turns), 7 passes
+# ----------------------------------------------------------------------------------------------
+def g13_plane_edges():
+    out = {}
+    N, dt, seed = 160, 1e-3, 95
+    d = np.double(299792458.0) * np.double(dt)
+    planes = [[d * k, np.nan, np.nan] for k in (1, 2, 3, 5)] + [[-d, np.nan, np.nan], [np.nan, 0.0, np.nan], [np.nan, np.nan, 1.0]]
+    rng = np.random.RandomState(seed + 1000)
+    sim = physicl.Simulation(cl_on=True)
+    sim.add_objs(_photons(N, rng))
+    upd = physicl.UpdateTimeStep(lambda s: np.double(dt))
+    nk = newton.NewtonianKinematicsStep()
+    sc = light.ScatterDeleteStep(np.double(0.0003), np.double(0.001))
+    meas = light.ScatterMeasureStep(None, True, [np.array(p, dtype=np.double) for p in planes])
+    sim.t, sim.dt, sim.ts = 0, 0, []
+    np.random.seed(seed)
+    for k in range(7):
+        for st in (upd, nk, sc, meas):
+            st.run(sim)
+    out.update(planes=np.array(planes, dtype=np.float64), measure_rows=np.array(meas.data, dtype=np.float64), N=np.int64(N),
+               dt=np.float64(dt), seed=np.int64(seed), final_uid=_state(sim.objects)["uid"])
+    _save("g13_plane_edges", **out)
+
+
+# ----------------------------------------------------------------------------------------------
 # G6  Measurement / code units (test/test_units.py:25-78, code_unit_scale_test.ipynb:55)
 # ----------------------------------------------------------------------------------------------
 def g6_units():
@@ -1005,6 +1032,7 @@ def main():
     g10_clprogram()
     g11_mixed()
     g12_kinds()
+    g13_plane_edges()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)
