@@ -833,13 +833,14 @@ def test_plain_objects_among_the_photons_as_the_reference_treats_them(golden, ta
     assert np.random.random() == float(z[tag + "_next_random"])
 
 
-def _edge_sim(z, **kw):
+def _edge_sim(z, iso=False, **kw):
     N, dt = int(z["N"]), float(z["dt"])
     sim = phys.Simulation(cl_on=True, exit=lambda s: s.t >= 6.5 * dt, **kw)
     sim.add_objs([phys.light.PhotonObject(v=np.array([phys.light.c, 0, 0], dtype=np.double), E=np.double(1.0), uid=i) for i in range(N)])
     sim.add_step(0, phys.UpdateTimeStep(lambda s: np.double(dt)))
     sim.add_step(1, phys.newton.NewtonianKinematicsStep())
-    sim.add_step(2, phys.light.ScatterDeleteStep(np.double(0.0003), np.double(0.001)))
+    sim.add_step(2, phys.light.ScatterIsotropicStep(A=np.double(0.0003), n=np.double(0.001)) if iso
+                 else phys.light.ScatterDeleteStep(np.double(0.0003), np.double(0.001)))
     meas = phys.light.ScatterMeasureStep(None, True, [np.array(p) for p in z["planes"]])
     sim.add_step(3, meas)
     return sim, meas
@@ -858,11 +859,15 @@ def test_planes_exactly_where_photons_stop_count_as_in_the_reference(golden):
     assert np.array_equal(rows, z["measure_rows"])
     assert np.array_equal([o.uid for o in sim.objects], z["final_uid"])
     assert (rows[:2, 2] == rows[:2, 1]).all() and rows[2, 2] == 0          # plane 1: on arrival (pass 1) and on leaving (pass 2)
-    out = []
-    for spl in (None, 1):
-        s, m = _edge_sim(z, rng="philox", seed=5, steps_per_launch=spl)
-        run(s)
-        out.append((np.array(m.data, dtype=np.float64), dict(s.schedule)))
-    assert out[0][1].get("fused_delete_multi", 0) >= 1 and not out[1][1].get("fused_delete_multi")
-    assert np.array_equal(out[0][0], out[1][0])
-    assert (out[0][0][:2, 2] == out[0][0][:2, 1]).all() and out[0][0][2, 2] == 0
+    for iso, sched in ((False, "fused_delete_multi"), (True, "fused_multi")):
+        out = []
+        for spl in (None, 1):
+            s, m = _edge_sim(z, iso=iso, rng="philox", seed=5, steps_per_launch=spl)
+            run(s)
+            out.append((np.array(m.data, dtype=np.float64), dict(s.schedule)))
+        assert out[0][1].get(sched, 0) >= 1 and not out[1][1].get(sched)
+        assert np.array_equal(out[0][0], out[1][0])
+        if not iso:
+            assert (out[0][0][:2, 2] == out[0][0][:2, 1]).all() and out[0][0][2, 2] == 0
+        else:                                                              # most photons still fly straight: both passes see them on plane 1
+            assert out[0][0][0, 2] == out[0][0][0, 1] and 0 < out[0][0][1, 2] < out[0][0][1, 1]
