@@ -1014,6 +1014,45 @@ def g6_unit_ops():
     print("wrote g6_unit_ops.json  %d expressions x 2 code scales" % len(UNIT_OPS))
 
 
+# ----------------------------------------------------------------------------------------------
+# G14  the public surface: every class and function the three modules define, parameter names / kinds, the defaults that
+#      are plain literals, base class names (NAMES only -- no source text)
+# ----------------------------------------------------------------------------------------------
+def g14_api():
+    import inspect
+    import json
+
+    def params(f):
+        out = []
+        for p in inspect.signature(f).parameters.values():
+            d = p.default
+            lit = None if d is inspect._empty else (repr(d) if isinstance(d, (bool, int, float, str, type(None), list)) else "<object>")
+            out.append([p.name, str(p.kind), lit])
+        return out
+
+    api = {}
+    for modname, mod in (("physicl", physicl), ("physicl.light", light), ("physicl.newton", newton)):
+        for name, obj in sorted(vars(mod).items()):
+            if name.startswith("_") or getattr(obj, "__module__", None) != modname:
+                continue
+            if inspect.isclass(obj):
+                entry = {"kind": "class", "bases": [b.__name__ for b in obj.__bases__], "methods": {}}
+                for mn, m in sorted(vars(obj).items()):
+                    if callable(m) and (not mn.startswith("_") or mn == "__init__"):
+                        try:
+                            entry["methods"][mn] = params(m)
+                        except (TypeError, ValueError):
+                            pass
+                api[modname + "." + name] = entry
+            elif inspect.isfunction(obj):
+                api[modname + "." + name] = {"kind": "function", "params": params(obj)}
+    consts = {k: float(np.asarray(getattr(light, k))) for k in ("c", "h", "kB")}
+    path = os.path.join(OUT, "g14_api.json")
+    with open(path, "w") as f:
+        json.dump({"api": api, "light_constants": consts}, f, indent=1, sort_keys=True)
+    print("wrote g14_api.json  %d names" % len(api))
+
+
 def main():
     only = sys.argv[1:]
     if only:                      # e.g. `make_golden.py g6_unit_ops` regenerates one fixture
@@ -1033,6 +1072,7 @@ def main():
     g11_mixed()
     g12_kinds()
     g13_plane_edges()
+    g14_api()
     g6_units()
     g6_unit_ops()
     # provenance: hashes of the kernel texts the reference generated (no text stored)

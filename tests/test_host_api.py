@@ -248,3 +248,53 @@ def test_limits_of_the_host_layer_are_the_headers():
     assert core._MAX_PLANES == _hip.MAX_PLANES == define("PCL_MAX_PLANES")
     assert light.TracePathMeasureStep.MAX_TRACKED == define("PCL_TRACE_MAX")
     assert (_hip.PHASE_ISOTROPIC, _hip.PHASE_DELETE) == (define("PCL_PHASE_ISOTROPIC"), define("PCL_PHASE_DELETE"))
+
+
+def test_public_surface_is_the_reference_s(tmp_path):
+    """tests/golden/g14_api.json: every class and function the reference's three modules define (read off the imported
+    reference by make_golden.py: names, parameter names and kinds, literal defaults, base class names).  Here: every name
+    exists, every method exists, its parameters start with the reference's (extras only behind them, with defaults), literal
+    defaults are equal, and the reference's base classes are among the class's ancestors."""
+    import inspect
+    import json
+    import os
+    import physicl
+    import physicl.light
+    import physicl.newton
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "g14_api.json")))
+    mods = {"physicl": physicl, "physicl.light": physicl.light, "physicl.newton": physicl.newton}
+
+    def check(full, fn, want):
+        got = list(inspect.signature(fn).parameters.values())
+        got = [p for p in got if p.kind is not inspect.Parameter.VAR_POSITIONAL or any(w[1] == "VAR_POSITIONAL" for w in want)]
+        assert len(got) >= len(want), full
+        for p, (name, kind, lit) in zip(got, want):
+            assert str(p.kind) == kind, (full, p.name)
+            if kind not in ("VAR_KEYWORD", "VAR_POSITIONAL"):
+                assert p.name == name, (full, p.name, name)
+            if lit is None:
+                assert p.default is inspect._empty, (full, name)
+            elif lit != "<object>":
+                assert repr(p.default) == lit, (full, name, p.default, lit)
+            else:
+                assert p.default is not inspect._empty, (full, name)
+        for p in got[len(want):]:                         # this build's own extras: optional, behind the reference's
+            assert p.default is not inspect._empty or p.kind in (inspect.Parameter.VAR_KEYWORD, inspect.Parameter.VAR_POSITIONAL), (full, p.name)
+
+    assert len(ref["api"]) >= 25
+    for full, e in ref["api"].items():
+        modname, name = full.rsplit(".", 1)
+        obj = getattr(mods[modname], name, None)
+        assert obj is not None, full
+        if e["kind"] == "function":
+            check(full, obj, e["params"])
+            continue
+        assert inspect.isclass(obj), full
+        ancestors = {c.__name__ for c in obj.__mro__}
+        assert set(e["bases"]) <= ancestors, (full, e["bases"], sorted(ancestors))
+        for mn, want in e["methods"].items():
+            m = getattr(obj, mn, None)
+            assert m is not None, (full, mn)
+            check(full + "." + mn, m, want)
+    for k, v in ref["light_constants"].items():
+        assert float(np.asarray(getattr(physicl.light, k))) == v
